@@ -1,0 +1,31 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        m = json.load(f)
+    return {c["name"]: c for c in m["cases"]}
+
+
+def golden_path(*parts):
+    return os.path.join(GOLDEN, *parts)
+
+
+def expected(case, name="stdout"):
+    with open(os.path.join(GOLDEN, "expected", case, name), "rb") as f:
+        return f.read()

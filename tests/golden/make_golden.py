@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the compiled reference.
+
+Run in the build container only (needs oracle/_ref/*, i.e. `make -C oracle ref`,
+which compiles the reference tools from /root/reference).  The inputs and the
+reference's outputs are committed as data; no reference source is stored.
+
+    python tests/golden/make_golden.py
+
+Layout written:
+    tests/golden/fastq/*            small FASTQ inputs (plain / gzip)
+    tests/golden/bam/*              small BAM + BAI inputs
+    tests/golden/expected/<case>/   stdout, and every file the tool wrote
+    tests/golden/manifest.json      case list: tool, argv, inputs, outputs
+"""
+import ctypes
+import gzip
+import hashlib
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from highperformancengs_amd import bamio  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+FQ = os.path.join(HERE, "fastq")
+BAM = os.path.join(HERE, "bam")
+EXP = os.path.join(HERE, "expected")
+
+A1 = """@r0 desc
+NAGATTTTCA
++
+@"9<G!=2/F
+@r1 desc
+GAAANATCTA
++
+B/=@D/7//>
+@r2 desc
+ATNACGAGNTNC
++
+43F@A:F#?0:;
+@r3 desc
+CGNGATNACNTGTAT
++
+#4HFF:++A/!-CD/
+@r4 desc
+NGNGTGNNATNC
++
+BD.<$?8ED-A;
+"""
+
+A3_SAM = """@SQ\tSN:c1\tLN:1000
+@SQ\tSN:c2\tLN:500
+r0\t0\tc1\t1\t30\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r1\t0\tc1\t1\t30\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r2\t0\tc1\t11\t30\t5M\t*\t0\t0\tACGTA\tIIIII
+r3\t0\tc1\t16\t30\t5=5X\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r4\t0\tc1\t100\t30\t5M5D5M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r5\t0\tc1\t105\t30\t5M\t*\t0\t0\tGGGCC\tIIIII
+r6\t0\tc1\t995\t30\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r7\t1024\tc2\t10\t30\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r8\t256\tc2\t10\t30\t10M\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII
+r9\t0\tc2\t20\t30\t3S7M\t*\t0\t0\tNNNGGGGCCC\tIIIIIIIIII
+"""
+
+
+def w(path, data):
+    with open(path, "wb") as f:
+        f.write(data if isinstance(data, bytes) else data.encode())
+
+
+def gz(path, data, level=6):
+    with open(path, "wb") as f:
+        f.write(gzip.compress(data if isinstance(data, bytes) else data.encode(), level, mtime=0))
+
+
+def make_fastq_inputs():
+    os.makedirs(FQ, exist_ok=True)
+    w(f"{FQ}/t.fq", A1)
+    assert hashlib.md5(A1.encode()).hexdigest() == "11d95bebc4e0dbe501c3fd46103c646b"
+    gz(f"{FQ}/t.fq.gz", A1)
+    w(f"{FQ}/empty.fq", b"")
+    w(f"{FQ}/nonl.fq", "@a\nACGT\n+\nIIII")                 # last line lacks its newline
+    w(f"{FQ}/crlf.fq", "@a\r\nACGT\r\n+\r\nIIII\r\n")
+    # three gzip members back to back: zlib reads them as one stream
+    one = gzip.compress(A1.encode(), 6, mtime=0)
+    w(f"{FQ}/multi.fq.gz", one * 3)
+    w(f"{FQ}/short.fq", "@s8\nACGTACGT\n+\nIIIIHHHH\n@s2\nAC\n+\nII\n@s5\nACGTA\n+\nABCDE\n")
+    # a zero-length read between normal ones (SeqLen[0] and the min-length rule)
+    w(f"{FQ}/len0.fq", "@a\nACGT\n+\nIIII\n@z\n\n+\n\n@b\nACGTAC\n+\n5?II5?\n")
+    # only zero-length reads
+    w(f"{FQ}/allzero.fq", "@z\n\n+\n\n@y\n\n+\n\n")
+    # truncated in the middle of a record (name+seq only)
+    w(f"{FQ}/trunc.fq", "@a\nACGT\n+\nIIII\n@b\nACGTACGTAC\n")
+    # name line longer than the 1024-byte gzgets buffer: the 4-line framing
+    # slips but stays deterministic (every byte the tally sees is defined)
+    rnd = random.Random(7)
+    longname = "@" + "".join(rnd.choice("abcdefgh") for _ in range(1023 + 120 - 1))
+    seq = "".join(rnd.choice("ACGT") for _ in range(130))
+    qual = "".join(chr(rnd.randint(35, 74)) for _ in range(130))
+    w(f"{FQ}/longname.fq", f"@ok\n{seq}\n+\n{qual}\n{longname}\n{seq}\n+\n{qual}\n@ok2\n{seq}\n+\n{qual}\n")
+    # synthetic inputs from the oracle's counter-based generator
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
+    orc.orc_synth_write_fastq.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64,
+                                          ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                          ctypes.c_int]
+    assert orc.orc_synth_write_fastq(f"{FQ}/syn_var_a.fq".encode(), 12345, 0, 1500, 30, 151, 0) == 0
+    assert orc.orc_synth_write_fastq(f"{FQ}/syn_var_b.fq.gz".encode(), 12345, 1500, 1500, 30, 151, 3) == 0
+    assert orc.orc_synth_write_fastq(f"{FQ}/syn_100.fq.gz".encode(), 777, 0, 4000, 100, 100, 4) == 0
+
+
+def make_bam_inputs():
+    os.makedirs(BAM, exist_ok=True)
+    assert hashlib.md5(A3_SAM.encode()).hexdigest() == "f9792b20778910249f9467da5a123f81"
+    refs, recs, hdr = bamio.records_from_sam(A3_SAM)
+    bamio.write_bam(f"{BAM}/e.bam", refs, recs, header_text=hdr)
+    # random cross-check set in the spirit of SURVEY A.4
+    rnd = random.Random(20240607)
+    refs = [("chr1", 100000), ("chr2", 50000), ("chrE", 3000)]  # chrE stays empty
+    cigars = ["100M", "40M2I58M", "30M5D70M", "10S50M100N40M", "20M3I20M4D57M", "5H95M", "50=50X"]
+    qlen = {"100M": 100, "40M2I58M": 100, "30M5D70M": 100, "10S50M100N40M": 100,
+            "20M3I20M4D57M": 100, "5H95M": 95, "50=50X": 100}
+    flags = [0, 16, 0, 16, 0, 16, 0, 16, 4, 256, 512, 1024, 1, 2048 + 16]
+    recs = []
+    for tid, (_, ln) in enumerate(refs[:2]):
+        pos = sorted(rnd.randrange(0, ln - 60) for _ in range(1000))
+        for i, p in enumerate(pos):
+            cg = rnd.choice(cigars)
+            seq = "".join(rnd.choice("ACGTN" if rnd.random() < .05 else "ACGT") for _ in range(qlen[cg]))
+            recs.append(bamio.BamRecord(tid=tid, pos=p, flag=rnd.choice(flags),
+                                        cigar=bamio.parse_cigar(cg), seq=seq, name=f"q{tid}_{i}"))
+    # a read at position 0 and reads overhanging the contig end
+    recs.insert(0, bamio.BamRecord(tid=0, pos=0, flag=0, cigar=bamio.parse_cigar("100M"), seq="A" * 100, name="p0"))
+    recs.sort(key=lambda r: (r.tid, r.pos))
+    recs.append(bamio.BamRecord(tid=1, pos=49990, flag=0, cigar=bamio.parse_cigar("100M"), seq="C" * 100, name="over"))
+    recs.append(bamio.BamRecord(tid=-1, pos=-1, flag=4, cigar=[], seq="ACGT", name="unm"))
+    bamio.write_bam(f"{BAM}/rand.bam", refs, recs)
+
+
+CASES = []
+
+
+def run_case(name, tool, args, inputs, cwd_outputs=True):
+    """Run a reference tool in a scratch dir holding copies of `inputs`."""
+    out_dir = os.path.join(EXP, name)
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    with tempfile.TemporaryDirectory() as td:
+        for src in inputs:
+            shutil.copy(src, td)
+            if src.endswith(".bam"):
+                shutil.copy(src + ".bai", td)
+        before = set(os.listdir(td))
+        p = subprocess.run([os.path.join(REF, tool)] + args, cwd=td, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+        w(os.path.join(out_dir, "stdout"), p.stdout)
+        files = sorted(set(os.listdir(td)) - before)
+        for f in files:
+            shutil.copy(os.path.join(td, f), os.path.join(out_dir, f))
+    CASES.append({"name": name, "tool": tool, "args": args,
+                  "inputs": [os.path.relpath(i, HERE) for i in inputs],
+                  "returncode": p.returncode, "files": files})
+    print(f"{name}: rc={p.returncode} stdout={len(p.stdout)}B files={files}")
+
+
+def main():
+    if not os.path.exists(os.path.join(REF, "fastq_count")):
+        sys.exit("oracle/_ref missing: run `make -C oracle ref` first")
+    make_fastq_inputs()
+    make_bam_inputs()
+    shutil.rmtree(EXP, ignore_errors=True)
+    fq = lambda n: os.path.join(FQ, n)  # noqa: E731
+    # ---- fastq_count -------------------------------------------------------
+    run_case("count_a1", "fastq_count", ["-H", "-L", "t.fq"], [fq("t.fq")])
+    run_case("count_a1_gz", "fastq_count", ["t.fq.gz"], [fq("t.fq.gz")])
+    for n in ["empty.fq", "nonl.fq", "crlf.fq", "multi.fq.gz", "short.fq", "len0.fq", "allzero.fq",
+              "trunc.fq", "longname.fq", "syn_var_a.fq", "syn_var_b.fq.gz", "syn_100.fq.gz"]:
+        run_case("count_" + n.split(".")[0], "fastq_count", ["-H", "-L", n], [fq(n)])
+    run_case("count_to_file", "fastq_count", ["-o", "report.txt", "-t", "1", "t.fq", "short.fq"],
+             [fq("t.fq"), fq("short.fq")])
+    # ---- fastq_count_kthread ----------------------------------------------
+    run_case("kthread_a1", "fastq_count_kthread", ["-H", "-L", "-o", "-", "t.fq", "t.fq.gz"],
+             [fq("t.fq"), fq("t.fq.gz")])
+    run_case("kthread_syn", "fastq_count_kthread",
+             ["-H", "-L", "-t", "2", "-o", "merged.tsv", "syn_var_a.fq", "syn_var_b.fq.gz", "syn_100.fq.gz"],
+             [fq("syn_var_a.fq"), fq("syn_var_b.fq.gz"), fq("syn_100.fq.gz")])
+    run_case("kthread_plain", "fastq_count_kthread", ["len0.fq", "short.fq"], [fq("len0.fq"), fq("short.fq")])
+    run_case("kthread_empty", "fastq_count_kthread", ["-H", "empty.fq"], [fq("empty.fq")])
+    # ---- fastq_trim --------------------------------------------------------
+    run_case("trim_a1", "fastq_trim", ["-i", "t.fq", "-s", "2", "-e", "8"], [fq("t.fq")])
+    run_case("trim_a1_default", "fastq_trim", ["-i", "t.fq.gz"], [fq("t.fq.gz")])
+    run_case("trim_a1_file", "fastq_trim", ["-i", "t.fq", "-s", "1", "-e", "12", "-o", "cut"], [fq("t.fq")])
+    run_case("trim_nonl", "fastq_trim", ["-i", "nonl.fq", "-e", "10"], [fq("nonl.fq")])
+    run_case("trim_short", "fastq_trim", ["-i", "short.fq", "-s", "3", "-e", "6"], [fq("short.fq")])
+    run_case("trim_crlf", "fastq_trim", ["-i", "crlf.fq", "-s", "1", "-e", "3"], [fq("crlf.fq")])
+    run_case("trim_syn_var", "fastq_trim", ["-i", "syn_var_b.fq.gz", "-s", "5", "-e", "80"], [fq("syn_var_b.fq.gz")])
+    run_case("trim_syn_100", "fastq_trim", ["-i", "syn_100.fq.gz", "-s", "0", "-e", "75", "-o", "t100"], [fq("syn_100.fq.gz")])
+    run_case("trim_multi", "fastq_trim", ["-i", "multi.fq.gz", "-s", "4", "-e", "9"], [fq("multi.fq.gz")])
+    run_case("trim_empty", "fastq_trim", ["-i", "empty.fq", "-e", "9"], [fq("empty.fq")])
+    # ---- bam2depth ---------------------------------------------------------
+    bm = lambda n: os.path.join(BAM, n)  # noqa: E731
+    run_case("depth_a3", "bam2depth", ["-w", "100", "-o", "d", "e.bam"], [bm("e.bam")])
+    run_case("depth_a3_wig", "bam2depth", ["-w", "100", "-W", "-o", "d", "e.bam"], [bm("e.bam")])
+    run_case("depth_a3_stdout", "bam2depth", ["-w", "250", "e.bam"], [bm("e.bam")])
+    run_case("depth_rand", "bam2depth", ["-o", "r", "rand.bam"], [bm("rand.bam")])
+    run_case("depth_rand_w1000", "bam2depth", ["-w", "1000", "-W", "-o", "r", "rand.bam"], [bm("rand.bam")])
+    run_case("depth_two_files", "bam2depth", ["-w", "500", "-o", "two", "e.bam", "rand.bam"], [bm("e.bam"), bm("rand.bam")])
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py",
+                   "reference_tools": "oracle/_ref (compiled from /root/reference by oracle/Makefile)",
+                   "cases": CASES}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

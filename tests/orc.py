@@ -1,0 +1,309 @@
+"""ctypes view of oracle/liborc.so (the CPU restatement; test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LEN_BINS, QUAL_ROWS = 512, 128
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class Counts(C.Structure):
+    _fields_ = [("seqlen", C.c_uint64 * LEN_BINS), ("quality", C.POINTER(C.c_uint64) * QUAL_ROWS)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("bases", C.c_double), ("min_len", C.c_uint32),
+                ("max_len", C.c_uint32), ("sum", C.c_uint64), ("q20", C.c_uint64), ("q30", C.c_uint64)]
+
+
+class Merged(C.Structure):
+    _fields_ = [("reads_u32", C.c_uint32), ("bases", C.c_double), ("min_len", C.c_uint32),
+                ("max_len", C.c_uint32), ("sum", C.c_uint64), ("q20", C.c_uint64), ("q30", C.c_uint64)]
+
+
+class Run(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32)]
+
+
+def _build():
+    so = os.path.join(ORACLE_DIR, "liborc.so")
+    src = [os.path.join(ORACLE_DIR, f) for f in ("hpn_oracle.c", "hpn_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liborc.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(_build())
+    L.orc_counts_new.restype = C.POINTER(Counts)
+    L.orc_counts_free.argtypes = [C.POINTER(Counts)]
+    L.orc_counts_add.argtypes = [C.POINTER(Counts), C.POINTER(Counts)]
+    L.orc_counts_flat_quality.argtypes = [C.POINTER(Counts), u64p]
+    L.orc_count_stream.argtypes = [C.c_char_p, C.POINTER(Counts)]
+    L.orc_count_soa.argtypes = [u8p, u64p, C.c_uint64, C.POINTER(Counts)]
+    L.orc_summarise.argtypes = [C.POINTER(Counts), C.POINTER(Summary)]
+    for f in ("orc_fmt_count_header", "orc_fmt_kthread_merged_header"):
+        getattr(L, f).argtypes = [C.c_char_p, C.c_size_t]
+    for f in ("orc_fmt_count_row", "orc_fmt_kthread_file_row"):
+        getattr(L, f).argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(Summary)]
+    L.orc_fmt_len_detail.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Counts), C.c_uint32, C.c_uint32]
+    L.orc_fmt_quality_matrix.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Counts), C.c_uint32]
+    L.orc_reduce_stats.argtypes = [C.POINTER(C.POINTER(Counts)), C.POINTER(Summary), C.c_int,
+                                   C.POINTER(Counts), C.POINTER(Merged)]
+    L.orc_fmt_kthread_merged_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Merged)]
+    L.orc_count_files_threaded.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int,
+                                           C.POINTER(Counts), C.POINTER(C.c_double)]
+    L.orc_trim_soa.argtypes = [u8p, u8p, u64p, C.c_uint64, C.c_int, C.c_int, u8p, u8p, u64p]
+    L.orc_depth_target.argtypes = [i32p, i32p, u32p, u32p, u32p, C.c_uint64, C.c_int32, C.c_uint32,
+                                   C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(Run)),
+                                   C.POINTER(C.c_uint64), f64p]
+    L.orc_window_add.argtypes = [i32p, i32p, u32p, i32p, u64p, u8p, C.c_uint64, C.c_uint32, C.c_int32,
+                                 u64p, u32p, u64p, u32p, u8p, C.POINTER(C.c_uint64)]
+    L.orc_window_gc_f32.argtypes = [i32p, i32p, u32p, i32p, u64p, u8p, C.c_uint64, C.c_uint32,
+                                    C.c_int32, u64p, f32p]
+    L.orc_mix64.argtypes = [C.c_uint64]
+    L.orc_mix64.restype = C.c_uint64
+    L.orc_synth_record.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, u8p, u8p]
+    L.orc_synth_len.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.orc_synth_len.restype = C.c_uint32
+    L.orc_synth_write_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                        C.c_uint32, C.c_int]
+    L.orc_synth_soa.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u8p, u8p, u64p]
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.free.argtypes = [C.c_void_p]
+    L._libc = libc
+    L.orc_trim_stream.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_fmt_bedgraph.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Run), C.c_uint64]
+    L.orc_fmt_depth_bins.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, f64p]
+    L.orc_fmt_wig_bins.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, f64p]
+    L.orc_fmt_window_report.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), u32p, C.c_uint32,
+                                        u64p, u32p, f32p, u32p, u8p]
+    _lib = L
+    return L
+
+
+# ---- helpers ----------------------------------------------------------------
+
+class CountsBox:
+    """Owns an orc_counts and exposes numpy copies."""
+
+    def __init__(self):
+        self.p = lib().orc_counts_new()
+
+    def __del__(self):
+        try:
+            lib().orc_counts_free(self.p)
+        except Exception:
+            pass
+
+    @property
+    def seqlen(self):
+        return np.array(self.p.contents.seqlen, dtype=np.uint64)
+
+    @property
+    def quality(self):
+        out = np.zeros(QUAL_ROWS * LEN_BINS, np.uint64)
+        lib().orc_counts_flat_quality(self.p, out)
+        return out.reshape(QUAL_ROWS, LEN_BINS)
+
+    def summary(self):
+        s = Summary()
+        lib().orc_summarise(self.p, C.byref(s))
+        return s
+
+
+def _fmt(fn, *args, cap=1 << 22):
+    buf = C.create_string_buffer(cap)
+    n = fn(buf, cap, *args)
+    assert n < cap
+    return buf.raw[:n]
+
+
+def count_stream(path):
+    box = CountsBox()
+    rc = lib().orc_count_stream(os.fsencode(path), box.p)
+    return rc, box
+
+
+def count_soa(qual, off):
+    box = CountsBox()
+    rc = lib().orc_count_soa(np.ascontiguousarray(qual, np.uint8), np.ascontiguousarray(off, np.uint64),
+                             len(off) - 1, box.p)
+    return rc, box
+
+
+def fastq_count_report(paths, names=None, header=False, length_detail=False):
+    """stdout of `fastq_count [-H] [-L] paths...` run with one thread (input order)."""
+    L = lib()
+    out = b""
+    if header:
+        out += _fmt(L.orc_fmt_count_header)
+    for i, p in enumerate(paths):
+        rc, box = count_stream(p)
+        assert rc == 0, rc
+        s = box.summary()
+        out += _fmt(L.orc_fmt_count_row, os.fsencode(names[i] if names else p), C.byref(s))
+        if length_detail:
+            out += _fmt(L.orc_fmt_len_detail, box.p, s.min_len, s.max_len)
+    return out
+
+
+def kthread_report(paths, names=None, header=False, length_detail=False):
+    """(merged text, [per-file tsv text]) of fastq_count_kthread."""
+    L = lib()
+    boxes, sums, per_file = [], (Summary * len(paths))(), []
+    for i, p in enumerate(paths):
+        rc, box = count_stream(p)
+        assert rc == 0
+        boxes.append(box)
+        s = box.summary()
+        sums[i] = s
+        t = _fmt(L.orc_fmt_count_header) if header else b""
+        t += _fmt(L.orc_fmt_kthread_file_row, os.fsencode(names[i] if names else p), C.byref(s))
+        if length_detail:
+            t += _fmt(L.orc_fmt_len_detail, box.p, s.min_len, s.max_len)
+            t += _fmt(L.orc_fmt_quality_matrix, box.p, s.max_len)
+        per_file.append(t)
+    arr = (C.POINTER(Counts) * len(paths))(*[b.p for b in boxes])
+    merged_box, m = CountsBox(), Merged()
+    L.orc_reduce_stats(arr, sums, len(paths), merged_box.p, C.byref(m))
+    out = _fmt(L.orc_fmt_kthread_merged_header) if header else b""
+    out += _fmt(L.orc_fmt_kthread_merged_row, C.byref(m))
+    if length_detail:
+        out += _fmt(L.orc_fmt_len_detail, merged_box.p, m.min_len, m.max_len)
+        out += _fmt(L.orc_fmt_quality_matrix, merged_box.p, m.max_len)
+    return out, per_file
+
+
+class _CFile:
+    def __init__(self):
+        self.tmp = tempfile.NamedTemporaryFile(delete=False)
+        self.tmp.close()
+        self.fp = lib()._libc.fopen(self.tmp.name.encode(), b"wb")
+
+    def read(self):
+        lib()._libc.fclose(self.fp)
+        with open(self.tmp.name, "rb") as f:
+            data = f.read()
+        os.unlink(self.tmp.name)
+        return data
+
+
+def trim_stream(path, S, E):
+    f = _CFile()
+    n = C.c_uint64(0)
+    rc = lib().orc_trim_stream(os.fsencode(path), S, E, f.fp, C.byref(n))
+    return rc, f.read(), n.value
+
+
+def trim_soa(seq, qual, off, S, E):
+    n = len(off) - 1
+    oseq, oqual = np.zeros(max(len(seq), 1), np.uint8), np.zeros(max(len(qual), 1), np.uint8)
+    ooff = np.zeros(n + 1, np.uint64)
+    rc = lib().orc_trim_soa(np.ascontiguousarray(seq, np.uint8), np.ascontiguousarray(qual, np.uint8),
+                            np.ascontiguousarray(off, np.uint64), n, S, E, oseq, oqual, ooff)
+    tot = int(ooff[-1])
+    return rc, oseq[:tot], oqual[:tot], ooff
+
+
+def depth_target(soa, tid, W, flag_mask=0x704):
+    """-> (rc, runs ndarray [n,3] int32, bins float64[target_len/W+1])"""
+    L = lib()
+    tlen = soa.refs[tid][1]
+    bins = np.zeros(tlen // W + 1, np.float64)
+    runs, nr = C.POINTER(Run)(), C.c_uint64(0)
+    rc = L.orc_depth_target(soa.tid, soa.pos, soa.flag, soa.cigar_off, soa.cigar, len(soa.tid), tid,
+                            tlen, W, flag_mask, C.byref(runs), C.byref(nr), bins)
+    if rc != 0:
+        return rc, None, None
+    arr = np.zeros((nr.value, 3), np.int32)
+    for i in range(nr.value):
+        arr[i] = (runs[i].start, runs[i].end, runs[i].depth)
+    L._libc.free(C.cast(runs, C.c_void_p))
+    return rc, arr, bins
+
+
+def bam2depth_text(soa, W, wig=False, flag_mask=0x704):
+    """(bedGraph, depth[, wig, chromSize]) text of bam2depth for one BAM."""
+    L = lib()
+    fb, fd, fw = _CFile(), _CFile(), _CFile()
+    chrom = b""
+    for tid, (name, tlen) in enumerate(soa.refs):
+        bins = np.zeros(tlen // W + 1, np.float64)
+        runs, nr = C.POINTER(Run)(), C.c_uint64(0)
+        rc = L.orc_depth_target(soa.tid, soa.pos, soa.flag, soa.cigar_off, soa.cigar, len(soa.tid),
+                                tid, tlen, W, flag_mask, C.byref(runs), C.byref(nr), bins)
+        assert rc == 0, rc
+        L.orc_fmt_bedgraph(fb.fp, name.encode(), runs, nr)
+        L.orc_fmt_depth_bins(fd.fp, name.encode(), tlen, W, bins)
+        L.orc_fmt_wig_bins(fw.fp, name.encode(), tlen, W, bins)
+        chrom += b"%s\t%d\n" % (name.encode(), tlen)
+        L._libc.free(C.cast(runs, C.c_void_p))
+    return fb.read(), fd.read(), fw.read(), chrom
+
+
+def window_offsets(refs, W):
+    off = np.zeros(len(refs) + 1, np.uint64)
+    for t, (_, ln) in enumerate(refs):
+        off[t + 1] = off[t] + np.uint64(ln // W + 1)
+    return off
+
+
+def window_counts(soa, W):
+    L = lib()
+    off = window_offsets(soa.refs, W)
+    tot = int(off[-1])
+    bins, gc, ln = np.zeros(tot, np.uint32), np.zeros(tot, np.uint64), np.zeros(tot, np.uint32)
+    touched = np.zeros(len(soa.refs), np.uint8)
+    nc = C.c_uint64(0)
+    rc = L.orc_window_add(soa.tid, soa.pos, soa.flag, soa.l_qseq, soa.seq_off, soa.seq4, len(soa.tid), W,
+                          len(soa.refs), off, bins, gc, ln, touched, C.byref(nc))
+    return rc, off, bins, gc, ln, touched, nc.value
+
+
+def window_report(soa, W):
+    L = lib()
+    rc, off, bins, gc, ln, touched, _ = window_counts(soa, W)
+    assert rc == 0
+    gcf = np.zeros(len(bins), np.float32)
+    rc = L.orc_window_gc_f32(soa.tid, soa.pos, soa.flag, soa.l_qseq, soa.seq_off, soa.seq4, len(soa.tid), W,
+                             len(soa.refs), off, gcf)
+    assert rc == 0
+    names = (C.c_char_p * len(soa.refs))(*[n.encode() for n, _ in soa.refs])
+    tl = np.array([l for _, l in soa.refs], np.uint32)
+    f = _CFile()
+    L.orc_fmt_window_report(f.fp, len(soa.refs), names, tl, W, off, bins, gcf, ln, touched)
+    return f.read()
+
+
+def synth_soa(seed, first, n, len_lo, len_hi):
+    """(seq u8[], qual u8[], off u64[n+1]) from the counter-based generator."""
+    L = lib()
+    lens = np.array([L.orc_synth_len(seed, first + i, len_lo, len_hi) for i in range(n)], np.uint64) \
+        if len_hi > len_lo else np.full(n, len_lo, np.uint64)
+    off = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    tot = int(off[-1])
+    seq, qual = np.zeros(max(tot, 1), np.uint8), np.zeros(max(tot, 1), np.uint8)
+    L.orc_synth_soa(seed, first, n, len_lo, len_hi, seq, qual, off)
+    return seq[:tot], qual[:tot], off

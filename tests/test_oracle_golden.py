@@ -1,0 +1,205 @@
+"""Pin the oracle (oracle/hpn_oracle.c) against the compiled reference tools.
+
+tests/golden/expected/* are byte-for-byte outputs of the reference binaries
+(tests/golden/make_golden.py); SURVEY.md Appendix A values are repeated inline.
+CPU only.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import expected, golden_path
+from highperformancengs_amd import bamio
+
+FQ = lambda n: golden_path("fastq", n)  # noqa: E731
+BAM = lambda n: golden_path("bam", n)  # noqa: E731
+
+
+def _args_flags(case):
+    a = case["args"]
+    return "-H" in a, "-L" in a
+
+
+@pytest.mark.parametrize("case", [
+    "count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "count_multi", "count_short",
+    "count_len0", "count_allzero", "count_trunc", "count_longname", "count_syn_var_a", "count_syn_var_b",
+    "count_syn_100"])
+def test_fastq_count_stdout(manifest, case):
+    c = manifest[case]
+    header, detail = _args_flags(c)
+    name = [a for a in c["args"] if not a.startswith("-")][-1]
+    got = orc.fastq_count_report([FQ(name)], names=[name], header=header, length_detail=detail)
+    assert got == expected(case)
+
+
+def test_fastq_count_appendix_a1_values():
+    # SURVEY.md Appendix A.1
+    assert expected("count_a1") == (
+        b"#Filename\tReadCount\tBaseCount\tMeanLen\tMinLen\tMaxLen\tQ20(%)\tQ30(%)\n"
+        b"t.fq\t5\t59\t12\t10\t15\t61.017\t38.983\n#Len:\t10\t11\t12\t13\t14\t15\n#Freq:\t2\t0\t2\t0\t0\t1\n")
+    assert expected("count_empty").endswith(b"empty.fq\t0\t0\t-nan\t0\t0\t-nan\t-nan\n#Len:\t0\n#Freq:\t0\n")
+    assert b"nonl.fq\t1\t4\t4\t4\t4\t100.000\t100.000\n" in expected("count_nonl")
+    assert b"crlf.fq\t1\t5\t5\t5\t5\t80.000\t80.000\n" in expected("count_crlf")
+    assert b"multi.fq.gz\t15\t177\t" in expected("count_multi")
+
+
+def test_fastq_count_to_file(manifest):
+    got = orc.fastq_count_report([FQ("t.fq"), FQ("short.fq")], names=["t.fq", "short.fq"])
+    assert got == expected("count_to_file", "report.txt")
+
+
+@pytest.mark.parametrize("case", ["kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty"])
+def test_kthread_reports(manifest, case):
+    c = manifest[case]
+    header, detail = _args_flags(c)
+    names = [os.path.basename(i) for i in c["inputs"]]
+    merged, per_file = orc.kthread_report([FQ(n) for n in names], names=names, header=header,
+                                          length_detail=detail)
+    if "-o" in c["args"] and c["args"][c["args"].index("-o") + 1] != "-":
+        assert merged == expected(case, c["args"][c["args"].index("-o") + 1])
+    else:
+        assert merged == expected(case)
+    for i, n in enumerate(names):
+        assert per_file[i] == expected(case, f"{n}.{i}.tsv"), n
+
+
+def test_kthread_a1_matrix_row33():
+    # Appendix A.1: row 33 ('!') of the merged 128 x 15 matrix
+    lines = expected("kthread_a1").split(b"\n")
+    assert lines[1] == b"10\t118\t12\t10\t15\t61.017\t38.983"
+    assert lines[3] == b"#Freq:\t4\t0\t4\t0\t0\t2"
+    assert lines[4 + 33] == b"\t".join(b"0 0 0 0 0 2 0 0 0 0 2 0 0 0 0".split())
+
+
+def test_count_soa_equals_stream():
+    # a split batch of the same reads gives the same accumulators
+    seq, qual, off = orc.synth_soa(12345, 0, 1500, 30, 151)
+    rc, a = orc.count_soa(qual, off)
+    assert rc == 0
+    rc, b = orc.count_stream(FQ("syn_var_a.fq"))
+    assert rc == 0
+    assert np.array_equal(a.seqlen, b.seqlen) and np.array_equal(a.quality, b.quality)
+
+
+def test_count_domain_errors():
+    rc, _ = orc.count_soa(np.full(600, 40, np.uint8), np.array([0, 600], np.uint64))
+    assert rc == -2  # len >= 512: SeqLen[] overrun in the reference
+    rc, _ = orc.count_soa(np.array([40, 200, 40], np.uint8), np.array([0, 3], np.uint64))
+    assert rc == -2  # quality byte >= 128: Quality[] row overrun in the reference
+
+
+def test_threaded_baseline_matches_serial(tmp_path):
+    import ctypes as C
+    L = orc.lib()
+    paths = []
+    for i in range(5):
+        p = str(tmp_path / f"s{i}.fq")
+        assert L.orc_synth_write_fastq(p.encode(), 99, i * 300, 300, 50, 150, 2 if i % 2 else 0) == 0
+        paths.append(p)
+    merged = orc.CountsBox()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    sec = C.c_double()
+    assert L.orc_count_files_threaded(arr, len(paths), 3, merged.p, C.byref(sec)) == 0
+    seq, qual, off = orc.synth_soa(99, 0, 1500, 50, 150)
+    rc, ref = orc.count_soa(qual, off)
+    assert np.array_equal(merged.seqlen, ref.seqlen) and np.array_equal(merged.quality, ref.quality)
+
+
+# ---- fastq_trim ---------------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["trim_a1", "trim_a1_default", "trim_a1_file", "trim_nonl", "trim_short",
+                                  "trim_crlf", "trim_syn_var", "trim_syn_100", "trim_multi", "trim_empty"])
+def test_trim_stream(manifest, case):
+    c = manifest[case]
+    a = c["args"]
+    S = int(a[a.index("-s") + 1]) if "-s" in a else 0
+    E = int(a[a.index("-e") + 1]) if "-e" in a else 400
+    rc, text, n = orc.trim_stream(FQ(a[a.index("-i") + 1]), S, E)
+    assert rc == 0
+    want = expected(case, a[a.index("-o") + 1] + ".trim.fastq") if "-o" in a else expected(case)
+    assert text == want
+    assert n == want.count(b"\n") // 4
+
+
+def test_trim_appendix_a1():
+    out = expected("trim_a1")
+    assert hashlib.md5(out).hexdigest() == "a8ec0edd85febad0a141fed2c5c03012"
+    assert out.startswith(b"@r0 desc\nGATTTT\n+\n9<G!=2\n@r1 desc\nAANATC\n+\n=@D/7/\n")
+    assert expected("trim_nonl") == b"@a\nACGT\n+\nIII\n"  # last char lost without final newline
+    assert expected("trim_short") == b"@s8\nTAC\n+\nIHH\n@s2\n\n+\n\n@s5\nTA\n+\nDE\n"
+
+
+def test_trim_soa_matches_stream_on_wellformed():
+    seq, qual, off = orc.synth_soa(12345, 1500, 1500, 30, 151)
+    rc, oseq, oqual, ooff = orc.trim_soa(seq, qual, off, 5, 80)
+    assert rc == 0
+    want = expected("trim_syn_var").split(b"\n")
+    for i in range(1500):
+        assert want[4 * i + 1] == oseq[int(ooff[i]):int(ooff[i + 1])].tobytes()
+        assert want[4 * i + 3] == oqual[int(ooff[i]):int(ooff[i + 1])].tobytes()
+
+
+# ---- bam2depth ------------------------------------------------------------------
+
+@pytest.mark.parametrize("case,bam,W", [("depth_a3", "e.bam", 100), ("depth_a3_wig", "e.bam", 100),
+                                        ("depth_rand", "rand.bam", 20000),
+                                        ("depth_rand_w1000", "rand.bam", 1000)])
+def test_bam2depth_text(manifest, case, bam, W):
+    soa = bamio.read_bam_records(BAM(bam))
+    bed, depth, wig, chrom = orc.bam2depth_text(soa, W)
+    c = manifest[case]
+    pre = c["args"][c["args"].index("-o") + 1]
+    assert bed == expected(case, f"{bam}.1.bedGraph")
+    assert depth == expected(case, f"{pre}.1.depth")
+    if "-W" in c["args"]:
+        assert wig == expected(case, f"{pre}.1.wig")
+        assert chrom == expected(case, f"{pre}.1.chromSize.txt")
+
+
+def test_bam2depth_appendix_a3():
+    assert expected("depth_a3", "e.bam.1.bedGraph") == (
+        b"c1\t0\t10\t2\nc1\t10\t15\t1\nc1\t99\t114\t1\nc1\t994\t1004\t1\nc2\t19\t26\t1\n")
+    d = expected("depth_a3", "d.1.depth").split(b"\n")
+    assert len(d) == 18 and d[10] == b"c1\t1000\t1000\t0.00"
+    nz = [x for x in d if x and not x.endswith(b"0.00")]
+    assert nz == [b"c1\t0\t100\t0.26", b"c1\t100\t200\t0.14", b"c1\t900\t1000\t0.06", b"c2\t0\t100\t0.07"]
+
+
+def test_bam2depth_stdout_and_second_file(manifest):
+    soa = bamio.read_bam_records(BAM("e.bam"))
+    _, depth, _, _ = orc.bam2depth_text(soa, 250)
+    assert depth == expected("depth_a3_stdout")
+    soa2 = bamio.read_bam_records(BAM("rand.bam"))
+    bed, depth, _, _ = orc.bam2depth_text(soa2, 500)
+    assert bed == expected("depth_two_files", "rand.bam.2.bedGraph")
+    assert depth == expected("depth_two_files", "two.2.depth")
+
+
+# ---- bam_sliding_count ------------------------------------------------------------
+# The reference tool needs libgd headers (gd.h, gdfontg.h) that this image lacks,
+# so it cannot be compiled here; the only pin is SURVEY.md Appendix A.3.
+
+def test_sliding_count_appendix_a3():
+    soa = bamio.read_bam_records(BAM("e.bam"))
+    text = orc.window_report(soa, 100).split(b"\n")
+    assert text[0].startswith(b"#chr\tchr_len\tchr_sum_read_count\tchr_sum_base\tchr_mean_cov\tchr_mean_GC%\t1\tcount\tGC%")
+    assert text[0].count(b"\tcount\t") == 11
+    r1 = text[1].split(b"\t")
+    r2 = text[2].split(b"\t")
+    assert r1[:12] == b"c1\t1000\t7\t60\t0.060000\t53.333336\t1\t5\t48.888889\t2\t1\t100.000000".split(b"\t")
+    assert r2[:12] == b"c2\t500\t3\t30\t0.060000\t56.666668\t1\t3\t56.666668\t2\t0\t0.000000".split(b"\t")
+    assert len(r1) == 6 + 3 * 11 and len(r2) == 6 + 3 * 6
+
+
+# ---- generator ---------------------------------------------------------------------
+
+def test_synth_generator_is_counter_based():
+    seq, qual, off = orc.synth_soa(5, 0, 200, 20, 90)
+    seq2, qual2, off2 = orc.synth_soa(5, 120, 80, 20, 90)
+    a, b = int(off[120]), int(off[200])
+    assert np.array_equal(qual[a:b], qual2) and np.array_equal(seq[a:b], seq2)
+    assert qual.min() >= 35 and qual.max() <= 74
+    assert set(np.unique(seq).tolist()) <= set(b"ACGTN")
