@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- fastq_count hot path on MI355X: Gbases/s and % of the HBM roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of hpn_fastq_tally over the rank's resident batch of synthetic
+reads (BASELINE.json configs[1]: 1e9 x 150 bp per GPU, generated in HBM by the
+counter-based generator), plus -- for N > 1 -- the one sum all-reduce of the
+count vector, plus the fetch of the counts to the host.  Inputs are resident in
+HBM when the timed region starts (inflate / PCIe are host work).
+Weak scaling: every rank holds its own 1e9-read shard (configs[4]: 8e9 reads on 8 GPUs).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=float, default=1e9, help="reads per GPU (BASELINE configs[1])")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--full-matrix", action="store_true", help="also build Quality[128][512] (kthread -L path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target wall time of the CPU baseline leg")
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------
+# CPU baseline leg: the only place bench.py touches oracle/ (reported, never the product)
+# --------------------------------------------------------------------------------------
+def cpu_baseline(read_len, target_s):
+    orc_so = os.path.join(ROOT, "oracle", "liborc.so")
+    if not os.path.exists(orc_so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liborc.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(orc_so)
+    L.orc_synth_write_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.orc_counts_new.restype = C.c_void_p
+    L.orc_counts_free.argtypes = [C.c_void_p]
+    L.orc_count_files_threaded.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+    cores = os.cpu_count() or 1
+    per_shard = 250_000
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "fastq_count_kthread")
+    kind = "reference" if os.access(ref_bin, os.X_OK) else "port"
+    td = tempfile.mkdtemp(prefix="hpn_cpu_")
+    try:
+        paths = [os.path.join(td, f"shard{i}.fq") for i in range(cores)]
+        with ThreadPoolExecutor(cores) as ex:  # the C writer releases the GIL
+            list(ex.map(lambda i: L.orc_synth_write_fastq(paths[i].encode(), 12345, i * per_shard, per_shard,
+                                                          read_len, read_len, 0), range(cores)))
+
+        def run(reps):
+            files = [p for p in paths for _ in range(reps)]
+            if kind == "reference":
+                t0 = time.perf_counter()
+                subprocess.run([ref_bin, "-t", str(cores), "-o", os.path.join(td, "merged.tsv")] + files,
+                               cwd=td, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                dt = time.perf_counter() - t0
+                for f in os.listdir(td):
+                    if f.endswith(".tsv"):
+                        os.unlink(os.path.join(td, f))
+                return dt
+            arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+            merged = L.orc_counts_new()
+            sec = C.c_double()
+            rc = L.orc_count_files_threaded(arr, len(files), cores, merged, C.byref(sec))
+            L.orc_counts_free(merged)
+            assert rc == 0
+            return sec.value
+
+        t1 = run(1)  # also warms the page cache
+        reps = max(1, min(64, int(target_s / max(t1, 1e-3))))
+        dt = run(reps)
+        bases = cores * reps * per_shard * read_len
+        return {"value": round(bases / dt / 1e9, 4), "unit": "Gbases/s", "cores": cores, "kind": kind,
+                "sample": f"{cores} plain FASTQ shards x {per_shard} reads x {read_len} bp, each listed {reps}x "
+                          f"({bases / 1e9:.2f} Gbases, {dt:.2f} s wall), fastq_count_kthread -t {cores} one thread per file"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    import torch.distributed as dist
+    import highperformancengs_amd as hp
+    from highperformancengs_amd import _lib, shard
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    ctx = hp.Context(local)
+
+    # ---- resident batch: this rank's shard of the N x 1e9-read job -------------------
+    L = a.read_len
+    n = int(a.reads)
+    free, _total = torch.cuda.mem_get_info()
+    need = n * (L + 8) + (1 << 30)
+    if need > free * 0.92:  # smaller HBM than expected: shrink the resident batch, say so
+        n = int(free * 0.92 - (1 << 30)) // (L + 8)
+    first = rank * n  # global record index of this shard (counter-based generator)
+    d_qual = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_fastq_dev(12345, first, n, L, d_qual, None, d_off)
+    ctx.sync()
+
+    # ---- the one collective: native RCCL on the context's stream, else torch.distributed --
+    allreduce = "none"
+    if world > 1:
+        try:
+            uid = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(hp.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            ctx.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            allreduce = "rccl-native"
+        except Exception as e:  # noqa: BLE001
+            allreduce = "torch.distributed"
+            if rank == 0:
+                print(f"[bench] native RCCL init failed ({e}); using torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if allreduce == "rccl-native" else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            allreduce = "torch.distributed"
+    flags = _lib.TALLY_QUAL_HIST if a.full_matrix else 0
+    words = _lib.TALLY_WORDS if a.full_matrix else _lib.W_BAD + 1
+    d_acc = ctx.tally_devptr()
+    kernel_ms = []
+
+    def step():
+        ctx.fastq_tally_dev(d_qual, d_off, n, flags=flags)
+        if allreduce == "rccl-native":
+            ctx.allreduce_u64(d_acc, words)
+        res = ctx.fastq_tally_fetch(qual_hist=a.full_matrix)
+        kernel_ms.append(ctx.last_kernel_ms(0))
+        if allreduce == "torch.distributed":
+            v = torch.from_numpy(shard.pack_counts(res.seqlen, res.total, res.q20, res.q30)).cuda()
+            shard.allreduce_counts(v)
+            return shard.unpack_counts(v.cpu().numpy())
+        return {"seqlen": res.seqlen.copy(), "total": res.total, "q20": res.q20, "q30": res.q30}
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- result sanity: counts are exact and closed-form checkable -----------------------
+    assert out["total"] == world * n * L, (out["total"], world, n, L)
+    assert int(out["seqlen"][L]) == world * n
+    q20, q30 = out["q20"] / out["total"], out["q30"] / out["total"]
+    assert abs(q20 - 0.55) < 1e-3 and abs(q30 - 0.30) < 1e-3, (q20, q30)
+
+    if rank == 0:
+        bases = world * n * L * a.steps
+        alg_bytes = n * L + (n + 1) * 8  # 1 B per base + 8 B per record, per launch
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if measured
+        if os.path.exists(tj):
+            try:
+                t = json.load(open(tj))
+                if t.get("reads_per_launch") == n and t.get("read_len") == L and not a.full_matrix:
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "Gbases/s processed (fastq_count, 150 bp)", "value": round(bases / dt / 1e9, 3),
+            "unit": "Gbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"fastq_count on {n:.3g} x {L} bp synthetic reads per GPU, resident in HBM "
+                                   f"(BASELINE configs[1]; gzip inflate is host work, excluded)",
+                       "reads_per_gpu": n, "read_len": L, "kernel": "k_tally_hist" if a.full_matrix else "k_tally_scan",
+                       "outputs": "SeqLen[512], sum, Q20, Q30" + (", Quality[128][512]" if a.full_matrix else ""),
+                       "parallelism": f"record-block shard x{world}", "allreduce": allreduce},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(L, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

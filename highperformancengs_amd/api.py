@@ -1,0 +1,216 @@
+"""Thin Python view of the C ABI, used by tests and bench.py.
+
+The drop-in surface of this project is the C ABI (include/hpngs.h) and the CLI
+tools built on it (csrc/tools); this module only moves pointers.  Host arrays are
+numpy, device arrays are anything with ``data_ptr()`` (torch tensors) or an int
+address.  Every failure raises ``HpnError``; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HpnError, Tally
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError(type(x))
+
+
+class TallyResult:
+    """Accumulators of count_read (fastq_count_kthread.c:116): numpy views over an hpn_tally."""
+
+    def __init__(self, qual_hist=False, nuc_hist=False):
+        self.c = Tally()
+        self.qual_hist = np.zeros((_lib.QUAL_ROWS, _lib.LEN_BINS), np.uint64) if qual_hist else None
+        self.nuc_hist = np.zeros((_lib.NUC_CODES, _lib.LEN_BINS), np.uint64) if nuc_hist else None
+        if qual_hist:
+            self.c.qual_hist = self.qual_hist.ctypes.data_as(C.POINTER(C.c_uint64))
+        if nuc_hist:
+            self.c.nuc_hist = self.nuc_hist.ctypes.data_as(C.POINTER(C.c_uint64))
+
+    @property
+    def seqlen(self):
+        return np.frombuffer(self.c.seqlen, dtype=np.uint64)
+
+    @property
+    def total(self):
+        return int(self.c.total)
+
+    @property
+    def q20(self):
+        return int(self.c.q20)
+
+    @property
+    def q30(self):
+        return int(self.c.q30)
+
+
+class Context:
+    """One per GPU (hpn_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.hpn_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise HpnError(rc, "hpn_ctx_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hpn_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise HpnError(rc, what, self.L.hpn_ctx_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.hpn_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None), "set_stream")
+
+    def sync(self):
+        self._ck(self.L.hpn_ctx_sync(self.h), "sync")
+
+    def last_kernel_ms(self, family=0):
+        ms = C.c_float()
+        self._ck(self.L.hpn_ctx_last_kernel_ms(self.h, family, C.byref(ms)), "last_kernel_ms")
+        return ms.value
+
+    # ---- fastq_count ------------------------------------------------------
+    def fastq_tally(self, qual, off, base=None, acc=None, qual_hist=False, nuc_hist=False):
+        """Host batch -> adds into `acc` (new TallyResult if None). Mirrors count_read."""
+        qual = np.ascontiguousarray(qual, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        if base is not None:
+            base = np.ascontiguousarray(base, np.uint8)
+        if acc is None:
+            acc = TallyResult(qual_hist, nuc_hist)
+        self._ck(self.L.hpn_fastq_tally(self.h, _ptr(qual), _ptr(base), _ptr(off), len(off) - 1, C.byref(acc.c)),
+                 "hpn_fastq_tally")
+        return acc
+
+    def fastq_tally_dev(self, d_qual, d_off, n, d_base=None, flags=0):
+        self._ck(self.L.hpn_fastq_tally_dev(self.h, _ptr(d_qual), _ptr(d_base), _ptr(d_off), n, flags),
+                 "hpn_fastq_tally_dev")
+
+    def fastq_tally_fetch(self, acc=None, qual_hist=False, nuc_hist=False):
+        if acc is None:
+            acc = TallyResult(qual_hist, nuc_hist)
+        self._ck(self.L.hpn_fastq_tally_fetch(self.h, C.byref(acc.c)), "hpn_fastq_tally_fetch")
+        return acc
+
+    def tally_devptr(self):
+        p = C.c_void_p()
+        self._ck(self.L.hpn_fastq_tally_devptr(self.h, C.byref(p)), "hpn_fastq_tally_devptr")
+        return p.value
+
+    # ---- fastq_trim -------------------------------------------------------
+    def fastq_trim(self, seq, qual, off, S, E):
+        seq = np.ascontiguousarray(seq, np.uint8)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        cap = max(int(off[-1] - off[0]), 1)
+        oseq, oqual, ooff = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(n + 1, np.uint64)
+        self._ck(self.L.hpn_fastq_trim(self.h, _ptr(seq), _ptr(qual), _ptr(off), n, S, E, _ptr(oseq), _ptr(oqual),
+                                       _ptr(ooff)), "hpn_fastq_trim")
+        tot = int(ooff[-1])
+        return oseq[:tot], oqual[:tot], ooff
+
+    def fastq_trim_dev(self, d_seq, d_qual, d_off, n, S, E, d_out_seq, d_out_qual, d_out_off):
+        self._ck(self.L.hpn_fastq_trim_dev(self.h, _ptr(d_seq), _ptr(d_qual), _ptr(d_off), n, S, E, _ptr(d_out_seq),
+                                           _ptr(d_out_qual), _ptr(d_out_off)), "hpn_fastq_trim_dev")
+
+    # ---- BAM --------------------------------------------------------------
+    @staticmethod
+    def _batch(soa, keep):
+        """hpn_bam_batch over numpy arrays / device tensors; `keep` pins the temporaries."""
+        b = _lib.BamBatch()
+        b.n = len(soa.tid)
+        for f in ("tid", "pos", "flag", "l_qseq", "cigar_off", "cigar", "seq_off", "seq4"):
+            a = getattr(soa, f, None)
+            if a is not None and isinstance(a, np.ndarray):
+                a = np.ascontiguousarray(a)
+                keep.append(a)
+            setattr(b, f, _ptr(a).value if a is not None else None)
+        return b
+
+    def depth_target(self, soa, tid, target_len, W, flag_mask=0x704, dev=False, runs_cap=None):
+        """One chromosome of bam2depth: (runs[n,3] int32, win_sum uint64[target_len//W+1])."""
+        keep = []
+        self._ck(self.L.hpn_depth_begin(self.h, tid, target_len, flag_mask), "hpn_depth_begin")
+        b = self._batch(soa, keep)
+        add = self.L.hpn_depth_add_dev if dev else self.L.hpn_depth_add
+        self._ck(add(self.h, C.byref(b)), "hpn_depth_add")
+        return self.depth_finish(target_len, W, runs_cap)
+
+    def depth_finish(self, target_len, W, runs_cap=None):
+        win = np.zeros(target_len // W + 1, np.uint64)
+        cap = runs_cap if runs_cap is not None else 1 << 16
+        while True:
+            runs = np.zeros((cap, 3), np.int32)
+            nr = C.c_uint64(0)
+            rc = self.L.hpn_depth_finish(self.h, W, _ptr(runs), cap, C.byref(nr), _ptr(win))
+            if rc == _lib.E_CAPACITY:
+                cap = int(nr.value)
+                continue
+            self._ck(rc, "hpn_depth_finish")
+            return runs[:nr.value], win
+
+    def window_counts(self, soa, win_off, W, dev=False):
+        keep = []
+        win_off = np.ascontiguousarray(win_off, np.uint64)
+        nt = len(win_off) - 1
+        self._ck(self.L.hpn_window_begin(self.h, nt, _ptr(win_off), W), "hpn_window_begin")
+        b = self._batch(soa, keep)
+        add = self.L.hpn_window_add_dev if dev else self.L.hpn_window_add
+        self._ck(add(self.h, C.byref(b)), "hpn_window_add")
+        tot = int(win_off[-1])
+        bins, gc, ln = np.zeros(tot, np.uint32), np.zeros(tot, np.uint64), np.zeros(tot, np.uint32)
+        touched = np.zeros(nt, np.uint8)
+        nc = C.c_uint64(0)
+        self._ck(self.L.hpn_window_finish(self.h, _ptr(bins), _ptr(gc), _ptr(ln), _ptr(touched), C.byref(nc)),
+                 "hpn_window_finish")
+        return bins, gc, ln, touched, nc.value
+
+    # ---- collectives / synthetic -----------------------------------------
+    def comm_init(self, rank, n_ranks, unique_id: bytes):
+        buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self.L.hpn_comm_init(self.h, rank, n_ranks, buf), "hpn_comm_init")
+
+    def allreduce_u64(self, d_vec, n):
+        self._ck(self.L.hpn_allreduce_u64(self.h, _ptr(d_vec), n), "hpn_allreduce_u64")
+
+    def synth_fastq_dev(self, seed, first, n, length, d_qual, d_base, d_off):
+        self._ck(self.L.hpn_synth_fastq_dev(self.h, seed, first, n, length, _ptr(d_qual), _ptr(d_base), _ptr(d_off)),
+                 "hpn_synth_fastq_dev")
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+    rc = _lib.lib().hpn_comm_unique_id(buf)
+    if rc != 0:
+        raise HpnError(rc, "hpn_comm_unique_id")
+    return bytes(buf)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _lib.lib().hpn_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,96 @@
+// hpn_ctx.hpp -- the per-GPU context behind the C ABI (include/hpngs.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "hpngs.h"
+
+namespace hpn {
+typedef unsigned long long u64;
+
+// device launchers (kernels/*.hip)
+hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t approx_bytes,
+                             u64 *d_acc, int n_cu, hipStream_t st);
+hipError_t launch_tally_hist(const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off, uint64_t n,
+                             bool qual_hist, bool nuc_hist, u64 *d_acc, int n_cu, hipStream_t st);
+hipError_t launch_synth_fastq(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t *d_qual,
+                              uint8_t *d_base, uint64_t *d_off, int n_cu, hipStream_t st);
+
+// A device buffer that only ever grows (staging for the host-buffer entry points).
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamCount = 4 };
+
+}  // namespace hpn
+
+struct hpn_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hpn::u64 *d_acc = nullptr;  // HPN_TALLY_WORDS
+    hpn::u64 *h_acc = nullptr;  // pinned mirror
+    hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;
+    hipEvent_t ev_beg[hpn::kFamCount] = {};
+    hipEvent_t ev_end[hpn::kFamCount] = {};
+    bool ev_valid[hpn::kFamCount] = {};
+    // bam2depth state
+    bool depth_open = false;
+    int32_t depth_tid = -1;
+    uint32_t depth_len = 0, depth_mask = 0;
+    uint64_t depth_slots = 0;  // int32 entries in the difference array
+    bool depth_scanned = false;
+    uint64_t depth_nruns = 0;
+    // bam_sliding_count state
+    bool win_open = false;
+    int32_t win_targets = 0;
+    uint32_t win_W = 0;
+    uint64_t win_total = 0;
+    // RCCL
+    void *comm = nullptr;
+    char err[512] = {0};
+};
+
+namespace hpn {
+
+inline int fail(hpn_ctx *c, int status, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+#define HPN_HIP(c, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return hpn::fail((c), HPN_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                             \
+    } while (0)
+
+inline int scratch_reserve(hpn_ctx *c, Scratch &s, size_t bytes)
+{
+    if (bytes <= s.cap) return HPN_OK;
+    if (s.p) HPN_HIP(c, hipFree(s.p));
+    s.p = nullptr;
+    s.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&s.p, want);
+    if (e != hipSuccess) {
+        s.p = nullptr;
+        return fail(c, HPN_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    s.cap = want;
+    return HPN_OK;
+}
+
+}  // namespace hpn

@@ -1,0 +1,206 @@
+/*
+ * hpngs.h -- C ABI of the MI355X (gfx950) scan kernels that stand in for the
+ * per-record loops of HighPerformanceNGS' fastq_count / fastq_trim / bam2depth /
+ * bam_sliding_count.
+ *
+ * The reference has no library API; its seams are three C call signatures
+ * (SURVEY.md §8b).  Each entry point below names the reference function it
+ * replaces (file:line relative to the reference checkout).  Conventions:
+ *   - plain C types, no exceptions; every call returns HPN_OK (0) or a negative
+ *     hpn_status; hpn_ctx_last_error() has the detail text;
+ *   - one hpn_ctx per GPU, used by one host thread at a time;
+ *   - "host" entry points take caller-owned host buffers, copy, launch, wait and
+ *     ADD into caller-owned accumulators, exactly like count_read adds into the
+ *     arrays its caller zeroed (fastq_count_kthread.c:116,126);
+ *   - "_dev" entry points take device pointers (hipMalloc / hpn_dev_malloc /
+ *     torch tensors), enqueue on the context's stream and return immediately;
+ *     results are collected by the matching "_fetch" call;
+ *   - there is NO CPU fallback: without a usable GPU every compute call fails
+ *     with HPN_E_NODEVICE.
+ */
+#ifndef HPNGS_H
+#define HPNGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPN_ABI_VERSION 1
+#define HPN_LEN_BINS 512   /* SeqLen[512]       fastq_count.c:111 */
+#define HPN_QUAL_ROWS 128  /* Quality[128][512] fastq_count.c:110 */
+#define HPN_NUC_CODES 5    /* T,C,A,G,N         Rgzfastq_uniq.c:97-108 */
+
+typedef enum hpn_status {
+    HPN_OK = 0,
+    HPN_E_NODEVICE = -1, /* no HIP device / runtime */
+    HPN_E_HIP = -2,      /* a HIP call failed */
+    HPN_E_ARG = -3,      /* bad argument */
+    HPN_E_DOMAIN = -4,   /* input on which the reference has undefined behaviour
+                            (read length >= 512, quality byte >= 128, position >= 2^28 ...) */
+    HPN_E_NOMEM = -5,
+    HPN_E_STATE = -6,    /* call sequence error (e.g. depth_add before depth_begin) */
+    HPN_E_RCCL = -7,
+    HPN_E_CAPACITY = -8  /* caller-provided output buffer too small; required size reported */
+} hpn_status;
+
+typedef struct hpn_ctx hpn_ctx;
+
+/* ---- library / context ----------------------------------------------------- */
+int hpn_abi_version(void);
+const char *hpn_strerror(int status);
+int hpn_device_count(int *n);
+/* `device` = HIP ordinal.  Creates the context's own non-blocking stream. */
+int hpn_ctx_create(int device, hpn_ctx **ctx);
+int hpn_ctx_destroy(hpn_ctx *ctx);
+/* Run on a caller-owned hipStream_t instead (e.g. torch's current stream);
+ * NULL restores the context's own stream. */
+int hpn_ctx_set_stream(hpn_ctx *ctx, void *hip_stream);
+int hpn_ctx_sync(hpn_ctx *ctx);
+const char *hpn_ctx_last_error(const hpn_ctx *ctx);
+/* Milliseconds the device spent in the most recent kernel launch group of the
+ * given family, measured with hipEvents on the context's stream (valid after
+ * the matching fetch/sync). Families: 0 tally, 1 trim, 2 depth, 3 window. */
+int hpn_ctx_last_kernel_ms(hpn_ctx *ctx, int family, float *ms);
+
+/* ---- memory helpers (thin wrappers; callers may use their own allocator) ---- */
+int hpn_dev_malloc(hpn_ctx *ctx, size_t bytes, void **dptr);
+int hpn_dev_free(hpn_ctx *ctx, void *dptr);
+int hpn_host_malloc(hpn_ctx *ctx, size_t bytes, void **hptr); /* pinned */
+int hpn_host_free(hpn_ctx *ctx, void *hptr);
+int hpn_memcpy_h2d(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream */
+int hpn_memcpy_d2h(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream */
+
+/* ---- fastq_count: replaces count_read's scan loop ------------------------------
+ * fastq_count.c:112-119 / fastq_count_kthread.c:126-135 (+ AssignQuality :29-35).
+ *
+ * A batch is structure-of-arrays: record i owns bytes [off[i], off[i+1]) of
+ * `qual` (the first seqLen bytes of its quality line) and, optionally, of
+ * `base` (its sequence line).  Adds into `acc`:
+ *   seqlen[l]            += #records of length l            (SeqLen[512])
+ *   total, q20, q30      += #bytes, #bytes >= 53, >= 63     (statQ(...,53,...,63,...), :37-47,124)
+ *   qual_hist[q*512+pos] += 1 per byte        if non-NULL   (Quality[128][512])
+ *   nuc_hist[c*512+pos]  += 1 per base        if non-NULL and `base` given
+ *                           (c: T0 C1 A2 G3 N4, any other byte counts as T,
+ *                            Rgzfastq_uniq.c:97-108)
+ * Domain (else HPN_E_DOMAIN, accumulators untouched): every length < 512,
+ * every quality byte < 128. */
+typedef struct hpn_tally {
+    uint64_t seqlen[HPN_LEN_BINS];
+    uint64_t total, q20, q30;
+    uint64_t *qual_hist; /* [HPN_QUAL_ROWS * HPN_LEN_BINS] or NULL */
+    uint64_t *nuc_hist;  /* [HPN_NUC_CODES * HPN_LEN_BINS] or NULL */
+} hpn_tally;
+
+#define HPN_TALLY_QUAL_HIST 1u /* also build Quality[128][512] */
+#define HPN_TALLY_NUC_HIST 2u  /* also build Nucleotide[5][512] (needs base) */
+
+int hpn_fastq_tally(hpn_ctx *ctx, const uint8_t *qual, const uint8_t *base_or_null,
+                    const uint64_t *off, uint64_t n_records, hpn_tally *acc);
+/* Device-resident batch; accumulates into the context's device accumulators. */
+int hpn_fastq_tally_dev(hpn_ctx *ctx, const uint8_t *d_qual, const uint8_t *d_base_or_null,
+                        const uint64_t *d_off, uint64_t n_records, uint32_t flags);
+/* Wait, add the device accumulators into `acc`, zero them. */
+int hpn_fastq_tally_fetch(hpn_ctx *ctx, hpn_tally *acc);
+/* The raw device accumulator block (uint64_t[HPN_TALLY_WORDS], layout below) for
+ * callers that reduce it across GPUs themselves (RCCL all-reduce). */
+#define HPN_TALLY_W_SEQLEN 0                                    /* [512] */
+#define HPN_TALLY_W_TOTAL 512
+#define HPN_TALLY_W_Q20 513
+#define HPN_TALLY_W_Q30 514
+#define HPN_TALLY_W_BAD 515                                     /* domain violations seen */
+#define HPN_TALLY_W_QUAL 516                                    /* [128*512] */
+#define HPN_TALLY_W_NUC (516 + HPN_QUAL_ROWS * HPN_LEN_BINS)    /* [5*512] */
+#define HPN_TALLY_WORDS (HPN_TALLY_W_NUC + HPN_NUC_CODES * HPN_LEN_BINS)
+int hpn_fastq_tally_devptr(hpn_ctx *ctx, uint64_t **d_acc);
+
+/* ---- fastq_trim: replaces readNextNode's cut --------------------------------------
+ * fastq_trim.c:76-77,83-84: out = line[min(S,len) .. min(E,len)) for the sequence
+ * and the quality line of every record.  out_off[0] = 0, out_off[i+1] = running
+ * total; out_seq/out_qual are packed.  Capacity of out_seq/out_qual: off[n]-off[0]
+ * bytes is always enough.  Domain: 0 <= S <= E. */
+int hpn_fastq_trim(hpn_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off,
+                   uint64_t n_records, int32_t S, int32_t E, uint8_t *out_seq, uint8_t *out_qual,
+                   uint64_t *out_off);
+int hpn_fastq_trim_dev(hpn_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual,
+                       const uint64_t *d_off, uint64_t n_records, int32_t S, int32_t E,
+                       uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off);
+
+/* ---- BAM record batches ---------------------------------------------------------------
+ * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),
+ * flattened to SoA by the host decoder: core fields, CIGAR words (len<<4|op,
+ * bam.h:97-110) and the 4-bit packed sequence (bam.h:260). */
+typedef struct hpn_bam_batch {
+    uint64_t n;
+    const int32_t *tid;
+    const int32_t *pos;
+    const uint32_t *flag;
+    const int32_t *l_qseq;
+    const uint32_t *cigar_off; /* [n+1] into cigar */
+    const uint32_t *cigar;
+    const uint64_t *seq_off;   /* [n+1] into seq4 (bytes); may be NULL for depth */
+    const uint8_t *seq4;       /* may be NULL for depth */
+} hpn_bam_batch;
+
+/* ---- bam2depth: replaces fetch_func + hash2BedGraph + overlap ----------------------
+ * bam2depth.c:86-110 (CIGAR-M difference array), :203-236 (sorted sweep -> runs of
+ * equal depth > 0), :132-176 (window sums).  One target (chromosome) at a time:
+ *   hpn_depth_begin(tid, target_len, flag_mask)   flag_mask = 0x704 for bam2depth
+ *                                                 (BAM_DEF_MASK, bam.h:124), 0x4 for bam2wig
+ *   hpn_depth_add(batch)            any number of times; records of other tids are skipped
+ *   hpn_depth_finish(W, ...)        runs (start,end,depth) ascending + per-window sum of coverage
+ * win_sum has target_len/W+1 entries (bam2depth.c:326) holding the exact integer
+ * sum of coverage over [kW, min((k+1)W, target_len)); the host prints win_sum/W
+ * with %.2f (output_bins :238-246).
+ * Domain: every breakpoint < 2^28 (int2char keeps 28 bits, hashtbl.c:243-249). */
+typedef struct hpn_run {
+    int32_t start, end, depth;
+} hpn_run;
+
+int hpn_depth_begin(hpn_ctx *ctx, int32_t tid, uint32_t target_len, uint32_t flag_mask);
+int hpn_depth_add(hpn_ctx *ctx, const hpn_bam_batch *host_batch);
+int hpn_depth_add_dev(hpn_ctx *ctx, const hpn_bam_batch *dev_batch);
+/* runs: caller buffer of runs_cap entries; *n_runs receives the number found
+ * (HPN_E_CAPACITY if it exceeds runs_cap; call again with a larger buffer --
+ * the scan result stays valid until the next hpn_depth_begin). */
+int hpn_depth_finish(hpn_ctx *ctx, uint32_t W, hpn_run *runs, uint64_t runs_cap, uint64_t *n_runs,
+                     uint64_t *win_sum);
+
+/* ---- bam_sliding_count: replaces fetch_func + cal_GC ----------------------------------
+ * bam_sliding_count.c:84-124.  Slot of a record = win_off[tid] + (uint16)(pos/W)
+ * (:117, including the 16-bit wrap).  Adds per slot: bins += 1, gc += #nibbles
+ * equal to 2 (C) or 4 (G), len += l_qseq; sets touched[tid].  Records with tid<0
+ * or flag&4 are skipped (:96-97).  All integer; the float32 replay of
+ * calc_winGC (:126-138) is host work (csrc/host/report.cpp). */
+int hpn_window_begin(hpn_ctx *ctx, int32_t n_targets, const uint64_t *win_off /*[n_targets+1]*/,
+                     uint32_t W);
+int hpn_window_add(hpn_ctx *ctx, const hpn_bam_batch *host_batch);
+int hpn_window_add_dev(hpn_ctx *ctx, const hpn_bam_batch *dev_batch);
+int hpn_window_finish(hpn_ctx *ctx, uint32_t *bins, uint64_t *gc, uint32_t *len, uint8_t *touched,
+                      uint64_t *n_count);
+
+/* ---- multi-GPU reduction of count vectors -----------------------------------
+ * One RCCL communicator per context; `unique_id` is the 128-byte ncclUniqueId
+ * produced by hpn_comm_unique_id on rank 0 and handed to every rank by the host
+ * program (file, pipe, torch.distributed ...).  hpn_allreduce_u64 sums a device
+ * vector in place over xGMI. */
+#define HPN_UNIQUE_ID_BYTES 128
+int hpn_comm_unique_id(uint8_t id[HPN_UNIQUE_ID_BYTES]);
+int hpn_comm_init(hpn_ctx *ctx, int rank, int n_ranks, const uint8_t id[HPN_UNIQUE_ID_BYTES]);
+int hpn_comm_destroy(hpn_ctx *ctx);
+int hpn_allreduce_u64(hpn_ctx *ctx, uint64_t *d_vec, size_t n);
+
+/* ---- synthetic inputs, generated in HBM -----------------------------------
+ * Counter-based: byte k of record r depends only on (seed, r, k), so any shard
+ * can be produced independently and checked on the CPU.  Quality bytes uniform
+ * in 35..74, bases A/C/G/T 24.75 % each + N 1 %.  Fixed read length `len`;
+ * d_off gets (first_record-relative) offsets i*len as uint64. */
+int hpn_synth_fastq_dev(hpn_ctx *ctx, uint64_t seed, uint64_t first_record, uint64_t n_records,
+                        uint32_t len, uint8_t *d_qual, uint8_t *d_base_or_null, uint64_t *d_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPNGS_H */

@@ -608,17 +608,21 @@ void orc_synth_record(uint64_t seed, uint64_t rec, uint32_t len, uint8_t *seq, u
 {
     static const char ACGT[4] = {'A', 'C', 'G', 'T'};
     uint64_t key = rec_key(seed, rec);
-    for (uint32_t k = 0; k < len; ++k) {
-        uint64_t j = k >> 2;
-        uint32_t sh = 16 * (k & 3);
-        if (qual) {
-            uint32_t u = (uint32_t)(orc_mix64(key + (2 * j + 1) * ORC_STEP) >> sh) & 0xffff;
-            qual[k] = (uint8_t)(35 + ((u * 40u) >> 16)); /* Phred 2..41, +33 */
-        }
-        if (seq) {
-            uint32_t u = (uint32_t)(orc_mix64(key + (2 * j + 2) * ORC_STEP) >> sh) & 0xffff;
-            uint32_t x = (u * 10000u) >> 16; /* 0..9999 */
-            seq[k] = x < 100 ? 'N' : (uint8_t)ACGT[(x - 100) / 2475];
+    for (uint32_t k0 = 0; k0 < len; k0 += 4) { /* one 64-bit word feeds 4 bytes */
+        uint64_t j = k0 >> 2;
+        uint64_t wq = qual ? orc_mix64(key + (2 * j + 1) * ORC_STEP) : 0;
+        uint64_t wb = seq ? orc_mix64(key + (2 * j + 2) * ORC_STEP) : 0;
+        for (uint32_t k = k0; k < k0 + 4 && k < len; ++k) {
+            uint32_t sh = 16 * (k & 3);
+            if (qual) {
+                uint32_t u = (uint32_t)(wq >> sh) & 0xffff;
+                qual[k] = (uint8_t)(35 + ((u * 40u) >> 16)); /* Phred 2..41, +33 */
+            }
+            if (seq) {
+                uint32_t u = (uint32_t)(wb >> sh) & 0xffff;
+                uint32_t x = (u * 10000u) >> 16; /* 0..9999 */
+                seq[k] = x < 100 ? 'N' : (uint8_t)ACGT[(x - 100) / 2475];
+            }
         }
     }
 }
