@@ -87,7 +87,8 @@ int hpn_ctx_destroy(hpn_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->comm) hpn_comm_destroy(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    Scratch *ss[] = {&c->s_a, &c->s_b, &c->s_c, &c->s_d, &c->s_e, &c->s_f, &c->s_g, &c->s_h};
+    Scratch *ss[] = {&c->s_a, &c->s_b, &c->s_c, &c->s_d, &c->s_e, &c->s_f, &c->s_g, &c->s_h, &c->d_diff, &c->d_runs,
+                     &c->d_win, &c->d_ws, &c->w_off, &c->w_bins, &c->w_len, &c->w_gc, &c->w_misc};
     for (Scratch *s : ss)
         if (s->p) (void)hipFree(s->p);
     if (c->d_acc) (void)hipFree(c->d_acc);

@@ -1,0 +1,254 @@
+// hpn_bam.hip -- C ABI of the bam2depth and bam_sliding_count record loops.
+#include <string.h>
+
+#include <vector>
+
+#include "hpn_ctx.hpp"
+
+namespace hpn {
+hipError_t launch_depth_scatter(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
+                                const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
+                                uint64_t slots, uint32_t *bad, int n_cu, hipStream_t st);
+uint64_t depth_scan_tiles(uint64_t slots);
+hipError_t launch_depth_scan(const int32_t *diff, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
+                             uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st);
+hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
+                             const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint32_t W, int32_t n_targets,
+                             const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
+                             u64 *n_count, uint32_t *bad, int n_cu, hipStream_t st);
+}  // namespace hpn
+
+using namespace hpn;
+
+namespace {
+constexpr uint64_t kPosLimit = 1ull << 28;   // int2char keeps 28 bits of a position (hashtbl.c:243-249)
+constexpr uint64_t kOverhang = 1ull << 21;   // room past target_len for reads hanging over the contig end
+
+// Copy one host array to a staging buffer on the context's stream.
+template <typename T>
+int stage(hpn_ctx *c, Scratch &s, const T *src, uint64_t count, const T **dev)
+{
+    int rc = scratch_reserve(c, s, count * sizeof(T) + 64);
+    if (rc != HPN_OK) return rc;
+    if (count) HPN_HIP(c, hipMemcpyAsync(s.p, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dev = (const T *)s.p;
+    return HPN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// ---- bam2depth -------------------------------------------------------------------------
+
+int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_mask)
+{
+    if (!c || tid < 0) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    uint64_t slots = (uint64_t)target_len + 1 + kOverhang;
+    if (slots > kPosLimit) slots = kPosLimit;
+    int rc = scratch_reserve(c, c->d_diff, slots * sizeof(int32_t) + 64);
+    if (rc != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->d_ws, 16 + 2 * depth_scan_tiles(slots) * sizeof(u64) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->w_misc, 64)) != HPN_OK) return rc;
+    HPN_HIP(c, hipMemsetAsync(c->d_diff.p, 0, slots * sizeof(int32_t), c->stream));
+    HPN_HIP(c, hipMemsetAsync(c->w_misc.p, 0, 64, c->stream));  // word 0: domain flag of the scatter
+    c->depth_open = true;
+    c->depth_tid = tid;
+    c->depth_len = target_len;
+    c->depth_mask = flag_mask;
+    c->depth_slots = slots;
+    c->depth_scanned = false;
+    return HPN_OK;
+}
+
+static int depth_add_common(hpn_ctx *c, const hpn_bam_batch *b)
+{
+    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
+    HPN_HIP(c, launch_depth_scatter(b->tid, b->pos, b->flag, b->cigar_off, b->cigar, b->n, c->depth_tid, c->depth_mask,
+                                    (int32_t *)c->d_diff.p, c->depth_slots, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
+    c->ev_valid[kFamDepth] = true;
+    c->depth_scanned = false;
+    return HPN_OK;
+}
+
+int hpn_depth_add_dev(hpn_ctx *c, const hpn_bam_batch *b)
+{
+    if (!c || !b) return HPN_E_ARG;
+    if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_add before hpn_depth_begin");
+    if (b->n && (!b->tid || !b->pos || !b->flag || !b->cigar_off || !b->cigar)) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    return depth_add_common(c, b);
+}
+
+int hpn_depth_add(hpn_ctx *c, const hpn_bam_batch *b)
+{
+    if (!c || !b) return HPN_E_ARG;
+    if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_add before hpn_depth_begin");
+    if (b->n == 0) return HPN_OK;
+    if (!b->tid || !b->pos || !b->flag || !b->cigar_off || !b->cigar) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    hpn_bam_batch d = *b;
+    const uint32_t c0 = b->cigar_off[0], c1 = b->cigar_off[b->n];
+    int rc;
+    if ((rc = stage(c, c->s_a, b->tid, b->n, &d.tid)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_b, b->pos, b->n, &d.pos)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_c, b->flag, b->n, &d.flag)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_d, b->cigar_off, b->n + 1, &d.cigar_off)) != HPN_OK) return rc;
+    const uint32_t *dc = nullptr;
+    if ((rc = stage(c, c->s_e, b->cigar + c0, (uint64_t)(c1 - c0), &dc)) != HPN_OK) return rc;
+    d.cigar = dc - c0;  // host indices stay valid
+    return depth_add_common(c, &d);
+}
+
+int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, uint64_t *n_runs, uint64_t *win_sum)
+{
+    if (!c || !n_runs || W == 0) return HPN_E_ARG;
+    if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_finish before hpn_depth_begin");
+    HPN_HIP(c, hipSetDevice(c->device));
+    const uint64_t windows = (uint64_t)c->depth_len / W + 1;  // bam2depth.c:326
+    int rc = scratch_reserve(c, c->d_win, windows * sizeof(u64) + 64);
+    if (rc != HPN_OK) return rc;
+    if (c->d_runs.cap == 0 && (rc = scratch_reserve(c, c->d_runs, (1u << 20) * sizeof(hpn_run))) != HPN_OK) return rc;
+    struct { uint32_t ticket, err; u64 n_runs; } head;
+    uint32_t bad = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint64_t dev_cap = c->d_runs.cap / sizeof(hpn_run);
+        HPN_HIP(c, hipMemsetAsync(c->d_win.p, 0, windows * sizeof(u64), c->stream));
+        HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
+        HPN_HIP(c, launch_depth_scan((const int32_t *)c->d_diff.p, c->depth_slots, c->depth_len, W, (hpn_run *)c->d_runs.p,
+                                     dev_cap, (u64 *)c->d_win.p, c->d_ws.p, c->stream));
+        HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
+        c->ev_valid[kFamDepth] = true;
+        HPN_HIP(c, hipMemcpyAsync(&head, c->d_ws.p, sizeof head, hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipMemcpyAsync(&bad, c->w_misc.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+        if (bad)
+            return fail(c, HPN_E_DOMAIN, "a CIGAR M block ends at or beyond position %llu (2^28 key limit of the reference, "
+                        "or more than %llu bases past the contig end)", (unsigned long long)c->depth_slots,
+                        (unsigned long long)kOverhang);
+        if (head.err) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
+        if (head.n_runs <= dev_cap) break;
+        // device buffer too small for this chromosome: grow it and redo the pass (diff is read-only)
+        if ((rc = scratch_reserve(c, c->d_runs, head.n_runs * sizeof(hpn_run))) != HPN_OK) return rc;
+    }
+    c->depth_scanned = true;
+    c->depth_nruns = head.n_runs;
+    *n_runs = head.n_runs;
+    if (win_sum) HPN_HIP(c, hipMemcpyAsync(win_sum, c->d_win.p, windows * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (head.n_runs > runs_cap || (!runs && head.n_runs)) {
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+        return fail(c, HPN_E_CAPACITY, "%llu runs, caller buffer holds %llu", (unsigned long long)head.n_runs,
+                    (unsigned long long)runs_cap);
+    }
+    if (head.n_runs)
+        HPN_HIP(c, hipMemcpyAsync(runs, c->d_runs.p, head.n_runs * sizeof(hpn_run), hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    return HPN_OK;
+}
+
+// ---- bam_sliding_count -------------------------------------------------------------------
+
+// w_misc layout (bytes): [0] depth bad flag (u32) | [8] n_count (u64) | [16] window bad (u32) | [64..] touched (u32 x n_targets)
+
+int hpn_window_begin(hpn_ctx *c, int32_t n_targets, const uint64_t *win_off, uint32_t W)
+{
+    if (!c || !win_off || n_targets <= 0 || W == 0 || W > 0x7fffffffu) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    const uint64_t total = win_off[n_targets];
+    for (int32_t t = 0; t < n_targets; ++t)
+        if (win_off[t + 1] < win_off[t]) return fail(c, HPN_E_ARG, "win_off decreases at target %d", t);
+    int rc;
+    if ((rc = scratch_reserve(c, c->w_off, (n_targets + 1) * sizeof(uint64_t))) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->w_bins, total * sizeof(uint32_t) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->w_len, total * sizeof(uint32_t) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->w_gc, total * sizeof(u64) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->w_misc, 64 + (uint64_t)n_targets * sizeof(uint32_t))) != HPN_OK) return rc;
+    HPN_HIP(c, hipMemcpyAsync(c->w_off.p, win_off, (n_targets + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HPN_HIP(c, hipMemsetAsync(c->w_bins.p, 0, total * sizeof(uint32_t), c->stream));
+    HPN_HIP(c, hipMemsetAsync(c->w_len.p, 0, total * sizeof(uint32_t), c->stream));
+    HPN_HIP(c, hipMemsetAsync(c->w_gc.p, 0, total * sizeof(u64), c->stream));
+    HPN_HIP(c, hipMemsetAsync(c->w_misc.p, 0, 64 + (uint64_t)n_targets * sizeof(uint32_t), c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));  // win_off is caller memory
+    c->win_open = true;
+    c->win_targets = n_targets;
+    c->win_W = W;
+    c->win_total = total;
+    c->depth_open = false;  // w_misc is shared with the depth state
+    return HPN_OK;
+}
+
+static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b)
+{
+    uint8_t *m = (uint8_t *)c->w_misc.p;
+    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamWindow], c->stream));
+    HPN_HIP(c, launch_window_add(b->tid, b->pos, b->flag, b->l_qseq, b->seq_off, b->seq4, b->n, c->win_W, c->win_targets,
+                                 (const uint64_t *)c->w_off.p, (uint32_t *)c->w_bins.p, (u64 *)c->w_gc.p,
+                                 (uint32_t *)c->w_len.p, (uint32_t *)(m + 64), (u64 *)(m + 8), (uint32_t *)(m + 16),
+                                 c->n_cu, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_end[kFamWindow], c->stream));
+    c->ev_valid[kFamWindow] = true;
+    return HPN_OK;
+}
+
+int hpn_window_add_dev(hpn_ctx *c, const hpn_bam_batch *b)
+{
+    if (!c || !b) return HPN_E_ARG;
+    if (!c->win_open) return fail(c, HPN_E_STATE, "hpn_window_add before hpn_window_begin");
+    if (b->n && (!b->tid || !b->pos || !b->flag || !b->l_qseq || !b->seq_off || !b->seq4)) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    return window_add_common(c, b);
+}
+
+int hpn_window_add(hpn_ctx *c, const hpn_bam_batch *b)
+{
+    if (!c || !b) return HPN_E_ARG;
+    if (!c->win_open) return fail(c, HPN_E_STATE, "hpn_window_add before hpn_window_begin");
+    if (b->n == 0) return HPN_OK;
+    if (!b->tid || !b->pos || !b->flag || !b->l_qseq || !b->seq_off || !b->seq4) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    hpn_bam_batch d = *b;
+    const uint64_t s0 = b->seq_off[0], s1 = b->seq_off[b->n];
+    int rc;
+    if ((rc = stage(c, c->s_a, b->tid, b->n, &d.tid)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_b, b->pos, b->n, &d.pos)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_c, b->flag, b->n, &d.flag)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_d, b->l_qseq, b->n, &d.l_qseq)) != HPN_OK) return rc;
+    if ((rc = stage(c, c->s_e, b->seq_off, b->n + 1, &d.seq_off)) != HPN_OK) return rc;
+    // keep the host's byte alignment pattern and 16 bytes of slack on both sides (aligned vector loads)
+    const size_t pad = 16 + (s0 & 15);
+    if ((rc = scratch_reserve(c, c->s_f, (s1 - s0) + 64)) != HPN_OK) return rc;
+    uint8_t *ds = (uint8_t *)c->s_f.p + pad;
+    if (s1 > s0) HPN_HIP(c, hipMemcpyAsync(ds, b->seq4 + s0, s1 - s0, hipMemcpyHostToDevice, c->stream));
+    d.seq4 = ds - s0;
+    return window_add_common(c, &d);
+}
+
+int hpn_window_finish(hpn_ctx *c, uint32_t *bins, uint64_t *gc, uint32_t *len, uint8_t *touched, uint64_t *n_count)
+{
+    if (!c || !bins || !gc || !len) return HPN_E_ARG;
+    if (!c->win_open) return fail(c, HPN_E_STATE, "hpn_window_finish before hpn_window_begin");
+    HPN_HIP(c, hipSetDevice(c->device));
+    const uint64_t total = c->win_total;
+    std::vector<uint8_t> misc(64 + (size_t)c->win_targets * sizeof(uint32_t));
+    HPN_HIP(c, hipMemcpyAsync(misc.data(), c->w_misc.p, misc.size(), hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(bins, c->w_bins.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(len, c->w_len.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(gc, c->w_gc.p, total * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    c->win_open = false;
+    uint32_t bad;
+    memcpy(&bad, misc.data() + 16, 4);
+    if (bad)
+        return fail(c, HPN_E_DOMAIN, "%s", (bad & 1) ? "record with tid >= n_targets"
+                                                     : "window index (unsigned short)(pos/W) beyond the target's windows "
+                                                       "(the reference would write out of bounds)");
+    if (n_count) memcpy(n_count, misc.data() + 8, 8);
+    if (touched) {
+        const uint32_t *t32 = (const uint32_t *)(misc.data() + 64);
+        for (int32_t t = 0; t < c->win_targets; ++t) touched[t] = t32[t] ? 1 : 0;
+    }
+    return HPN_OK;
+}
+
+}  // extern "C"

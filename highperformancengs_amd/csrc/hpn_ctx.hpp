@@ -35,7 +35,9 @@ struct hpn_ctx {
     hipStream_t stream = nullptr;
     hpn::u64 *d_acc = nullptr;  // HPN_TALLY_WORDS
     hpn::u64 *h_acc = nullptr;  // pinned mirror
-    hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;
+    hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;  // staging of host batches
+    hpn::Scratch d_diff, d_runs, d_win, d_ws;             // bam2depth: difference array, runs, window sums, scan workspace
+    hpn::Scratch w_off, w_bins, w_len, w_gc, w_misc;      // bam_sliding_count accumulators
     hipEvent_t ev_beg[hpn::kFamCount] = {};
     hipEvent_t ev_end[hpn::kFamCount] = {};
     bool ev_valid[hpn::kFamCount] = {};
@@ -46,6 +48,7 @@ struct hpn_ctx {
     uint64_t depth_slots = 0;  // int32 entries in the difference array
     bool depth_scanned = false;
     uint64_t depth_nruns = 0;
+    uint64_t depth_runs_cap = 0;  // entries the device runs buffer holds
     // bam_sliding_count state
     bool win_open = false;
     int32_t win_targets = 0;

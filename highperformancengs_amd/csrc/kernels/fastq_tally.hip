@@ -351,11 +351,14 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
             if (s30) atomicAdd(&acc[HPN_TALLY_W_Q30], s30);
         }
         if (h) atomicAdd(&acc[HPN_TALLY_W_BAD], (u64)1);
-        if (bytes) atomicAdd(&acc[HPN_TALLY_W_TOTAL], bytes);
+        if (kQualHist && bytes) atomicAdd(&acc[HPN_TALLY_W_TOTAL], bytes);
     }
+    // SeqLen / sum come from this kernel only when it replaces the flat scan
+    // (quality matrix requested); a nucleotide-only launch runs beside k_tally_scan.
     for (int i = tid; i <= HPN_LEN_BINS; i += kHistThreads) {
         const uint32_t h = s.lhist[i];
-        if (h) atomicAdd(&acc[i < HPN_LEN_BINS ? HPN_TALLY_W_SEQLEN + i : HPN_TALLY_W_BAD], (u64)h);
+        if (h && (kQualHist || i == HPN_LEN_BINS))
+            atomicAdd(&acc[i < HPN_LEN_BINS ? HPN_TALLY_W_SEQLEN + i : HPN_TALLY_W_BAD], (u64)h);
     }
 }
 

@@ -1,0 +1,132 @@
+// fastq_trim.hip -- gfx950 kernels behind hpn_fastq_trim (include/hpngs.h).
+//
+// Replaces the cut of readNextNode (reference fastq_trim.c:76-77,83-84):
+//   out = line[min(S,len) .. min(E,len))   for the sequence and the quality line.
+//
+//   k_trim_scan  new length of every record + device-wide exclusive scan
+//                (single pass, decoupled look-back, scan.hpp) -> out_off[n+1]
+//   k_trim_copy  substring gather: one wave walks 64 records whose boundaries it
+//                loaded with one coalesced read; per record the 64 lanes copy
+//                consecutive bytes (source and destination spans are both
+//                contiguous, so every wave access is one or two cache lines).
+// Bound: HBM, read 2*sum(len) + 16 n, write 2*sum(newlen) + 8 n bytes.
+#include "scan.hpp"
+
+namespace hpn {
+
+constexpr int kTrimThreads = 256;
+constexpr int kTrimPerThread = 4;
+constexpr int kTrimTile = kTrimThreads * kTrimPerThread;
+
+__device__ __forceinline__ uint64_t cut_len(uint64_t len, uint64_t S, uint64_t E)
+{
+    return (E < len ? E : len) - (S < len ? S : len);
+}
+
+__global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__restrict__ off, uint64_t n,
+                                                           uint64_t S, uint64_t E,
+                                                           uint64_t *__restrict__ out_off,
+                                                           u64 *__restrict__ status,
+                                                           uint32_t *__restrict__ ticket,
+                                                           uint32_t *__restrict__ err)
+{
+    __shared__ u64 s_wave[kTrimThreads / kWave];
+    __shared__ u64 s_excl;
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // tiles in start order: look-back never waits on a tile not yet running
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    const uint64_t base = tile * kTrimTile + (uint64_t)tid * kTrimPerThread;
+    uint64_t o[kTrimPerThread + 1];
+#pragma unroll
+    for (int k = 0; k <= kTrimPerThread; ++k) o[k] = base + k <= n ? off[base + k] : 0;
+    uint64_t nl[kTrimPerThread];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kTrimPerThread; ++k) {
+        nl[k] = base + k < n ? cut_len(o[k + 1] - o[k], S, E) : 0;
+        mine += nl[k];
+    }
+    u64 wtotal;
+    const u64 wexcl = wave_excl_scan(mine, wtotal);
+    if (lane_id() == kWave - 1) s_wave[wave_id()] = wtotal;
+    __syncthreads();
+    u64 before = 0, aggregate = 0;
+#pragma unroll
+    for (int w = 0; w < kTrimThreads / kWave; ++w) {
+        if (w < wave_id()) before += s_wave[w];
+        aggregate += s_wave[w];
+    }
+    if (wave_id() == 0) {
+        const u64 ex = scan_lookback(status, tile, aggregate, err);
+        if (lane_id() == 0) s_excl = ex;
+    }
+    __syncthreads();
+    u64 run = s_excl + before + wexcl;
+#pragma unroll
+    for (int k = 0; k < kTrimPerThread; ++k) {
+        if (base + k < n) out_off[base + k] = run;
+        run += nl[k];
+        if (base + k + 1 == n) out_off[n] = run;
+    }
+    if (n == 0 && tile == 0 && tid == 0) out_off[0] = 0;
+}
+
+__global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__restrict__ seq,
+                                                           const uint8_t *__restrict__ qual,
+                                                           const uint64_t *__restrict__ off,
+                                                           const uint64_t *__restrict__ out_off, uint64_t n,
+                                                           uint64_t S, uint64_t E,
+                                                           uint8_t *__restrict__ out_seq,
+                                                           uint8_t *__restrict__ out_qual)
+{
+    const uint64_t nwaves = (uint64_t)gridDim.x * (kTrimThreads / kWave);
+    const uint64_t wave = (uint64_t)blockIdx.x * (kTrimThreads / kWave) + wave_id();
+    const int lane = lane_id();
+    for (uint64_t r0 = wave * kWave; r0 < n; r0 += nwaves * kWave) {
+        const uint64_t r = r0 + lane;
+        uint64_t a = 0, len = 0, d = 0;
+        if (r < n) {
+            a = off[r];
+            len = off[r + 1] - a;
+            d = out_off[r];
+        }
+        const uint64_t b = S < len ? S : len;
+        const uint32_t cnt = (uint32_t)((E < len ? E : len) - b);
+        const uint64_t src = a + b;
+        const int m = (int)min((uint64_t)kWave, n - r0);
+        for (int j = 0; j < m; ++j) {  // wave-uniform: broadcast record j's spans
+            const uint64_t sj = __shfl(src, j, kWave), dj = __shfl(d, j, kWave);
+            const uint32_t cj = __shfl(cnt, j, kWave);
+            for (uint32_t i = lane; i < cj; i += kWave) {
+                out_seq[dj + i] = seq[sj + i];
+                out_qual[dj + i] = qual[sj + i];
+            }
+        }
+    }
+}
+
+hipError_t launch_trim(const uint8_t *d_seq, const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t S,
+                       uint64_t E, uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off, u64 *d_status,
+                       uint32_t *d_ticket_err, int n_cu, hipStream_t st)
+{
+    const uint64_t ntile = n / kTrimTile + 1;
+    hipError_t e = hipMemsetAsync(d_status, 0, ntile * sizeof(u64), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trim_scan, dim3((unsigned)ntile), dim3(kTrimThreads), 0, st, d_off, n, S, E, d_out_off, d_status,
+                       d_ticket_err, d_ticket_err + 1);
+    if (n) {
+        uint64_t want = (n + kTrimThreads - 1) / kTrimThreads;
+        const uint64_t cap = (uint64_t)n_cu * 8;
+        hipLaunchKernelGGL(k_trim_copy, dim3((unsigned)(want < cap ? want : cap)), dim3(kTrimThreads), 0, st, d_seq,
+                           d_qual, d_off, d_out_off, n, S, E, d_out_seq, d_out_qual);
+    }
+    return hipGetLastError();
+}
+
+uint64_t trim_status_words(uint64_t n) { return n / kTrimTile + 1; }
+
+}  // namespace hpn

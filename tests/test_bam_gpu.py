@@ -1,0 +1,182 @@
+"""GPU parity: hpn_depth_* and hpn_window_* (HIP, through the C ABI) vs the oracle's dense
+model and vs the reference bam2depth's golden files.  Bit-exact: integers only."""
+import numpy as np
+import pytest
+
+import orc
+from bam_synth import fmt_bedgraph, fmt_depth, make_soa
+from conftest import expected, golden_path
+from highperformancengs_amd import bamio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available()
+    import highperformancengs_amd as hp
+    c = hp.Context(0)
+    yield c
+    c.close()
+
+
+def _depth_all(ctx, soa, W, mask=0x704):
+    bed, dep = b"", b""
+    for tid, (name, tlen) in enumerate(soa.refs):
+        runs, win = ctx.depth_target(soa, tid, tlen, W, mask)
+        rc, wruns, wbins = orc.depth_target(soa, tid, W, mask)
+        assert rc == 0
+        assert np.array_equal(runs, wruns), (name, len(runs), len(wruns))
+        assert np.array_equal(win.astype(np.float64), wbins), name
+        bed += fmt_bedgraph(name, runs)
+        dep += fmt_depth(name, tlen, W, win)
+    return bed, dep
+
+
+@pytest.mark.parametrize("case,bam,W,pre", [("depth_a3", "e.bam", 100, "d"), ("depth_rand", "rand.bam", 20000, "r"),
+                                            ("depth_rand_w1000", "rand.bam", 1000, "r")])
+def test_bam2depth_golden_files(ctx, case, bam, W, pre):
+    soa = bamio.read_bam_records(golden_path("bam", bam))
+    bed, dep = _depth_all(ctx, soa, W)
+    assert bed == expected(case, f"{bam}.1.bedGraph")
+    assert dep == expected(case, f"{pre}.1.depth")
+
+
+@pytest.mark.parametrize("n,seed,W", [(0, 1, 1000), (1, 2, 50), (5000, 3, 20000), (200_000, 4, 20000),
+                                      (200_000, 5, 777), (50_000, 6, 1)])
+def test_depth_synthetic(ctx, n, seed, W):
+    refs = [("chrA", 3_000_000), ("chrB", 1_234_567), ("tiny", 300), ("chrC", 40_000)]
+    if W == 1:
+        refs = [("chrA", 300_000), ("tiny", 300)]
+    soa = make_soa(n, refs, seed)
+    _depth_all(ctx, soa, W)
+    _depth_all(ctx, soa, W, mask=0x4)  # bam2wig's filter (bam2wig.c:88)
+
+
+def test_depth_position_zero_and_overhang(ctx):
+    refs = [("c", 1000)]
+    sam = "@SQ\tSN:c\tLN:1000\n" + "".join(
+        f"r{i}\t0\tc\t{p}\t30\t{cg}\t*\t0\t0\t*\t*\n" for i, (p, cg) in enumerate(
+            [(1, "10M"), (1, "10M"), (11, "5M"), (11, "5M"), (16, "3M"), (990, "50M"), (995, "5M10D20M"), (1000, "1M")]))
+    r, recs, _ = bamio.records_from_sam(sam)
+    soa = bamio.BamSoA(refs=r, tid=np.array([x.tid for x in recs], np.int32), pos=np.array([x.pos for x in recs], np.int32),
+                       flag=np.zeros(len(recs), np.uint32), l_qseq=np.zeros(len(recs), np.int32),
+                       cigar_off=np.concatenate([[0], np.cumsum([len(x.cigar) for x in recs])]).astype(np.uint32),
+                       cigar=np.concatenate([x.cigar for x in recs]).astype(np.uint32),
+                       seq_off=np.zeros(len(recs) + 1, np.uint64), seq4=np.zeros(1, np.uint8))
+    bed, _ = _depth_all(ctx, soa, 100)
+    # equal-depth neighbours merge across a breakpoint (bam2depth.c:212-214); runs are not clipped at target_len
+    assert bed.startswith(b"c\t0\t15\t2\nc\t15\t18\t1\n")
+    assert bed.endswith(b"\t1039\t1\n")  # 990+50M runs to 1039, past LN:1000
+
+
+def test_depth_incremental_batches_and_capacity(ctx):
+    import ctypes as C
+    from highperformancengs_amd import _lib
+    refs = [("chrA", 2_000_000)]
+    soa = make_soa(60_000, refs, 11)
+    whole_runs, whole_win = ctx.depth_target(soa, 0, refs[0][1], 5000)
+    # same records in three hpn_depth_add calls
+    L, keep = ctx.L, []
+    assert L.hpn_depth_begin(ctx.h, 0, refs[0][1], 0x704) == 0
+    cuts = [0, 20_000, 20_001, 60_000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = bamio.BamSoA(refs=refs, tid=soa.tid[a:b], pos=soa.pos[a:b], flag=soa.flag[a:b], l_qseq=soa.l_qseq[a:b],
+                            cigar_off=soa.cigar_off[a:b + 1], cigar=soa.cigar, seq_off=soa.seq_off[a:b + 1], seq4=soa.seq4)
+        bb = ctx._batch(part, keep)
+        assert L.hpn_depth_add(ctx.h, C.byref(bb)) == 0
+    # too small a caller buffer reports the needed size
+    small = np.zeros((10, 3), np.int32)
+    nr = C.c_uint64(0)
+    rc = L.hpn_depth_finish(ctx.h, 5000, small.ctypes.data, 10, C.byref(nr), None)
+    assert rc == _lib.E_CAPACITY and nr.value == len(whole_runs)
+    runs, win = ctx.depth_finish(refs[0][1], 5000)
+    assert np.array_equal(runs, whole_runs) and np.array_equal(win, whole_win)
+    # other window size on the same difference array
+    runs2, win2 = ctx.depth_finish(refs[0][1], 333)
+    assert np.array_equal(runs2, whole_runs) and win2.sum() == whole_win.sum()
+
+
+def test_depth_domain_error(ctx):
+    import highperformancengs_amd as hp
+    from highperformancengs_amd import _lib
+    refs = [("big", 300_000_000)]
+    soa = make_soa(10, refs, 1, cigars=["100M"])
+    soa.pos[:] = np.arange(10) * 1000 + 268_435_400  # ends beyond 2^28: the reference's 28-bit keys alias
+    with pytest.raises(hp.HpnError) as e:
+        ctx.depth_target(soa, 0, refs[0][1], 20000)
+    assert e.value.status == _lib.E_DOMAIN
+
+
+# ---- bam_sliding_count ------------------------------------------------------------------
+
+def _window_check(ctx, soa, W):
+    rc, off, wb, wg, wl, wt, wn = orc.window_counts(soa, W)
+    assert rc == 0
+    bins, gc, ln, touched, nc = ctx.window_counts(soa, off, W)
+    assert np.array_equal(bins, wb) and np.array_equal(gc, wg) and np.array_equal(ln, wl)
+    assert np.array_equal(touched, wt) and nc == wn
+    return off, bins, gc, ln, touched
+
+
+def test_window_appendix_a3(ctx):
+    soa = bamio.read_bam_records(golden_path("bam", "e.bam"))
+    off, bins, gc, ln, touched = _window_check(ctx, soa, 100)
+    # c1 has 7 reads / 60 bases, window 1 holds 5 reads; c2 3 reads / 30 bases
+    assert bins[:11].sum() == 7 and ln[:11].sum() == 60 and bins[0] == 5 and bins[1] == 1
+    assert bins[11:].sum() == 3 and ln[11:].sum() == 30
+    assert "%f" % (np.float32(gc[0]) / np.float32(ln[0]) * np.float32(100)) == "48.888889"
+
+
+@pytest.mark.parametrize("n,seed,W,sort", [(0, 1, 1000, True), (1, 2, 50, True), (5000, 3, 20000, True),
+                                           (300_000, 4, 20000, True), (300_000, 5, 500, True),
+                                           (100_000, 6, 1000, False), (77_777, 7, 64, False)])
+def test_window_synthetic(ctx, n, seed, W, sort):
+    refs = [("chrA", 3_000_000), ("chrB", 1_234_567), ("tiny", 300), ("chrC", 40_000)]
+    soa = make_soa(n, refs, seed, sort=sort)
+    _window_check(ctx, soa, W)
+
+
+def test_window_index_wraps_like_unsigned_short(ctx):
+    # target_len / W + 1 > 65536: (unsigned short)(pos / W) wraps (bam_sliding_count.c:117)
+    refs = [("long", 10_000_000)]
+    soa = make_soa(20_000, refs, 9)
+    off, bins, *_ = _window_check(ctx, soa, 100)
+    assert int(off[-1]) == 100_001 and bins[65536:].sum() == 0 and bins.sum() > 0
+
+
+def test_window_domain_error(ctx):
+    import highperformancengs_amd as hp
+    from highperformancengs_amd import _lib
+    refs = [("c", 1000)]
+    soa = make_soa(10, refs, 1)
+    soa.pos[3] = 5000  # beyond the contig: window 50 of 11 -> the reference writes out of bounds
+    with pytest.raises(hp.HpnError) as e:
+        ctx.window_counts(soa, orc.window_offsets(refs, 100), 100)
+    assert e.value.status == _lib.E_DOMAIN
+
+
+def test_device_resident_batch(ctx):
+    """Device-resident SoA (the _dev entry points) on 2e6 records vs the oracle."""
+    import torch
+    refs = [("chr1", 30_000_000), ("chr2", 20_000_000)]
+    soa = make_soa(2_000_000, refs, 21)
+
+    class Dev:
+        pass
+    d = Dev()
+    for f in ("tid", "pos", "l_qseq"):
+        setattr(d, f, torch.from_numpy(getattr(soa, f)).cuda())
+    d.flag = torch.from_numpy(soa.flag.view(np.int32)).cuda()
+    d.cigar_off = torch.from_numpy(soa.cigar_off.view(np.int32)).cuda()
+    d.cigar = torch.from_numpy(soa.cigar.view(np.int32)).cuda()
+    d.seq_off = torch.from_numpy(soa.seq_off.view(np.int64)).cuda()
+    d.seq4 = torch.from_numpy(soa.seq4).cuda()
+    for tid, (name, tlen) in enumerate(refs):
+        runs, win = ctx.depth_target(d, tid, tlen, 20000, dev=True)
+        rc, wruns, wbins = orc.depth_target(soa, tid, 20000)
+        assert np.array_equal(runs, wruns) and np.array_equal(win.astype(np.float64), wbins)
+    rc, off, wb, wg, wl, wt, wn = orc.window_counts(soa, 20000)
+    bins, gc, ln, touched, nc = ctx.window_counts(d, off, 20000, dev=True)
+    assert np.array_equal(bins, wb) and np.array_equal(gc, wg) and np.array_equal(ln, wl) and nc == wn
