@@ -1,0 +1,210 @@
+// bam_reader.hpp -- host ingest for the BAM tools: BGZF file -> header + SoA record batches.
+//
+// Stands where samopen / samread / bam_read1 / bgzf_read stand in the reference
+// (samtools-0.1.19: sam.c:46,132; bam.c:81,191; bgzf.c:214,307,342).  Records are
+// decoded into the structure-of-arrays layout of hpn_bam_batch (include/hpngs.h):
+// exactly the fields the two fetch_func callbacks read (bam2depth.c:86-110,
+// bam_sliding_count.c:93-124): tid, pos, flag, l_qseq, CIGAR words, packed sequence.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+#include "hpngs.h"
+
+namespace hpn {
+
+class BgzfReader {
+public:
+    bool open(const char *path)
+    {
+        fp_ = fopen(path, "rb");
+        return fp_ != nullptr;
+    }
+    ~BgzfReader()
+    {
+        if (fp_) fclose(fp_);
+    }
+    // Read exactly n bytes of the uncompressed stream; returns bytes read (< n at EOF).
+    size_t read(void *dst, size_t n)
+    {
+        uint8_t *out = (uint8_t *)dst;
+        size_t got = 0;
+        while (got < n) {
+            if (pos_ == block_.size() && !next_block()) break;
+            size_t k = block_.size() - pos_;
+            if (k > n - got) k = n - got;
+            memcpy(out + got, block_.data() + pos_, k);
+            pos_ += k, got += k;
+        }
+        return got;
+    }
+    const char *error() const { return err_; }
+
+private:
+    bool next_block()
+    {
+        for (;;) {  // empty blocks (the EOF marker) are skipped
+            uint8_t h[18];
+            size_t k = fread(h, 1, 18, fp_);
+            if (k == 0) return false;
+            if (k != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') {
+                err_ = "not a BGZF block";
+                return false;
+            }
+            const unsigned bsize = (h[16] | (h[17] << 8)) + 1u;
+            const unsigned xlen = h[10] | (h[11] << 8);
+            const unsigned clen = bsize - xlen - 12 - 8;
+            comp_.resize(bsize - 18);
+            if (fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size()) {
+                err_ = "truncated BGZF block";
+                return false;
+            }
+            const uint8_t *cdata = comp_.data() + (xlen - 6);
+            uint32_t isize;
+            memcpy(&isize, comp_.data() + comp_.size() - 4, 4);
+            block_.resize(isize);
+            pos_ = 0;
+            if (isize == 0) continue;
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) {
+                err_ = "inflateInit2 failed";
+                return false;
+            }
+            zs.next_in = (Bytef *)cdata;
+            zs.avail_in = clen;
+            zs.next_out = block_.data();
+            zs.avail_out = isize;
+            int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) {
+                err_ = "inflate failed";
+                return false;
+            }
+            return true;
+        }
+    }
+    FILE *fp_ = nullptr;
+    std::vector<uint8_t> comp_, block_;
+    size_t pos_ = 0;
+    const char *err_ = nullptr;
+};
+
+struct BamHeader {
+    std::vector<std::string> target_name;
+    std::vector<uint32_t> target_len;
+    int32_t n_targets() const { return (int32_t)target_name.size(); }
+};
+
+struct BamBatch {
+    std::vector<int32_t> tid, pos, l_qseq;
+    std::vector<uint32_t> flag, cigar_off{0}, cigar;
+    std::vector<uint64_t> seq_off{0};
+    std::vector<uint8_t> seq4;
+    uint64_t n() const { return tid.size(); }
+    void clear()
+    {
+        tid.clear(), pos.clear(), l_qseq.clear(), flag.clear(), cigar.clear(), seq4.clear();
+        cigar_off.assign(1, 0), seq_off.assign(1, 0);
+    }
+    hpn_bam_batch view()
+    {
+        seq4.reserve(seq4.size() + 16);  // aligned 16-byte reads may look past the end
+        hpn_bam_batch b;
+        b.n = n();
+        b.tid = tid.data(), b.pos = pos.data(), b.flag = flag.data(), b.l_qseq = l_qseq.data();
+        b.cigar_off = cigar_off.data(), b.cigar = cigar.data();
+        b.seq_off = seq_off.data(), b.seq4 = seq4.data();
+        return b;
+    }
+};
+
+class BamReader {
+public:
+    // samopen(fn, "rb") + bam_header_read (bam.c:81)
+    bool open(const char *path, BamHeader &h)
+    {
+        if (!z_.open(path)) return false;
+        char magic[4];
+        int32_t l_text, n_ref;
+        if (z_.read(magic, 4) != 4 || memcmp(magic, "BAM\1", 4)) return false;
+        if (z_.read(&l_text, 4) != 4) return false;
+        std::vector<char> text((size_t)l_text);
+        if (z_.read(text.data(), text.size()) != text.size()) return false;
+        if (z_.read(&n_ref, 4) != 4) return false;
+        for (int32_t i = 0; i < n_ref; ++i) {
+            int32_t l_name, l_ref;
+            if (z_.read(&l_name, 4) != 4) return false;
+            std::vector<char> nm((size_t)l_name);
+            if (z_.read(nm.data(), nm.size()) != nm.size()) return false;
+            if (z_.read(&l_ref, 4) != 4) return false;
+            h.target_name.emplace_back(nm.data());
+            h.target_len.push_back((uint32_t)l_ref);
+        }
+        return true;
+    }
+
+    // bam_read1 (bam.c:191): append one record; false at end of file.
+    // want_seq: keep the 4-bit sequence (bam_sliding_count); depth needs CIGAR only.
+    bool next(BamBatch &b, bool want_seq)
+    {
+        if (pending_) {  // record pushed back by the caller
+            pending_ = false;
+            append(b, want_seq);
+            return true;
+        }
+        int32_t block_size;
+        if (z_.read(&block_size, 4) != 4) return false;
+        rec_.resize((size_t)block_size);
+        if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return false;
+        append(b, want_seq);
+        return true;
+    }
+    // tid of the record `next` would deliver, without consuming it (INT32_MIN at EOF)
+    int32_t peek_tid()
+    {
+        if (!pending_) {
+            int32_t block_size;
+            if (z_.read(&block_size, 4) != 4) return INT32_MIN;
+            rec_.resize((size_t)block_size);
+            if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return INT32_MIN;
+            pending_ = true;
+        }
+        int32_t t;
+        memcpy(&t, rec_.data(), 4);
+        return t;
+    }
+
+private:
+    void append(BamBatch &b, bool want_seq)
+    {
+        // bam1_core_t on disk (bam.h:178-187): refID, pos, bin_mq_nl, flag_nc, l_seq, ...
+        const uint8_t *p = rec_.data();
+        int32_t tid, pos, l_seq;
+        uint32_t bin_mq_nl, flag_nc;
+        memcpy(&tid, p, 4), memcpy(&pos, p + 4, 4), memcpy(&bin_mq_nl, p + 8, 4), memcpy(&flag_nc, p + 12, 4);
+        memcpy(&l_seq, p + 16, 4);
+        const uint32_t l_name = bin_mq_nl & 0xff, n_cigar = flag_nc & 0xffff, flag = flag_nc >> 16;
+        const uint8_t *cig = p + 32 + l_name;
+        b.tid.push_back(tid), b.pos.push_back(pos), b.flag.push_back(flag), b.l_qseq.push_back(l_seq);
+        const size_t c0 = b.cigar.size();
+        b.cigar.resize(c0 + n_cigar);
+        if (n_cigar) memcpy(b.cigar.data() + c0, cig, 4 * (size_t)n_cigar);
+        b.cigar_off.push_back((uint32_t)b.cigar.size());
+        if (want_seq) {
+            const uint8_t *sq = cig + 4 * (size_t)n_cigar;
+            b.seq4.insert(b.seq4.end(), sq, sq + (size_t)((l_seq + 1) >> 1));
+        }
+        b.seq_off.push_back(b.seq4.size());
+    }
+    BgzfReader z_;
+    std::vector<uint8_t> rec_;
+    bool pending_ = false;
+};
+
+}  // namespace hpn

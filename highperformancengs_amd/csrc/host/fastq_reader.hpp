@@ -1,0 +1,186 @@
+// fastq_reader.hpp -- host ingest for the FASTQ tools: gzip/plain stream -> SoA batches.
+//
+// The reference reads EXACTLY four gzgets() lines per record into one reused
+// 1024-byte buffer and never validates them (fastq_count.c:107,112-118;
+// fastq_trim.c:67-89).  Everything odd it does on odd input (lines longer than
+// the buffer, a missing final newline, CRLF, truncated records) follows from
+// that.  LineSource::gets reproduces zlib's gzgets contract on top of gzread
+// with a large buffer; Framer keeps the same persistent 1024-byte buffer, so the
+// bytes handed to the GPU are exactly the bytes the reference's loop would tally.
+#pragma once
+#include <fcntl.h>
+#include <stdint.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+namespace hpn {
+
+constexpr int kLineBuf = 1024;  // fastq_count.c:107
+
+// open_input_stream (IO_stream.h:122-136): a name starting with '-' (or empty) is
+// stdin; anything else is open()+gzdopen(fd,"rb"), which reads plain files, gzip
+// and concatenated gzip members alike.  The reference passes O_CREAT and so
+// creates a missing input as an empty file; this does too (drop-in behaviour).
+inline gzFile open_input_stream(const char *name)
+{
+    int fd;
+    if (strncmp(name, "-", 1) == 0 || !strcmp(name, "")) {
+        fd = STDIN_FILENO;
+    } else {
+        fd = open(name, O_CREAT | O_RDONLY, 0666);
+        if (fd == -1) fprintf(stderr, "Failed to create input file (%s)", name);
+    }
+    return gzdopen(fd, "rb");
+}
+
+class LineSource {
+public:
+    explicit LineSource(gzFile f, size_t cap = 4u << 20) : f_(f), buf_(cap) {}
+
+    // zlib gzgets(file, dst, len): copy until len-1 chars or through '\n' or to the
+    // end of data; NUL-terminate if anything was copied; NULL (dst untouched) if
+    // nothing was.  `past` mirrors what gzeof() reports: a read ran beyond the data.
+    char *gets(char *dst, int len)
+    {
+        if (len < 1) return nullptr;
+        unsigned left = (unsigned)len - 1;
+        char *out = dst;
+        bool eol = false;
+        while (left && !eol) {
+            if (have_ == 0 && !fill()) {
+                past_ = true;
+                break;
+            }
+            size_t n = have_ < left ? have_ : left;
+            const char *nl = (const char *)memchr(cur_, '\n', n);
+            if (nl) {
+                n = (size_t)(nl - cur_) + 1;
+                eol = true;
+            }
+            memcpy(out, cur_, n);
+            out += n, cur_ += n, have_ -= n, left -= (unsigned)n;
+        }
+        if (out == dst) return nullptr;
+        *out = 0;
+        return dst;
+    }
+    bool eof() const { return past_; }  // gzeof()
+
+private:
+    bool fill()
+    {
+        if (done_) return false;
+        int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+        if (n <= 0) {
+            done_ = true;
+            return false;
+        }
+        cur_ = buf_.data();
+        have_ = (size_t)n;
+        return true;
+    }
+    gzFile f_;
+    std::vector<char> buf_;
+    const char *cur_ = nullptr;
+    size_t have_ = 0;
+    bool done_ = false, past_ = false;
+};
+
+// One batch of records as structure of arrays (what hpn_fastq_tally / hpn_fastq_trim take).
+struct FastqBatch {
+    std::vector<uint8_t> seq, qual;
+    std::vector<uint64_t> off{0};
+    std::vector<std::string> names;  // fastq_trim only
+    uint64_t n() const { return off.size() - 1; }
+    void clear()
+    {
+        seq.clear(), qual.clear(), names.clear();
+        off.assign(1, 0);
+    }
+};
+
+// count_read's framing (fastq_count.c:112-119): per record, line 2 gives
+// seqLen = (uint16_t)(strlen - 1) and the first seqLen bytes of whatever the
+// buffer holds after the 4th gzgets are "the quality".  want_seq additionally
+// keeps the first seqLen bytes of the buffer after the 2nd gzgets.
+class CountFramer {
+public:
+    explicit CountFramer(gzFile f) : src_(f) { memset(buf_, 0, sizeof buf_); }
+
+    // Appends up to max_records records / max_bytes bytes; returns false once the
+    // stream is exhausted (the batch may still hold the last records).
+    // *domain_err is set when the reference would index out of its arrays.
+    bool fill(FastqBatch &b, uint64_t max_records, uint64_t max_bytes, bool want_seq, bool *domain_err)
+    {
+        while (b.n() < max_records && b.qual.size() < max_bytes) {
+            if (!src_.gets(buf_, kLineBuf)) return false;   // name line; NULL ends the loop (:112)
+            src_.gets(buf_, kLineBuf);                      // sequence line (return value ignored, :113)
+            const uint16_t len = (uint16_t)(strlen(buf_) - 1);  // :114, including the uint16 wrap
+            if (len >= 512) {                               // SeqLen[512] overrun in the reference
+                *domain_err = true;
+                return false;
+            }
+            if (want_seq) b.seq.insert(b.seq.end(), (uint8_t *)buf_, (uint8_t *)buf_ + len);
+            src_.gets(buf_, kLineBuf);                      // '+' line
+            src_.gets(buf_, kLineBuf);                      // quality line
+            b.qual.insert(b.qual.end(), (uint8_t *)buf_, (uint8_t *)buf_ + len);
+            b.off.push_back(b.off.back() + len);
+        }
+        return true;
+    }
+
+private:
+    LineSource src_;
+    char buf_[kLineBuf];
+};
+
+// readNextNode's framing (fastq_trim.c:67-89): buffer zeroed per record, EOF is
+// tested with gzeof() AFTER the name line was read, every line loses its last
+// character (the '\n', or a real character when the final newline is missing).
+class TrimFramer {
+public:
+    explicit TrimFramer(gzFile f) : src_(f) {}
+
+    bool fill(FastqBatch &b, uint64_t max_records, uint64_t max_bytes)
+    {
+        char buf[kLineBuf];
+        while (b.n() < max_records && b.seq.size() < max_bytes) {
+            memset(buf, 0, sizeof buf);                     // :97
+            char *p = src_.gets(buf, kLineBuf);
+            if (src_.eof() || !p) return false;             // :69-70
+            chop(buf);
+            b.names.emplace_back(buf);
+            src_.gets(buf, kLineBuf);
+            chop(buf);
+            const size_t ls = strlen(buf);
+            b.seq.insert(b.seq.end(), (uint8_t *)buf, (uint8_t *)buf + ls);
+            src_.gets(buf, kLineBuf);
+            src_.gets(buf, kLineBuf);
+            chop(buf);
+            // One offset array serves both lines.  The reference cuts each line with
+            // strncpy, i.e. up to that line's own NUL; when the two lines differ in
+            // length the shorter is NUL-padded to the longer and the writer prints
+            // each cut as a C string, which gives the same bytes.
+            const size_t lq = strlen(buf), lr = ls > lq ? ls : lq;
+            b.seq.insert(b.seq.end(), lr - ls, (uint8_t)0);
+            b.qual.insert(b.qual.end(), (uint8_t *)buf, (uint8_t *)buf + lq);
+            b.qual.insert(b.qual.end(), lr - lq, (uint8_t)0);
+            b.off.push_back(b.off.back() + lr);
+        }
+        return true;
+    }
+
+private:
+    static void chop(char *s)
+    {
+        const size_t l = strlen(s);
+        if (l) s[l - 1] = 0;  // (the reference writes s[-1] on an empty string)
+    }
+    LineSource src_;
+};
+
+}  // namespace hpn

@@ -1,0 +1,153 @@
+// bam2depth -- drop-in for the reference tool of the same name (bam2depth.c): per-position
+// coverage of CIGAR-M blocks as bedGraph + per-window mean depth, the record loop and the
+// breakpoint sweep running on MI355X through libhpngs.
+//
+//   bam2depth [-o OUT] [-w W] [-W] [-r REGION] [-s INT] [-h] a.bam b.bam ...
+//
+// Writes ./<basename(bam)>.<n>.bedGraph, OUT.<n>.depth and with -W OUT.<n>.wig +
+// OUT.<n>.chromSize.txt (bam2depth.c:312-321).  Like the reference it insists on
+// <bam>.bai (:112-119) although it reads the coordinate-sorted file front to back:
+// bam_fetch(tid, 0, 1<<29) per target visits exactly the target's records.
+// -r / -s are parsed and unused, as in the reference (:281-285).
+#include <err.h>
+#include <getopt.h>
+#include <libgen.h>
+
+#include "../host/bam_reader.hpp"
+#include "../host/report.hpp"
+
+using namespace hpn;
+
+#define BAM_DEF_MASK (4 | 256 | 512 | 1024) /* bam.h:124 */
+
+static void usage(const char *prog)
+{
+    fprintf(stderr,
+            "\nUsage: %s [-o OUTFILE] [-w WINDOW_SIZE] [-r chr1:1-2000000] [-W] [-s 0] [-h] bamFile1 bamFile2 ..\n"
+            "  Converts indexed BAM files to bedGraph and reports the mean depth per window\n"
+            "  (MI355X build of HighPerformanceNGS bam2depth).\n\n"
+            "   [-o OUTPUT_FILE]  output prefix\n"
+            "   [-w WINDOW_SIZE]  window size, default 20000\n"
+            "   [-W]              also write wig + chromSize files\n"
+            "   [-r], [-s]        accepted, unused\n"
+            "   [-h]              this help\n\n",
+            prog);
+    exit(1);
+}
+
+static bool index_exists(const char *bam)
+{
+    std::string a = std::string(bam) + ".bai", b = bam;
+    if (access(a.c_str(), R_OK) == 0) return true;
+    if (b.size() > 3 && b.compare(b.size() - 3, 3, "bam") == 0) {  // x.bam -> x.bai (bam_index.c: bam_index_load_local)
+        b.replace(b.size() - 3, 3, "bai");
+        if (access(b.c_str(), R_OK) == 0) return true;
+    }
+    return false;
+}
+
+int main(int argc, char *argv[])
+{
+    const char *outfile = "-";
+    uint32_t window = 20000;
+    int wig = 0;
+    if (argc < 2) usage(argv[0]);
+    int opt;
+    while ((opt = getopt(argc, argv, "o:w:r:s:Wh?")) != -1) {
+        switch (opt) {
+        case 'o': outfile = optarg; break;
+        case 'w': window = (uint32_t)atoi(optarg); break;
+        case 'W': wig++; break;
+        case 'r':  // falls through into -s in the reference
+        case 's': break;
+        case '?':
+        case 'h': usage(argv[0]); break;
+        default: fprintf(stderr, "error parameter!\n"); break;
+        }
+    }
+    if (window == 0) {
+        fprintf(stderr, "bam2depth: window size must be positive\n");
+        return 2;
+    }
+    char **infiles = argv + optind;
+    const int n_in = argc - optind;
+    const long long begin = usec();
+
+    hpn_ctx *ctx = nullptr;
+    int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
+    if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+
+    char suffix[64];
+    for (int i = 0; i < n_in; ++i) {
+        BamReader bam;
+        BamHeader hdr;
+        if (!bam.open(infiles[i], hdr)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        std::string nm = infiles[i];
+        snprintf(suffix, sizeof suffix, ".%u.bedGraph", i + 1);
+        FILE *bedGraph = fcreat_outfile(basename(&nm[0]), suffix);
+        snprintf(suffix, sizeof suffix, ".%u.depth", i + 1);
+        FILE *depth = fcreat_outfile(outfile, suffix);
+        FILE *WIG = nullptr, *chrSize = nullptr;
+        if (wig) {
+            snprintf(suffix, sizeof suffix, ".%u.wig", i + 1);
+            WIG = fcreat_outfile(outfile, suffix);
+            snprintf(suffix, sizeof suffix, ".%u.chromSize.txt", i + 1);
+            chrSize = fcreat_outfile(outfile, suffix);
+        }
+        if (!index_exists(infiles[i])) {
+            fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
+            exit(1);
+        }
+        BamBatch batch;
+        std::vector<hpn_run> runs(1u << 20);
+        std::vector<uint64_t> win;
+        for (int32_t j = 0; j < hdr.n_targets(); ++j) {
+            const uint32_t tlen = hdr.target_len[j];
+            const char *name = hdr.target_name[j].c_str();
+            if ((rc = hpn_depth_begin(ctx, j, tlen, BAM_DEF_MASK)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");
+            // the target's records are contiguous in a coordinate-sorted file
+            for (;;) {
+                int32_t t = bam.peek_tid();
+                while (t != INT32_MIN && t >= 0 && t < j) {  // out of order: not reachable through the index either
+                    batch.clear();
+                    bam.next(batch, false);
+                    t = bam.peek_tid();
+                }
+                batch.clear();
+                while (t == j && batch.n() < (4u << 20)) {
+                    bam.next(batch, false);
+                    t = bam.peek_tid();
+                }
+                if (batch.n()) {
+                    hpn_bam_batch v = batch.view();
+                    if ((rc = hpn_depth_add(ctx, &v)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
+                }
+                if (t != j) break;
+            }
+            win.assign((size_t)tlen / window + 1, 0);
+            uint64_t n_runs = 0;
+            rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
+            if (rc == HPN_E_CAPACITY) {
+                runs.resize(n_runs);
+                rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
+            }
+            if (rc != HPN_OK) die_hpn(ctx, rc, name);
+            print_bedgraph(bedGraph, name, runs.data(), n_runs);
+            print_depth_bins(depth, name, tlen, window, win.data());
+            if (wig) {
+                print_wig_bins(WIG, name, tlen, window, win.data());
+                fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
+            }
+            fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
+        }
+        fclose(bedGraph);
+        fclose(depth);
+        if (wig) {
+            fclose(WIG);
+            fclose(chrSize);
+        }
+        fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
+    }
+    hpn_ctx_destroy(ctx);
+    return 0;
+}

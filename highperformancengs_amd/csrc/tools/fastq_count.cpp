@@ -1,0 +1,111 @@
+// fastq_count -- drop-in for the reference tool of the same name (fastq_count.c), with the
+// per-record tally (count_read's loop, :112-119) running on MI355X through libhpngs.
+//
+//   fastq_count [-o OUT] [-t N] [-H] [-L] [-h] file1.fq[.gz] file2.fq[.gz] ...
+//
+// Same flags, same report bytes: one row per file, printed in completion order under
+// a lock, one host thread per file in batches of -t (fastq_count.c:213-230).
+// Differences, all outside the report: a read longer than 511 or a quality byte
+// >= 128 is an error here (the reference overruns its arrays); HPN_DEVICE picks the GPU.
+#include <getopt.h>
+#include <pthread.h>
+
+#include <mutex>
+#include <thread>
+
+#include "../host/fastq_reader.hpp"
+#include "../host/report.hpp"
+
+using namespace hpn;
+
+static struct {
+    char **infiles;
+    const char *outfile;
+    int numInfiles, thread, header, LengthDetail;
+} g;
+static std::mutex g_lock;
+static int g_ndev = 1, g_dev0 = 0;
+
+static void usage(const char *prog)
+{
+    fprintf(stderr,
+            "\nUsage: %s file1.fq file2.fq ... [-o outfile] [-t thread] [-H] [-L] [-h]\n"
+            "  Counts reads, bases, mean/min/max length and %%Q20 / %%Q30 of plain or gzip FASTQ files\n"
+            "  (MI355X build of HighPerformanceNGS fastq_count).\n\n"
+            "   [-o OUTPUT] output file, default stdout\n"
+            "   [-H]        print the header line\n"
+            "   [-L]        also print the read length histogram\n"
+            "   [-t N]      files processed concurrently, default min(#files, #cpus)\n"
+            "   [-h]        this help\n\n",
+            prog);
+    exit(1);
+}
+
+static void count_file(const char *infile, FILE *out, int slot)
+{
+    hpn_ctx *ctx = nullptr;
+    int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
+    if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    gzFile fq = open_input_stream(infile);
+    hpn_tally acc;
+    memset(&acc, 0, sizeof acc);
+    {
+        CountFramer framer(fq);
+        FastqBatch batch;
+        bool more = true, bad = false;
+        while (more) {
+            batch.clear();
+            more = framer.fill(batch, 8u << 20, 1ull << 30, false, &bad);
+            if (bad) {
+                fprintf(stderr, "%s: read longer than 511 bases (outside fastq_count's SeqLen[512])\n", infile);
+                exit(2);
+            }
+            rc = hpn_fastq_tally(ctx, batch.qual.data(), nullptr, batch.off.data(), batch.n(), &acc);
+            if (rc != HPN_OK) die_hpn(ctx, rc, infile);
+        }
+    }
+    gzclose(fq);
+    const CountSummary s = summarise(acc);
+    {
+        std::lock_guard<std::mutex> lk(g_lock);  // pthread_mutex_lock (fastq_count.c:126)
+        print_count_row(out, infile, acc, s);
+        if (g.LengthDetail) print_len_detail(out, acc.seqlen, s.min_len, s.max_len);
+    }
+    hpn_ctx_destroy(ctx);
+}
+
+int main(int argc, char *argv[])
+{
+    g.outfile = "-";
+    g.thread = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    int opt;
+    while ((opt = getopt(argc, argv, "o:t:HLh?")) != -1) {
+        switch (opt) {
+        case 'o': g.outfile = optarg; break;
+        case 't': g.thread = atoi(optarg); break;
+        case 'H': g.header++; break;
+        case 'L': g.LengthDetail++; break;
+        case '?':
+        case 'h': usage(argv[0]); break;
+        default: fprintf(stderr, "error parameter!\n"); break;
+        }
+    }
+    g.infiles = argv + optind;
+    g.numInfiles = argc - optind;
+    if (g.numInfiles < g.thread) g.thread = g.numInfiles;
+    if (g.thread < 1) g.thread = 1;
+    if (const char *d = getenv("HPN_DEVICE")) g_dev0 = atoi(d), g_ndev = 1;
+    else if (hpn_device_count(&g_ndev) != HPN_OK || g_ndev < 1) die_hpn(nullptr, HPN_E_NODEVICE, "fastq_count");
+
+    const long long begin = usec();
+    FILE *out = fopen_output_stream(g.outfile);
+    if (g.header) print_count_header(out);
+    for (int i = 0; i < g.numInfiles; i += g.thread) {
+        std::vector<std::thread> th;
+        for (int j = 0; j < g.thread && i + j < g.numInfiles; ++j) th.emplace_back(count_file, g.infiles[i + j], out, j);
+        for (auto &t : th) t.join();
+    }
+    fprintf(stderr, "Finished at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
+    fclose(out);
+    return 0;
+}

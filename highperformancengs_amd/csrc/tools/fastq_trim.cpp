@@ -1,0 +1,95 @@
+// fastq_trim -- drop-in for the reference tool of the same name (fastq_trim.c): cut every
+// read to cycles [S, E), the substring gather running on MI355X through libhpngs.
+//
+//   fastq_trim [-i IN] [-o OUT] [-s S] [-e E] [-h]        (-v and -z are accepted and ignored)
+//
+// Output OUT.trim.fastq (stdout when OUT starts with '-'): name, seq[S:min(E,len)], "+",
+// qual[S:min(E,len)] (fastq_trim.c:101).  Domain: 0 <= S <= E and S <= every read's
+// length (beyond a read's end the reference copies stale buffer bytes; this prints an
+// empty line there).
+#include <getopt.h>
+
+#include "../host/fastq_reader.hpp"
+#include "../host/report.hpp"
+
+using namespace hpn;
+
+static void usage(const char *prog)
+{
+    fprintf(stderr,
+            "\nUsage: %s [-i Infile] [-o OUTFILE] [-s start] [-e end] [-h]\n"
+            "  Cuts the reads of a plain or gzip FASTQ file to the given cycles\n"
+            "  (MI355X build of HighPerformanceNGS fastq_trim).\n\n"
+            "   [-i Infile]  input, default stdin\n"
+            "   [-o OUTPUT]  output prefix (writes OUTPUT.trim.fastq), default stdout\n"
+            "   [-s Start]   0-based start position, default 0\n"
+            "   [-e End]     1-based end position, default 400\n"
+            "   [-h]         this help\n\n",
+            prog);
+    exit(1);
+}
+
+int main(int argc, char *argv[])
+{
+    const char *infile = "-", *outfile = "-";
+    int start = 0, end = 400;
+    if (argc < 2) usage(argv[0]);
+    int opt;
+    while ((opt = getopt(argc, argv, "i:o:s:e:vzh?")) != -1) {
+        switch (opt) {
+        case 'i': infile = optarg; break;
+        case 'o': outfile = optarg; break;
+        case 'v': break;
+        case 'z': break;
+        case 's': start = atoi(optarg); break;
+        case 'e': end = atoi(optarg); break;
+        case '?':
+        case 'h': usage(argv[0]); break;
+        default: fprintf(stderr, "error parameter!\n"); break;
+        }
+    }
+    if (start < 0 || end < start) {
+        fprintf(stderr, "fastq_trim: need 0 <= start <= end (got -s %d -e %d)\n", start, end);
+        return 2;
+    }
+    hpn_ctx *ctx = nullptr;
+    int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
+    if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+
+    gzFile in = open_input_stream(infile);
+    FILE *out = fcreat_outfile(outfile, ".trim.fastq");
+    unsigned long reads = 0;
+    const long long begin = usec();
+    {
+        TrimFramer framer(in);
+        FastqBatch b;
+        std::vector<uint8_t> oseq, oqual;
+        std::vector<uint64_t> ooff;
+        bool more = true;
+        while (more) {
+            b.clear();
+            more = framer.fill(b, 4u << 20, 512ull << 20);
+            const uint64_t n = b.n();
+            if (!n) continue;
+            oseq.resize(b.seq.size() + 1), oqual.resize(b.qual.size() + 1), ooff.resize(n + 1);
+            rc = hpn_fastq_trim(ctx, b.seq.data(), b.qual.data(), b.off.data(), n, start, end, oseq.data(), oqual.data(),
+                                ooff.data());
+            if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_trim");
+            for (uint64_t i = 0; i < n; ++i) {  // fprintf("%s\n%s\n+\n%s\n") (:101): each cut ends at its first NUL
+                const uint64_t a = ooff[i], len = ooff[i + 1] - a;
+                fputs(b.names[i].c_str(), out);
+                fputc('\n', out);
+                fwrite(oseq.data() + a, 1, strnlen((const char *)oseq.data() + a, len), out);
+                fputs("\n+\n", out);
+                fwrite(oqual.data() + a, 1, strnlen((const char *)oqual.data() + a, len), out);
+                fputc('\n', out);
+            }
+            reads += n;
+        }
+    }
+    fprintf(stderr, "Total_reads: %lu\nFinished in %.3f s\n", reads, (double)(usec() - begin) / CLOCKS_PER_SEC);
+    gzclose(in);
+    fclose(out);
+    hpn_ctx_destroy(ctx);
+    return 0;
+}

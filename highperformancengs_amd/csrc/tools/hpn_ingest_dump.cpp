@@ -1,0 +1,65 @@
+// hpn_ingest_dump -- developer/test utility: run the host ingest (no GPU) and dump the
+// structure-of-arrays batch the tools would hand to libhpngs.  Used by the CPU test
+// suite to check the gzgets-framing emulation and the BAM decoder.
+//
+//   hpn_ingest_dump count FILE   -> u64 n, u64 off[n+1], u8 qual[off[n]], u8 seq[off[n]]
+//   hpn_ingest_dump trim  FILE   -> u64 n, u64 off[n+1], u8 seq[..], u8 qual[..], then n NUL-terminated names
+//   hpn_ingest_dump bam   FILE   -> u64 n, i32 tid[n], i32 pos[n], u32 flag[n], i32 l_qseq[n],
+//                                   u32 cigar_off[n+1], u32 cigar[..], u64 seq_off[n+1], u8 seq4[..]
+#include <stdio.h>
+
+#include "../host/bam_reader.hpp"
+#include "../host/fastq_reader.hpp"
+
+using namespace hpn;
+
+template <typename T>
+static void put(const std::vector<T> &v)
+{
+    if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), stdout);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) {
+        fprintf(stderr, "usage: %s count|trim|bam FILE\n", argv[0]);
+        return 1;
+    }
+    const std::string mode = argv[1];
+    if (mode == "count" || mode == "trim") {
+        gzFile f = open_input_stream(argv[2]);
+        FastqBatch b;
+        bool bad = false;
+        if (mode == "count") {
+            CountFramer fr(f);
+            while (fr.fill(b, ~0ull, ~0ull, true, &bad)) {}
+        } else {
+            TrimFramer fr(f);
+            while (fr.fill(b, ~0ull, ~0ull)) {}
+        }
+        gzclose(f);
+        if (bad) return 3;
+        const uint64_t n = b.n();
+        fwrite(&n, 8, 1, stdout);
+        put(b.off);
+        if (mode == "count") put(b.qual), put(b.seq);
+        else {
+            put(b.seq), put(b.qual);
+            for (auto &s : b.names) fwrite(s.c_str(), 1, s.size() + 1, stdout);
+        }
+        return 0;
+    }
+    if (mode == "bam") {
+        BamReader r;
+        BamHeader h;
+        if (!r.open(argv[2], h)) return 2;
+        BamBatch b;
+        while (r.next(b, true)) {}
+        const uint64_t n = b.n();
+        fwrite(&n, 8, 1, stdout);
+        put(b.tid), put(b.pos), put(b.flag), put(b.l_qseq), put(b.cigar_off), put(b.cigar), put(b.seq_off), put(b.seq4);
+        fprintf(stderr, "%d targets\n", h.n_targets());
+        return 0;
+    }
+    return 1;
+}

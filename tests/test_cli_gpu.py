@@ -1,0 +1,92 @@
+"""GPU: the CLI tools are drop-ins -- same argv, same stdout, same files, byte for byte,
+as the compiled reference tools recorded in tests/golden/ (make_golden.py)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import orc
+from conftest import GOLDEN, expected, golden_path
+from highperformancengs_amd import bamio
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "highperformancengs_amd", "bin")
+
+CASES = ["count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "count_multi", "count_short",
+         "count_len0", "count_allzero", "count_trunc", "count_longname", "count_syn_var_a", "count_syn_var_b",
+         "count_syn_100", "count_to_file", "kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty",
+         "trim_a1", "trim_a1_default", "trim_a1_file", "trim_nonl", "trim_short", "trim_crlf", "trim_syn_var",
+         "trim_syn_100", "trim_multi", "trim_empty",
+         "depth_a3", "depth_a3_wig", "depth_a3_stdout", "depth_rand", "depth_rand_w1000", "depth_two_files"]
+
+
+def _run(tool, args, inputs, cwd):
+    for src in inputs:
+        shutil.copy(src, cwd)
+        if src.endswith(".bam"):
+            shutil.copy(src + ".bai", cwd)
+    before = set(os.listdir(cwd))
+    p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p, sorted(set(os.listdir(cwd)) - before)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_drop_in(manifest, case, tmp_path):
+    c = manifest[case]
+    args = list(c["args"])
+    if c["tool"] == "fastq_count" and "-t" not in args:
+        args = ["-t", "1"] + args  # rows are printed in completion order; one at a time = input order
+    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path)
+    assert p.returncode == c["returncode"], p.stderr.decode()
+    assert p.stdout == expected(case), p.stderr.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+
+
+def test_fastq_trim_reports_total_reads(tmp_path):
+    p, _ = _run("fastq_trim", ["-i", "t.fq", "-s", "2", "-e", "8"], [golden_path("fastq", "t.fq")], tmp_path)
+    assert p.stderr.startswith(b"Total_reads: 5\nFinished in ")
+
+
+def test_bam2depth_requires_index(tmp_path):
+    shutil.copy(golden_path("bam", "e.bam"), tmp_path)
+    p = subprocess.run([os.path.join(BIN, "bam2depth"), "-o", "d", "e.bam"], cwd=tmp_path, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"BAM indexing file is not available" in p.stderr
+
+
+@pytest.mark.parametrize("bam,W", [("e.bam", 100), ("rand.bam", 20000), ("rand.bam", 700)])
+def test_bam_sliding_count_report(bam, W, tmp_path):
+    # reference tool unbuildable here (needs libgd): pinned by SURVEY A.3 + the oracle's restatement
+    p, files = _run("bam_sliding_count", ["-w", str(W), "-o", "s", bam], [golden_path("bam", bam)], tmp_path)
+    assert p.returncode == 0 and files == ["s.txt"], p.stderr.decode()
+    got = open(tmp_path / "s.txt", "rb").read()
+    soa = bamio.read_bam_records(golden_path("bam", bam))
+    assert got == orc.window_report(soa, W)
+    if bam == "e.bam":
+        rows = got.split(b"\n")
+        assert rows[1].split(b"\t")[:12] == b"c1\t1000\t7\t60\t0.060000\t53.333336\t1\t5\t48.888889\t2\t1\t100.000000".split(b"\t")
+        assert rows[2].split(b"\t")[:12] == b"c2\t500\t3\t30\t0.060000\t56.666668\t1\t3\t56.666668\t2\t0\t0.000000".split(b"\t")
+
+
+def test_bam_sliding_count_region(tmp_path):
+    p, files = _run("bam_sliding_count", ["-w", "1000", "-r", "chr2:1,001-20000", "-o", "reg", "rand.bam"],
+                    [golden_path("bam", "rand.bam")], tmp_path)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout == b"chr2\t1000\t20000\n"
+    soa = bamio.read_bam_records(golden_path("bam", "rand.bam"))
+    import numpy as np
+    keep = []
+    for i in range(len(soa.tid)):
+        cg = soa.cigar[soa.cigar_off[i]:soa.cigar_off[i + 1]]
+        rend = soa.pos[i] + (sum(int(w) >> 4 for w in cg if (int(w) & 15) in (0, 2, 3, 7, 8)) if len(cg) else 1)
+        keep.append(soa.tid[i] == 1 and rend > 1000 and soa.pos[i] < 20000)
+    keep = np.array(keep)
+    sub = bamio.BamSoA(refs=soa.refs, tid=soa.tid[keep], pos=soa.pos[keep], flag=soa.flag[keep], l_qseq=soa.l_qseq[keep],
+                       cigar_off=np.zeros(keep.sum() + 1, np.uint32), cigar=np.zeros(1, np.uint32),
+                       seq_off=np.concatenate([[0], np.cumsum((soa.l_qseq[keep] + 1) // 2)]).astype(np.uint64),
+                       seq4=np.concatenate([soa.seq4[int(soa.seq_off[i]):int(soa.seq_off[i + 1])] for i in np.nonzero(keep)[0]]))
+    assert open(tmp_path / "reg.txt", "rb").read() == orc.window_report(sub, 1000)

@@ -1,0 +1,99 @@
+"""CPU: the host ingest of the CLI tools (no GPU): gzgets-framing emulation and BAM decode.
+
+hpn_ingest_dump runs the same CountFramer / TrimFramer / BamReader the tools use and
+dumps the batch; tallying that batch with the oracle must equal the oracle's own
+4 x gzgets stream loop (which is pinned to the reference by test_oracle_golden.py)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import expected, golden_path
+from highperformancengs_amd import bamio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "highperformancengs_amd", "bin")
+DUMP = os.path.join(BIN, "hpn_ingest_dump")
+FASTQS = ["t.fq", "t.fq.gz", "empty.fq", "nonl.fq", "crlf.fq", "multi.fq.gz", "short.fq", "len0.fq", "allzero.fq",
+          "trunc.fq", "longname.fq", "syn_var_a.fq", "syn_var_b.fq.gz", "syn_100.fq.gz"]
+
+
+def _dump(mode, path):
+    p = subprocess.run([DUMP, mode, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    return p.stdout
+
+
+@pytest.mark.parametrize("name", FASTQS)
+def test_count_framing_equals_gzgets_loop(name):
+    raw = _dump("count", golden_path("fastq", name))
+    n = struct.unpack_from("<Q", raw)[0]
+    off = np.frombuffer(raw, np.uint64, n + 1, 8)
+    tot = int(off[-1])
+    qual = np.frombuffer(raw, np.uint8, tot, 8 + 8 * (n + 1))
+    rc, a = orc.count_soa(qual, off)
+    rc2, b = orc.count_stream(golden_path("fastq", name))
+    assert rc == 0 and rc2 == 0
+    assert np.array_equal(a.seqlen, b.seqlen) and np.array_equal(a.quality, b.quality)
+
+
+@pytest.mark.parametrize("case,name,S,E", [("trim_a1", "t.fq", 2, 8), ("trim_nonl", "nonl.fq", 0, 10),
+                                           ("trim_short", "short.fq", 3, 6), ("trim_crlf", "crlf.fq", 1, 3),
+                                           ("trim_syn_var", "syn_var_b.fq.gz", 5, 80), ("trim_multi", "multi.fq.gz", 4, 9),
+                                           ("trim_empty", "empty.fq", 0, 9), ("trim_a1_default", "t.fq.gz", 0, 400)])
+def test_trim_framing_plus_cut_equals_reference_text(case, name, S, E):
+    raw = _dump("trim", golden_path("fastq", name))
+    n = struct.unpack_from("<Q", raw)[0]
+    off = np.frombuffer(raw, np.uint64, n + 1, 8)
+    tot = int(off[-1])
+    p = 8 + 8 * (n + 1)
+    seq = np.frombuffer(raw, np.uint8, tot, p)
+    qual = np.frombuffer(raw, np.uint8, tot, p + tot)
+    names = raw[p + 2 * tot:].split(b"\0")[:n]
+    rc, oseq, oqual, ooff = orc.trim_soa(seq, qual, off, S, E)
+    assert rc == 0
+    text = b""
+    for i in range(n):
+        a, b = int(ooff[i]), int(ooff[i + 1])
+        cs = oseq[a:b].tobytes().split(b"\0")[0]
+        cq = oqual[a:b].tobytes().split(b"\0")[0]
+        text += names[i] + b"\n" + cs + b"\n+\n" + cq + b"\n"
+    assert text == expected(case)
+
+
+@pytest.mark.parametrize("bam", ["e.bam", "rand.bam"])
+def test_bam_decoder_equals_python_decoder(bam):
+    raw = _dump("bam", golden_path("bam", bam))
+    soa = bamio.read_bam_records(golden_path("bam", bam))
+    n = struct.unpack_from("<Q", raw)[0]
+    assert n == len(soa.tid)
+    p = 8
+    for name, dt, cnt in (("tid", np.int32, n), ("pos", np.int32, n), ("flag", np.uint32, n), ("l_qseq", np.int32, n),
+                          ("cigar_off", np.uint32, n + 1)):
+        a = np.frombuffer(raw, dt, cnt, p)
+        p += a.nbytes
+        assert np.array_equal(a, getattr(soa, name)), name
+    cig = np.frombuffer(raw, np.uint32, len(soa.cigar), p)
+    p += cig.nbytes
+    assert np.array_equal(cig, soa.cigar)
+    so = np.frombuffer(raw, np.uint64, n + 1, p)
+    p += so.nbytes
+    assert np.array_equal(so, soa.seq_off)
+    assert np.array_equal(np.frombuffer(raw, np.uint8, len(soa.seq4), p), soa.seq4)
+
+
+@pytest.mark.parametrize("tool", ["fastq_count", "fastq_count_kthread", "fastq_trim", "bam2depth", "bam_sliding_count"])
+def test_tools_exist_and_print_usage(tool):
+    p = subprocess.run([os.path.join(BIN, tool), "-h"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"Usage:" in p.stderr and p.stdout == b""
+
+
+def test_tools_fail_loudly_without_a_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = subprocess.run([os.path.join(BIN, "fastq_count"), golden_path("fastq", "t.fq")], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=tmp_path)
+    assert p.returncode != 0 and p.stdout == b"" and b"no usable HIP device" in p.stderr
