@@ -241,11 +241,12 @@ int hpn_fastq_tally_devptr(hpn_ctx *c, uint64_t **d_acc)
 int hpn_fastq_tally(hpn_ctx *c, const uint8_t *qual, const uint8_t *base, const uint64_t *off, uint64_t n,
                     hpn_tally *acc)
 {
-    if (!c || !off || !acc || (!qual && n)) return HPN_E_ARG;
+    if (!c || !off || !acc) return HPN_E_ARG;
     HPN_HIP(c, hipSetDevice(c->device));
     const uint64_t b0 = off[0], b1 = off[n];
     if (b1 < b0) return fail(c, HPN_E_ARG, "offsets decrease");
     const uint64_t nbytes = b1 - b0;
+    if (nbytes && !qual) return fail(c, HPN_E_ARG, "qual is NULL");
     const uint32_t flags = (acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0) | (acc->nuc_hist && base ? HPN_TALLY_NUC_HIST : 0);
     // Stage [b0, b1) so that device address == scratch + 16 + (host offset - b0) keeps
     // the host offsets valid unchanged: the kernels index qual[off[i]].

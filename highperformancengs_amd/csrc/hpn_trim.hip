@@ -39,11 +39,12 @@ int hpn_fastq_trim_dev(hpn_ctx *c, const uint8_t *d_seq, const uint8_t *d_qual, 
 int hpn_fastq_trim(hpn_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint64_t n, int32_t S,
                    int32_t E, uint8_t *out_seq, uint8_t *out_qual, uint64_t *out_off)
 {
-    if (!c || !off || !out_off || (n && (!seq || !qual || !out_seq || !out_qual))) return HPN_E_ARG;
+    if (!c || !off || !out_off) return HPN_E_ARG;
     HPN_HIP(c, hipSetDevice(c->device));
     const uint64_t b0 = off[0], b1 = off[n];
     if (b1 < b0) return fail(c, HPN_E_ARG, "offsets decrease");
     const uint64_t nbytes = b1 - b0;
+    if (nbytes && (!seq || !qual || !out_seq || !out_qual)) return fail(c, HPN_E_ARG, "NULL array");
     int rc;
     if ((rc = scratch_reserve(c, c->s_a, nbytes + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->s_b, nbytes + 64)) != HPN_OK) return rc;

@@ -122,22 +122,39 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
         }
     }
 
-    // ---- record lengths ----
-    const uint64_t ltiles = (n + kLenTile - 1) / kLenTile;
-    for (uint64_t t = blockIdx.x; t < ltiles; t += gridDim.x) {
-        uint64_t a[kLenPerThread], b[kLenPerThread];
+    // ---- record lengths: off[] read once, as 16-byte pairs {off[e], off[e+1]} ----
+    // e0 = first 16-byte aligned element; pair p holds elements e0+2p, e0+2p+1; the
+    // boundary after the pair comes from the next lane (lane 63 reads it itself).
+    const uint64_t e0 = ((uintptr_t)off >> 3) & 1;
+    if (e0 && blockIdx.x == 0 && tid == 0 && n) {  // record 0 sits in front of the first aligned pair
+        const uint64_t len = off[1] - off[0];
+        atomicAdd(&s_hist[len < HPN_LEN_BINS ? (uint32_t)len : (uint32_t)HPN_LEN_BINS], 1u);
+    }
+    if (n + 1 > e0) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 *pairs = reinterpret_cast<const u64x2 *>(off + e0);
+        const uint64_t npair = (n + 1 - e0 + 1) >> 1;
+        const uint64_t ptiles = (npair + kLenTile - 1) / kLenTile;
+        for (uint64_t t = blockIdx.x; t < ptiles; t += gridDim.x) {
+            u64x2 v[kLenPerThread];
+            uint64_t nx[kLenPerThread];
 #pragma unroll
-        for (int k = 0; k < kLenPerThread; ++k) {
-            const uint64_t i = t * kLenTile + (uint64_t)k * kScanThreads + tid;
-            const bool valid = i < n;
-            a[k] = valid ? off[i] : 0;
-            b[k] = valid ? off[i + 1] : 0;
-        }
+            for (int k = 0; k < kLenPerThread; ++k) {
+                const uint64_t p = t * kLenTile + (uint64_t)k * kScanThreads + tid;
+                v[k] = p < npair ? __builtin_nontemporal_load(pairs + p) : u64x2{0, 0};
+                const uint64_t e = e0 + 2 * p + 2;  // element after the pair
+                nx[k] = (lane_id() == kWave - 1 && e <= n) ? off[e] : 0;
+            }
 #pragma unroll
-        for (int k = 0; k < kLenPerThread; ++k) {
-            const uint64_t i = t * kLenTile + (uint64_t)k * kScanThreads + tid;
-            const uint64_t len = b[k] - a[k];
-            hist_len(s_hist, i < n, len < HPN_LEN_BINS ? (uint32_t)len : (uint32_t)HPN_LEN_BINS);
+            for (int k = 0; k < kLenPerThread; ++k) {
+                const uint64_t p = t * kLenTile + (uint64_t)k * kScanThreads + tid;
+                const uint64_t e = e0 + 2 * p;      // record e = [off[e], off[e+1]), record e+1 = [off[e+1], off[e+2])
+                const uint64_t from_next = __shfl_down(v[k][0], 1, kWave);
+                const uint64_t after = lane_id() == kWave - 1 ? nx[k] : from_next;
+                const uint64_t l0 = v[k][1] - v[k][0], l1 = after - v[k][1];
+                hist_len(s_hist, p < npair && e < n, l0 < HPN_LEN_BINS ? (uint32_t)l0 : (uint32_t)HPN_LEN_BINS);
+                hist_len(s_hist, p < npair && e + 1 < n, l1 < HPN_LEN_BINS ? (uint32_t)l1 : (uint32_t)HPN_LEN_BINS);
+            }
         }
     }
 

@@ -44,8 +44,6 @@ def fmt_bedgraph(name, runs):
 
 def fmt_depth(name, tlen, W, win_sum):
     """output_bins (bam2depth.c:238-246): bins[k]/W with %.2f; bins are exact integers in double."""
-    out = b""
-    for k in range(tlen // W + 1):
-        we = min(W * (k + 1), tlen)
-        out += b"%s\t%d\t%d\t%s\n" % (name.encode(), W * k, we, ("%.2f" % (float(int(win_sum[k])) / W)).encode())
-    return out
+    nm = name.encode()
+    return b"".join(b"%s\t%d\t%d\t%s\n" % (nm, W * k, min(W * (k + 1), tlen), ("%.2f" % (float(int(win_sum[k])) / W)).encode())
+                    for k in range(tlen // W + 1))
