@@ -61,9 +61,9 @@ int hpn_ctx_create(int device, hpn_ctx **out)
         c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = HPN_E_HIP; break; }
         c->stream = c->own_stream;
-        if (hipMalloc((void **)&c->d_acc, HPN_TALLY_WORDS * sizeof(u64)) != hipSuccess) { rc = HPN_E_NOMEM; break; }
+        if (hipMalloc((void **)&c->d_acc, (HPN_TALLY_WORDS + 16) * sizeof(u64)) != hipSuccess) { rc = HPN_E_NOMEM; break; }
         if (hipHostMalloc((void **)&c->h_acc, HPN_TALLY_WORDS * sizeof(u64), hipHostMallocDefault) != hipSuccess) { rc = HPN_E_NOMEM; break; }
-        if (hipMemsetAsync(c->d_acc, 0, HPN_TALLY_WORDS * sizeof(u64), c->stream) != hipSuccess) { rc = HPN_E_HIP; break; }
+        if (hipMemsetAsync(c->d_acc, 0, (HPN_TALLY_WORDS + 16) * sizeof(u64), c->stream) != hipSuccess) { rc = HPN_E_HIP; break; }
         for (int f = 0; f < kFamCount; ++f) {
             if (hipEventCreate(&c->ev_beg[f]) != hipSuccess || hipEventCreate(&c->ev_end[f]) != hipSuccess) { rc = HPN_E_HIP; break; }
         }
@@ -191,7 +191,7 @@ static int tally_launch(hpn_ctx *c, const uint8_t *d_qual, const uint8_t *d_base
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamTally], c->stream));
     // Without the Quality matrix the flat scan gives everything fastq_count prints;
     // with it, the histogram kernel also produces SeqLen / sum / Q20 / Q30 in its pass.
-    if (!qh) HPN_HIP(c, launch_tally_scan(d_qual, d_off, n, approx_bytes, c->d_acc, c->n_cu, c->stream));
+    if (!qh) HPN_HIP(c, launch_tally_scan(d_qual, d_off, n, approx_bytes, c->d_acc, c->d_sched(), c->n_cu, c->stream));
     if (qh || nh) HPN_HIP(c, launch_tally_hist(d_qual, d_base, d_off, n, qh, nh, c->d_acc, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamTally], c->stream));
     c->ev_valid[kFamTally] = true;

@@ -12,7 +12,7 @@ typedef unsigned long long u64;
 
 // device launchers (kernels/*.hip)
 hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t approx_bytes,
-                             u64 *d_acc, int n_cu, hipStream_t st);
+                             u64 *d_acc, u64 *d_sched, int n_cu, hipStream_t st);
 hipError_t launch_tally_hist(const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off, uint64_t n,
                              bool qual_hist, bool nuc_hist, u64 *d_acc, int n_cu, hipStream_t st);
 hipError_t launch_synth_fastq(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t *d_qual,
@@ -33,7 +33,8 @@ struct hpn_ctx {
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hpn::u64 *d_acc = nullptr;  // HPN_TALLY_WORDS
+    hpn::u64 *d_acc = nullptr;  // HPN_TALLY_WORDS, followed by 16 words of kernel scheduling state
+    hpn::u64 *d_sched() const { return d_acc + HPN_TALLY_WORDS; }
     hpn::u64 *h_acc = nullptr;  // pinned mirror
     hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;  // staging of host batches
     hpn::Scratch d_diff, d_runs, d_win, d_ws;             // bam2depth: difference array, runs, window sums, scan workspace

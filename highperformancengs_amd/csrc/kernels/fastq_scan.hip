@@ -1,0 +1,200 @@
+// fastq_scan.hip -- K1 `k_tally_scan`: what fastq_count prints, from one flat pass.
+//
+// Replaces the scan loop of count_read (reference fastq_count.c:112-119,
+// fastq_count_kthread.c:126-135; AssignQuality :29-35) for the default report:
+// SeqLen[512], sum, sum(q>=53), sum(q>=63) (statSeqLen :63-74, statQ :37-47,124).
+// Quality[q][pos] is only ever reduced over pos and over q>=53 / q>=63, so the
+// positions are not needed: the byte range [off[0], off[n]) of qual[] is scanned
+// flat with 16-byte loads and SWAR compares; off[] is read once, as 16-byte
+// pairs, for the length histogram.
+//
+// Work = byte tiles (256 lanes x U x 16 B) followed by pair tiles, handed out in
+// chunks of 8 tiles from ONE device counter (fetched one chunk ahead, so the
+// atomic's latency hides under the current chunk).  All workgroups therefore
+// stream one compact, advancing window of HBM and finish together; a static
+// grid-stride split lets workgroups drift apart over a 158 GB launch and
+// cost 3 % (scripts/k1_split.py, profiles/r01).
+// Bound: HBM read, 1 B per base + 8 B per record.  No MFMA: no contraction here.
+#include <stdlib.h>
+
+#include "tally_util.hpp"
+
+namespace hpn {
+
+constexpr int kScanThreads = 256;
+constexpr int kPairPerThread = 4;
+constexpr int kPairTile = kScanThreads * kPairPerThread;  // 1024 pairs = 2048 records = 16 KiB of off[]
+constexpr int kChunkTiles = 8;
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+template <int U, bool kNt, bool kDyn>
+__global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__restrict__ qual,
+                                                            const uint64_t *__restrict__ off, uint64_t n,
+                                                            u64 *__restrict__ acc, u64 *__restrict__ sched)
+{
+    constexpr int kTileVec = kScanThreads * U;  // 16-byte vectors per byte tile
+    __shared__ uint32_t s_hist[HPN_LEN_BINS + 1];  // last bin: length out of domain
+    __shared__ uint32_t s_red[3][kScanThreads / kWave];
+    __shared__ u64 s_chunk[2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= HPN_LEN_BINS; i += kScanThreads) s_hist[i] = 0;
+
+    // ---- geometry: bytes [off[0], off[n]) as 16-byte vectors from an aligned base ----
+    const uint64_t b0 = off[0], b1 = off[n];
+    const uint64_t nbytes = b1 > b0 ? b1 - b0 : 0;
+    const uint8_t *pbeg = qual + b0;
+    const int a0 = (int)((uintptr_t)pbeg & 15);
+    const u32 *vec = reinterpret_cast<const u32 *>(pbeg - a0);  // vector i = bytes [16i-a0, 16i-a0+16)
+    const uint64_t nv = nbytes ? (a0 + nbytes + 15) >> 4 : 0;
+    const uint64_t nvec = nv > 2 ? nv - 2 : 0;  // vectors 1 .. nv-2 are whole; first and last may be partial
+    const uint64_t btiles = (nvec + kTileVec - 1) / kTileVec;
+    // off[] as pairs {off[e], off[e+1]} from the first 16-byte aligned element e0
+    const uint64_t e0 = ((uintptr_t)off >> 3) & 1;
+    const u64x2 *pairs = reinterpret_cast<const u64x2 *>(off + e0);
+    const uint64_t npair = n + 1 > e0 ? (n + 1 - e0 + 1) >> 1 : 0;
+    const uint64_t ptiles = (npair + kPairTile - 1) / kPairTile;
+    const uint64_t tiles = btiles + ptiles;
+
+    uint32_t c20 = 0, c30 = 0, hi = 0;
+    auto ld = [](const u32 *p) { return kNt ? __builtin_nontemporal_load(p) : *p; };
+
+    auto byte_tile = [&](uint64_t t) {
+        const uint64_t base = 1 + t * kTileVec + tid;
+        u32 v[U];
+        if ((t + 1) * kTileVec <= nvec) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) v[k] = ld(vec + base + (uint64_t)k * kScanThreads);
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint64_t idx = base + (uint64_t)k * kScanThreads;
+                v[k] = idx < nv - 1 ? ld(vec + idx) : u32{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) swar16(v[k], c20, c30, hi);
+    };
+
+    // pair p holds elements e0+2p, e0+2p+1; the boundary after the pair comes from the
+    // next lane (lane 63 reads it itself): record e = [off[e], off[e+1]), e+1 = [off[e+1], off[e+2])
+    auto pair_tile = [&](uint64_t t) {
+        u64x2 v[kPairPerThread];
+        uint64_t nx[kPairPerThread];
+#pragma unroll
+        for (int k = 0; k < kPairPerThread; ++k) {
+            const uint64_t p = t * kPairTile + (uint64_t)k * kScanThreads + tid;
+            v[k] = p < npair ? __builtin_nontemporal_load(pairs + p) : u64x2{0, 0};
+            const uint64_t e = e0 + 2 * p + 2;
+            nx[k] = (lane_id() == kWave - 1 && e <= n) ? off[e] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kPairPerThread; ++k) {
+            const uint64_t p = t * kPairTile + (uint64_t)k * kScanThreads + tid;
+            const uint64_t e = e0 + 2 * p;
+            const uint64_t from_next = __shfl_down(v[k][0], 1, kWave);
+            const uint64_t after = lane_id() == kWave - 1 ? nx[k] : from_next;
+            const uint64_t l0 = v[k][1] - v[k][0], l1 = after - v[k][1];
+            hist_len(s_hist, p < npair && e < n, l0 < HPN_LEN_BINS ? (uint32_t)l0 : (uint32_t)HPN_LEN_BINS);
+            hist_len(s_hist, p < npair && e + 1 < n, l1 < HPN_LEN_BINS ? (uint32_t)l1 : (uint32_t)HPN_LEN_BINS);
+        }
+    };
+    auto do_tile = [&](uint64_t t) {
+        if (t < btiles) byte_tile(t);
+        else pair_tile(t - btiles);
+    };
+
+    if (kDyn) {
+        const uint64_t nchunk = (tiles + kChunkTiles - 1) / kChunkTiles;
+        if (tid == 0) s_chunk[0] = atomicAdd(&sched[0], (u64)1);
+        __syncthreads();  // also orders the s_hist clear before its first use
+        int par = 0;
+        uint64_t c = s_chunk[0];
+        while (c < nchunk) {
+            u64 nxt = 0;
+            if (tid == 0) nxt = atomicAdd(&sched[0], (u64)1);  // in flight while this chunk streams
+            const uint64_t t1 = min((c + 1) * kChunkTiles, tiles);
+            for (uint64_t t = c * kChunkTiles; t < t1; ++t) do_tile(t);
+            if (tid == 0) s_chunk[par ^ 1] = nxt;
+            __syncthreads();
+            par ^= 1;
+            c = s_chunk[par];
+        }
+    } else {
+        __syncthreads();
+        for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) do_tile(t);
+    }
+
+    if (blockIdx.x == 0 && tid == 0) {
+        if (nv) {  // the two possibly partial vectors at the ends of the byte range
+            const int e = (int)min((uint64_t)16, (uint64_t)a0 + nbytes);
+            swar16(mask_bytes(vec[0], a0, e), c20, c30, hi);
+            if (nv > 1) swar16(mask_bytes(vec[nv - 1], 0, (int)((a0 + nbytes) - ((nv - 1) << 4))), c20, c30, hi);
+        }
+        if (e0 && n) {  // record 0 sits in front of the first aligned pair
+            const uint64_t len = off[1] - off[0];
+            atomicAdd(&s_hist[len < HPN_LEN_BINS ? (uint32_t)len : (uint32_t)HPN_LEN_BINS], 1u);
+        }
+    }
+
+    // ---- workgroup reduction, one global atomic per counter per workgroup ----
+    c20 = wave_sum(c20);
+    c30 = wave_sum(c30);
+    hi = wave_or(hi);
+    if (lane_id() == 0) {
+        s_red[0][wave_id()] = c20;
+        s_red[1][wave_id()] = c30;
+        s_red[2][wave_id()] = hi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u64 s20 = 0, s30 = 0;
+        uint32_t h = 0;
+        for (int w = 0; w < kScanThreads / kWave; ++w) s20 += s_red[0][w], s30 += s_red[1][w], h |= s_red[2][w];
+        if (s20) atomicAdd(&acc[HPN_TALLY_W_Q20], s20);
+        if (s30) atomicAdd(&acc[HPN_TALLY_W_Q30], s30);
+        if (h & 0x80808080u) atomicAdd(&acc[HPN_TALLY_W_BAD], (u64)1);
+        if (blockIdx.x == 0) atomicAdd(&acc[HPN_TALLY_W_TOTAL], (u64)nbytes);
+    }
+    for (int i = tid; i <= HPN_LEN_BINS; i += kScanThreads) {
+        const uint32_t h = s_hist[i];
+        if (h) atomicAdd(&acc[i < HPN_LEN_BINS ? HPN_TALLY_W_SEQLEN + i : HPN_TALLY_W_BAD], (u64)h);
+    }
+    if (kDyn && tid == 0) {
+        // the last workgroup to leave rewinds the chunk counter for the next launch;
+        // every other workgroup made its final fetch before it signed off here
+        if (atomicAdd(&sched[1], (u64)1) == (u64)gridDim.x - 1) {
+            atomicExch(&sched[0], (u64)0);
+            atomicExch(&sched[1], (u64)0);
+        }
+    }
+}
+
+// Tuning knobs for A/B runs (scripts/k1_sweep.py): HPN_K1_VARIANT = unroll*100 + nt*10 + dyn
+// (default 811: 8 loads in flight, non-temporal, dynamic chunks), HPN_K1_WG_PER_CU.
+hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t approx_bytes,
+                             u64 *d_acc, u64 *d_sched, int n_cu, hipStream_t st)
+{
+    const char *ev = getenv("HPN_K1_VARIANT"), *eg = getenv("HPN_K1_WG_PER_CU");
+    const int variant = ev ? atoi(ev) : 811;
+    const int unroll = variant / 100;
+    const uint64_t per_cu = eg ? (uint64_t)atoi(eg) : 4;  // 4 workgroups of 4 waves per CU (sweep: 4 >= 8 >= 16)
+    if (unroll <= 0) return hipErrorInvalidValue;
+    const uint64_t tiles = approx_bytes / (16ull * kScanThreads * unroll) + n / (2 * kPairTile) + 2;
+    const uint64_t want = (variant % 10) ? (tiles + kChunkTiles - 1) / kChunkTiles : tiles;
+    const uint64_t cap = (uint64_t)n_cu * per_cu;
+    const dim3 grid((unsigned)(want < cap ? want : cap)), block(kScanThreads);
+    switch (variant) {
+#define HPN_K1(U, NT, DYN) \
+    case U * 100 + NT * 10 + DYN: \
+        hipLaunchKernelGGL((k_tally_scan<U, NT, DYN>), grid, block, 0, st, d_qual, d_off, n, d_acc, d_sched); \
+        break;
+        HPN_K1(4, 1, 0) HPN_K1(4, 1, 1) HPN_K1(8, 0, 0) HPN_K1(8, 0, 1) HPN_K1(8, 1, 0) HPN_K1(8, 1, 1) HPN_K1(16, 1, 0)
+        HPN_K1(16, 1, 1)
+#undef HPN_K1
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace hpn
