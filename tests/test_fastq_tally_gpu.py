@@ -65,7 +65,8 @@ def test_appendix_a1_batch(ctx):
 
 @pytest.mark.parametrize("n,lo,hi", [(1, 1, 1), (1, 511, 511), (7, 0, 3), (64, 150, 150), (65, 150, 150),
                                      (1000, 100, 100), (1025, 30, 151), (5000, 1, 511), (20000, 150, 150),
-                                     (70000, 36, 36), (3000, 0, 0)])
+                                     (70000, 36, 36), (3000, 0, 0), (3000, 300, 300), (1500, 511, 511),
+                                     (4000, 16, 16), (4000, 15, 15), (2500, 255, 257), (66000, 250, 250)])
 def test_synthetic_batches(ctx, n, lo, hi):
     seq, qual, off = orc.synth_soa(n * 31 + lo, 0, n, lo, hi)
     _check(ctx, qual, off, seq)
