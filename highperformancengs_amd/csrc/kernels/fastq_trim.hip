@@ -95,13 +95,28 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__res
         const uint64_t b = S < len ? S : len;
         const uint32_t cnt = (uint32_t)((E < len ? E : len) - b);
         const uint64_t src = a + b;
-        const int m = (int)min((uint64_t)kWave, n - r0);
-        for (int j = 0; j < m; ++j) {  // wave-uniform: broadcast record j's spans
+        // Four records per wave-instruction: the 16 lanes of quarter g serve record
+        // 4*it + g, 16 bytes per lane through unaligned dwordx4 accesses.  A span that is
+        // not a multiple of 16 ends with one overlapping 16-byte piece (same bytes written
+        // twice); spans shorter than 16 are copied bytewise by the quarter's first lanes.
+        const int sub = lane & 15, g = lane >> 4;
+#pragma unroll 2
+        for (int it = 0; it < kWave / 4; ++it) {
+            const int j = 4 * it + g;
             const uint64_t sj = __shfl(src, j, kWave), dj = __shfl(d, j, kWave);
             const uint32_t cj = __shfl(cnt, j, kWave);
-            for (uint32_t i = lane; i < cj; i += kWave) {
-                out_seq[dj + i] = seq[sj + i];
-                out_qual[dj + i] = qual[sj + i];
+            if (cj >= 16) {
+                for (uint32_t i = 16u * sub; i < cj; i += 256) {
+                    const uint32_t o = min(i, cj - 16);
+                    u32 s4, q4;
+                    __builtin_memcpy(&s4, seq + sj + o, 16);
+                    __builtin_memcpy(&q4, qual + sj + o, 16);
+                    __builtin_memcpy(out_seq + dj + o, &s4, 16);
+                    __builtin_memcpy(out_qual + dj + o, &q4, 16);
+                }
+            } else if ((uint32_t)sub < cj) {
+                out_seq[dj + sub] = seq[sj + sub];
+                out_qual[dj + sub] = qual[sj + sub];
             }
         }
     }
