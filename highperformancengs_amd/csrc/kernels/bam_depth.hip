@@ -14,6 +14,8 @@
 //       carry the coverage prefix and the run count between workgroups.
 // Bounds: K3 atomic rate (2 x 4 B per M block); K4 HBM read of 4 B per position,
 // + 12 B per run + 8 B per window written.
+#include <stdlib.h>
+
 #include "scan.hpp"
 
 namespace hpn {
@@ -129,36 +131,6 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
             starts += (d[k] != 0 && c > 0);  // coverage changed here to a positive depth: a run starts
         }
     }
-    if (W) {  // sum of coverage per window, clipped at target_len (overlap(), :132-176)
-        const uint64_t tile_lo = tile * kDsTile, tile_hi = min(tile_lo + kDsTile, (uint64_t)target_len);
-        if (tile_lo < tile_hi) {
-            const bool one_window = (tile_lo / W) == ((tile_hi - 1) / W);
-            if (one_window) {
-                u64 s = 0;
-#pragma unroll
-                for (int k = 0; k < kDsPer; ++k) s += (p0 + k < target_len) ? (u64)(uint32_t)cov[k] : 0;
-#pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
-                if (lane_id() == 0 && s) atomicAdd(&out.win_sum[tile_lo / W], s);
-            } else {
-                u64 s = 0;
-                uint64_t w = p0 / W;
-#pragma unroll
-                for (int k = 0; k < kDsPer; ++k) {
-                    const uint64_t p = p0 + k;
-                    if (p >= target_len) break;
-                    const uint64_t wk = p / W;
-                    if (wk != w) {
-                        if (s) atomicAdd(&out.win_sum[w], s);
-                        s = 0, w = wk;
-                    }
-                    s += (u64)(uint32_t)cov[k];
-                }
-                if (s) atomicAdd(&out.win_sum[w], s);
-            }
-        }
-    }
-
     // ---- chain 2: number of runs started before each lane ------------------------------
     const u64 wex2 = wave_excl_scan((u64)starts, wtot);
     if (lane_id() == kWave - 1) s_w[wave_id()] = wtot;
@@ -177,22 +149,78 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     u64 idx = ((s_x & kScanValueMask) + before + wex2);  // runs started before this lane's first position
     // A run [s, e) of depth c: at s coverage becomes c > 0; at e it changes again.  With idx = number
     // of runs started before position p: a start at p is run idx, a run ending at p is run idx-1.
+    // At 30x nearly every run starts and ends inside one lane's 16 positions: such a run is
+    // written as ONE 12-byte store; only runs that cross into another lane are written in two
+    // pieces ({start, -, depth} here, `end` by the lane that sees the next change point).
     {
+        typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
         int64_t prev = cov_in;
+        bool pending = false;  // a run started in this lane and not yet closed
+        int32_t rs = 0, rd = 0;
 #pragma unroll
         for (int k = 0; k < kDsPer; ++k) {
             if (d[k] != 0) {
-                const uint64_t p = p0 + k;
-                if (prev > 0 && idx - 1 < out.runs_cap) out.runs[idx - 1].end = (int32_t)p;
+                const int32_t p = (int32_t)(p0 + k);
+                if (prev > 0 && idx - 1 < out.runs_cap) {
+                    if (pending) *reinterpret_cast<i32x3 *>(&out.runs[idx - 1]) = i32x3{rs, p, rd};
+                    else out.runs[idx - 1].end = p;
+                }
+                pending = false;
                 if (cov[k] > 0) {
-                    if (idx < out.runs_cap) {
-                        out.runs[idx].start = (int32_t)p;
-                        out.runs[idx].depth = cov[k];
-                    }
+                    rs = p, rd = cov[k], pending = true;
                     ++idx;
                 }
             }
             prev = cov[k];
+        }
+        if (pending && idx - 1 < out.runs_cap) {
+            out.runs[idx - 1].start = rs;
+            out.runs[idx - 1].depth = rd;
+        }
+    }
+    // ---- window sums (overlap(), bam2depth.c:132-176): sum of coverage per window, clipped at
+    // target_len.  Done last, so that these atomics do not sit in front of the look-back loads in
+    // the wave's vmcnt queue.  A wave covers 1024 consecutive positions: when those touch at most
+    // two windows (W >= 1024, the tool's default is 20000) it reduces both partial sums and issues
+    // at most two atomics; per-lane atomics on one address cost ~4 ms per chr1-sized pass.
+    if (W) {
+        const uint32_t q0 = (uint32_t)p0;                                   // positions are < 2^28
+        const uint32_t wave_lo = (uint32_t)(tile * kDsTile) + (uint32_t)wave_id() * (kWave * kDsPer);
+        const uint32_t wave_hi = (uint32_t)min((uint64_t)wave_lo + kWave * kDsPer, (uint64_t)target_len);
+        if (wave_lo < wave_hi) {
+            const uint32_t w0 = wave_lo / W;                                 // one 32-bit division per lane
+            const uint32_t nb = (w0 + 1) * W;                                // first position of window w0+1
+            if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
+                u64 sa = 0, sb = 0;
+#pragma unroll
+                for (int k = 0; k < kDsPer; ++k) {
+                    const uint32_t p = q0 + k;
+                    const u64 c = p < target_len ? (u64)(uint32_t)cov[k] : 0;
+                    if (p < nb) sa += c;
+                    else sb += c;
+                }
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) sa += __shfl_xor(sa, o, kWave), sb += __shfl_xor(sb, o, kWave);
+                if (lane_id() == 0) {
+                    if (sa) atomicAdd(&out.win_sum[w0], sa);
+                    if (sb) atomicAdd(&out.win_sum[w0 + 1], sb);
+                }
+            } else {  // many small windows under one wave: per-lane segments
+                u64 s = 0;
+                uint32_t w = q0 / W;
+                uint32_t nbl = (w + 1) * W;
+#pragma unroll
+                for (int k = 0; k < kDsPer; ++k) {
+                    const uint32_t p = q0 + k;
+                    if (p >= target_len) break;
+                    if (p == nbl) {
+                        if (s) atomicAdd(&out.win_sum[w], s);
+                        s = 0, ++w, nbl += W;
+                    }
+                    s += (u64)(uint32_t)cov[k];
+                }
+                if (s) atomicAdd(&out.win_sum[w], s);
+            }
         }
     }
     if (tile == (slots - 1) / kDsTile && tid == kDsThreads - 1) *out.n_runs = idx;
@@ -223,6 +251,10 @@ hipError_t launch_depth_scan(const int32_t *diff, uint64_t slots, uint32_t targe
     u64 *n_runs = (u64 *)ws + 1;
     u64 *st_cov = (u64 *)ws + 2, *st_cnt = st_cov + tiles;
     DepthOut out{runs, runs_cap, n_runs, win_sum};
+    if (const char *dbg = getenv("HPN_K4_DEBUG")) {  // timing experiments only: 1 = no run writes, 2 = no window sums
+        if (atoi(dbg) & 1) out.runs_cap = 0;
+        if (atoi(dbg) & 2) W = 0;
+    }
     hipLaunchKernelGGL(k_depth_scan, dim3((unsigned)tiles), dim3(kDsThreads), 0, st, diff, slots, target_len, W, out, st_cov,
                        st_cnt, ticket, ticket + 1);
     return hipGetLastError();
