@@ -5,11 +5,15 @@
 // fastq_trim.c:67-89).  Everything odd it does on odd input (lines longer than
 // the buffer, a missing final newline, CRLF, truncated records) follows from
 // that.  LineSource::gets reproduces zlib's gzgets contract on top of gzread
-// with a large buffer; Framer keeps the same persistent 1024-byte buffer, so the
-// bytes handed to the GPU are exactly the bytes the reference's loop would tally.
+// with a large buffer; the framers keep the same persistent 1024-byte buffer, so
+// the bytes handed to the GPU are exactly the bytes the reference's loop would tally.
+//
+// Batches are fixed-capacity buffers that are allocated once (pinned when the
+// caller passes hpn_host_malloc) and refilled: no growth, no page-fault churn.
 #pragma once
 #include <fcntl.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -34,7 +38,9 @@ inline gzFile open_input_stream(const char *name)
         fd = open(name, O_CREAT | O_RDONLY, 0666);
         if (fd == -1) fprintf(stderr, "Failed to create input file (%s)", name);
     }
-    return gzdopen(fd, "rb");
+    gzFile f = gzdopen(fd, "rb");
+    if (f) gzbuffer(f, 1u << 20);
+    return f;
 }
 
 class LineSource {
@@ -44,7 +50,9 @@ public:
     // zlib gzgets(file, dst, len): copy until len-1 chars or through '\n' or to the
     // end of data; NUL-terminate if anything was copied; NULL (dst untouched) if
     // nothing was.  `past` mirrors what gzeof() reports: a read ran beyond the data.
-    char *gets(char *dst, int len)
+    // *n receives the number of characters copied (strlen of the result unless the
+    // data holds NUL bytes).
+    char *gets(char *dst, int len, size_t *n = nullptr)
     {
         if (len < 1) return nullptr;
         unsigned left = (unsigned)len - 1;
@@ -55,15 +63,16 @@ public:
                 past_ = true;
                 break;
             }
-            size_t n = have_ < left ? have_ : left;
-            const char *nl = (const char *)memchr(cur_, '\n', n);
+            size_t k = have_ < left ? have_ : left;
+            const char *nl = (const char *)memchr(cur_, '\n', k);
             if (nl) {
-                n = (size_t)(nl - cur_) + 1;
+                k = (size_t)(nl - cur_) + 1;
                 eol = true;
             }
-            memcpy(out, cur_, n);
-            out += n, cur_ += n, have_ -= n, left -= (unsigned)n;
+            memcpy(out, cur_, k);
+            out += k, cur_ += k, have_ -= k, left -= (unsigned)k;
         }
+        if (n) *n = (size_t)(out - dst);
         if (out == dst) return nullptr;
         *out = 0;
         return dst;
@@ -91,32 +100,65 @@ private:
 };
 
 // One batch of records as structure of arrays (what hpn_fastq_tally / hpn_fastq_trim take).
+// off[i] is relative to the start of seq / qual; off[0] = 0.
 struct FastqBatch {
-    std::vector<uint8_t> seq, qual;
-    std::vector<uint64_t> off{0};
+    typedef void *(*alloc_fn)(size_t);
+    typedef void (*free_fn)(void *);
+
+    uint8_t *seq = nullptr, *qual = nullptr;
+    uint64_t *off = nullptr;
+    size_t cap_bytes = 0, cap_recs = 0, nbytes = 0, nrec = 0;
     std::vector<std::string> names;  // fastq_trim only
-    uint64_t n() const { return off.size() - 1; }
+    free_fn release = nullptr;
+
+    // room for max_bytes bytes per array (+1 KiB: one more record always fits) and max_recs records
+    bool init(size_t max_bytes, size_t max_recs, bool with_seq, alloc_fn a = malloc, free_fn f = free)
+    {
+        release = f;
+        cap_bytes = max_bytes, cap_recs = max_recs;
+        qual = (uint8_t *)a(max_bytes + kLineBuf);
+        if (with_seq) seq = (uint8_t *)a(max_bytes + kLineBuf);
+        off = (uint64_t *)a((max_recs + 1) * sizeof(uint64_t));
+        if (!qual || !off || (with_seq && !seq)) return false;
+        off[0] = 0;
+        return true;
+    }
+    ~FastqBatch()
+    {
+        if (release) {
+            if (qual) release(qual);
+            if (seq) release(seq);
+            if (off) release(off);
+        }
+    }
+    uint64_t n() const { return nrec; }
+    bool full() const { return nrec >= cap_recs || nbytes >= cap_bytes; }
     void clear()
     {
-        seq.clear(), qual.clear(), names.clear();
-        off.assign(1, 0);
+        nbytes = nrec = 0;
+        names.clear();
+    }
+    void push(size_t len)
+    {
+        nbytes += len;
+        off[++nrec] = nbytes;
     }
 };
 
 // count_read's framing (fastq_count.c:112-119): per record, line 2 gives
 // seqLen = (uint16_t)(strlen - 1) and the first seqLen bytes of whatever the
-// buffer holds after the 4th gzgets are "the quality".  want_seq additionally
-// keeps the first seqLen bytes of the buffer after the 2nd gzgets.
+// buffer holds after the 4th gzgets are "the quality".  With b.seq allocated it
+// additionally keeps the first seqLen bytes of the buffer after the 2nd gzgets.
 class CountFramer {
 public:
     explicit CountFramer(gzFile f) : src_(f) { memset(buf_, 0, sizeof buf_); }
 
-    // Appends up to max_records records / max_bytes bytes; returns false once the
-    // stream is exhausted (the batch may still hold the last records).
+    // Appends records until the batch is full; returns false once the stream is
+    // exhausted (the batch may still hold the last records).
     // *domain_err is set when the reference would index out of its arrays.
-    bool fill(FastqBatch &b, uint64_t max_records, uint64_t max_bytes, bool want_seq, bool *domain_err)
+    bool fill(FastqBatch &b, bool *domain_err)
     {
-        while (b.n() < max_records && b.qual.size() < max_bytes) {
+        while (!b.full()) {
             if (!src_.gets(buf_, kLineBuf)) return false;   // name line; NULL ends the loop (:112)
             src_.gets(buf_, kLineBuf);                      // sequence line (return value ignored, :113)
             const uint16_t len = (uint16_t)(strlen(buf_) - 1);  // :114, including the uint16 wrap
@@ -124,11 +166,11 @@ public:
                 *domain_err = true;
                 return false;
             }
-            if (want_seq) b.seq.insert(b.seq.end(), (uint8_t *)buf_, (uint8_t *)buf_ + len);
+            if (b.seq) memcpy(b.seq + b.nbytes, buf_, len);
             src_.gets(buf_, kLineBuf);                      // '+' line
             src_.gets(buf_, kLineBuf);                      // quality line
-            b.qual.insert(b.qual.end(), (uint8_t *)buf_, (uint8_t *)buf_ + len);
-            b.off.push_back(b.off.back() + len);
+            memcpy(b.qual + b.nbytes, buf_, len);
+            b.push(len);
         }
         return true;
     }
@@ -145,10 +187,10 @@ class TrimFramer {
 public:
     explicit TrimFramer(gzFile f) : src_(f) {}
 
-    bool fill(FastqBatch &b, uint64_t max_records, uint64_t max_bytes)
+    bool fill(FastqBatch &b)
     {
         char buf[kLineBuf];
-        while (b.n() < max_records && b.seq.size() < max_bytes) {
+        while (!b.full()) {
             memset(buf, 0, sizeof buf);                     // :97
             char *p = src_.gets(buf, kLineBuf);
             if (src_.eof() || !p) return false;             // :69-70
@@ -157,7 +199,7 @@ public:
             src_.gets(buf, kLineBuf);
             chop(buf);
             const size_t ls = strlen(buf);
-            b.seq.insert(b.seq.end(), (uint8_t *)buf, (uint8_t *)buf + ls);
+            memcpy(b.seq + b.nbytes, buf, ls);
             src_.gets(buf, kLineBuf);
             src_.gets(buf, kLineBuf);
             chop(buf);
@@ -166,10 +208,10 @@ public:
             // length the shorter is NUL-padded to the longer and the writer prints
             // each cut as a C string, which gives the same bytes.
             const size_t lq = strlen(buf), lr = ls > lq ? ls : lq;
-            b.seq.insert(b.seq.end(), lr - ls, (uint8_t)0);
-            b.qual.insert(b.qual.end(), (uint8_t *)buf, (uint8_t *)buf + lq);
-            b.qual.insert(b.qual.end(), lr - lq, (uint8_t)0);
-            b.off.push_back(b.off.back() + lr);
+            memset(b.seq + b.nbytes + ls, 0, lr - ls);
+            memcpy(b.qual + b.nbytes, buf, lq);
+            memset(b.qual + b.nbytes + lq, 0, lr - lq);
+            b.push(lr);
         }
         return true;
     }

@@ -13,8 +13,8 @@
 #include <mutex>
 #include <thread>
 
-#include "../host/fastq_reader.hpp"
 #include "../host/report.hpp"
+#include "../host/tally_stream.hpp"
 
 using namespace hpn;
 
@@ -49,21 +49,13 @@ static void count_file(const char *infile, FILE *out, int slot)
     gzFile fq = open_input_stream(infile);
     hpn_tally acc;
     memset(&acc, 0, sizeof acc);
-    {
-        CountFramer framer(fq);
-        FastqBatch batch;
-        bool more = true, bad = false;
-        while (more) {
-            batch.clear();
-            more = framer.fill(batch, 8u << 20, 1ull << 30, false, &bad);
-            if (bad) {
-                fprintf(stderr, "%s: read longer than 511 bases (outside fastq_count's SeqLen[512])\n", infile);
-                exit(2);
-            }
-            rc = hpn_fastq_tally(ctx, batch.qual.data(), nullptr, batch.off.data(), batch.n(), &acc);
-            if (rc != HPN_OK) die_hpn(ctx, rc, infile);
-        }
+    bool too_long = false;
+    rc = tally_stream(ctx, fq, &acc, &too_long);  // count_read's loop (:112-119), tally on the GPU
+    if (too_long) {
+        fprintf(stderr, "%s: read longer than 511 bases (outside fastq_count's SeqLen[512])\n", infile);
+        exit(2);
     }
+    if (rc != HPN_OK) die_hpn(ctx, rc, infile);
     gzclose(fq);
     const CountSummary s = summarise(acc);
     {

@@ -15,8 +15,8 @@
 #include <atomic>
 #include <thread>
 
-#include "../host/fastq_reader.hpp"
 #include "../host/report.hpp"
+#include "../host/tally_stream.hpp"
 
 using namespace hpn;
 
@@ -55,21 +55,13 @@ static void count_file(FileAcc &fa, const char *infile, int tid)
     int rc = hpn_ctx_create(g_dev0 + tid % g_ndev, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
     gzFile fq = open_input_stream(infile);
-    {
-        CountFramer framer(fq);
-        FastqBatch batch;
-        bool more = true, bad = false;
-        while (more) {
-            batch.clear();
-            more = framer.fill(batch, 8u << 20, 1ull << 30, false, &bad);
-            if (bad) {
-                fprintf(stderr, "%s: read longer than 511 bases (outside SeqLen[512])\n", infile);
-                exit(2);
-            }
-            rc = hpn_fastq_tally(ctx, batch.qual.data(), nullptr, batch.off.data(), batch.n(), &fa.t);
-            if (rc != HPN_OK) die_hpn(ctx, rc, infile);
-        }
+    bool too_long = false;
+    rc = tally_stream(ctx, fq, &fa.t, &too_long);  // count_read's loop (:126-135), tally on the GPU
+    if (too_long) {
+        fprintf(stderr, "%s: read longer than 511 bases (outside SeqLen[512])\n", infile);
+        exit(2);
     }
+    if (rc != HPN_OK) die_hpn(ctx, rc, infile);
     gzclose(fq);
     hpn_ctx_destroy(ctx);
     fa.s = summarise(fa.t);

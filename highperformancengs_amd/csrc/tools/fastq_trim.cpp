@@ -63,17 +63,17 @@ int main(int argc, char *argv[])
     {
         TrimFramer framer(in);
         FastqBatch b;
-        std::vector<uint8_t> oseq, oqual;
-        std::vector<uint64_t> ooff;
+        const size_t kBytes = 64u << 20, kRecs = 1u << 20;
+        if (!b.init(kBytes, kRecs, true)) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
+        std::vector<uint8_t> oseq(kBytes + kLineBuf), oqual(kBytes + kLineBuf);
+        std::vector<uint64_t> ooff(kRecs + 1);
         bool more = true;
         while (more) {
             b.clear();
-            more = framer.fill(b, 4u << 20, 512ull << 20);
+            more = framer.fill(b);
             const uint64_t n = b.n();
             if (!n) continue;
-            oseq.resize(b.seq.size() + 1), oqual.resize(b.qual.size() + 1), ooff.resize(n + 1);
-            rc = hpn_fastq_trim(ctx, b.seq.data(), b.qual.data(), b.off.data(), n, start, end, oseq.data(), oqual.data(),
-                                ooff.data());
+            rc = hpn_fastq_trim(ctx, b.seq, b.qual, b.off, n, start, end, oseq.data(), oqual.data(), ooff.data());
             if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_trim");
             for (uint64_t i = 0; i < n; ++i) {  // fprintf("%s\n%s\n+\n%s\n") (:101): each cut ends at its first NUL
                 const uint64_t a = ooff[i], len = ooff[i + 1] - a;

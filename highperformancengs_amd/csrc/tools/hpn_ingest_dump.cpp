@@ -28,24 +28,33 @@ int main(int argc, char **argv)
     const std::string mode = argv[1];
     if (mode == "count" || mode == "trim") {
         gzFile f = open_input_stream(argv[2]);
+        // small batches on purpose: the dump is the concatenation of many refills
         FastqBatch b;
-        bool bad = false;
-        if (mode == "count") {
-            CountFramer fr(f);
-            while (fr.fill(b, ~0ull, ~0ull, true, &bad)) {}
-        } else {
-            TrimFramer fr(f);
-            while (fr.fill(b, ~0ull, ~0ull)) {}
+        if (!b.init(1u << 16, 1u << 10, true)) return 4;
+        std::vector<uint64_t> off{0};
+        std::vector<uint8_t> seq, qual;
+        std::vector<std::string> names;
+        bool bad = false, more = true;
+        CountFramer cf(f);
+        TrimFramer tf(f);
+        while (more) {
+            b.clear();
+            more = mode == "count" ? cf.fill(b, &bad) : tf.fill(b);
+            if (bad) return 3;
+            const uint64_t base = off.back();
+            for (uint64_t i = 0; i < b.n(); ++i) off.push_back(base + b.off[i + 1]);
+            seq.insert(seq.end(), b.seq, b.seq + b.nbytes);
+            qual.insert(qual.end(), b.qual, b.qual + b.nbytes);
+            names.insert(names.end(), b.names.begin(), b.names.end());
         }
         gzclose(f);
-        if (bad) return 3;
-        const uint64_t n = b.n();
+        const uint64_t n = off.size() - 1;
         fwrite(&n, 8, 1, stdout);
-        put(b.off);
-        if (mode == "count") put(b.qual), put(b.seq);
+        put(off);
+        if (mode == "count") put(qual), put(seq);
         else {
-            put(b.seq), put(b.qual);
-            for (auto &s : b.names) fwrite(s.c_str(), 1, s.size() + 1, stdout);
+            put(seq), put(qual);
+            for (auto &s : names) fwrite(s.c_str(), 1, s.size() + 1, stdout);
         }
         return 0;
     }
