@@ -21,6 +21,8 @@ __device__ uint32_t pattern(int mode, uint32_t tid, int k, uint32_t &x)
     case 5: return q * 257 + (k % 150) / 2;          // every lane at the same cycle (read-per-lane mapping)
     case 6: return p2 * 128 + q;                     // cycle-major
     case 7: return q * 257 + ((lane + k * 64) % 150) / 2;  // byte-interleaved lanes (lane = consecutive bytes)
+    case 8: return q * 256 + ((tid + k * 1024) % 150);     // u32 counters, row stride 256: bank = cycle % 32, lanes = consecutive cycles
+    case 9: return q * 288 + ((tid + k * 1024) % 150);     // same, rows of 288 words (cycles < 288)
     default: return 0;
     }
 }
@@ -85,5 +87,7 @@ int main()
     run<5>("random q, all lanes at the same cycle");
     run<6>("cycle-major [p2][128]");
     run<7>("byte-interleaved lanes");
+    run<8>("u32 counters, stride 256, lanes = consecutive cycles");
+    run<9>("u32 counters, stride 288, lanes = consecutive cycles");
     return 0;
 }
