@@ -35,7 +35,7 @@
 namespace hpn {
 
 constexpr int kHistThreads = 1024;
-constexpr int kHistRecs = 1024;                  // records per chunk (= threads: one tail per lane)
+constexpr int kHistRecs = 4096;                  // records per chunk: 600 KB at 150 bp between barriers
 constexpr int kRound = 4;                        // vectors per lane per round
 constexpr int kRowWords = HPN_LEN_BINS / 2 + 1;  // 256 dwords of packed u16 pairs + 1 pad
 constexpr uint32_t kFlushReads = 65535;          // a counter gets at most one hit per read
@@ -137,8 +137,10 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
     auto fetch = [&](u32 (&vec)[kRound], uint32_t (&half)[kRound]) {
 #pragma unroll
         for (int m = 0; m < kRound; ++m) {
+            // no branch around the load (an idle lane re-reads the chunk's first bytes): the
+            // compiler then counts the loads in flight (vmcnt(4)) instead of draining them all
             const bool on = w < items;
-            vec[m] = on ? load_unaligned16(addr(r, v)) : u32{0, 0, 0, 0};
+            vec[m] = load_unaligned16(on ? addr(r, v) : p0);
             half[m] = on ? 8u * v : ~0u;
             step();
         }
@@ -163,19 +165,22 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
     }
     // tails: the last len0 % 16 bytes of every read, one lane per read
     const uint32_t rem = len0 & 15u;
-    if (rem && threadIdx.x < cnt) {
-        const uint8_t *q = addr(threadIdx.x, nvr);
+    if (rem) {
 #pragma unroll 1
-        for (uint32_t k = 0; k < rem; ++k) {
-            const uint32_t byte = q[k];
-            if (kQual) {
-                if (byte >= HPN_QUAL_ROWS) {
-                    t.bad = 1;
-                    continue;
+        for (uint32_t rr = threadIdx.x; rr < cnt; rr += kHistThreads) {
+            const uint8_t *q = addr(rr, nvr);
+#pragma unroll 1
+            for (uint32_t k = 0; k < rem; ++k) {
+                const uint32_t byte = q[k];
+                if (kQual) {
+                    if (byte >= HPN_QUAL_ROWS) {
+                        t.bad = 1;
+                        continue;
+                    }
+                    t.c20 += byte >= 53, t.c30 += byte >= 63;
                 }
-                t.c20 += byte >= 53, t.c30 += byte >= 63;
+                bump<kQual>(hist, byte, 16u * nvr + k);
             }
-            bump<kQual>(hist, byte, 16u * nvr + k);
         }
     }
 }
@@ -269,17 +274,21 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
         }
         __syncthreads();
         const uint32_t len0 = s.loff[1];
-        const bool valid = (uint32_t)tid < cnt;
-        uint32_t len = 0;
-        if (valid) {
-            len = s.loff[tid + 1] - s.loff[tid];
-            if (len >= HPN_LEN_BINS) len = HPN_LEN_BINS, t.bad = 1;
+        bool all_same = true;
+        for (uint32_t i = tid; i < (uint32_t)kHistRecs; i += kHistThreads) {  // same trip count in every lane (ballots inside)
+            const bool valid = i < cnt;
+            uint32_t len = 0;
+            if (valid) {
+                len = s.loff[i + 1] - s.loff[i];
+                if (len >= HPN_LEN_BINS) len = HPN_LEN_BINS, t.bad = 1;
+                all_same = all_same && len == len0;
+            }
+            hist_len(s.lhist, valid, len);
         }
-        hist_len(s.lhist, valid, len);
         // an over-long record poisons position tracking: stop tallying bytes, the batch
         // is rejected as a whole (HPN_E_DOMAIN) once `bad` is seen
         if (!__syncthreads_or((int)t.bad)) {
-            const bool uniform = __syncthreads_and((int)(!valid || len == len0)) && len0 >= 16;
+            const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16;
             if (tid == 0) bytes += s.loff[cnt];
             if (uniform) {
                 if (kQualHist) stream_uniform<true>(s, qual, base_off, cnt, len0, t);
