@@ -125,6 +125,58 @@ inline void print_wig_bins(FILE *out, const char *chr, uint32_t target_len, uint
         if (win_sum[k]) fprintf(out, "%d\t%.2f\n", (int)(W * k), (double)win_sum[k] / W);
 }
 
+// ---- bam2wig -----------------------------------------------------------------------------------
+
+// bam2wig's window bins.  Its overlap() (bam2wig.c:131-175) closes windows at (k+1)W-1
+// INCLUSIVE and carries its window cursor from one run to the next, so a run that ends on
+// a window's last base moves the cursor past a window the next run may still start in.
+// The bins are therefore not a per-window sum of coverage; they are reproduced by feeding
+// the runs (ascending, as the device scan emits them) through the same cursor.
+// bins: target_len / W + 2 doubles (the reference may touch one past its own array).
+inline void wig_bins_from_runs(const hpn_run *runs, uint64_t n_runs, uint32_t target_len, uint32_t W, double *bins)
+{
+    const int windows = (int)(target_len / W + 1);
+    for (int k = 0; k <= windows; ++k) bins[k] = 0.0;
+    int cur = 0, hit = 0;  // window cursor; windows the previous run added to
+    for (uint64_t i = 0; i < n_runs; ++i) {
+        const uint32_t rs = (uint32_t)runs[i].start, re = (uint32_t)runs[i].end;
+        const double depth = (double)runs[i].depth;
+        if (hit > 1) cur = cur - hit >= 0 ? cur - hit : 0;
+        hit = 0;
+        for (; cur <= windows;) {
+            const uint32_t lo = W * (uint32_t)cur;
+            uint32_t hi = ((uint32_t)cur + 1) * W - 1;
+            if (hi > target_len) hi = target_len;
+            if (re < lo) break;
+            if (rs < lo) {          // run began in an earlier window
+                ++hit;
+                if (re < hi) {
+                    bins[cur] += (re - lo) * depth;
+                    break;
+                }
+                bins[cur++] += (hi - lo + 1) * depth;
+            } else if (rs <= hi) {  // run begins in this window
+                ++hit;
+                if (re <= hi) {
+                    bins[cur] += (re - rs) * depth;
+                    break;
+                }
+                bins[cur++] += (hi - rs) * depth;
+            } else {
+                ++cur;
+            }
+        }
+    }
+}
+
+inline void print_wig_bins_d(FILE *out, const char *chr, uint32_t target_len, uint32_t W, const double *bins)
+{   // bam2wig.c output_bins_wig (:245-252): same text as bam2depth's wig writer
+    const uint32_t windows = target_len / W + 1;
+    fprintf(out, "variableStep chrom=%s span=%d\n", chr, (int)W);
+    for (uint32_t k = 0; k < windows; ++k)
+        if (bins[k]) fprintf(out, "%d\t%.2f\n", (int)(W * k), bins[k] / W);
+}
+
 // ---- bam_sliding_count ---------------------------------------------------------------------
 
 // calc_winGC + output_count_GC (bam_sliding_count.c:126-164).  The reference keeps GC[k]

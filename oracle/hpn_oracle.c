@@ -477,6 +477,45 @@ int orc_fmt_wig_bins(FILE *out, const char *chr, uint32_t target_len, uint32_t W
     return ORC_OK;
 }
 
+/* bam2wig.c:131-175, called once per emitted run in ascending order (:213-231). */
+void orc_wig_bins(const orc_run *runs, uint64_t n_runs, uint32_t target_len, uint32_t W, double *bins)
+{
+    const int windows = (int)(target_len / W + 1);
+    for (int k = 0; k <= windows; ++k) bins[k] = 0.0;
+    int j = 0, touched = 0; /* j, subject_count of hash2BedGraph */
+    for (uint64_t i = 0; i < n_runs; ++i) {
+        const uint32_t s = (uint32_t)runs[i].start, e = (uint32_t)runs[i].end;
+        const double d = (double)runs[i].depth;
+        if (touched > 1) j = (j - touched >= 0) ? j - touched : 0; /* step back over the windows of the previous run */
+        touched = 0;
+        while (j <= windows) {
+            const uint32_t ws = W * (uint32_t)j;
+            uint32_t we = ((uint32_t)j + 1) * W - 1; /* inclusive end */
+            if (we > target_len) we = target_len;
+            if (e < ws) break;
+            if (s < ws) {
+                if (e < we) {
+                    bins[j] += (e - ws) * d;
+                    touched++;
+                    break;
+                }
+                bins[j++] += (we - ws + 1) * d;
+                touched++;
+            } else if (s <= we) {
+                if (e <= we) {
+                    bins[j] += (e - s) * d;
+                    touched++;
+                    break;
+                }
+                bins[j++] += (we - s) * d;
+                touched++;
+            } else {
+                j++;
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* bam_sliding_count                                                         */
 /* ------------------------------------------------------------------------- */

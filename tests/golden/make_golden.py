@@ -212,6 +212,12 @@ def main():
     run_case("depth_rand", "bam2depth", ["-o", "r", "rand.bam"], [bm("rand.bam")])
     run_case("depth_rand_w1000", "bam2depth", ["-w", "1000", "-W", "-o", "r", "rand.bam"], [bm("rand.bam")])
     run_case("depth_two_files", "bam2depth", ["-w", "500", "-o", "two", "e.bam", "rand.bam"], [bm("e.bam"), bm("rand.bam")])
+    # ---- bam2wig -----------------------------------------------------------
+    run_case("wig_a3", "bam2wig", ["-w", "100", "-o", "w", "e.bam"], [bm("e.bam")])
+    run_case("wig_a3_w7", "bam2wig", ["-w", "7", "-o", "w", "e.bam"], [bm("e.bam")])
+    run_case("wig_rand", "bam2wig", ["-o", "w", "rand.bam"], [bm("rand.bam")])
+    run_case("wig_rand_w1000", "bam2wig", ["-w", "1000", "-o", "w", "rand.bam"], [bm("rand.bam")])
+    run_case("wig_rand_w37", "bam2wig", ["-w", "37", "-o", "w", "e.bam", "rand.bam"], [bm("e.bam"), bm("rand.bam")])
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "reference_tools": "oracle/_ref (compiled from /root/reference by oracle/Makefile)",

@@ -74,6 +74,7 @@ def lib():
     L.orc_depth_target.argtypes = [i32p, i32p, u32p, u32p, u32p, C.c_uint64, C.c_int32, C.c_uint32,
                                    C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(Run)),
                                    C.POINTER(C.c_uint64), f64p]
+    L.orc_wig_bins.argtypes = [C.POINTER(Run), C.c_uint64, C.c_uint32, C.c_uint32, f64p]
     L.orc_window_add.argtypes = [i32p, i32p, u32p, i32p, u64p, u8p, C.c_uint64, C.c_uint32, C.c_int32,
                                  u64p, u32p, u64p, u32p, u8p, C.POINTER(C.c_uint64)]
     L.orc_window_gc_f32.argtypes = [i32p, i32p, u32p, i32p, u64p, u8p, C.c_uint64, C.c_uint32,
@@ -260,6 +261,34 @@ def bam2depth_text(soa, W, wig=False, flag_mask=0x704):
         chrom += b"%s\t%d\n" % (name.encode(), tlen)
         L._libc.free(C.cast(runs, C.c_void_p))
     return fb.read(), fd.read(), fw.read(), chrom
+
+
+def bam2wig_text(soa, W):
+    """(wig, chromSize) text of bam2wig for one BAM: filter BAM_FUNMAP only, inclusive-end overlap replay."""
+    L = lib()
+    fw = _CFile()
+    chrom = b""
+    for tid, (name, tlen) in enumerate(soa.refs):
+        dummy = np.zeros(tlen // W + 1, np.float64)
+        runs, nr = C.POINTER(Run)(), C.c_uint64(0)
+        rc = L.orc_depth_target(soa.tid, soa.pos, soa.flag, soa.cigar_off, soa.cigar, len(soa.tid), tid, tlen, W, 0x4,
+                                C.byref(runs), C.byref(nr), dummy)
+        assert rc == 0, rc
+        bins = np.zeros(tlen // W + 2, np.float64)
+        L.orc_wig_bins(runs, nr, tlen, W, bins)
+        L.orc_fmt_wig_bins(fw.fp, name.encode(), tlen, W, bins)
+        chrom += b"%s\t%d\n" % (name.encode(), tlen)
+        L._libc.free(C.cast(runs, C.c_void_p))
+    return fw.read(), chrom
+
+
+def wig_bins_from_runs(runs, tlen, W):
+    """bam2wig's bins (float64[tlen//W+1]) from an (n,3) int32 run array."""
+    L = lib()
+    arr = (Run * len(runs))(*[Run(int(a), int(b), int(c)) for a, b, c in runs])
+    bins = np.zeros(tlen // W + 2, np.float64)
+    L.orc_wig_bins(arr, len(runs), tlen, W, bins)
+    return bins[:tlen // W + 1]
 
 
 def window_offsets(refs, W):

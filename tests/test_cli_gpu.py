@@ -19,7 +19,8 @@ CASES = ["count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "
          "count_syn_100", "count_to_file", "kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty",
          "trim_a1", "trim_a1_default", "trim_a1_file", "trim_nonl", "trim_short", "trim_crlf", "trim_syn_var",
          "trim_syn_100", "trim_multi", "trim_empty",
-         "depth_a3", "depth_a3_wig", "depth_a3_stdout", "depth_rand", "depth_rand_w1000", "depth_two_files"]
+         "depth_a3", "depth_a3_wig", "depth_a3_stdout", "depth_rand", "depth_rand_w1000", "depth_two_files",
+         "wig_a3", "wig_a3_w7", "wig_rand", "wig_rand_w1000", "wig_rand_w37"]
 
 
 def _run(tool, args, inputs, cwd):

@@ -84,7 +84,8 @@ def test_bam_decoder_equals_python_decoder(bam):
     assert np.array_equal(np.frombuffer(raw, np.uint8, len(soa.seq4), p), soa.seq4)
 
 
-@pytest.mark.parametrize("tool", ["fastq_count", "fastq_count_kthread", "fastq_trim", "bam2depth", "bam_sliding_count"])
+@pytest.mark.parametrize("tool", ["fastq_count", "fastq_count_kthread", "fastq_trim", "bam2depth", "bam2wig",
+                                  "bam_sliding_count"])
 def test_tools_exist_and_print_usage(tool):
     p = subprocess.run([os.path.join(BIN, tool), "-h"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"Usage:" in p.stderr and p.stdout == b""

@@ -178,6 +178,18 @@ def test_bam2depth_stdout_and_second_file(manifest):
     assert depth == expected("depth_two_files", "two.2.depth")
 
 
+# ---- bam2wig ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case,bam,W,n", [("wig_a3", "e.bam", 100, 1), ("wig_a3_w7", "e.bam", 7, 1),
+                                          ("wig_rand", "rand.bam", 20000, 1), ("wig_rand_w1000", "rand.bam", 1000, 1),
+                                          ("wig_rand_w37", "e.bam", 37, 1), ("wig_rand_w37", "rand.bam", 37, 2)])
+def test_bam2wig_text(case, bam, W, n):
+    soa = bamio.read_bam_records(BAM(bam))
+    wig, chrom = orc.bam2wig_text(soa, W)
+    assert wig == expected(case, f"w.{n}.wig")
+    assert chrom == expected(case, f"w.{n}.chromSize.txt")
+
+
 # ---- bam_sliding_count ------------------------------------------------------------
 # The reference tool needs libgd headers (gd.h, gdfontg.h) that this image lacks,
 # so it cannot be compiled here; the only pin is SURVEY.md Appendix A.3.
