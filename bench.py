@@ -55,10 +55,13 @@ def cpu_baseline(read_len, target_s):
     L.orc_counts_free.argtypes = [C.c_void_p]
     L.orc_count_files_threaded.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
     cores = os.cpu_count() or 1
-    per_shard = 250_000
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "fastq_count_kthread")
     kind = "reference" if os.access(ref_bin, os.X_OK) else "port"
     td = tempfile.mkdtemp(prefix="hpn_cpu_")
+    # one plain-text shard per core (the reference parallelises per file), bounded to 8 GB
+    # and to a quarter of the free space of the temp directory
+    budget = min(8 << 30, shutil.disk_usage(td).free // 4)
+    per_shard = int(max(10_000, min(250_000, budget // (cores * (2 * read_len + 16)))))
     try:
         paths = [os.path.join(td, f"shard{i}.fq") for i in range(cores)]
         with ThreadPoolExecutor(cores) as ex:  # the C writer releases the GIL
@@ -217,7 +220,11 @@ def main():
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(L, a.cpu_seconds)
+            try:
+                line["cpu_baseline"] = cpu_baseline(L, a.cpu_seconds)
+            except Exception as e:  # noqa: BLE001  (a reported baseline must not take the GPU line down)
+                line["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "hpn_ctx.hpp"
 
 using namespace hpn;
@@ -32,23 +34,30 @@ struct Rccl {
     bool ok = false;
 };
 
+void rccl_load(Rccl &r);
+
 Rccl &rccl()
 {
     static Rccl r;
-    if (r.h) return r;
+    static std::once_flag once;  // contexts of several host threads may initialise concurrently
+    std::call_once(once, [] { rccl_load(r); });
+    return r;
+}
+
+void rccl_load(Rccl &r)
+{
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
         r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (r.h) break;
     }
-    if (!r.h) return r;
+    if (!r.h) return;
     r.GetUniqueId = (int (*)(ncclUniqueId *))dlsym(r.h, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(r.h, "ncclCommInitRank");
     r.CommDestroy = (int (*)(ncclComm_t))dlsym(r.h, "ncclCommDestroy");
     r.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))dlsym(r.h, "ncclAllReduce");
     r.GetErrorString = (const char *(*)(int))dlsym(r.h, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
-    return r;
 }
 
 }  // namespace
