@@ -65,6 +65,10 @@ SYMBOLS = [
     ("hpn_fastq_tally_devptr", _int, [_vp, C.POINTER(_vp)]),
     ("hpn_fastq_trim", _int, [_vp, _vp, _vp, _vp, _u64, _i32, _i32, _vp, _vp, _vp]),
     ("hpn_fastq_trim_dev", _int, [_vp, _vp, _vp, _vp, _u64, _i32, _i32, _vp, _vp, _vp]),
+    ("hpn_fastq_qtrim_points", _int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
+    ("hpn_fastq_qtrim_points_dev", _int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
+    ("hpn_fastq_trim_points", _int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    ("hpn_fastq_trim_points_dev", _int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("hpn_depth_begin", _int, [_vp, _i32, _u32, _u32]),
     ("hpn_depth_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_add_dev", _int, [_vp, C.POINTER(BamBatch)]),

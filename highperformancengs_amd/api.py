@@ -137,6 +137,29 @@ class Context:
         self._ck(self.L.hpn_fastq_trim_dev(self.h, _ptr(d_seq), _ptr(d_qual), _ptr(d_off), n, S, E, _ptr(d_out_seq),
                                            _ptr(d_out_qual), _ptr(d_out_off)), "hpn_fastq_trim_dev")
 
+    # ---- extension: quality-threshold trim points --------------------------
+    def fastq_qtrim_points(self, qual, off, threshold):
+        qual = np.ascontiguousarray(qual, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        beg, end = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        self._ck(self.L.hpn_fastq_qtrim_points(self.h, _ptr(qual), _ptr(off), n, threshold, _ptr(beg), _ptr(end)),
+                 "hpn_fastq_qtrim_points")
+        return beg[:n], end[:n]
+
+    def fastq_trim_points(self, seq, qual, off, beg, end):
+        seq = np.ascontiguousarray(seq, np.uint8)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        beg, end = np.ascontiguousarray(beg, np.uint32), np.ascontiguousarray(end, np.uint32)
+        n = len(off) - 1
+        cap = max(int(off[-1] - off[0]), 1)
+        oseq, oqual, ooff = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(n + 1, np.uint64)
+        self._ck(self.L.hpn_fastq_trim_points(self.h, _ptr(seq), _ptr(qual), _ptr(off), n, _ptr(beg), _ptr(end),
+                                              _ptr(oseq), _ptr(oqual), _ptr(ooff)), "hpn_fastq_trim_points")
+        tot = int(ooff[-1])
+        return oseq[:tot], oqual[:tot], ooff
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

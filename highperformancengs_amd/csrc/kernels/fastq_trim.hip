@@ -20,11 +20,14 @@ constexpr int kTrimTile = kTrimThreads * kTrimPerThread;
 
 __device__ __forceinline__ uint64_t cut_len(uint64_t len, uint64_t S, uint64_t E)
 {
-    return (E < len ? E : len) - (S < len ? S : len);
+    const uint64_t b = S < len ? S : len, e = E < len ? E : len;
+    return e > b ? e - b : 0;
 }
 
 __global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__restrict__ off, uint64_t n,
                                                            uint64_t S, uint64_t E,
+                                                           const uint32_t *__restrict__ pbeg,
+                                                           const uint32_t *__restrict__ pend,
                                                            uint64_t *__restrict__ out_off,
                                                            u64 *__restrict__ status,
                                                            uint32_t *__restrict__ ticket,
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__re
     u64 mine = 0;
 #pragma unroll
     for (int k = 0; k < kTrimPerThread; ++k) {
-        nl[k] = base + k < n ? cut_len(o[k + 1] - o[k], S, E) : 0;
+        // fixed cycles [S,E) of fastq_trim, or this record's own points (quality-threshold trim)
+        nl[k] = base + k < n ? cut_len(o[k + 1] - o[k], pbeg ? pbeg[base + k] : S, pend ? pend[base + k] : E) : 0;
         mine += nl[k];
     }
     u64 wtotal;
@@ -78,6 +82,8 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__res
                                                            const uint64_t *__restrict__ off,
                                                            const uint64_t *__restrict__ out_off, uint64_t n,
                                                            uint64_t S, uint64_t E,
+                                                           const uint32_t *__restrict__ pbeg,
+                                                           const uint32_t *__restrict__ pend,
                                                            uint8_t *__restrict__ out_seq,
                                                            uint8_t *__restrict__ out_qual)
 {
@@ -86,14 +92,17 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__res
     const int lane = lane_id();
     for (uint64_t r0 = wave * kWave; r0 < n; r0 += nwaves * kWave) {
         const uint64_t r = r0 + lane;
-        uint64_t a = 0, len = 0, d = 0;
+        uint64_t a = 0, len = 0, d = 0, Sr = S, Er = E;
         if (r < n) {
             a = off[r];
             len = off[r + 1] - a;
             d = out_off[r];
+            if (pbeg) Sr = pbeg[r];
+            if (pend) Er = pend[r];
         }
-        const uint64_t b = S < len ? S : len;
-        const uint32_t cnt = (uint32_t)((E < len ? E : len) - b);
+        const uint64_t b = Sr < len ? Sr : len;
+        const uint64_t e = Er < len ? Er : len;
+        const uint32_t cnt = e > b ? (uint32_t)(e - b) : 0u;
         const uint64_t src = a + b;
         // Four records per wave-instruction: the 16 lanes of quarter g serve record
         // 4*it + g, 16 bytes per lane through unaligned dwordx4 accesses.  A span that is
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__res
 }
 
 hipError_t launch_trim(const uint8_t *d_seq, const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t S,
-                       uint64_t E, uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off, u64 *d_status,
+                       uint64_t E, const uint32_t *d_beg, const uint32_t *d_end, uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off, u64 *d_status,
                        uint32_t *d_ticket_err, int n_cu, hipStream_t st)
 {
     const uint64_t ntile = n / kTrimTile + 1;
@@ -131,14 +140,67 @@ hipError_t launch_trim(const uint8_t *d_seq, const uint8_t *d_qual, const uint64
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trim_scan, dim3((unsigned)ntile), dim3(kTrimThreads), 0, st, d_off, n, S, E, d_out_off, d_status,
+    hipLaunchKernelGGL(k_trim_scan, dim3((unsigned)ntile), dim3(kTrimThreads), 0, st, d_off, n, S, E, d_beg, d_end, d_out_off, d_status,
                        d_ticket_err, d_ticket_err + 1);
     if (n) {
         uint64_t want = (n + kTrimThreads - 1) / kTrimThreads;
         const uint64_t cap = (uint64_t)n_cu * 8;
         hipLaunchKernelGGL(k_trim_copy, dim3((unsigned)(want < cap ? want : cap)), dim3(kTrimThreads), 0, st, d_seq,
-                           d_qual, d_off, d_out_off, n, S, E, d_out_seq, d_out_qual);
+                           d_qual, d_off, d_out_off, n, S, E, d_beg, d_end, d_out_seq, d_out_qual);
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// EXTENSION (no reference counterpart): quality-threshold trim points.
+// Per record: beg = index of the first quality byte >= T, end = 1 + index of the last
+// one (beg = end = 0 when there is none).  One wave per record: 64 bytes per step, one
+// ballot, first / last set bit by ffs / clz.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kTrimThreads) void k_qtrim_points(const uint8_t *__restrict__ qual,
+                                                              const uint64_t *__restrict__ off, uint64_t n,
+                                                              uint32_t T, uint32_t *__restrict__ out_beg,
+                                                              uint32_t *__restrict__ out_end)
+{
+    const uint64_t nwaves = (uint64_t)gridDim.x * (kTrimThreads / kWave);
+    const uint64_t wave = (uint64_t)blockIdx.x * (kTrimThreads / kWave) + wave_id();
+    const int lane = lane_id();
+    for (uint64_t r0 = wave * kWave; r0 < n; r0 += nwaves * kWave) {
+        // the wave owns 64 records: boundaries by one coalesced read, then record by record
+        const uint64_t r = r0 + lane;
+        uint64_t a = 0, len = 0;
+        if (r < n) {
+            a = off[r];
+            len = off[r + 1] - a;
+        }
+        uint32_t my_beg = 0, my_end = 0;
+        const int m = (int)min((uint64_t)kWave, n - r0);
+        for (int j = 0; j < m; ++j) {
+            const uint64_t aj = __shfl(a, j, kWave), lj = __shfl(len, j, kWave);
+            uint32_t first = 0xffffffffu, last = 0;
+            for (uint64_t base = 0; base < lj; base += kWave) {
+                const uint64_t i = base + lane;
+                const uint32_t q = i < lj ? qual[aj + i] : 0u;
+                const u64 hit = __ballot(i < lj && q >= T);
+                if (hit) {
+                    if (first == 0xffffffffu) first = (uint32_t)base + (uint32_t)__builtin_ctzll(hit);
+                    last = (uint32_t)base + 64u - (uint32_t)__builtin_clzll(hit);
+                }
+            }
+            if (lane == j) my_beg = first == 0xffffffffu ? 0u : first, my_end = last;
+        }
+        if (r < n) out_beg[r] = my_beg, out_end[r] = my_end;
+    }
+}
+
+hipError_t launch_qtrim_points(const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint32_t T, uint32_t *d_beg,
+                               uint32_t *d_end, int n_cu, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t want = (n + kTrimThreads - 1) / kTrimThreads;
+    const uint64_t cap = (uint64_t)n_cu * 8;
+    hipLaunchKernelGGL(k_qtrim_points, dim3((unsigned)(want < cap ? want : cap)), dim3(kTrimThreads), 0, st, d_qual, d_off, n,
+                       T, d_beg, d_end);
     return hipGetLastError();
 }
 

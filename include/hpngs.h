@@ -128,6 +128,25 @@ int hpn_fastq_trim_dev(hpn_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual
                        const uint64_t *d_off, uint64_t n_records, int32_t S, int32_t E,
                        uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off);
 
+/* ---- EXTENSION: quality-threshold trim points ----------------------------------------
+ * No reference counterpart: the reference's fastq_trim is the fixed-cycle cut above
+ * (SURVEY.md §0.1 D3); BASELINE.json's north_star asks for a quality-threshold
+ * trim-point scan as well.  Definition used here, per record:
+ *   beg = index of the first quality byte >= threshold
+ *   end = 1 + index of the last quality byte >= threshold     (beg = end = 0 if none)
+ * hpn_fastq_trim_points cuts every record to its own [beg[i], end[i]) (clamped to the
+ * record), with the same packed outputs as hpn_fastq_trim. */
+int hpn_fastq_qtrim_points(hpn_ctx *ctx, const uint8_t *qual, const uint64_t *off, uint64_t n_records,
+                           uint32_t threshold, uint32_t *beg, uint32_t *end);
+int hpn_fastq_qtrim_points_dev(hpn_ctx *ctx, const uint8_t *d_qual, const uint64_t *d_off, uint64_t n_records,
+                               uint32_t threshold, uint32_t *d_beg, uint32_t *d_end);
+int hpn_fastq_trim_points(hpn_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off,
+                          uint64_t n_records, const uint32_t *beg, const uint32_t *end, uint8_t *out_seq,
+                          uint8_t *out_qual, uint64_t *out_off);
+int hpn_fastq_trim_points_dev(hpn_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, const uint64_t *d_off,
+                              uint64_t n_records, const uint32_t *d_beg, const uint32_t *d_end,
+                              uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off);
+
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),
  * flattened to SoA by the host decoder: core fields, CIGAR words (len<<4|op,

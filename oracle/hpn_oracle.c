@@ -376,6 +376,42 @@ int orc_trim_soa(const uint8_t *seq, const uint8_t *qual, const uint64_t *off, u
     return ORC_OK;
 }
 
+/* extension: quality-threshold trim points (no reference counterpart) */
+void orc_qtrim_points(const uint8_t *qual, const uint64_t *off, uint64_t n, uint32_t threshold,
+                      uint32_t *beg, uint32_t *end)
+{
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint8_t *q = qual + off[r];
+        uint64_t len = off[r + 1] - off[r], b = 0, e = 0;
+        int seen = 0;
+        for (uint64_t i = 0; i < len; ++i)
+            if (q[i] >= threshold) {
+                if (!seen) b = i, seen = 1;
+                e = i + 1;
+            }
+        beg[r] = (uint32_t)b;
+        end[r] = (uint32_t)e;
+    }
+}
+
+int orc_trim_points_soa(const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint64_t n,
+                        const uint32_t *beg, const uint32_t *end, uint8_t *out_seq, uint8_t *out_qual,
+                        uint64_t *out_off)
+{
+    uint64_t o = 0;
+    out_off[0] = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        uint64_t len = off[r + 1] - off[r];
+        uint64_t b = beg[r] < len ? beg[r] : len, e = end[r] < len ? end[r] : len;
+        if (e < b) e = b;
+        memcpy(out_seq + o, seq + off[r] + b, e - b);
+        memcpy(out_qual + o, qual + off[r] + b, e - b);
+        o += e - b;
+        out_off[r + 1] = o;
+    }
+    return ORC_OK;
+}
+
 /* ------------------------------------------------------------------------- */
 /* bam2depth: dense model of fetch_func + hash2BedGraph + overlap            */
 /* ------------------------------------------------------------------------- */

@@ -71,6 +71,8 @@ def lib():
     L.orc_count_files_threaded.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int,
                                            C.POINTER(Counts), C.POINTER(C.c_double)]
     L.orc_trim_soa.argtypes = [u8p, u8p, u64p, C.c_uint64, C.c_int, C.c_int, u8p, u8p, u64p]
+    L.orc_qtrim_points.argtypes = [u8p, u64p, C.c_uint64, C.c_uint32, u32p, u32p]
+    L.orc_trim_points_soa.argtypes = [u8p, u8p, u64p, C.c_uint64, u32p, u32p, u8p, u8p, u64p]
     L.orc_depth_target.argtypes = [i32p, i32p, u32p, u32p, u32p, C.c_uint64, C.c_int32, C.c_uint32,
                                    C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(Run)),
                                    C.POINTER(C.c_uint64), f64p]

@@ -103,3 +103,28 @@ def test_device_resident_closed_form(ctx):
     rc, wseq, wqual, woff = orc.trim_soa(seq, qual, off, S, E)
     assert np.array_equal(oq[w0 * (E - S):(w0 + m) * (E - S)].cpu().numpy(), wqual)
     assert np.array_equal(ob[w0 * (E - S):(w0 + m) * (E - S)].cpu().numpy(), wseq)
+
+
+# ---- extension: quality-threshold trim points (no reference counterpart) ------------
+
+@pytest.mark.parametrize("n,lo,hi,T", [(1, 10, 10, 53), (500, 0, 5, 40), (3000, 30, 151, 53), (3000, 30, 151, 63),
+                                       (2000, 150, 150, 75), (2000, 150, 150, 0), (4000, 1, 511, 60), (70, 64, 64, 50),
+                                       (70, 65, 129, 70)])
+def test_qtrim_points_and_cut(ctx, n, lo, hi, T):
+    seq, qual, off = orc.synth_soa(n + T, 0, n, lo, hi)
+    wb, we = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    orc.lib().orc_qtrim_points(qual if len(qual) else np.zeros(1, np.uint8), off, n, T, wb, we)
+    gb, ge = ctx.fastq_qtrim_points(qual, off, T)
+    assert np.array_equal(gb, wb) and np.array_equal(ge, we)
+    cap = max(len(qual), 1)
+    wseq, wqual, woff = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(n + 1, np.uint64)
+    orc.lib().orc_trim_points_soa(seq if len(seq) else np.zeros(1, np.uint8), qual if len(qual) else np.zeros(1, np.uint8),
+                                  off, n, wb, we, wseq, wqual, woff)
+    gseq, gqual, goff = ctx.fastq_trim_points(seq, qual, off, gb, ge)
+    tot = int(woff[-1])
+    assert np.array_equal(goff, woff) and np.array_equal(gseq, wseq[:tot]) and np.array_equal(gqual, wqual[:tot])
+    # every kept base run starts and ends with a base at or above the threshold
+    for i in range(min(n, 200)):
+        a, b = int(goff[i]), int(goff[i + 1])
+        if b > a:
+            assert gqual[a] >= T and gqual[b - 1] >= T
