@@ -5,13 +5,22 @@
 // decoded into the structure-of-arrays layout of hpn_bam_batch (include/hpngs.h):
 // exactly the fields the two fetch_func callbacks read (bam2depth.c:86-110,
 // bam_sliding_count.c:93-124): tid, pos, flag, l_qseq, CIGAR words, packed sequence.
+//
+// BGZF blocks are independent deflate streams (<= 64 KiB each), so they are inflated
+// by a small pool of threads and handed to the decoder in file order;
+// the reference inflates them one after the other on the calling thread.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hpngs.h"
@@ -20,13 +29,30 @@ namespace hpn {
 
 class BgzfReader {
 public:
-    bool open(const char *path)
+    // threads: inflate workers (0 = min(8, online CPUs), overridable with HPN_BGZF_THREADS)
+    bool open(const char *path, int threads = 0)
     {
         fp_ = fopen(path, "rb");
-        return fp_ != nullptr;
+        if (!fp_) return false;
+        if (threads <= 0) {
+            const char *e = getenv("HPN_BGZF_THREADS");
+            long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+            threads = (int)(n < 1 ? 1 : n > 8 ? 8 : n);
+        }
+        slots_.resize((size_t)threads * 4);
+        io_ = std::thread([this] { io_loop(); });
+        for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work_loop(); });
+        return true;
     }
     ~BgzfReader()
     {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (io_.joinable()) io_.join();
+        for (auto &t : workers_) t.join();
         if (fp_) fclose(fp_);
     }
     // Read exactly n bytes of the uncompressed stream; returns bytes read (< n at EOF).
@@ -35,10 +61,13 @@ public:
         uint8_t *out = (uint8_t *)dst;
         size_t got = 0;
         while (got < n) {
-            if (pos_ == block_.size() && !next_block()) break;
-            size_t k = block_.size() - pos_;
+            if (!cur_ || pos_ == cur_->data.size()) {
+                if (!next_block()) break;
+                continue;
+            }
+            size_t k = cur_->data.size() - pos_;
             if (k > n - got) k = n - got;
-            memcpy(out + got, block_.data() + pos_, k);
+            memcpy(out + got, cur_->data.data() + pos_, k);
             pos_ += k, got += k;
         }
         return got;
@@ -46,51 +75,137 @@ public:
     const char *error() const { return err_; }
 
 private:
+    enum State { kFree, kRaw, kBusy, kDone };
+    struct Slot {
+        State st = kFree;
+        std::vector<uint8_t> raw, data;
+        uint32_t isize = 0;
+        bool bad = false;
+    };
+
+    // file order = slot order (round robin): the reader fills slot w_, the consumer takes slot r_
+    void io_loop()
+    {
+        for (;;) {
+            Slot *s;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || slots_[w_ % slots_.size()].st == kFree; });
+                if (stop_) return;
+                s = &slots_[w_ % slots_.size()];
+            }
+            uint8_t h[18];
+            const size_t k = fread(h, 1, 18, fp_);
+            bool eof = k == 0, bad = false;
+            if (!eof) {
+                if (k != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') {
+                    bad = true;
+                } else {
+                    const unsigned bsize = (h[16] | (h[17] << 8)) + 1u;
+                    const unsigned xlen = h[10] | (h[11] << 8);
+                    if (bsize < 26u || xlen < 6u || bsize < xlen + 20u) {
+                        bad = true;
+                    } else if (s->raw.resize(bsize - 18), fread(s->raw.data(), 1, s->raw.size(), fp_) != s->raw.size()) {
+                        bad = true;
+                    } else {
+                        memcpy(&s->isize, s->raw.data() + s->raw.size() - 4, 4);
+                        // drop the rest of the extra field: raw = deflate data + crc32 + isize
+                        s->raw.erase(s->raw.begin(), s->raw.begin() + (xlen - 6));
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (eof || bad) {
+                    end_at_ = w_;  // no block at index w_: end of stream (or error)
+                    if (bad) err_ = "not a BGZF block / truncated file";
+                } else {
+                    s->st = kRaw;
+                    ++w_;
+                }
+            }
+            cv_.notify_all();
+            if (eof || bad) return;
+        }
+    }
+    void work_loop()
+    {
+        for (;;) {
+            Slot *s = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] {
+                    if (stop_) return true;
+                    for (auto &x : slots_)
+                        if (x.st == kRaw) return true;
+                    return false;
+                });
+                if (stop_) return;
+                for (auto &x : slots_)
+                    if (x.st == kRaw) {
+                        s = &x;
+                        break;
+                    }
+                s->st = kBusy;
+            }
+            s->data.resize(s->isize);
+            s->bad = false;
+            if (s->isize) {
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) s->bad = true;
+                else {
+                    zs.next_in = s->raw.data();
+                    zs.avail_in = (uInt)(s->raw.size() - 8);
+                    zs.next_out = s->data.data();
+                    zs.avail_out = s->isize;
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END) s->bad = true;
+                    inflateEnd(&zs);
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                s->st = kDone;
+            }
+            cv_.notify_all();
+        }
+    }
     bool next_block()
     {
-        for (;;) {  // empty blocks (the EOF marker) are skipped
-            uint8_t h[18];
-            size_t k = fread(h, 1, 18, fp_);
-            if (k == 0) return false;
-            if (k != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') {
-                err_ = "not a BGZF block";
-                return false;
-            }
-            const unsigned bsize = (h[16] | (h[17] << 8)) + 1u;
-            const unsigned xlen = h[10] | (h[11] << 8);
-            const unsigned clen = bsize - xlen - 12 - 8;
-            comp_.resize(bsize - 18);
-            if (fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size()) {
-                err_ = "truncated BGZF block";
-                return false;
-            }
-            const uint8_t *cdata = comp_.data() + (xlen - 6);
-            uint32_t isize;
-            memcpy(&isize, comp_.data() + comp_.size() - 4, 4);
-            block_.resize(isize);
-            pos_ = 0;
-            if (isize == 0) continue;
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) {
-                err_ = "inflateInit2 failed";
-                return false;
-            }
-            zs.next_in = (Bytef *)cdata;
-            zs.avail_in = clen;
-            zs.next_out = block_.data();
-            zs.avail_out = isize;
-            int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) {
+        std::unique_lock<std::mutex> lk(m_);
+        if (cur_) {  // give the consumed slot back
+            cur_->st = kFree;
+            cur_ = nullptr;
+            ++r_;
+            cv_.notify_all();
+        }
+        for (;;) {
+            Slot &s = slots_[r_ % slots_.size()];
+            cv_.wait(lk, [&] { return s.st == kDone || (end_at_ != ~0ull && r_ >= end_at_); });
+            if (s.st != kDone) return false;  // end of stream
+            if (s.bad) {
                 err_ = "inflate failed";
                 return false;
             }
-            return true;
+            cur_ = &s;
+            pos_ = 0;
+            if (!s.data.empty()) return true;
+            s.st = kFree;  // empty block (the EOF marker): skip it
+            cur_ = nullptr;
+            ++r_;
+            cv_.notify_all();
         }
     }
+
     FILE *fp_ = nullptr;
-    std::vector<uint8_t> comp_, block_;
+    std::vector<Slot> slots_;
+    std::thread io_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    uint64_t w_ = 0, r_ = 0, end_at_ = ~0ull;
+    bool stop_ = false;
+    Slot *cur_ = nullptr;
     size_t pos_ = 0;
     const char *err_ = nullptr;
 };
@@ -153,7 +268,7 @@ public:
     // want_seq: keep the 4-bit sequence (bam_sliding_count); depth needs CIGAR only.
     bool next(BamBatch &b, bool want_seq)
     {
-        if (pending_) {  // record pushed back by the caller
+        if (pending_) {  // record looked at by peek_tid
             pending_ = false;
             append(b, want_seq);
             return true;

@@ -102,9 +102,44 @@ inline void print_quality_matrix(FILE *out, const uint64_t *qual_hist, uint32_t 
 
 // ---- bam2depth -------------------------------------------------------------------------
 
-inline void print_bedgraph(FILE *out, const char *chr, const hpn_run *runs, uint64_t n)  // bam2depth.c:217
+// "%d" of a non-negative int, written backwards from `end`; returns the first character
+inline char *put_int(char *end, int32_t v)
 {
-    for (uint64_t i = 0; i < n; ++i) fprintf(out, "%s\t%d\t%d\t%d\n", chr, runs[i].start, runs[i].end, runs[i].depth);
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    do {
+        *--end = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    if (v < 0) *--end = '-';
+    return end;
+}
+
+// "%s\t%d\t%d\t%d\n" per run (bam2depth.c:217).  hg38 at 30x is ~1e9 such lines: they are
+// formatted by hand into a 4 MiB buffer instead of one fprintf each (same bytes).
+inline void print_bedgraph(FILE *out, const char *chr, const hpn_run *runs, uint64_t n)
+{
+    const size_t lc = strlen(chr);
+    std::vector<char> buf((4u << 20) + lc + 64);
+    char *p = buf.data(), *const lim = buf.data() + (4u << 20);
+    char num[16];
+    for (uint64_t i = 0; i < n; ++i) {
+        memcpy(p, chr, lc);
+        p += lc;
+        const int32_t f[3] = {runs[i].start, runs[i].end, runs[i].depth};
+        for (int k = 0; k < 3; ++k) {
+            *p++ = '\t';
+            char *s = put_int(num + 16, f[k]);
+            const size_t l = (size_t)(num + 16 - s);
+            memcpy(p, s, l);
+            p += l;
+        }
+        *p++ = '\n';
+        if (p >= lim) {
+            fwrite(buf.data(), 1, (size_t)(p - buf.data()), out);
+            p = buf.data();
+        }
+    }
+    if (p != buf.data()) fwrite(buf.data(), 1, (size_t)(p - buf.data()), out);
 }
 
 inline void print_depth_bins(FILE *out, const char *chr, uint32_t target_len, uint32_t W, const uint64_t *win_sum)
