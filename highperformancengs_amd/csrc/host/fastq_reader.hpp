@@ -18,34 +18,63 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <memory>
 #include <string>
 #include <vector>
+
+#include "bam_reader.hpp"  // BgzfReader
 
 namespace hpn {
 
 constexpr int kLineBuf = 1024;  // fastq_count.c:107
 
+// A byte source: zlib's gzFile (plain text, gzip, concatenated members -- what the
+// reference reads with), or, for regular files that are BGZF (bgzip output), the
+// threaded block inflater.  Both deliver the same byte stream; only the speed differs.
+struct InStream {
+    gzFile gz = nullptr;
+    std::shared_ptr<BgzfReader> bz;
+    int read(void *dst, unsigned n) { return bz ? (int)bz->read(dst, n) : gzread(gz, dst, n); }
+    void close()
+    {
+        if (gz) gzclose(gz);
+        gz = nullptr;
+        bz.reset();
+    }
+};
+
 // open_input_stream (IO_stream.h:122-136): a name starting with '-' (or empty) is
 // stdin; anything else is open()+gzdopen(fd,"rb"), which reads plain files, gzip
 // and concatenated gzip members alike.  The reference passes O_CREAT and so
 // creates a missing input as an empty file; this does too (drop-in behaviour).
-inline gzFile open_input_stream(const char *name)
+inline InStream open_input_stream(const char *name)
 {
+    InStream in;
     int fd;
     if (strncmp(name, "-", 1) == 0 || !strcmp(name, "")) {
         fd = STDIN_FILENO;
     } else {
         fd = open(name, O_CREAT | O_RDONLY, 0666);
         if (fd == -1) fprintf(stderr, "Failed to create input file (%s)", name);
+        uint8_t h[18];  // BGZF: gzip member with the 'BC' extra subfield first (SAM spec 4.1)
+        if (fd != -1 && pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) &&
+            h[12] == 'B' && h[13] == 'C' && !getenv("HPN_NO_BGZF")) {
+            auto bz = std::make_shared<BgzfReader>();
+            if (bz->open(name)) {
+                close(fd);
+                in.bz = bz;
+                return in;
+            }
+        }
     }
-    gzFile f = gzdopen(fd, "rb");
-    if (f) gzbuffer(f, 1u << 20);
-    return f;
+    in.gz = gzdopen(fd, "rb");
+    if (in.gz) gzbuffer(in.gz, 1u << 20);
+    return in;
 }
 
 class LineSource {
 public:
-    explicit LineSource(gzFile f, size_t cap = 4u << 20) : f_(f), buf_(cap) {}
+    explicit LineSource(InStream f, size_t cap = 4u << 20) : f_(f), buf_(cap) {}
 
     // zlib gzgets(file, dst, len): copy until len-1 chars or through '\n' or to the
     // end of data; NUL-terminate if anything was copied; NULL (dst untouched) if
@@ -83,7 +112,7 @@ private:
     bool fill()
     {
         if (done_) return false;
-        int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+        int n = f_.read(buf_.data(), (unsigned)buf_.size());
         if (n <= 0) {
             done_ = true;
             return false;
@@ -92,7 +121,7 @@ private:
         have_ = (size_t)n;
         return true;
     }
-    gzFile f_;
+    InStream f_;
     std::vector<char> buf_;
     const char *cur_ = nullptr;
     size_t have_ = 0;
@@ -151,7 +180,7 @@ struct FastqBatch {
 // additionally keeps the first seqLen bytes of the buffer after the 2nd gzgets.
 class CountFramer {
 public:
-    explicit CountFramer(gzFile f) : src_(f) { memset(buf_, 0, sizeof buf_); }
+    explicit CountFramer(const InStream &f) : src_(f) { memset(buf_, 0, sizeof buf_); }
 
     // Appends records until the batch is full; returns false once the stream is
     // exhausted (the batch may still hold the last records).
@@ -185,7 +214,7 @@ private:
 // character (the '\n', or a real character when the final newline is missing).
 class TrimFramer {
 public:
-    explicit TrimFramer(gzFile f) : src_(f) {}
+    explicit TrimFramer(const InStream &f) : src_(f) {}
 
     bool fill(FastqBatch &b)
     {

@@ -15,7 +15,7 @@ constexpr size_t kBatchRecs = 2u << 20;    // records per batch (short reads)
 
 // Returns HPN_OK, an hpn_status, or HPN_E_DOMAIN with *too_long set when a read of 512+
 // bases shows up (the reference would overrun SeqLen[512]).
-inline int tally_stream(hpn_ctx *ctx, gzFile fq, hpn_tally *acc, bool *too_long)
+inline int tally_stream(hpn_ctx *ctx, const InStream &fq, hpn_tally *acc, bool *too_long)
 {
     struct Slot {
         FastqBatch b;

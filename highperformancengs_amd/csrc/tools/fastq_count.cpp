@@ -46,7 +46,7 @@ static void count_file(const char *infile, FILE *out, int slot)
     hpn_ctx *ctx = nullptr;
     int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
-    gzFile fq = open_input_stream(infile);
+    InStream fq = open_input_stream(infile);
     hpn_tally acc;
     memset(&acc, 0, sizeof acc);
     bool too_long = false;
@@ -56,7 +56,7 @@ static void count_file(const char *infile, FILE *out, int slot)
         exit(2);
     }
     if (rc != HPN_OK) die_hpn(ctx, rc, infile);
-    gzclose(fq);
+    fq.close();
     const CountSummary s = summarise(acc);
     {
         std::lock_guard<std::mutex> lk(g_lock);  // pthread_mutex_lock (fastq_count.c:126)

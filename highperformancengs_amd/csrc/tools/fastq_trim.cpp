@@ -56,7 +56,7 @@ int main(int argc, char *argv[])
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
 
-    gzFile in = open_input_stream(infile);
+    InStream in = open_input_stream(infile);
     FILE *out = fcreat_outfile(outfile, ".trim.fastq");
     unsigned long reads = 0;
     const long long begin = usec();
@@ -88,7 +88,7 @@ int main(int argc, char *argv[])
         }
     }
     fprintf(stderr, "Total_reads: %lu\nFinished in %.3f s\n", reads, (double)(usec() - begin) / CLOCKS_PER_SEC);
-    gzclose(in);
+    in.close();
     fclose(out);
     hpn_ctx_destroy(ctx);
     return 0;

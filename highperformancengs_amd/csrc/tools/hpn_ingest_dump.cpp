@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     }
     const std::string mode = argv[1];
     if (mode == "count" || mode == "trim") {
-        gzFile f = open_input_stream(argv[2]);
+        InStream f = open_input_stream(argv[2]);
         // small batches on purpose: the dump is the concatenation of many refills
         FastqBatch b;
         if (!b.init(1u << 16, 1u << 10, true)) return 4;
@@ -47,7 +47,7 @@ int main(int argc, char **argv)
             qual.insert(qual.end(), b.qual, b.qual + b.nbytes);
             names.insert(names.end(), b.names.begin(), b.names.end());
         }
-        gzclose(f);
+        f.close();
         const uint64_t n = off.size() - 1;
         fwrite(&n, 8, 1, stdout);
         put(off);

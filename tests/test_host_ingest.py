@@ -98,3 +98,29 @@ def test_tools_fail_loudly_without_a_gpu(tmp_path):
     p = subprocess.run([os.path.join(BIN, "fastq_count"), golden_path("fastq", "t.fq")], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, cwd=tmp_path)
     assert p.returncode != 0 and p.stdout == b"" and b"no usable HIP device" in p.stderr
+
+
+def test_bgzf_fastq_goes_through_the_threaded_inflater(tmp_path):
+    """bgzip-style FASTQ (BGZF = gzip members with a 'BC' extra field): same bytes as zlib's
+    gzread gives the reference, inflated block-parallel by the host reader."""
+    from highperformancengs_amd.bamio import _Bgzf
+    text = open(golden_path("fastq", "syn_var_a.fq"), "rb").read() * 40  # ~12 MB, a few hundred blocks
+    p = str(tmp_path / "syn.fq.gz")
+    with open(p, "wb") as fh:
+        z = _Bgzf(fh)
+        for i in range(0, len(text), 50000):
+            z.write(text[i:i + 50000])
+        z.close()
+    raws = []
+    for env in ({}, {"HPN_NO_BGZF": "1"}, {"HPN_BGZF_THREADS": "1"}):
+        r = subprocess.run([DUMP, "count", p], stdout=subprocess.PIPE, check=True, env={**os.environ, **env})
+        raws.append(r.stdout)
+    assert raws[0] == raws[1] == raws[2]
+    raw = raws[0]
+    n = struct.unpack_from("<Q", raw)[0]
+    assert n == 1500 * 40
+    off = np.frombuffer(raw, np.uint64, n + 1, 8)
+    qual = np.frombuffer(raw, np.uint8, int(off[-1]), 8 + 8 * (n + 1))
+    rc, a = orc.count_soa(qual, off)
+    rc2, b = orc.count_stream(p)
+    assert rc == 0 and rc2 == 0 and np.array_equal(a.seqlen, b.seqlen) and np.array_equal(a.quality, b.quality)
