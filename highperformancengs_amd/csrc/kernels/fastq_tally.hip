@@ -5,40 +5,39 @@
 // the per-cycle nucleotide tally of Rgzfastq_uniq.c:50-57 (Nucleotide[5][512]).
 // The default report needs neither: that is K1, fastq_scan.hip.
 //
-// One 1024-thread workgroup per CU owns a histogram image in LDS: 16-bit counters
-// packed two per dword (row stride 257 dwords: bank = (sym + cycle/2) % 32), flushed
-// with 64-bit global atomics before any counter can wrap (a counter gets at most
-// one hit per read -> every <= 65,535 reads).  Records are taken in chunks of 1024
-// whose boundaries sit in LDS.
+// One 1024-thread workgroup per CU owns a histogram image in LDS: 32-bit counters,
+// 128 symbol rows x cycles 0..255, row stride 256 dwords, so that
+//     bank(symbol, cycle) = cycle % 32        -- independent of the symbol.
+// Cycles 256..511 (reads longer than 256 bases) go to the global matrix directly.
+// The image is flushed once, at the end of the kernel (a 32-bit counter cannot wrap
+// within one launch); sum / Q20 / Q30 are row sums taken during that flush.
 //
-//   chunk of equal-length reads (the normal case, len >= 16):
-//     work item = (read r, vector v): bytes [16v, 16v+16) OF THE READ, fetched with
-//     one unaligned 16-byte load.  The cycle of byte k is 16v+k: even base, no wrap
-//     into the next read, so every lane of a wave runs the same 16 straight-line
-//     ds_add_u32 (2 VALU + 1 LDS per byte, half-word selected at compile time).
-//     A lane's items are (tid + 1024 m); (r, v) advance by a per-chunk constant.
-//     Loads run one round of four vectors ahead of the tally.  sum / Q20 / Q30 and
-//     the domain check are SWAR on the vector.  The len%16 tail bytes of each read
-//     are walked by one lane per read.
-//   anything else (ragged lengths, reads shorter than 16):
-//     aligned vectors of the chunk's byte range, binary search over the LDS
+//   chunk of equal-length reads, 16 <= len <= 256 (the normal case):
+//     a wave walks 64-byte spans of the chunk; lane l takes byte l of the span with a
+//     byte load (64 B per wave-instruction, fully coalesced, no alignment cases).  The
+//     lanes of a half-wave then sit at 32 CONSECUTIVE cycles = 32 different banks: the
+//     ds_add_u32 is conflict-free (16 lane-ops/clk/CU measured, against ~10.5 for the
+//     16-bytes-per-lane mapping and ~12.6 for random words, scripts/lds_atomic_ubench.hip).
+//     The cycle of a lane advances by (1024 mod len) per span: one division per chunk.
+//     Eight spans are in flight per wave, one round ahead of the round being tallied.
+//   anything else (ragged lengths, very short or very long reads):
+//     aligned 16-byte vectors of the chunk's byte range, binary search over the LDS
 //     boundaries per vector, per-byte walk.
 //
-// PMC history (profiles/r01b): memory-aligned vectors made lanes diverge on cycle
-// parity and on read boundaries, which doubled the LDS and VALU instruction
-// counts (2.05 LDS and 16-30 VALU wave-instructions per 64 bytes).
-// LDS bound on MI355X (scripts/lds_atomic_ubench.hip): ds_add_u32 runs at 16
-// lane-ops/cycle/CU conflict-free and ~10.5 for this address pattern, i.e. ~5.9e12
-// tallied bytes/s for the chip.  No MFMA: there is no contraction here.
+// PMC history (profiles/r01b): 16-bytes-per-lane vectors made lanes diverge on cycle
+// parity / read boundaries (2x LDS and VALU instruction counts), then ran at the
+// random-scatter bank-conflict rate (70 % of LDS cycles were conflict cycles).
+// No MFMA: there is no contraction here.
 #include "tally_util.hpp"
 
 namespace hpn {
 
 constexpr int kHistThreads = 1024;
-constexpr int kHistRecs = 4096;                  // records per chunk: 600 KB at 150 bp between barriers
-constexpr int kRound = 4;                        // vectors per lane per round
-constexpr int kRowWords = HPN_LEN_BINS / 2 + 1;  // 256 dwords of packed u16 pairs + 1 pad
-constexpr uint32_t kFlushReads = 65535;          // a counter gets at most one hit per read
+constexpr int kHistWaves = kHistThreads / kWave;
+constexpr int kHistRecs = 4096;    // records per chunk: 600 KB at 150 bp between barriers
+constexpr int kSpanRound = 8;      // 64-byte spans a wave keeps in flight (16 measured the same)
+constexpr int kLdsCycles = 256;    // cycles held in LDS; later cycles go to global atomics
+constexpr int kRowWords = kLdsCycles;
 
 // Symbol code of a base for Nucleotide[5][512] (reference Rgzfastq_uniq.c:97-108:
 // T/U 0, C 1, A 2, G 3, N and '.' 4, every other byte 0).
@@ -58,137 +57,89 @@ struct HistLds {
     uint32_t nh[HPN_NUC_CODES * kRowWords];
     uint32_t loff[kHistRecs + 1];
     uint32_t lhist[HPN_LEN_BINS + 1];
-    uint32_t red[3][kHistThreads / kWave];
+    u64 red[3][kHistWaves];
+};
+
+// One symbol at one cycle: LDS image for cycles < 256, the global matrix beyond.
+// A quality byte >= 128 has no row (the reference would write out of bounds): flagged.
+struct HiTot {  // quality bytes tallied at cycles >= 256 (they bypass the LDS image and its row sums)
+    uint32_t tot = 0, c20 = 0, c30 = 0;
 };
 
 template <bool kQual>
-__device__ __forceinline__ uint32_t hist_row(uint32_t byte)
+__device__ __forceinline__ void bump(uint32_t *hist, u64 *__restrict__ gacc, uint32_t byte, uint32_t pos, uint32_t &bad,
+                                     HiTot &hi)
 {
-    return (kQual ? byte : nuc_code(byte)) * kRowWords;
-}
-
-__device__ __forceinline__ uint32_t byte_of(const u32 &v, int k) { return (v[k >> 2] >> (8 * (k & 3))) & 0xffu; }
-
-// One symbol at one cycle.
-template <bool kQual>
-__device__ __forceinline__ void bump(uint32_t *hist, uint32_t byte, uint32_t pos)
-{
-    atomicAdd(&hist[hist_row<kQual>(byte) + (pos >> 1)], 1u << ((pos & 1) << 4));
-}
-
-// 16 bytes of one read starting at the EVEN cycle 2*half.
-template <bool kQual>
-__device__ __forceinline__ void add16(uint32_t *hist, const u32 &v, uint32_t half)
-{
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-        atomicAdd(&hist[hist_row<kQual>(byte_of(v, k)) + half + (k >> 1)], (k & 1) ? 0x10000u : 1u);
-}
-
-struct Tot {
-    uint32_t c20, c30, bad;
-};
-
-// sum / Q20 / Q30 + domain check of bytes [k0,k1) of a quality vector; false = skip it
-template <bool kQual>
-__device__ __forceinline__ bool vec_totals(const u32 &v, int k0, int k1, Tot &t)
-{
-    if (!kQual) return true;
-    uint32_t hb = 0;
-    swar16((k0 == 0 && k1 == 16) ? v : mask_bytes(v, k0, k1), t.c20, t.c30, hb);
-    if (hb & 0x80808080u) {  // quality byte >= 128: batch rejected; keep LDS indices in range
-        t.bad = 1;
-        return false;
+    if (kQual && byte >= HPN_QUAL_ROWS) {
+        bad = 1;
+        return;
     }
-    return true;
+    const uint32_t row = kQual ? byte : nuc_code(byte);
+    if (pos < (uint32_t)kLdsCycles) {
+        atomicAdd(&hist[row * kRowWords + pos], 1u);
+    } else {
+        atomicAdd(&gacc[row * HPN_LEN_BINS + pos], (u64)1);
+        if (kQual) hi.tot += 1, hi.c20 += byte >= 53, hi.c30 += byte >= 63;
+    }
 }
 
-// 16 bytes from any address (hardware unaligned access; the compiler emits one
-// global_load_dwordx4 for the align-1 copy).
-__device__ __forceinline__ u32 load_unaligned16(const uint8_t *p)
-{
-    u32 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-
-// Equal-length chunk (len0 >= 16): cnt reads of len0 bytes starting at arr + base_off.
+// Equal-length chunk, 16 <= len0 <= 256: cnt reads of len0 bytes starting at arr + base_off.
 template <bool kQual>
 __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint32_t cnt,
-                                               uint32_t len0, Tot &t)
+                                               uint32_t len0, uint32_t &bad)
 {
     uint32_t *hist = kQual ? s.qh : s.nh;
     const uint8_t *p0 = arr + base_off;
-    const uint32_t nvr = len0 >> 4;               // whole vectors per read
-    const uint32_t items = cnt * nvr;
-    // item w = r * nvr + v; a lane's items are w0 + 1024 m: (r, v) advance by (dr, dv) with carry
-    const uint32_t dr = kHistThreads / nvr, dv = kHistThreads - dr * nvr;
-    uint32_t w = threadIdx.x;
-    uint32_t r = w / nvr, v = w - r * nvr;        // the one division per chunk
-    auto step = [&]() {
-        w += kHistThreads;
-        r += dr, v += dv;
-        if (v >= nvr) v -= nvr, ++r;
+    const uint32_t B = cnt * len0;
+    const uint32_t lane = (uint32_t)lane_id();
+    // this wave's spans are wid, wid+16, ...: byte index of the lane in its span m is b + 1024 m
+    uint32_t b = 64u * (uint32_t)wave_id() + lane;
+    if (b >= B) return;
+    const uint32_t step = (64u * kHistWaves) % len0;  // cycle advance from one of the wave's spans to the next
+    uint32_t pos = b % len0;                          // the one division per chunk
+    auto next_pos = [&](uint32_t p) {
+        p += step;
+        return min(p, p - len0);  // p < len0 ? p : p - len0, in unsigned arithmetic
     };
-    auto addr = [&](uint32_t rr, uint32_t vv) { return p0 + (size_t)rr * len0 + 16u * vv; };
-
-    u32 va[kRound], vb[kRound];
-    uint32_t ha[kRound], hb[kRound];  // cycle/2 of byte 0, or ~0u = no item
-    auto fetch = [&](u32 (&vec)[kRound], uint32_t (&half)[kRound]) {
+    uint32_t va[kSpanRound], vb[kSpanRound];
+    auto fetch = [&](uint32_t (&v)[kSpanRound], uint32_t b0) {
 #pragma unroll
-        for (int m = 0; m < kRound; ++m) {
-            // no branch around the load (an idle lane re-reads the chunk's first bytes): the
-            // compiler then counts the loads in flight (vmcnt(4)) instead of draining them all
-            const bool on = w < items;
-            vec[m] = load_unaligned16(on ? addr(r, v) : p0);
-            half[m] = on ? 8u * v : ~0u;
-            step();
+        for (int m = 0; m < kSpanRound; ++m) {
+            const uint32_t bb = b0 + (uint32_t)m * 64u * kHistWaves;
+            v[m] = p0[min(bb, B - 1)];  // never branch around a load: the waits stay counted
         }
     };
-    auto tally = [&](u32 (&vec)[kRound], uint32_t (&half)[kRound]) {
+    auto tally = [&](const uint32_t (&v)[kSpanRound], uint32_t b0) {
 #pragma unroll
-        for (int m = 0; m < kRound; ++m)
-            if (half[m] != ~0u && vec_totals<kQual>(vec[m], 0, 16, t)) add16<kQual>(hist, vec[m], half[m]);
+        for (int m = 0; m < kSpanRound; ++m) {
+            const uint32_t bb = b0 + (uint32_t)m * 64u * kHistWaves;
+            const uint32_t byte = v[m];
+            const uint32_t row = kQual ? byte : nuc_code(byte);
+            if (kQual && byte >= HPN_QUAL_ROWS) bad = (bb < B) ? 1u : bad;
+            else if (bb < B) atomicAdd(&hist[row * kRowWords + pos], 1u);
+            pos = next_pos(pos);
+        }
     };
-    if (items) {
-        fetch(va, ha);
-        for (;;) {
-            const bool more_b = w < items;  // w now points at round B's first item of this lane
-            fetch(vb, hb);
-            tally(va, ha);
-            if (!more_b) break;
-            const bool more_a = w < items;
-            fetch(va, ha);
-            tally(vb, hb);
-            if (!more_a) break;
-        }
-    }
-    // tails: the last len0 % 16 bytes of every read, one lane per read
-    const uint32_t rem = len0 & 15u;
-    if (rem) {
-#pragma unroll 1
-        for (uint32_t rr = threadIdx.x; rr < cnt; rr += kHistThreads) {
-            const uint8_t *q = addr(rr, nvr);
-#pragma unroll 1
-            for (uint32_t k = 0; k < rem; ++k) {
-                const uint32_t byte = q[k];
-                if (kQual) {
-                    if (byte >= HPN_QUAL_ROWS) {
-                        t.bad = 1;
-                        continue;
-                    }
-                    t.c20 += byte >= 53, t.c30 += byte >= 63;
-                }
-                bump<kQual>(hist, byte, 16u * nvr + k);
-            }
-        }
+    const uint32_t round = (uint32_t)kSpanRound * 64u * kHistWaves;
+    fetch(va, b);
+    for (;;) {
+        const uint32_t b1 = b + round;
+        fetch(vb, b1);  // unconditional (addresses are clamped): no branch around loads
+        tally(va, b);
+        if (b1 >= B) break;
+        const uint32_t b2 = b1 + round;
+        fetch(va, b2);
+        tally(vb, b1);
+        if (b2 >= B) break;
+        b = b2;
     }
 }
 
-// Ragged chunk: aligned vectors of the byte range, each located by binary search.
+// Any chunk: aligned vectors of the byte range, each located by binary search.
 // Records are [loff[lo-1], loff[lo]).
 template <bool kQual>
-__device__ __forceinline__ void stream_ragged(HistLds &s, const uint8_t *arr, uint64_t base_off, uint32_t cnt, Tot &t)
+__device__ __forceinline__ void stream_ragged(HistLds &s, u64 *__restrict__ gacc, const uint8_t *arr,
+                                              uint64_t base_off, uint32_t cnt, uint32_t &bad, HiTot &over)
 {
     const uint32_t B = s.loff[cnt];
     if (B == 0) return;
@@ -203,7 +154,6 @@ __device__ __forceinline__ void stream_ragged(HistLds &s, const uint8_t *arr, ui
         const int rel = (int)(16 * j) - a0;
         const int k0 = rel < 0 ? -rel : 0;
         const int k1 = min(16, (int)B - rel);
-        if (!vec_totals<kQual>(v, k0, k1, t)) continue;
         uint32_t b = (uint32_t)(rel + k0);
         uint32_t lo = 1, hi = cnt;
         while (lo < hi) {  // first boundary above b
@@ -220,21 +170,24 @@ __device__ __forceinline__ void stream_ragged(HistLds &s, const uint8_t *arr, ui
                 pos = 0;
             }
             const uint32_t wd = k < 4 ? v[0] : k < 8 ? v[1] : k < 12 ? v[2] : v[3];
-            bump<kQual>(hist, (wd >> (8 * (k & 3))) & 0xffu, pos);
+            bump<kQual>(hist, gacc, (wd >> (8 * (k & 3))) & 0xffu, pos, bad, over);
             ++b, ++pos;
         }
     }
 }
 
-__device__ __forceinline__ void hist_flush(uint32_t *lds, int rows, u64 *__restrict__ gacc)
+// LDS image -> global matrix; returns this lane's share of (sum, sum over rows >= 53, >= 63).
+__device__ __forceinline__ void hist_flush(const uint32_t *lds, int rows, u64 *__restrict__ gacc, u64 &tot, u64 &t20,
+                                           u64 &t30)
 {
     for (int w = threadIdx.x; w < rows * kRowWords; w += kHistThreads) {
         const uint32_t v = lds[w];
         if (v) {
             const int r = w / kRowWords, c = w - r * kRowWords;
-            if (v & 0xffffu) atomicAdd(&gacc[r * HPN_LEN_BINS + 2 * c], (u64)(v & 0xffffu));
-            if (v >> 16) atomicAdd(&gacc[r * HPN_LEN_BINS + 2 * c + 1], (u64)(v >> 16));
-            lds[w] = 0;
+            atomicAdd(&gacc[r * HPN_LEN_BINS + c], (u64)v);
+            tot += v;
+            if (r >= 53) t20 += v;
+            if (r >= 63) t30 += v;
         }
     }
 }
@@ -252,22 +205,15 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
     for (int i = tid; i <= HPN_LEN_BINS; i += kHistThreads) s.lhist[i] = 0;
     __syncthreads();
 
-    Tot t{0, 0, 0};
-    uint32_t since_flush = 0;
-    u64 bytes = 0;
+    uint32_t bad = 0;
+    u64 *gq = acc + HPN_TALLY_W_QUAL, *gn = acc + HPN_TALLY_W_NUC;
+    HiTot hi;
     const uint64_t nchunk = (n + kHistRecs - 1) / kHistRecs;
     for (uint64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
         const uint64_t r0 = ch * kHistRecs;
         const uint32_t cnt = (uint32_t)min((uint64_t)kHistRecs, n - r0);
-        if (since_flush + cnt > kFlushReads) {
-            __syncthreads();
-            if (kQualHist) hist_flush(s.qh, HPN_QUAL_ROWS, acc + HPN_TALLY_W_QUAL);
-            if (kNucHist) hist_flush(s.nh, HPN_NUC_CODES, acc + HPN_TALLY_W_NUC);
-            since_flush = 0;
-        }
-        since_flush += cnt;
         const uint64_t base_off = off[r0];
-        // chunk-relative boundaries; a chunk spans < 1024*512 bytes inside the domain
+        // chunk-relative boundaries; a chunk spans < 4096*512 bytes inside the domain
         for (uint32_t i = tid; i <= cnt; i += kHistThreads) {
             const uint64_t d = off[r0 + i] - base_off;
             s.loff[i] = d > 0x7fffffffull ? 0x7fffffffu : (uint32_t)d;
@@ -280,50 +226,53 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
             uint32_t len = 0;
             if (valid) {
                 len = s.loff[i + 1] - s.loff[i];
-                if (len >= HPN_LEN_BINS) len = HPN_LEN_BINS, t.bad = 1;
+                if (len >= HPN_LEN_BINS) len = HPN_LEN_BINS, bad = 1;
                 all_same = all_same && len == len0;
             }
             hist_len(s.lhist, valid, len);
         }
         // an over-long record poisons position tracking: stop tallying bytes, the batch
         // is rejected as a whole (HPN_E_DOMAIN) once `bad` is seen
-        if (!__syncthreads_or((int)t.bad)) {
-            const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16;
-            if (tid == 0) bytes += s.loff[cnt];
+        if (!__syncthreads_or((int)bad)) {
+            const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16 && len0 <= (uint32_t)kLdsCycles;
             if (uniform) {
-                if (kQualHist) stream_uniform<true>(s, qual, base_off, cnt, len0, t);
-                if (kNucHist) stream_uniform<false>(s, base, base_off, cnt, len0, t);
+                if (kQualHist) stream_uniform<true>(s, qual, base_off, cnt, len0, bad);
+                if (kNucHist) stream_uniform<false>(s, base, base_off, cnt, len0, bad);
             } else {
-                if (kQualHist) stream_ragged<true>(s, qual, base_off, cnt, t);
-                if (kNucHist) stream_ragged<false>(s, base, base_off, cnt, t);
+                if (kQualHist) stream_ragged<true>(s, gq, qual, base_off, cnt, bad, hi);
+                if (kNucHist) stream_ragged<false>(s, gn, base, base_off, cnt, bad, hi);
             }
         }
         __syncthreads();
     }
     __syncthreads();
-    if (kQualHist) hist_flush(s.qh, HPN_QUAL_ROWS, acc + HPN_TALLY_W_QUAL);
-    if (kNucHist) hist_flush(s.nh, HPN_NUC_CODES, acc + HPN_TALLY_W_NUC);
+    u64 tot = hi.tot, t20 = hi.c20, t30 = hi.c30, ntot = 0, n20 = 0, n30 = 0;
+    if (kQualHist) hist_flush(s.qh, HPN_QUAL_ROWS, gq, tot, t20, t30);
+    if (kNucHist) hist_flush(s.nh, HPN_NUC_CODES, gn, ntot, n20, n30);
 
-    const uint32_t c20 = wave_sum(t.c20), c30 = wave_sum(t.c30), bad = wave_or(t.bad);
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        tot += __shfl_xor(tot, o, kWave);
+        t20 += __shfl_xor(t20, o, kWave);
+        t30 += __shfl_xor(t30, o, kWave);
+    }
+    bad = wave_or(bad);
     if (lane_id() == 0) {
-        s.red[0][wave_id()] = c20;
-        s.red[1][wave_id()] = c30;
-        s.red[2][wave_id()] = bad;
+        s.red[0][wave_id()] = tot;
+        s.red[1][wave_id()] = t20;
+        s.red[2][wave_id()] = t30;
+        if (bad) atomicAdd(&acc[HPN_TALLY_W_BAD], (u64)1);
     }
     __syncthreads();
-    if (tid == 0) {
-        u64 s20 = 0, s30 = 0;
-        uint32_t h = 0;
-        for (int w = 0; w < kHistThreads / kWave; ++w) s20 += s.red[0][w], s30 += s.red[1][w], h |= s.red[2][w];
-        if (kQualHist) {
-            if (s20) atomicAdd(&acc[HPN_TALLY_W_Q20], s20);
-            if (s30) atomicAdd(&acc[HPN_TALLY_W_Q30], s30);
-        }
-        if (h) atomicAdd(&acc[HPN_TALLY_W_BAD], (u64)1);
-        if (kQualHist && bytes) atomicAdd(&acc[HPN_TALLY_W_TOTAL], bytes);
+    if (tid == 0 && kQualHist) {
+        u64 a = 0, b20 = 0, b30 = 0;
+        for (int w = 0; w < kHistWaves; ++w) a += s.red[0][w], b20 += s.red[1][w], b30 += s.red[2][w];
+        if (a) atomicAdd(&acc[HPN_TALLY_W_TOTAL], a);
+        if (b20) atomicAdd(&acc[HPN_TALLY_W_Q20], b20);
+        if (b30) atomicAdd(&acc[HPN_TALLY_W_Q30], b30);
     }
-    // SeqLen / sum come from this kernel only when it replaces the flat scan
-    // (quality matrix requested); a nucleotide-only launch runs beside k_tally_scan.
+    // SeqLen comes from this kernel only when it replaces the flat scan (quality matrix
+    // requested); a nucleotide-only launch runs beside k_tally_scan.
     for (int i = tid; i <= HPN_LEN_BINS; i += kHistThreads) {
         const uint32_t h = s.lhist[i];
         if (h && (kQualHist || i == HPN_LEN_BINS))
