@@ -109,30 +109,44 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
             v[m] = p0[min(bb, B - 1)];  // never branch around a load: the waits stay counted
         }
     };
-    auto tally = [&](const uint32_t (&v)[kSpanRound], uint32_t b0) {
+    // A quality byte >= 128 has no row: its bit 7 is OR-ed into `seen` (checked once per chunk,
+    // the batch is then rejected) and the row index is masked so that the LDS address stays in
+    // range -- no compare, no exec-mask juggling in the loop (the per-step predicate cost 6 SALU
+    // + 5 VALU per byte in the first version of this loop, PMC profiles/r01b).
+    uint32_t seen = 0;
+    auto tally = [&](const uint32_t (&v)[kSpanRound], uint32_t b0, bool whole) {
 #pragma unroll
         for (int m = 0; m < kSpanRound; ++m) {
-            const uint32_t bb = b0 + (uint32_t)m * 64u * kHistWaves;
             const uint32_t byte = v[m];
-            const uint32_t row = kQual ? byte : nuc_code(byte);
-            if (kQual && byte >= HPN_QUAL_ROWS) bad = (bb < B) ? 1u : bad;
-            else if (bb < B) atomicAdd(&hist[row * kRowWords + pos], 1u);
+            const uint32_t row = kQual ? (byte & (HPN_QUAL_ROWS - 1)) : nuc_code(byte);
+            if (whole) {
+                if (kQual) seen |= byte;
+                atomicAdd(&hist[row * kRowWords + pos], 1u);
+            } else if (b0 + (uint32_t)m * 64u * kHistWaves < B) {
+                if (kQual) seen |= byte;
+                atomicAdd(&hist[row * kRowWords + pos], 1u);
+            }
             pos = next_pos(pos);
         }
     };
     const uint32_t round = (uint32_t)kSpanRound * 64u * kHistWaves;
     fetch(va, b);
     for (;;) {
+        // rounds that lie entirely inside the chunk for the WHOLE wave take the predicate-free body
         const uint32_t b1 = b + round;
         fetch(vb, b1);  // unconditional (addresses are clamped): no branch around loads
-        tally(va, b);
+        const uint32_t wave_last = b - lane + 63u + round - 64u * kHistWaves;  // last byte the wave touches this round
+        if (wave_last < B) tally(va, b, true);
+        else tally(va, b, false);
         if (b1 >= B) break;
         const uint32_t b2 = b1 + round;
         fetch(va, b2);
-        tally(vb, b1);
+        if (wave_last + round < B) tally(vb, b1, true);
+        else tally(vb, b1, false);
         if (b2 >= B) break;
         b = b2;
     }
+    if (seen & 0x80u) bad = 1;
 }
 
 // Any chunk: aligned vectors of the byte range, each located by binary search.
