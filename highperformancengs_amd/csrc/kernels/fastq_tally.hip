@@ -6,28 +6,33 @@
 // The default report needs neither: that is K1, fastq_scan.hip.
 //
 // One 1024-thread workgroup per CU owns a histogram image in LDS: 32-bit counters,
-// 128 symbol rows x cycles 0..255, row stride 256 dwords, so that
-//     bank(symbol, cycle) = cycle % 32        -- independent of the symbol.
+// 128 symbol rows x cycles 0..255, 256 dwords per row, cycles stored transposed in
+// groups of four:  word(row, cycle) = row*256 + (cycle & 3)*64 + (cycle >> 2).
 // Cycles 256..511 (reads longer than 256 bases) go to the global matrix directly.
 // The image is flushed once, at the end of the kernel (a 32-bit counter cannot wrap
 // within one launch); sum / Q20 / Q30 are row sums taken during that flush.
 //
 //   chunk of equal-length reads, 16 <= len <= 256 (the normal case):
-//     a wave walks 64-byte spans of the chunk; lane l takes byte l of the span with a
-//     byte load (64 B per wave-instruction, fully coalesced, no alignment cases).  The
-//     lanes of a half-wave then sit at 32 CONSECUTIVE cycles = 32 different banks: the
-//     ds_add_u32 is conflict-free (16 lane-ops/clk/CU measured, against ~10.5 for the
-//     16-bytes-per-lane mapping and ~12.6 for random words, scripts/lds_atomic_ubench.hip).
-//     The cycle of a lane advances by (1024 mod len) per span: one division per chunk.
-//     Eight spans are in flight per wave, one round ahead of the round being tallied.
+//     work item = (read r, group j) = cycles 4j..4j+3 OF THE READ, one unaligned dword
+//     load.  Byte k of the item goes to word row*256 + k*64 + j, so the 32 lanes of a
+//     half-wave (consecutive j) hit 32 different banks for every k, whatever the symbols
+//     are: conflict-free ds_add_u32 (16 lane-ops/clk/CU measured, against ~10.5 for
+//     16-bytes-per-lane vectors and ~12.6 for random words, scripts/lds_atomic_ubench.hip),
+//     2 VALU + 1 LDS per byte, no per-byte compare: bit 7 of every byte is OR-ed into one
+//     flag and the row index is masked.  A lane's items are tid + 1024 m; (r, j) advance by
+//     a per-chunk constant with carry (one division per chunk).  Eight dwords per lane are
+//     in flight, one round ahead of the round being tallied, behind counted vmcnt waits.
+//     The len%4 tail bytes of each read are walked by one lane per read.
 //   anything else (ragged lengths, very short or very long reads):
 //     aligned 16-byte vectors of the chunk's byte range, binary search over the LDS
 //     boundaries per vector, per-byte walk.
 //
-// PMC history (profiles/r01b): 16-bytes-per-lane vectors made lanes diverge on cycle
-// parity / read boundaries (2x LDS and VALU instruction counts), then ran at the
-// random-scatter bank-conflict rate (70 % of LDS cycles were conflict cycles).
-// No MFMA: there is no contraction here.
+// PMC history (profiles/r01b), 2e8 x 150 bp: 22.5 ms aligned 16-B vectors + binary search;
+// 14.9 -> lanes diverged on cycle parity / read boundaries (2x LDS and VALU instruction
+// counts); 12.1 read-aligned 16-B vectors, LDS at the random-scatter conflict rate (70 % of
+// LDS cycles were conflict cycles); 11.1 byte loads, conflict-free but too few bytes in
+// flight per request slot and 6 SALU + 11 VALU per byte; 10.1 predicate-free body;
+// 8.8 ms this form.  No MFMA: there is no contraction here.
 #include "tally_util.hpp"
 
 namespace hpn {
@@ -35,7 +40,7 @@ namespace hpn {
 constexpr int kHistThreads = 1024;
 constexpr int kHistWaves = kHistThreads / kWave;
 constexpr int kHistRecs = 4096;    // records per chunk: 600 KB at 150 bp between barriers
-constexpr int kSpanRound = 8;      // 64-byte spans a wave keeps in flight (16 measured the same)
+constexpr int kSpanRound = 8;      // dword items a lane keeps in flight
 constexpr int kLdsCycles = 256;    // cycles held in LDS; later cycles go to global atomics
 constexpr int kRowWords = kLdsCycles;
 
@@ -60,12 +65,22 @@ struct HistLds {
     u64 red[3][kHistWaves];
 };
 
-// One symbol at one cycle: LDS image for cycles < 256, the global matrix beyond.
-// A quality byte >= 128 has no row (the reference would write out of bounds): flagged.
+// Index of (row, cycle) inside the LDS image.  Cycles are stored TRANSPOSED in groups of four:
+//     word(row, cycle) = row * 256 + (cycle & 3) * 64 + (cycle >> 2)
+// A lane that holds the four bytes of cycles 4j..4j+3 of a read adds byte k at word
+// row*256 + k*64 + j: the 32 lanes of a half-wave (consecutive j) hit 32 different banks for
+// every k, whatever the symbols are.
+__device__ __forceinline__ uint32_t lds_word(uint32_t row, uint32_t pos)
+{
+    return row * kRowWords + ((pos & 3u) << 6) + (pos >> 2);
+}
+
 struct HiTot {  // quality bytes tallied at cycles >= 256 (they bypass the LDS image and its row sums)
     uint32_t tot = 0, c20 = 0, c30 = 0;
 };
 
+// One symbol at one cycle: LDS image for cycles < 256, the global matrix beyond.
+// A quality byte >= 128 has no row (the reference would write out of bounds): flagged.
 template <bool kQual>
 __device__ __forceinline__ void bump(uint32_t *hist, u64 *__restrict__ gacc, uint32_t byte, uint32_t pos, uint32_t &bad,
                                      HiTot &hi)
@@ -76,77 +91,93 @@ __device__ __forceinline__ void bump(uint32_t *hist, u64 *__restrict__ gacc, uin
     }
     const uint32_t row = kQual ? byte : nuc_code(byte);
     if (pos < (uint32_t)kLdsCycles) {
-        atomicAdd(&hist[row * kRowWords + pos], 1u);
+        atomicAdd(&hist[lds_word(row, pos)], 1u);
     } else {
         atomicAdd(&gacc[row * HPN_LEN_BINS + pos], (u64)1);
         if (kQual) hi.tot += 1, hi.c20 += byte >= 53, hi.c30 += byte >= 63;
     }
 }
 
+// 4 bytes from any address (hardware unaligned access: one global_load_dword).
+__device__ __forceinline__ uint32_t load_unaligned4(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // Equal-length chunk, 16 <= len0 <= 256: cnt reads of len0 bytes starting at arr + base_off.
+// Work item = (read r, group j) = cycles 4j..4j+3 of read r, one unaligned dword load
+// (256 B per wave-instruction: four times the bytes in flight of byte loads, which ran into
+// the per-CU limit on outstanding requests).  A lane's items are tid + 1024 m; (r, j) advance
+// by a per-chunk constant with carry: one division per chunk.
 template <bool kQual>
 __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint32_t cnt,
                                                uint32_t len0, uint32_t &bad)
 {
     uint32_t *hist = kQual ? s.qh : s.nh;
     const uint8_t *p0 = arr + base_off;
-    const uint32_t B = cnt * len0;
-    const uint32_t lane = (uint32_t)lane_id();
-    // this wave's spans are wid, wid+16, ...: byte index of the lane in its span m is b + 1024 m
-    uint32_t b = 64u * (uint32_t)wave_id() + lane;
-    if (b >= B) return;
-    const uint32_t step = (64u * kHistWaves) % len0;  // cycle advance from one of the wave's spans to the next
-    uint32_t pos = b % len0;                          // the one division per chunk
-    auto next_pos = [&](uint32_t p) {
-        p += step;
-        return min(p, p - len0);  // p < len0 ? p : p - len0, in unsigned arithmetic
-    };
-    uint32_t va[kSpanRound], vb[kSpanRound];
-    auto fetch = [&](uint32_t (&v)[kSpanRound], uint32_t b0) {
+    const uint32_t ngr = len0 >> 2;               // whole 4-cycle groups per read
+    const uint32_t items = cnt * ngr;
+    const uint32_t dr = kHistThreads / ngr, dj = kHistThreads - dr * ngr;
+    uint32_t w = threadIdx.x;
+    uint32_t r = w / ngr, j = w - r * ngr;        // the one division per chunk
+    uint32_t va[kSpanRound], vb[kSpanRound], ja[kSpanRound], jb[kSpanRound];
+    auto fetch = [&](uint32_t (&v)[kSpanRound], uint32_t (&jj)[kSpanRound]) {
 #pragma unroll
         for (int m = 0; m < kSpanRound; ++m) {
-            const uint32_t bb = b0 + (uint32_t)m * 64u * kHistWaves;
-            v[m] = p0[min(bb, B - 1)];  // never branch around a load: the waits stay counted
+            // no branch around the load (an idle lane re-reads the chunk's first bytes): the
+            // compiler then counts the loads in flight instead of draining them all
+            const bool on = w < items;
+            v[m] = load_unaligned4(on ? p0 + (size_t)r * len0 + 4u * j : p0);
+            jj[m] = on ? j : ~0u;
+            w += kHistThreads;
+            r += dr, j += dj;
+            if (j >= ngr) j -= ngr, ++r;
         }
     };
-    // A quality byte >= 128 has no row: its bit 7 is OR-ed into `seen` (checked once per chunk,
-    // the batch is then rejected) and the row index is masked so that the LDS address stays in
-    // range -- no compare, no exec-mask juggling in the loop (the per-step predicate cost 6 SALU
-    // + 5 VALU per byte in the first version of this loop, PMC profiles/r01b).
+    // A quality byte >= 128 has no row: bit 7 of every byte is OR-ed into `seen` (checked once
+    // per chunk; the batch is then rejected) and the row index is masked to 7 bits so that the
+    // LDS address stays in range: no compare, no exec-mask juggling per byte.
     uint32_t seen = 0;
-    auto tally = [&](const uint32_t (&v)[kSpanRound], uint32_t b0, bool whole) {
+    auto tally = [&](const uint32_t (&v)[kSpanRound], const uint32_t (&jj)[kSpanRound]) {
 #pragma unroll
         for (int m = 0; m < kSpanRound; ++m) {
-            const uint32_t byte = v[m];
-            const uint32_t row = kQual ? (byte & (HPN_QUAL_ROWS - 1)) : nuc_code(byte);
-            if (whole) {
-                if (kQual) seen |= byte;
-                atomicAdd(&hist[row * kRowWords + pos], 1u);
-            } else if (b0 + (uint32_t)m * 64u * kHistWaves < B) {
-                if (kQual) seen |= byte;
-                atomicAdd(&hist[row * kRowWords + pos], 1u);
+            if (jj[m] == ~0u) continue;
+            const uint32_t d = v[m];
+            if (kQual) seen |= d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t byte = (d >> (8 * k)) & (kQual ? 0x7fu : 0xffu);
+                const uint32_t row = kQual ? byte : nuc_code(byte);
+                atomicAdd(&hist[row * kRowWords + 64 * k + jj[m]], 1u);
             }
-            pos = next_pos(pos);
         }
     };
-    const uint32_t round = (uint32_t)kSpanRound * 64u * kHistWaves;
-    fetch(va, b);
-    for (;;) {
-        // rounds that lie entirely inside the chunk for the WHOLE wave take the predicate-free body
-        const uint32_t b1 = b + round;
-        fetch(vb, b1);  // unconditional (addresses are clamped): no branch around loads
-        const uint32_t wave_last = b - lane + 63u + round - 64u * kHistWaves;  // last byte the wave touches this round
-        if (wave_last < B) tally(va, b, true);
-        else tally(va, b, false);
-        if (b1 >= B) break;
-        const uint32_t b2 = b1 + round;
-        fetch(va, b2);
-        if (wave_last + round < B) tally(vb, b1, true);
-        else tally(vb, b1, false);
-        if (b2 >= B) break;
-        b = b2;
+    if (items) {
+        fetch(va, ja);
+        for (;;) {
+            const bool more_b = w < items;
+            fetch(vb, jb);
+            tally(va, ja);
+            if (!more_b) break;
+            const bool more_a = w < items;
+            fetch(va, ja);
+            tally(vb, jb);
+            if (!more_a) break;
+        }
     }
-    if (seen & 0x80u) bad = 1;
+    if (seen & 0x80808080u) bad = 1;
+    // tails: the last len0 % 4 bytes of every read, one lane per read
+    const uint32_t rem = len0 & 3u;
+    if (rem) {
+        HiTot unused;
+#pragma unroll 1
+        for (uint32_t rr = threadIdx.x; rr < cnt; rr += kHistThreads) {
+            const uint8_t *q = p0 + (size_t)rr * len0 + 4u * ngr;
+            for (uint32_t k = 0; k < rem; ++k) bump<kQual>(hist, nullptr, q[k], 4u * ngr + k, bad, unused);
+        }
+    }
 }
 
 // Any chunk: aligned vectors of the byte range, each located by binary search.
@@ -197,8 +228,8 @@ __device__ __forceinline__ void hist_flush(const uint32_t *lds, int rows, u64 *_
     for (int w = threadIdx.x; w < rows * kRowWords; w += kHistThreads) {
         const uint32_t v = lds[w];
         if (v) {
-            const int r = w / kRowWords, c = w - r * kRowWords;
-            atomicAdd(&gacc[r * HPN_LEN_BINS + c], (u64)v);
+            const int r = w / kRowWords, c = w - r * kRowWords;  // c = (cycle & 3) * 64 + (cycle >> 2)
+            atomicAdd(&gacc[r * HPN_LEN_BINS + 4 * (c & 63) + (c >> 6)], (u64)v);
             tot += v;
             if (r >= 53) t20 += v;
             if (r >= 63) t30 += v;
