@@ -251,10 +251,6 @@ hipError_t launch_depth_scan(const int32_t *diff, uint64_t slots, uint32_t targe
     u64 *n_runs = (u64 *)ws + 1;
     u64 *st_cov = (u64 *)ws + 2, *st_cnt = st_cov + tiles;
     DepthOut out{runs, runs_cap, n_runs, win_sum};
-    if (const char *dbg = getenv("HPN_K4_DEBUG")) {  // timing experiments only: 1 = no run writes, 2 = no window sums
-        if (atoi(dbg) & 1) out.runs_cap = 0;
-        if (atoi(dbg) & 2) W = 0;
-    }
     hipLaunchKernelGGL(k_depth_scan, dim3((unsigned)tiles), dim3(kDsThreads), 0, st, diff, slots, target_len, W, out, st_cov,
                        st_cnt, ticket, ticket + 1);
     return hipGetLastError();
