@@ -31,6 +31,14 @@ class Tally(C.Structure):
                 ("q30", C.c_uint64), ("qual_hist", C.POINTER(C.c_uint64)), ("nuc_hist", C.POINTER(C.c_uint64))]
 
 
+class TextInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_bytes", C.c_uint64), ("carry_bytes", C.c_uint64),
+                ("irregular", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+TEXT_NUL, TEXT_LONG_LINE, TEXT_RAGGED, TEXT_PARTIAL, TEXT_LEN, TEXT_DENSE = 1, 2, 4, 8, 16, 32
+
+
 class Run(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32)]
 
@@ -69,6 +77,9 @@ SYMBOLS = [
     ("hpn_fastq_qtrim_points_dev", _int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     ("hpn_fastq_trim_points", _int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("hpn_fastq_trim_points_dev", _int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    ("hpn_fastq_text_begin", _int, [_vp]),
+    ("hpn_fastq_text_count", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
+    ("hpn_fastq_text_trim", _int, [_vp, _vp, _u64, _int, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_depth_begin", _int, [_vp, _i32, _u32, _u32]),
     ("hpn_depth_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_add_dev", _int, [_vp, C.POINTER(BamBatch)]),

@@ -160,6 +160,36 @@ class Context:
         tot = int(ooff[-1])
         return oseq[:tot], oqual[:tot], ooff
 
+    # ---- raw-text front end (device-side framing) ------------------------------
+    def text_begin(self):
+        self._ck(self.L.hpn_fastq_text_begin(self.h), "hpn_fastq_text_begin")
+
+    @staticmethod
+    def _text(chunk):
+        if isinstance(chunk, (bytes, bytearray, memoryview)):
+            chunk = np.frombuffer(chunk, np.uint8)
+        if isinstance(chunk, np.ndarray):
+            chunk = np.ascontiguousarray(chunk, np.uint8)
+            return chunk, chunk.size
+        return chunk, chunk.numel()  # device tensor
+
+    def text_count(self, chunk, last=False, flags=0):
+        """One chunk of FASTQ text -> device accumulators; returns the hpn_text_info."""
+        chunk, n = self._text(chunk)
+        info = _lib.TextInfo()
+        self._ck(self.L.hpn_fastq_text_count(self.h, _ptr(chunk) if n else None, n, int(bool(last)), flags, C.byref(info)),
+                 "hpn_fastq_text_count")
+        return info
+
+    def text_trim(self, chunk, S, E, last=False):
+        """One chunk of FASTQ text -> (trimmed text bytes, hpn_text_info)."""
+        chunk, n = self._text(chunk)
+        info = _lib.TextInfo()
+        out = np.zeros(n + 8192, np.uint8)
+        self._ck(self.L.hpn_fastq_text_trim(self.h, _ptr(chunk) if n else None, n, int(bool(last)), S, E, _ptr(out), out.size,
+                                            C.byref(info)), "hpn_fastq_text_trim")
+        return out[:0 if info.irregular else int(info.n_bytes)].tobytes(), info
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

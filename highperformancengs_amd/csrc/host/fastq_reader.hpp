@@ -34,7 +34,20 @@ constexpr int kLineBuf = 1024;  // fastq_count.c:107
 struct InStream {
     gzFile gz = nullptr;
     std::shared_ptr<BgzfReader> bz;
-    int read(void *dst, unsigned n) { return bz ? (int)bz->read(dst, n) : gzread(gz, dst, n); }
+    // bytes that were already taken from the stream and are to be served again first
+    // (the text front end hands an irregular stream back to the exact framer this way)
+    std::shared_ptr<const std::vector<char>> pre;
+    size_t pre_pos = 0;
+    int read(void *dst, unsigned n)
+    {
+        if (pre && pre_pos < pre->size()) {
+            const size_t k = pre->size() - pre_pos < n ? pre->size() - pre_pos : n;
+            memcpy(dst, pre->data() + pre_pos, k);
+            pre_pos += k;
+            return (int)k;
+        }
+        return bz ? (int)bz->read(dst, n) : gzread(gz, dst, n);
+    }
     void close()
     {
         if (gz) gzclose(gz);

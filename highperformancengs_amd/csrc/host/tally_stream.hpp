@@ -6,6 +6,7 @@
 // while the GPU copies and scans batch k, the host frames batch k+1.
 #pragma once
 #include "../host/fastq_reader.hpp"
+#include "../host/text_stream.hpp"
 #include "hpngs.h"
 
 namespace hpn {
@@ -58,6 +59,50 @@ inline int tally_stream(hpn_ctx *ctx, const InStream &fq, hpn_tally *acc, bool *
         s.b.qual = nullptr, s.b.off = nullptr;
         hpn_dev_free(ctx, s.d_qual), hpn_dev_free(ctx, s.d_off);
     }
+    return rc;
+}
+
+// The same through the raw-text front end: the reader thread delivers bytes, the GPU frames
+// and tallies them.  *irregular is set (and nothing is added to acc) when the text is not
+// regular FASTQ in the sense of include/hpngs.h; the caller then runs tally_stream.
+inline int tally_text_stream(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *irregular)
+{
+    *irregular = false;
+    TextPump pump(ctx, path, text_chunk_bytes());
+    if (!pump.ok()) return HPN_E_NOMEM;
+    const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
+    int rc = hpn_fastq_text_begin(ctx);
+    TextPump::Chunk c;
+    while (rc == HPN_OK && pump.next(c)) {
+        hpn_text_info info;
+        rc = hpn_fastq_text_count(ctx, c.p, c.n, c.eof, flags, &info);
+        pump.recycle(c);
+        if (rc == HPN_OK && info.irregular) {
+            *irregular = true;
+            break;
+        }
+    }
+    if (*irregular || rc != HPN_OK) {  // drop whatever earlier chunks added on the device
+        hpn_tally scratch;
+        memset(&scratch, 0, sizeof scratch);
+        (void)hpn_fastq_tally_fetch(ctx, &scratch);
+        return rc;
+    }
+    return hpn_fastq_tally_fetch(ctx, acc);
+}
+
+// One input file of fastq_count / fastq_count_kthread (count_read, fastq_count.c:106-133).
+inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_long)
+{
+    const bool is_stdin = strncmp(path, "-", 1) == 0 || !strcmp(path, "");
+    if (text_path_enabled() && !is_stdin) {  // an irregular stream is framed again from its first byte
+        bool irregular = false;
+        const int rc = tally_text_stream(ctx, path, acc, &irregular);
+        if (!irregular) return rc;
+    }
+    InStream fq = open_input_stream(path);
+    const int rc = tally_stream(ctx, fq, acc, too_long);
+    fq.close();
     return rc;
 }
 

@@ -1,0 +1,213 @@
+// text_stream.hpp -- raw text of one FASTQ input -> pinned chunks for the device framer.
+//
+// The reference's tools spend their FASTQ time in gzgets (fastq_count.c:112-118,
+// fastq_trim.c:67-89).  With hpn_fastq_text_count / hpn_fastq_text_trim the framing runs
+// on the GPU, so the host only has to deliver bytes: a reader thread fills pinned chunks
+//   - plain regular files: parallel pread straight into the pinned buffer,
+//   - gzip: zlib gzread (inflate is the bound, as in the reference),
+//   - BGZF: the block-parallel inflater (bam_reader.hpp),
+// while the caller's thread submits the previous chunk.  The chunk that hits the end of
+// the data carries eof = true (it may be empty).
+#pragma once
+#include <sys/stat.h>
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "fastq_reader.hpp"
+#include "hpngs.h"
+
+namespace hpn {
+
+inline size_t text_chunk_bytes()
+{
+    const char *e = getenv("HPN_TEXT_CHUNK");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 64 ? (size_t)v : (size_t)32 << 20;
+}
+inline bool text_path_enabled()
+{
+    const char *e = getenv("HPN_TEXT");
+    return !(e && e[0] == '0');
+}
+
+class TextPump {
+public:
+    struct Chunk {
+        uint8_t *p = nullptr;
+        size_t n = 0;
+        bool eof = false;
+        int idx = -1;
+    };
+
+    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3) : ctx_(ctx), cap_(chunk)
+    {
+        struct stat sb;
+        uint8_t magic[2] = {0, 0};
+        const bool is_stdin = strncmp(path, "-", 1) == 0 || !strcmp(path, "");
+        if (!is_stdin && stat(path, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            const int fd = open(path, O_RDONLY);
+            if (fd >= 0) {
+                const ssize_t k = pread(fd, magic, 2, 0);
+                if (k < 2 || magic[0] != 0x1f || magic[1] != 0x8b) {  // zlib would copy it through unchanged
+                    fd_ = fd;
+                } else {
+                    close(fd);
+                }
+            }
+        }
+        if (fd_ < 0) in_ = open_input_stream(path);
+        for (int i = 0; i < nbuf; ++i) {
+            void *p = nullptr;
+            if (hpn_host_malloc(ctx_, cap_ + 64, &p) != HPN_OK) break;
+            buf_.push_back((uint8_t *)p);
+            free_.push_back(i);
+        }
+        ok_ = (int)buf_.size() == nbuf && (fd_ >= 0 || in_.gz || in_.bz);
+        if (ok_) th_ = std::thread([this] { loop(); });
+    }
+    ~TextPump()
+    {
+        halt();
+        for (uint8_t *p : buf_) hpn_host_free(ctx_, p);
+        if (fd_ >= 0) close(fd_);
+        if (!handed_over_) in_.close();
+    }
+    bool ok() const { return ok_; }
+
+    // Next filled chunk in stream order; false once the eof chunk has been handed out.
+    bool next(Chunk &c)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !full_.empty() || done_; });
+        if (full_.empty()) return false;
+        c = full_.front();
+        full_.pop_front();
+        return true;
+    }
+    void recycle(const Chunk &c)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            free_.push_back(c.idx);
+        }
+        cv_.notify_all();
+    }
+
+    // Stop reading.  Every byte that was read but not handed out is appended to `rest`,
+    // and the returned stream continues right behind those bytes.
+    InStream stop(std::vector<char> &rest)
+    {
+        halt();
+        for (const Chunk &c : full_) rest.insert(rest.end(), (const char *)c.p, (const char *)c.p + c.n);
+        full_.clear();
+        if (fd_ >= 0) {
+            lseek(fd_, (off_t)pos_, SEEK_SET);
+            in_.gz = gzdopen(fd_, "rb");
+            if (in_.gz) gzbuffer(in_.gz, 1u << 20);
+            fd_ = -1;
+        }
+        handed_over_ = true;
+        return in_;
+    }
+
+private:
+    void halt()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+
+    size_t fill(uint8_t *dst)
+    {
+        if (fd_ >= 0) {  // plain file: a few threads pull disjoint pieces out of the page cache
+            static const int kThreads = [] {
+                const char *e = getenv("HPN_READ_THREADS");
+                const long n = e ? atol(e) : 4;
+                return (int)(n < 1 ? 1 : n > 32 ? 32 : n);
+            }();
+            const size_t piece = (cap_ / (size_t)kThreads + 4095) & ~(size_t)4095;
+            std::vector<size_t> got((size_t)kThreads, 0);
+            auto pull = [&](int t) {
+                const size_t lo = (size_t)t * piece, hi = lo + piece < cap_ ? lo + piece : cap_;
+                size_t g = 0;
+                while (lo + g < hi) {
+                    const ssize_t k = pread(fd_, dst + lo + g, hi - lo - g, (off_t)(pos_ + lo + g));
+                    if (k <= 0) break;
+                    g += (size_t)k;
+                }
+                got[(size_t)t] = g;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < kThreads && (size_t)t * piece < cap_; ++t) th.emplace_back(pull, t);
+            pull(0);
+            for (auto &t : th) t.join();
+            size_t n = 0;
+            for (int t = 0; t < kThreads; ++t) {  // contiguous prefix: a short piece is the end of the file
+                const size_t lo = (size_t)t * piece, want = lo >= cap_ ? 0 : (lo + piece < cap_ ? piece : cap_ - lo);
+                n += got[(size_t)t];
+                if (got[(size_t)t] < want) break;
+            }
+            pos_ += n;
+            return n;
+        }
+        size_t n = 0;
+        while (n < cap_) {
+            const size_t ask = cap_ - n < ((size_t)1 << 28) ? cap_ - n : (size_t)1 << 28;
+            const int k = in_.read(dst + n, (unsigned)ask);
+            if (k <= 0) break;
+            n += (size_t)k;
+        }
+        return n;
+    }
+
+    void loop()
+    {
+        for (;;) {
+            int idx;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return !free_.empty() || stop_; });
+                if (stop_) break;
+                idx = free_.front();
+                free_.pop_front();
+            }
+            Chunk c;
+            c.idx = idx;
+            c.p = buf_[(size_t)idx];
+            c.n = fill(c.p);
+            c.eof = c.n < cap_;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                full_.push_back(c);
+                if (c.eof) done_ = true;
+            }
+            cv_.notify_all();
+            if (c.eof) return;
+        }
+        std::lock_guard<std::mutex> lk(m_);
+        done_ = true;
+    }
+
+    hpn_ctx *ctx_;
+    size_t cap_;
+    int fd_ = -1;
+    uint64_t pos_ = 0;
+    InStream in_;
+    bool ok_ = false, handed_over_ = false;
+    std::vector<uint8_t *> buf_;
+    std::deque<int> free_;
+    std::deque<Chunk> full_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;
+    bool stop_ = false, done_ = false;
+};
+
+}  // namespace hpn

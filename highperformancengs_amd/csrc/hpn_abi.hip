@@ -88,11 +88,14 @@ int hpn_ctx_destroy(hpn_ctx *c)
     if (c->comm) hpn_comm_destroy(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     Scratch *ss[] = {&c->s_a, &c->s_b, &c->s_c, &c->s_d, &c->s_e, &c->s_f, &c->s_g, &c->s_h, &c->d_diff, &c->d_runs,
-                     &c->d_win, &c->d_ws, &c->w_off, &c->w_bins, &c->w_len, &c->w_gc, &c->w_misc};
+                     &c->d_win, &c->d_ws, &c->w_off, &c->w_bins, &c->w_len, &c->w_gc, &c->w_misc, &c->t_slot[0], &c->t_slot[1],
+                     &c->t_nl, &c->t_off, &c->t_status, &c->t_pq, &c->t_ps, &c->t_out};
     for (Scratch *s : ss)
         if (s->p) (void)hipFree(s->p);
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->h_acc) (void)hipHostFree(c->h_acc);
+    if (c->t_state) (void)hipFree(c->t_state);
+    if (c->h_tstate) (void)hipHostFree(c->h_tstate);
     for (int f = 0; f < kFamCount; ++f) {
         if (c->ev_beg[f]) (void)hipEventDestroy(c->ev_beg[f]);
         if (c->ev_end[f]) (void)hipEventDestroy(c->ev_end[f]);
@@ -183,8 +186,11 @@ int hpn_memcpy_d2h(hpn_ctx *c, void *dst, const void *src, size_t bytes)
 
 // ---- fastq tally -----------------------------------------------------------------
 
-static int tally_launch(hpn_ctx *c, const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off,
-                        uint64_t n, uint64_t approx_bytes, uint32_t flags)
+}  // extern "C"
+
+// shared with the raw-text front end (hpn_text.hip)
+int hpn::tally_launch(hpn_ctx *c, const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off, uint64_t n,
+                      uint64_t approx_bytes, uint32_t flags)
 {
     const bool qh = flags & HPN_TALLY_QUAL_HIST, nh = flags & HPN_TALLY_NUC_HIST;
     if (nh && !d_base) return fail(c, HPN_E_ARG, "HPN_TALLY_NUC_HIST needs the base array");
@@ -197,6 +203,8 @@ static int tally_launch(hpn_ctx *c, const uint8_t *d_qual, const uint8_t *d_base
     c->ev_valid[kFamTally] = true;
     return HPN_OK;
 }
+
+extern "C" {
 
 int hpn_fastq_tally_dev(hpn_ctx *c, const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off,
                         uint64_t n, uint32_t flags)

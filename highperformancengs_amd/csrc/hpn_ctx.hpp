@@ -7,6 +7,7 @@
 
 #include "hpngs.h"
 
+struct hpn_ctx;
 namespace hpn {
 typedef unsigned long long u64;
 
@@ -15,6 +16,8 @@ hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint6
                              u64 *d_acc, u64 *d_sched, int n_cu, hipStream_t st);
 hipError_t launch_tally_hist(const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off, uint64_t n,
                              bool qual_hist, bool nuc_hist, u64 *d_acc, int n_cu, hipStream_t st);
+int tally_launch(hpn_ctx *c, const uint8_t *d_qual, const uint8_t *d_base, const uint64_t *d_off, uint64_t n,
+                 uint64_t approx_bytes, uint32_t flags);
 hipError_t launch_synth_fastq(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint8_t *d_qual,
                               uint8_t *d_base, uint64_t *d_off, int n_cu, hipStream_t st);
 
@@ -24,7 +27,7 @@ struct Scratch {
     size_t cap = 0;
 };
 
-enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamCount = 4 };
+enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamText = 4, kFamCount = 5 };
 
 }  // namespace hpn
 
@@ -55,6 +58,13 @@ struct hpn_ctx {
     int32_t win_targets = 0;
     uint32_t win_W = 0;
     uint64_t win_total = 0;
+    // raw-text front end: two device slots (carry area + chunk), line index, offsets, packed lines
+    hpn::Scratch t_slot[2], t_nl, t_off, t_status, t_pq, t_ps, t_out;
+    uint32_t *t_state = nullptr;    // device state block of the framing kernels
+    uint32_t *h_tstate = nullptr;   // pinned mirror
+    bool t_open = false;
+    int t_cur = 0;
+    uint32_t t_carry = 0, t_tail = 0;  // carry bytes and where they start in slot[t_cur ^ 1]
     // RCCL
     void *comm = nullptr;
     char err[512] = {0};

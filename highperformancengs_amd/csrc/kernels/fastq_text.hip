@@ -1,0 +1,386 @@
+// fastq_text.hip -- gfx950 kernels of the raw-text front end (hpn_fastq_text_*).
+//
+// The reference frames a FASTQ stream with four gzgets() calls per record into
+// one 1024-byte buffer (fastq_count.c:112-118, fastq_trim.c:67-89).  On REGULAR
+// text -- no NUL byte, every line at most 1022 characters + '\n', whole
+// records, quality line not shorter than the sequence line -- that loop is a
+// pure function of the newline positions, and these kernels compute it on the
+// device from the raw bytes:
+//
+//   k_text_lines    newline index: every workgroup counts the '\n' of its 16 KiB
+//                   tile (SWAR on dwordx4 loads), one decoupled look-back chain
+//                   (scan.hpp) turns the counts into global line numbers, and the
+//                   position of line j's '\n' lands in nl[j].
+//   k_text_records  one thread per record = 4 lines: checks the regularity
+//                   conditions above, derives the record's length (count) or
+//                   output size (trim) and scans it into off[] with a second
+//                   look-back chain.  Everything irregular raises a flag; the host
+//                   then frames that stream with the exact gzgets emulation.
+//   k_text_gather   count: quality (and sequence) lines -> packed arrays for
+//                   k_tally_scan / k_tally_hist.
+//   k_text_trim     trim: writes "name\nseq[S:E]\n+\nqual[S:E]\n" (fastq_trim.c:101)
+//                   for every record straight into the output text.
+//
+// Bound: HBM (one read of the text per kernel, 4 B per line, 8 B per record);
+// in the tools the PCIe copy of the text is ~100x slower than these kernels.
+#include "scan.hpp"
+
+namespace hpn {
+
+constexpr int kTxtThreads = 256;
+constexpr int kTxtRows = 4;                                     // 16-byte words per thread
+constexpr uint32_t kTxtTile = kTxtThreads * kTxtRows * 16;      // bytes per workgroup
+constexpr int kRecPerThread = 4;
+constexpr uint32_t kRecTile = kTxtThreads * kRecPerThread;      // records per workgroup
+
+// device state block (uint32 words), zeroed before every chunk
+enum { kTsLines = 0, kTsRecs, kTsFlags, kTsUnterminated, kTsConsumed, kTsTotalLo, kTsTotalHi, kTsErr, kTsTicket1, kTsTicket2, kTsWords = 16 };
+
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x)  // 0x80 in exactly the bytes of x that are 0
+{
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+}
+__device__ __forceinline__ uint32_t pack4(uint32_t m)  // 0x80 flags of 4 bytes -> 4 bits
+{
+    return ((((m >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan32(uint32_t v, uint32_t &total)
+{
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, kWave);
+        if (lane_id() >= o) inc += t;
+    }
+    total = __shfl(inc, kWave - 1, kWave);
+    return inc - v;
+}
+
+// text = slot[begin, end).  With `last`, a final line that lacks its '\n' is closed by a
+// virtual one at position `end` (state word kTsUnterminated tells the record kernel).
+__global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__restrict__ slot, uint32_t begin,
+                                                            uint32_t end, int last, uint32_t *__restrict__ nl,
+                                                            uint32_t nl_cap, u64 *__restrict__ status,
+                                                            uint32_t *__restrict__ st)
+{
+    __shared__ uint32_t s_w[kTxtRows][kTxtThreads / kWave];
+    __shared__ u64 s_excl;
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(&st[kTsTicket1], 1u);  // tiles in start order (look-back never waits on a tile not yet running)
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t a0 = begin & ~15u;
+    uint32_t mask[kTxtRows], cnt[kTxtRows], nul = 0;
+#pragma unroll
+    for (int k = 0; k < kTxtRows; ++k) {
+        const uint32_t p = a0 + tile * kTxtTile + (uint32_t)(k * kTxtThreads + tid) * 16u;
+        uint32_t m = 0;
+        if (p < end) {
+            const u32 w = load_stream16((const u32 *)(slot + p));
+            uint32_t z = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                m |= pack4(zero_bytes(w[d] ^ 0x0a0a0a0au)) << (4 * d);
+                z |= pack4(zero_bytes(w[d])) << (4 * d);
+            }
+            const uint32_t lo = p < begin ? begin - p : 0u;
+            const uint32_t hi = end - p >= 16u ? 16u : end - p;
+            const uint32_t valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            m &= valid;
+            nul |= z & valid;
+            if (last && end > begin && end - 1u >= p && end - 1u - p < 16u) {  // this word holds the last byte of the stream
+                if (!((m >> (end - 1u - p)) & 1u)) {
+                    m |= 1u << hi;  // virtual '\n' at position end
+                    st[kTsUnterminated] = 1u;
+                }
+            }
+        }
+        mask[k] = m;
+        cnt[k] = (uint32_t)__builtin_popcount(m);
+    }
+    uint32_t excl[kTxtRows];
+#pragma unroll
+    for (int k = 0; k < kTxtRows; ++k) {
+        uint32_t wt;
+        excl[k] = wave_excl_scan32(cnt[k], wt);
+        if (lane_id() == kWave - 1) s_w[k][wave_id()] = wt;
+    }
+    __syncthreads();
+    uint32_t aggregate = 0, before[kTxtRows];
+#pragma unroll
+    for (int k = 0; k < kTxtRows; ++k) {
+#pragma unroll
+        for (int w = 0; w < kTxtThreads / kWave; ++w) {
+            if (w == wave_id()) before[k] = aggregate;
+            aggregate += s_w[k][w];
+        }
+    }
+    if (wave_id() == 0) {
+        const u64 ex = scan_lookback(status, tile, aggregate, &st[kTsErr]);
+        if (lane_id() == 0) s_excl = ex;
+    }
+    __syncthreads();
+    const u64 tile_base = s_excl;
+    bool dense = false;
+#pragma unroll
+    for (int k = 0; k < kTxtRows; ++k) {
+        const uint32_t p = a0 + tile * kTxtTile + (uint32_t)(k * kTxtThreads + tid) * 16u;
+        u64 g = tile_base + before[k] + excl[k];
+        uint32_t m = mask[k];
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            if (g < nl_cap) nl[g] = p + (uint32_t)j;
+            else dense = true;
+            ++g;
+        }
+    }
+    if (nul) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_NUL);
+    if (dense) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_DENSE);
+    if (tile == gridDim.x - 1 && tid == 0) {
+        const u64 n = tile_base + aggregate;
+        st[kTsLines] = n > nl_cap ? nl_cap : (uint32_t)n;
+    }
+}
+
+__device__ __forceinline__ uint32_t trim_cut(uint32_t l, uint32_t S, uint32_t E, uint32_t &b)
+{
+    b = S < l ? S : l;
+    const uint32_t e = E < l ? E : l;
+    return e > b ? e - b : 0u;
+}
+
+// Launched with an upper bound of tiles (the line count lives on the device).
+template <bool kTrim>
+__global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__restrict__ nl, uint32_t begin,
+                                                              uint32_t end, int last, uint32_t S, uint32_t E,
+                                                              uint32_t carry_cap, uint64_t *__restrict__ off,
+                                                              u64 *__restrict__ status, uint32_t *__restrict__ st)
+{
+    __shared__ u64 s_wave[kTxtThreads / kWave];
+    __shared__ u64 s_excl;
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(&st[kTsTicket2], 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t n_lines = st[kTsLines];
+    const uint32_t n = n_lines >> 2;
+    const uint32_t unterminated = st[kTsUnterminated];
+    if (tile == 0 && tid == 0) {
+        st[kTsRecs] = n;
+        uint32_t consumed = n ? nl[4u * n - 1u] + 1u : begin;
+        if (consumed > end) consumed = end;  // the virtual newline
+        st[kTsConsumed] = consumed;
+        const uint32_t left = end - consumed;
+        uint32_t f = 0;
+        if (last && left) f |= HPN_TEXT_PARTIAL;
+        if (!last && left > carry_cap) f |= HPN_TEXT_LONG_LINE;
+        if (kTrim && unterminated) f |= HPN_TEXT_PARTIAL;
+        if (f) atomicOr(&st[kTsFlags], f);
+        if (n == 0) {
+            off[0] = 0;
+            st[kTsTotalLo] = st[kTsTotalHi] = 0;
+        }
+    }
+    if ((u64)tile * kRecTile >= n) return;  // nothing here, and nobody looks back at this tile
+    const uint32_t base = tile * kRecTile + (uint32_t)tid * kRecPerThread;
+    uint32_t val[kRecPerThread], flags = 0;
+    uint32_t prev = base && base < n ? nl[4u * base - 1u] : begin - 1u;
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kRecPerThread; ++k) {
+        const uint32_t r = base + k;
+        val[k] = 0;
+        if (r < n) {
+            const u32 e = *(const u32 *)(nl + 4u * r);  // the record's four line ends
+            const uint32_t L1 = e[0] - prev, L2 = e[1] - e[0], L3 = e[2] - e[1];  // lengths with the '\n'
+            uint32_t L4 = e[3] - e[2];
+            if (L1 > 1023u || L2 > 1023u || L3 > 1023u || L4 > 1023u) flags |= HPN_TEXT_LONG_LINE;  // gzgets would split it
+            const uint32_t len = L2 - 1u;
+            if (kTrim) {
+                if (L4 != L2) flags |= HPN_TEXT_RAGGED;
+                uint32_t b;
+                val[k] = L1 + 2u * trim_cut(len, S, E, b) + 4u;
+            } else {
+                if (unterminated && r == n - 1u && (n_lines & 3u) == 0u) L4 -= 1u;  // no '\n' in the buffer after the last gzgets
+                if (L4 < len) flags |= HPN_TEXT_RAGGED;  // the reference would tally stale buffer bytes
+                if (len >= HPN_LEN_BINS) flags |= HPN_TEXT_LEN;
+                val[k] = len;
+            }
+            prev = e[3];
+        }
+        mine += val[k];
+    }
+    if (flags) atomicOr(&st[kTsFlags], flags);
+    u64 wtotal;
+    const u64 wexcl = wave_excl_scan(mine, wtotal);
+    if (lane_id() == kWave - 1) s_wave[wave_id()] = wtotal;
+    __syncthreads();
+    u64 before = 0, aggregate = 0;
+#pragma unroll
+    for (int w = 0; w < kTxtThreads / kWave; ++w) {
+        if (w < wave_id()) before += s_wave[w];
+        aggregate += s_wave[w];
+    }
+    if (wave_id() == 0) {
+        const u64 ex = scan_lookback(status, tile, aggregate, &st[kTsErr]);
+        if (lane_id() == 0) s_excl = ex;
+    }
+    __syncthreads();
+    u64 run = s_excl + before + wexcl;
+#pragma unroll
+    for (int k = 0; k < kRecPerThread; ++k) {
+        const uint32_t r = base + k;
+        if (r < n) off[r] = run;
+        run += val[k];
+        if (r + 1u == n) {
+            off[n] = run;
+            st[kTsTotalLo] = (uint32_t)run;
+            st[kTsTotalHi] = (uint32_t)(run >> 32);
+        }
+    }
+}
+
+// 16 lanes copy one span: 16-byte unaligned pieces, the last one overlapping its
+// predecessor; spans shorter than 16 bytewise.
+__device__ __forceinline__ void copy_span(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t cnt, int sub)
+{
+    if (cnt >= 16u) {
+        for (uint32_t i = 16u * (uint32_t)sub; i < cnt; i += 256u) {
+            const uint32_t o = min(i, cnt - 16u);
+            u32 v;
+            __builtin_memcpy(&v, src + o, 16);
+            __builtin_memcpy(dst + o, &v, 16);
+        }
+    } else if ((uint32_t)sub < cnt) {
+        dst[sub] = src[sub];
+    }
+}
+
+__global__ __launch_bounds__(kTxtThreads) void k_text_gather(const uint8_t *__restrict__ slot,
+                                                             const uint32_t *__restrict__ nl,
+                                                             const uint64_t *__restrict__ off, uint32_t n,
+                                                             uint8_t *__restrict__ out_qual,
+                                                             uint8_t *__restrict__ out_seq)
+{
+    const uint32_t nwaves = gridDim.x * (kTxtThreads / kWave);
+    const uint32_t wave = blockIdx.x * (kTxtThreads / kWave) + wave_id();
+    const int lane = lane_id(), sub = lane & 15, g = lane >> 4;
+    for (uint32_t r0 = wave * kWave; r0 < n; r0 += nwaves * kWave) {
+        const uint32_t r = r0 + lane;
+        uint32_t qs = 0, ss = 0, cnt = 0;
+        uint64_t d = 0;
+        if (r < n) {
+            const u32 e = *(const u32 *)(nl + 4u * r);
+            ss = e[0] + 1u, qs = e[2] + 1u, cnt = e[1] - e[0] - 1u;
+            d = off[r];
+        }
+#pragma unroll 2
+        for (int it = 0; it < kWave / 4; ++it) {  // four records per wave-instruction
+            const int j = 4 * it + g;
+            const uint32_t qj = __shfl(qs, j, kWave), sj = __shfl(ss, j, kWave), cj = __shfl(cnt, j, kWave);
+            const uint64_t dj = __shfl(d, j, kWave);
+            copy_span(slot + qj, out_qual + dj, cj, sub);
+            if (out_seq) copy_span(slot + sj, out_seq + dj, cj, sub);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kTxtThreads) void k_text_trim(const uint8_t *__restrict__ slot,
+                                                           const uint32_t *__restrict__ nl, uint32_t begin,
+                                                           const uint64_t *__restrict__ off, uint32_t n, uint32_t S,
+                                                           uint32_t E, uint8_t *__restrict__ out)
+{
+    const uint32_t nwaves = gridDim.x * (kTxtThreads / kWave);
+    const uint32_t wave = blockIdx.x * (kTxtThreads / kWave) + wave_id();
+    const int lane = lane_id(), sub = lane & 15, g = lane >> 4;
+    for (uint32_t r0 = wave * kWave; r0 < n; r0 += nwaves * kWave) {
+        const uint32_t r = r0 + lane;
+        uint32_t p0 = 0, L1 = 0, ss = 0, qs = 0, cut = 0;
+        uint64_t d = 0;
+        if (r < n) {
+            const u32 e = *(const u32 *)(nl + 4u * r);
+            p0 = r ? nl[4u * r - 1u] + 1u : begin;
+            L1 = e[0] + 1u - p0;  // name line with its '\n'
+            uint32_t b;
+            cut = trim_cut(e[1] - e[0] - 1u, S, E, b);
+            ss = e[0] + 1u + b, qs = e[2] + 1u + b;
+            d = off[r];
+        }
+#pragma unroll 2
+        for (int it = 0; it < kWave / 4; ++it) {
+            const int j = 4 * it + g;
+            const uint32_t pj = __shfl(p0, j, kWave), lj = __shfl(L1, j, kWave), sj = __shfl(ss, j, kWave);
+            const uint32_t qj = __shfl(qs, j, kWave), cj = __shfl(cut, j, kWave);
+            const uint64_t dj = __shfl(d, j, kWave);
+            if (r0 + (uint32_t)j >= n) continue;
+            uint8_t *o = out + dj;
+            copy_span(slot + pj, o, lj, sub);               // "%s\n"  name
+            copy_span(slot + sj, o + lj, cj, sub);          // "%s"    seq[S:min(E,len)]
+            copy_span(slot + qj, o + lj + cj + 3u, cj, sub);  // "%s"    qual[S:min(E,len)]
+            if (sub == 0) {
+                o[lj + cj] = '\n', o[lj + cj + 1u] = '+', o[lj + cj + 2u] = '\n';  // "\n+\n"
+                o[lj + 2u * cj + 3u] = '\n';
+            }
+        }
+    }
+}
+
+uint64_t text_tiles1(uint32_t begin, uint32_t end)
+{
+    const uint64_t span = (uint64_t)end - (begin & ~15u);
+    const uint64_t t = (span + kTxtTile - 1) / kTxtTile;
+    return t ? t : 1;
+}
+uint64_t text_tiles2(uint32_t nl_cap) { return (uint64_t)(nl_cap / 4u) / kRecTile + 1; }
+
+// frame: newline index + record validation / scan.  d_status holds text_tiles1 + text_tiles2 words.
+hipError_t launch_text_frame(const uint8_t *d_slot, uint32_t begin, uint32_t end, int last, bool trim, uint32_t S,
+                             uint32_t E, uint32_t carry_cap, uint32_t *d_nl, uint32_t nl_cap, uint64_t *d_off,
+                             u64 *d_status, uint32_t *d_state, hipStream_t st)
+{
+    const uint64_t t1 = text_tiles1(begin, end), t2 = text_tiles2(nl_cap);
+    hipError_t e = hipMemsetAsync(d_status, 0, (t1 + t2) * sizeof(u64), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_state, 0, kTsWords * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_text_lines, dim3((unsigned)t1), dim3(kTxtThreads), 0, st, d_slot, begin, end, last, d_nl, nl_cap,
+                       d_status, d_state);
+    if (trim)
+        hipLaunchKernelGGL(k_text_records<true>, dim3((unsigned)t2), dim3(kTxtThreads), 0, st, d_nl, begin, end, last, S, E,
+                           carry_cap, d_off, d_status + t1, d_state);
+    else
+        hipLaunchKernelGGL(k_text_records<false>, dim3((unsigned)t2), dim3(kTxtThreads), 0, st, d_nl, begin, end, last, S,
+                           E, carry_cap, d_off, d_status + t1, d_state);
+    return hipGetLastError();
+}
+
+static unsigned copy_grid(uint32_t n, int n_cu)
+{
+    uint64_t want = ((uint64_t)n + kTxtThreads - 1) / kTxtThreads;
+    const uint64_t cap = (uint64_t)n_cu * 8;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+hipError_t launch_text_gather(const uint8_t *d_slot, const uint32_t *d_nl, const uint64_t *d_off, uint32_t n,
+                              uint8_t *d_out_qual, uint8_t *d_out_seq, int n_cu, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_text_gather, dim3(copy_grid(n, n_cu)), dim3(kTxtThreads), 0, st, d_slot, d_nl, d_off, n,
+                       d_out_qual, d_out_seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_trim(const uint8_t *d_slot, const uint32_t *d_nl, uint32_t begin, const uint64_t *d_off, uint32_t n,
+                            uint32_t S, uint32_t E, uint8_t *d_out, int n_cu, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_text_trim, dim3(copy_grid(n, n_cu)), dim3(kTxtThreads), 0, st, d_slot, d_nl, begin, d_off, n, S, E,
+                       d_out);
+    return hipGetLastError();
+}
+
+}  // namespace hpn

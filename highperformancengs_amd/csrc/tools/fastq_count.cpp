@@ -46,17 +46,15 @@ static void count_file(const char *infile, FILE *out, int slot)
     hpn_ctx *ctx = nullptr;
     int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
-    InStream fq = open_input_stream(infile);
     hpn_tally acc;
     memset(&acc, 0, sizeof acc);
     bool too_long = false;
-    rc = tally_stream(ctx, fq, &acc, &too_long);  // count_read's loop (:112-119), tally on the GPU
+    rc = tally_file(ctx, infile, &acc, &too_long);  // count_read's loop (:112-119), tally on the GPU
     if (too_long) {
         fprintf(stderr, "%s: read longer than 511 bases (outside fastq_count's SeqLen[512])\n", infile);
         exit(2);
     }
     if (rc != HPN_OK) die_hpn(ctx, rc, infile);
-    fq.close();
     const CountSummary s = summarise(acc);
     {
         std::lock_guard<std::mutex> lk(g_lock);  // pthread_mutex_lock (fastq_count.c:126)

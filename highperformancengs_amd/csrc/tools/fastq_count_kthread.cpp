@@ -54,15 +54,13 @@ static void count_file(FileAcc &fa, const char *infile, int tid)
     hpn_ctx *ctx = nullptr;
     int rc = hpn_ctx_create(g_dev0 + tid % g_ndev, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
-    InStream fq = open_input_stream(infile);
     bool too_long = false;
-    rc = tally_stream(ctx, fq, &fa.t, &too_long);  // count_read's loop (:126-135), tally on the GPU
+    rc = tally_file(ctx, infile, &fa.t, &too_long);  // count_read's loop (:126-135), tally on the GPU
     if (too_long) {
         fprintf(stderr, "%s: read longer than 511 bases (outside SeqLen[512])\n", infile);
         exit(2);
     }
     if (rc != HPN_OK) die_hpn(ctx, rc, infile);
-    fq.close();
     hpn_ctx_destroy(ctx);
     fa.s = summarise(fa.t);
     if (g.header) print_count_header(fa.out);            // :140

@@ -10,6 +10,7 @@
 #include <getopt.h>
 
 #include "../host/fastq_reader.hpp"
+#include "../host/text_stream.hpp"
 #include "../host/report.hpp"
 
 using namespace hpn;
@@ -56,11 +57,50 @@ int main(int argc, char *argv[])
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
 
-    InStream in = open_input_stream(infile);
     FILE *out = fcreat_outfile(outfile, ".trim.fastq");
     unsigned long reads = 0;
     const long long begin = usec();
-    {
+    InStream in;
+    bool exact = !text_path_enabled();
+    if (!exact) {
+        // Fast path: raw text to the GPU, trimmed text back (framing, cut and formatting on the
+        // device).  At the first chunk that is not regular FASTQ the bytes not yet written
+        // out -- the carried-over tail, this chunk, whatever the reader has queued -- go to
+        // the exact framer below; records before them are unaffected (readNextNode zeroes its
+        // buffer per record, fastq_trim.c:97, so framing has no memory across records).
+        const size_t chunk = text_chunk_bytes();
+        TextPump pump(ctx, infile, chunk);
+        if (!pump.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
+        void *obuf = nullptr;
+        const size_t ocap = chunk + 8192 + 64;
+        if ((rc = hpn_host_malloc(ctx, ocap, &obuf)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
+        if ((rc = hpn_fastq_text_begin(ctx)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
+        std::vector<char> carry;  // host copy of the bytes the device carries over
+        TextPump::Chunk c;
+        while (pump.next(c)) {
+            hpn_text_info info;
+            rc = hpn_fastq_text_trim(ctx, c.p, c.n, c.eof, start, end, obuf, ocap, &info);
+            if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_text_trim");
+            if (info.irregular) {
+                auto rest = std::make_shared<std::vector<char>>(std::move(carry));
+                rest->insert(rest->end(), (const char *)c.p, (const char *)c.p + c.n);
+                pump.recycle(c);
+                in = pump.stop(*rest);
+                in.pre = rest;
+                exact = true;
+                break;
+            }
+            fwrite(obuf, 1, info.n_bytes, out);
+            reads += info.n_records;
+            carry.insert(carry.end(), (const char *)c.p, (const char *)c.p + c.n);
+            carry.erase(carry.begin(), carry.end() - (ptrdiff_t)info.carry_bytes);
+            pump.recycle(c);
+        }
+        hpn_host_free(ctx, obuf);
+    } else {
+        in = open_input_stream(infile);
+    }
+    if (exact) {
         TrimFramer framer(in);
         FastqBatch b;
         const size_t kBytes = 64u << 20, kRecs = 1u << 20;

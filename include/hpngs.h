@@ -62,7 +62,8 @@ int hpn_ctx_sync(hpn_ctx *ctx);
 const char *hpn_ctx_last_error(const hpn_ctx *ctx);
 /* Milliseconds the device spent in the most recent kernel launch group of the
  * given family, measured with hipEvents on the context's stream (valid after
- * the matching fetch/sync). Families: 0 tally, 1 trim, 2 depth, 3 window. */
+ * the matching fetch/sync). Families: 0 tally, 1 trim, 2 depth, 3 window,
+ * 4 text framing. */
 int hpn_ctx_last_kernel_ms(hpn_ctx *ctx, int family, float *ms);
 
 /* ---- memory helpers (thin wrappers; callers may use their own allocator) ---- */
@@ -146,6 +147,53 @@ int hpn_fastq_trim_points(hpn_ctx *ctx, const uint8_t *seq, const uint8_t *qual,
 int hpn_fastq_trim_points_dev(hpn_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, const uint64_t *d_off,
                               uint64_t n_records, const uint32_t *d_beg, const uint32_t *d_end,
                               uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t *d_out_off);
+
+/* ---- raw FASTQ text front end: the 4 x gzgets framing on the device ----------------------
+ * fastq_count.c:112-118 and fastq_trim.c:67-89 frame a stream with four gzgets()
+ * calls per record into one 1024-byte buffer.  On REGULAR text that loop is a pure
+ * function of the newline positions, and these calls evaluate it on the GPU from the
+ * raw (decompressed) bytes: no host pass over the text at all.  Regular means
+ *   - no NUL byte, every line at most 1022 characters + '\n' (gzgets would split it);
+ *   - the stream ends with a whole record (count: the very last '\n' may be missing,
+ *     the reference then drops nothing it would tally);
+ *   - count: the quality line is not shorter than the sequence line (the reference
+ *     would tally stale buffer bytes), read length < 512;
+ *   - trim: sequence and quality line have the same length.
+ * Anything else is DETECTED, never mis-framed: the call reports the reasons in
+ * info->irregular, adds nothing, and closes the text stream; the caller then frames
+ * that input with the exact gzgets emulation (csrc/host/fastq_reader.hpp) and
+ * hpn_fastq_tally / hpn_fastq_trim.
+ *
+ * A stream is fed in chunks of any size (< 2^31 bytes) cut anywhere; the bytes of an
+ * unfinished trailing record stay on the device and are prepended to the next chunk.
+ * `text` may be a host pointer (pinned: the copy is asynchronous; the call returns
+ * after the copy has completed, so the buffer may be reused at once) or a device
+ * pointer.  `last` != 0 marks the final chunk (nbytes may be 0). */
+typedef struct hpn_text_info {
+    uint64_t n_records;   /* records framed by this call */
+    uint64_t n_bytes;     /* count: sum of their lengths; trim: bytes of output text */
+    uint64_t carry_bytes; /* tail bytes kept for the next chunk */
+    uint32_t irregular;   /* HPN_TEXT_* reasons, 0 = chunk processed */
+    uint32_t reserved;
+} hpn_text_info;
+
+#define HPN_TEXT_NUL 1u        /* NUL byte in the text */
+#define HPN_TEXT_LONG_LINE 2u  /* line of 1023+ characters */
+#define HPN_TEXT_RAGGED 4u     /* quality line shorter than (trim: different from) the sequence line */
+#define HPN_TEXT_PARTIAL 8u    /* stream ends inside a record */
+#define HPN_TEXT_LEN 16u       /* read of 512+ bases (count) */
+#define HPN_TEXT_DENSE 32u     /* more than one line per 4 bytes: not worth indexing */
+
+int hpn_fastq_text_begin(hpn_ctx *ctx);
+/* count_read's loop: adds into the context's device accumulators exactly like
+ * hpn_fastq_tally_dev (collect with hpn_fastq_tally_fetch).  tally_flags: HPN_TALLY_*. */
+int hpn_fastq_text_count(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, uint32_t tally_flags,
+                         hpn_text_info *info);
+/* readNextNode + fprintf("%s\n%s\n+\n%s\n") (fastq_trim.c:67-89,101): writes the
+ * trimmed records of this chunk as text into out_text (host or device pointer,
+ * capacity out_cap; nbytes + 8192 always suffices). */
+int hpn_fastq_text_trim(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, int32_t S, int32_t E,
+                        void *out_text, uint64_t out_cap, hpn_text_info *info);
 
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),

@@ -23,13 +23,14 @@ CASES = ["count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "
          "wig_a3", "wig_a3_w7", "wig_rand", "wig_rand_w1000", "wig_rand_w37"]
 
 
-def _run(tool, args, inputs, cwd):
+def _run(tool, args, inputs, cwd, env=None):
     for src in inputs:
         shutil.copy(src, cwd)
         if src.endswith(".bam"):
             shutil.copy(src + ".bai", cwd)
     before = set(os.listdir(cwd))
-    p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, **(env or {})})
     return p, sorted(set(os.listdir(cwd)) - before)
 
 
@@ -40,6 +41,25 @@ def test_drop_in(manifest, case, tmp_path):
     if c["tool"] == "fastq_count" and "-t" not in args:
         args = ["-t", "1"] + args  # rows are printed in completion order; one at a time = input order
     p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path)
+    assert p.returncode == c["returncode"], p.stderr.decode()
+    assert p.stdout == expected(case), p.stderr.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+
+
+# The FASTQ tools frame regular text on the GPU (hpn_fastq_text_*) and everything else with
+# the exact gzgets emulation on the host: both routes, and a chunk size that cuts records
+# every few bytes, must give the reference's bytes.
+@pytest.mark.parametrize("env", [{"HPN_TEXT": "0"}, {"HPN_TEXT_CHUNK": "100"}, {"HPN_TEXT_CHUNK": "4099"}],
+                         ids=["host-framer", "chunk100", "chunk4099"])
+@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("count_", "kthread_", "trim_"))])
+def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
+    c = manifest[case]
+    args = list(c["args"])
+    if c["tool"] == "fastq_count" and "-t" not in args:
+        args = ["-t", "1"] + args
+    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, env)
     assert p.returncode == c["returncode"], p.stderr.decode()
     assert p.stdout == expected(case), p.stderr.decode()
     assert files == c["files"]
