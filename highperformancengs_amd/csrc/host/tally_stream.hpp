@@ -68,20 +68,33 @@ inline int tally_stream(hpn_ctx *ctx, const InStream &fq, hpn_tally *acc, bool *
 inline int tally_text_stream(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *irregular)
 {
     *irregular = false;
+    const bool timing = getenv("HPN_TIMING") != nullptr;  // phase times on stderr (diagnostics only)
+    const double t0 = wall_s();
     TextPump pump(ctx, path, text_chunk_bytes());
     if (!pump.ok()) return HPN_E_NOMEM;
     const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
     int rc = hpn_fastq_text_begin(ctx);
     TextPump::Chunk c;
+    double t_wait = 0, t_gpu = 0, t1 = wall_s();
+    const double t_setup = t1 - t0;
+    uint64_t bytes = 0;
     while (rc == HPN_OK && pump.next(c)) {
         hpn_text_info info;
+        const double t2 = wall_s();
+        t_wait += t2 - t1;
         rc = hpn_fastq_text_count(ctx, c.p, c.n, c.eof, flags, &info);
+        bytes += c.n;
         pump.recycle(c);
+        t1 = wall_s();
+        t_gpu += t1 - t2;
         if (rc == HPN_OK && info.irregular) {
             *irregular = true;
             break;
         }
     }
+    if (timing)
+        fprintf(stderr, "[hpn] %s: %.1f MB  setup %.3f s  waiting for the reader %.3f s  copy+frame+tally %.3f s\n", path,
+                bytes / 1e6, t_setup, t_wait, t_gpu);
     if (*irregular || rc != HPN_OK) {  // drop whatever earlier chunks added on the device
         hpn_tally scratch;
         memset(&scratch, 0, sizeof scratch);

@@ -10,6 +10,7 @@
 // the data carries eof = true (it may be empty).
 #pragma once
 #include <sys/stat.h>
+#include <time.h>
 
 #include <condition_variable>
 #include <deque>
@@ -20,6 +21,13 @@
 #include "hpngs.h"
 
 namespace hpn {
+
+inline double wall_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 inline size_t text_chunk_bytes()
 {
@@ -208,6 +216,85 @@ private:
     std::condition_variable cv_;
     std::thread th_;
     bool stop_ = false, done_ = false;
+};
+
+// Output side of fastq_trim's fast path: pinned buffers the GPU result is copied into, written
+// to the FILE in submission order by a thread of their own, so that writing chunk k overlaps
+// with the copy / framing / trimming of chunk k+1.
+class AsyncWriter {
+public:
+    AsyncWriter(hpn_ctx *ctx, FILE *out, size_t cap, int nbuf = 2) : ctx_(ctx), out_(out)
+    {
+        for (int i = 0; i < nbuf; ++i) {
+            void *p = nullptr;
+            if (hpn_host_malloc(ctx_, cap, &p) != HPN_OK) break;
+            buf_.push_back(p);
+            free_.push_back(i);
+        }
+        ok_ = (int)buf_.size() == nbuf;
+        if (ok_) th_ = std::thread([this] { loop(); });
+    }
+    ~AsyncWriter()
+    {
+        finish();
+        for (void *p : buf_) hpn_host_free(ctx_, p);
+    }
+    bool ok() const { return ok_; }
+    void *acquire(int *idx)  // a buffer nobody is writing from
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !free_.empty(); });
+        *idx = free_.front();
+        free_.pop_front();
+        return buf_[(size_t)*idx];
+    }
+    void submit(int idx, size_t n)  // n may be 0: the buffer just goes back
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            todo_.push_back({idx, n});
+        }
+        cv_.notify_all();
+    }
+    void finish()  // everything submitted is in the FILE when this returns
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+
+private:
+    void loop()
+    {
+        for (;;) {
+            std::pair<int, size_t> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return !todo_.empty() || stop_; });
+                if (todo_.empty()) return;
+                job = todo_.front();
+                todo_.pop_front();
+            }
+            if (job.second) fwrite(buf_[(size_t)job.first], 1, job.second, out_);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                free_.push_back(job.first);
+            }
+            cv_.notify_all();
+        }
+    }
+    hpn_ctx *ctx_;
+    FILE *out_;
+    bool ok_ = false, stop_ = false;
+    std::vector<void *> buf_;
+    std::deque<int> free_;
+    std::deque<std::pair<int, size_t>> todo_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;
 };
 
 }  // namespace hpn

@@ -7,7 +7,7 @@
 // pure function of the newline positions, and these kernels compute it on the
 // device from the raw bytes:
 //
-//   k_text_lines    newline index: every workgroup counts the '\n' of its 16 KiB
+//   k_text_lines    newline index: every workgroup counts the '\n' of its 64 KiB
 //                   tile (SWAR on dwordx4 loads), one decoupled look-back chain
 //                   (scan.hpp) turns the counts into global line numbers, and the
 //                   position of line j's '\n' lands in nl[j].
@@ -28,7 +28,7 @@
 namespace hpn {
 
 constexpr int kTxtThreads = 256;
-constexpr int kTxtRows = 4;                                     // 16-byte words per thread
+constexpr int kTxtRows = 16;                                    // 16-byte words per thread
 constexpr uint32_t kTxtTile = kTxtThreads * kTxtRows * 16;      // bytes per workgroup
 constexpr int kRecPerThread = 4;
 constexpr uint32_t kRecTile = kTxtThreads * kRecPerThread;      // records per workgroup
@@ -163,13 +163,10 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__
     __shared__ u64 s_excl;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
-    if (tid == 0) s_tile = atomicAdd(&st[kTsTicket2], 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile;
     const uint32_t n_lines = st[kTsLines];
     const uint32_t n = n_lines >> 2;
     const uint32_t unterminated = st[kTsUnterminated];
-    if (tile == 0 && tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         st[kTsRecs] = n;
         uint32_t consumed = n ? nl[4u * n - 1u] + 1u : begin;
         if (consumed > end) consumed = end;  // the virtual newline
@@ -185,7 +182,12 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__
             st[kTsTotalLo] = st[kTsTotalHi] = 0;
         }
     }
-    if ((u64)tile * kRecTile >= n) return;  // nothing here, and nobody looks back at this tile
+    // The grid is an upper bound; only the workgroups that have records take a ticket (the
+    // same-address atomic is the serial part of the kernel), in start order.
+    if ((u64)blockIdx.x * kRecTile >= n) return;
+    if (tid == 0) s_tile = atomicAdd(&st[kTsTicket2], 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
     const uint32_t base = tile * kRecTile + (uint32_t)tid * kRecPerThread;
     uint32_t val[kRecPerThread], flags = 0;
     uint32_t prev = base && base < n ? nl[4u * base - 1u] : begin - 1u;

@@ -44,8 +44,10 @@ static void usage(const char *prog)
 static void count_file(const char *infile, FILE *out, int slot)
 {
     hpn_ctx *ctx = nullptr;
+    const double t0 = wall_s();
     int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] %s: context %.3f s\n", infile, wall_s() - t0);
     hpn_tally acc;
     memset(&acc, 0, sizeof acc);
     bool too_long = false;

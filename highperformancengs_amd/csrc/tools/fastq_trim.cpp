@@ -71,17 +71,25 @@ int main(int argc, char *argv[])
         const size_t chunk = text_chunk_bytes();
         TextPump pump(ctx, infile, chunk);
         if (!pump.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
-        void *obuf = nullptr;
         const size_t ocap = chunk + 8192 + 64;
-        if ((rc = hpn_host_malloc(ctx, ocap, &obuf)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
+        AsyncWriter writer(ctx, out, ocap);  // chunk k is written while chunk k+1 is on the GPU
+        if (!writer.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
         if ((rc = hpn_fastq_text_begin(ctx)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
         std::vector<char> carry;  // host copy of the bytes the device carries over
         TextPump::Chunk c;
+        double t_wait = 0, t_gpu = 0, t1 = wall_s();
         while (pump.next(c)) {
             hpn_text_info info;
+            int oi;
+            void *obuf = writer.acquire(&oi);
+            const double t2 = wall_s();
+            t_wait += t2 - t1;
             rc = hpn_fastq_text_trim(ctx, c.p, c.n, c.eof, start, end, obuf, ocap, &info);
+            const double t3 = wall_s();
+            t_gpu += t3 - t2;
             if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_text_trim");
             if (info.irregular) {
+                writer.submit(oi, 0);
                 auto rest = std::make_shared<std::vector<char>>(std::move(carry));
                 rest->insert(rest->end(), (const char *)c.p, (const char *)c.p + c.n);
                 pump.recycle(c);
@@ -90,13 +98,22 @@ int main(int argc, char *argv[])
                 exact = true;
                 break;
             }
-            fwrite(obuf, 1, info.n_bytes, out);
+            writer.submit(oi, info.n_bytes);
             reads += info.n_records;
-            carry.insert(carry.end(), (const char *)c.p, (const char *)c.p + c.n);
-            carry.erase(carry.begin(), carry.end() - (ptrdiff_t)info.carry_bytes);
+            if (info.carry_bytes <= c.n) {  // the unfinished record lies within this chunk
+                carry.assign((const char *)c.p + c.n - info.carry_bytes, (const char *)c.p + c.n);
+            } else {  // ... or began in an earlier one
+                carry.erase(carry.begin(), carry.end() - (ptrdiff_t)(info.carry_bytes - c.n));
+                carry.insert(carry.end(), (const char *)c.p, (const char *)c.p + c.n);
+            }
             pump.recycle(c);
+            t1 = wall_s();
         }
-        hpn_host_free(ctx, obuf);
+        const double t4 = wall_s();
+        writer.finish();
+        if (getenv("HPN_TIMING"))
+            fprintf(stderr, "[hpn] waiting for reader / writer %.3f s  copy+frame+trim+copy back %.3f s  final drain %.3f s\n", t_wait,
+                    t_gpu, wall_s() - t4);
     } else {
         in = open_input_stream(infile);
     }

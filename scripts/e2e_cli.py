@@ -42,6 +42,15 @@ for label, files in (("plain", plain), ("gzip", gz)):
             print(f"{tool:22s} {label:5s} {who:9s} {shards} files x {per} reads: {dt:7.3f} s  {bases/dt/1e9:7.3f} Gbases/s  rc={p.returncode}")
         if len(outs) == 2:
             print("   reports identical:", outs["reference"] == outs["hpngs"])
+    outs = {}
+    for who, d in (("reference", REF), ("hpngs", BIN)):  # one stream: no file-level parallelism to hide behind
+        exe = os.path.join(d, "fastq_count")
+        if os.access(exe, os.X_OK):
+            dt, p = run([exe, "-o", os.path.join(td, f"{who}.1.txt"), files[0]])
+            outs[who] = open(os.path.join(td, f"{who}.1.txt")).read()
+            print(f"{'fastq_count':22s} {label:5s} {who:9s} 1 file x {per} reads: {dt:7.3f} s  {per*rl/dt/1e9:7.3f} Gbases/s  rc={p.returncode}")
+    if len(outs) == 2:
+        print("   reports identical:", outs["reference"] == outs["hpngs"])
     if label == "plain":
         for who, d in (("reference", REF), ("hpngs", BIN)):
             exe = os.path.join(d, "fastq_trim")
