@@ -16,6 +16,15 @@
 
 namespace hpn {
 
+// End of main: everything the tool wrote is flushed and closed by now.  Skipping the HIP
+// runtime's teardown (unpinning buffers, freeing device memory, unloading code objects: 80-160 ms)
+// changes nothing observable; the driver reclaims all of it with the process.
+[[noreturn]] inline void quick_exit_ok()
+{
+    fflush(NULL);
+    _exit(0);
+}
+
 inline long long usec()
 {
     struct timeval tv;

@@ -29,16 +29,51 @@ inline double wall_s()
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-inline size_t text_chunk_bytes()
-{
-    const char *e = getenv("HPN_TEXT_CHUNK");
-    const long long v = e ? atoll(e) : 0;
-    return v >= 64 ? (size_t)v : (size_t)32 << 20;
-}
 inline bool text_path_enabled()
 {
     const char *e = getenv("HPN_TEXT");
     return !(e && e[0] == '0');
+}
+
+// Files in flight at once (set by the tools): scales the default chunk so that the pinned
+// footprint of a run stays near 100 MB however many workers there are.
+inline int &text_workers_in_flight()
+{
+    static int n = 1;
+    return n;
+}
+inline size_t text_chunk_bytes()
+{
+    const char *e = getenv("HPN_TEXT_CHUNK");
+    const long long v = e ? atoll(e) : 0;
+    if (v >= 64) return (size_t)v;
+    const size_t c = ((size_t)32 << 20) / (size_t)text_workers_in_flight();
+    return c < ((size_t)4 << 20) ? (size_t)4 << 20 : c;
+}
+
+// How many of the `requested` workers (-t) to start.  gzip input is inflate-bound at a few
+// hundred MB/s per file, so every file gets its worker, as in the reference.  Plain files
+// stream at tens of GB/s per worker: a few lanes saturate PCIe, and each further GPU context
+// only adds start-up (15-30 ms of hardware-queue creation each, serialised by the driver) --
+// one lane per 4 GiB of input, four at most.
+inline int text_workers(char **files, int n, int requested)
+{
+    if (!text_path_enabled() || getenv("HPN_ALL_WORKERS")) return requested;
+    uint64_t plain = 0;
+    for (int i = 0; i < n; ++i) {
+        struct stat sb;
+        if (strncmp(files[i], "-", 1) == 0 || !strcmp(files[i], "") || stat(files[i], &sb) != 0 || !S_ISREG(sb.st_mode))
+            return requested;
+        uint8_t magic[2] = {0, 0};
+        const int fd = open(files[i], O_RDONLY);
+        const ssize_t k = fd >= 0 ? pread(fd, magic, 2, 0) : 0;
+        if (fd >= 0) close(fd);
+        if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return requested;
+        plain += (uint64_t)sb.st_size;
+    }
+    int lanes = (int)(plain >> 32) + 1;
+    if (lanes > 4) lanes = 4;
+    return lanes < requested ? lanes : requested;
 }
 
 class TextPump {
@@ -67,6 +102,12 @@ public:
             }
         }
         if (fd_ < 0) in_ = open_input_stream(path);
+        if (!is_stdin && stat(path, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            // small inputs get small buffers (pinning memory costs ~0.3 ms per MB): the whole
+            // plain file + 1 byte, or 16 x the compressed size, rounded up to 64 KiB
+            const uint64_t guess = ((fd_ >= 0 ? (uint64_t)sb.st_size + 1 : (uint64_t)sb.st_size * 16) + 65535) & ~(uint64_t)65535;
+            if (guess < cap_) cap_ = (size_t)guess;
+        }
         for (int i = 0; i < nbuf; ++i) {
             void *p = nullptr;
             if (hpn_host_malloc(ctx_, cap_ + 64, &p) != HPN_OK) break;
@@ -84,6 +125,7 @@ public:
         if (!handed_over_) in_.close();
     }
     bool ok() const { return ok_; }
+    size_t chunk_bytes() const { return cap_; }
 
     // Next filled chunk in stream order; false once the eof chunk has been handed out.
     bool next(Chunk &c)

@@ -148,6 +148,5 @@ int main(int argc, char *argv[])
         }
         fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
     }
-    hpn_ctx_destroy(ctx);
-    return 0;
+    quick_exit_ok();
 }

@@ -183,6 +183,5 @@ int main(int argc, char *argv[])
         fclose(out);
     }
     fprintf(stderr, "Done output %s.txt at %.3f s\n", outfile, (double)(usec() - begin) / CLOCKS_PER_SEC);
-    hpn_ctx_destroy(ctx);
-    return 0;
+    quick_exit_ok();
 }

@@ -10,6 +10,7 @@
 #include <getopt.h>
 #include <pthread.h>
 
+#include <atomic>
 #include <mutex>
 #include <thread>
 
@@ -24,6 +25,7 @@ static struct {
     int numInfiles, thread, header, LengthDetail;
 } g;
 static std::mutex g_lock;
+static std::atomic<int> g_next{0};
 static int g_ndev = 1, g_dev0 = 0;
 
 static void usage(const char *prog)
@@ -41,13 +43,9 @@ static void usage(const char *prog)
     exit(1);
 }
 
-static void count_file(const char *infile, FILE *out, int slot)
+static void count_file(hpn_ctx *ctx, const char *infile, FILE *out)
 {
-    hpn_ctx *ctx = nullptr;
-    const double t0 = wall_s();
-    int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
-    if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
-    if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] %s: context %.3f s\n", infile, wall_s() - t0);
+    int rc;
     hpn_tally acc;
     memset(&acc, 0, sizeof acc);
     bool too_long = false;
@@ -63,7 +61,18 @@ static void count_file(const char *infile, FILE *out, int slot)
         print_count_row(out, infile, acc, s);
         if (g.LengthDetail) print_len_detail(out, acc.seqlen, s.min_len, s.max_len);
     }
-    hpn_ctx_destroy(ctx);
+}
+
+// One worker = one host thread + one GPU context, like one kt_for worker of the reference;
+// it takes the next unprocessed file (fastq_count.c:213-230 runs them in waves of T).
+static void worker(int slot, FILE *out)
+{
+    hpn_ctx *ctx = nullptr;
+    const double t0 = wall_s();
+    const int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
+    if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] worker %d: context %.3f s\n", slot, wall_s() - t0);
+    for (int i; (i = g_next.fetch_add(1)) < g.numInfiles;) count_file(ctx, g.infiles[i], out);
 }
 
 int main(int argc, char *argv[])
@@ -92,12 +101,14 @@ int main(int argc, char *argv[])
     const long long begin = usec();
     FILE *out = fopen_output_stream(g.outfile);
     if (g.header) print_count_header(out);
-    for (int i = 0; i < g.numInfiles; i += g.thread) {
+    {
+        const int workers = text_workers(g.infiles, g.numInfiles, g.thread);
+        text_workers_in_flight() = workers;
         std::vector<std::thread> th;
-        for (int j = 0; j < g.thread && i + j < g.numInfiles; ++j) th.emplace_back(count_file, g.infiles[i + j], out, j);
+        for (int j = 0; j < workers && j < g.numInfiles; ++j) th.emplace_back(worker, j, out);
         for (auto &t : th) t.join();
     }
     fprintf(stderr, "Finished at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
     fclose(out);
-    return 0;
+    quick_exit_ok();
 }

@@ -49,11 +49,9 @@ static void usage(const char *prog)
     exit(1);
 }
 
-static void count_file(FileAcc &fa, const char *infile, int tid)
+static void count_file(hpn_ctx *ctx, FileAcc &fa, const char *infile)
 {
-    hpn_ctx *ctx = nullptr;
-    int rc = hpn_ctx_create(g_dev0 + tid % g_ndev, &ctx);
-    if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    int rc;
     bool too_long = false;
     rc = tally_file(ctx, infile, &fa.t, &too_long);  // count_read's loop (:126-135), tally on the GPU
     if (too_long) {
@@ -61,7 +59,6 @@ static void count_file(FileAcc &fa, const char *infile, int tid)
         exit(2);
     }
     if (rc != HPN_OK) die_hpn(ctx, rc, infile);
-    hpn_ctx_destroy(ctx);
     fa.s = summarise(fa.t);
     if (g.header) print_count_header(fa.out);            // :140
     print_kthread_file_row(fa.out, infile, fa.t, fa.s);  // :141
@@ -109,9 +106,14 @@ int main(int argc, char *argv[])
         }
         std::atomic<long> next{0};
         std::vector<std::thread> th;
-        for (int t = 0; t < (g.thread < 1 ? 1 : g.thread); ++t)
-            th.emplace_back([&, t] {
-                for (long i; (i = next.fetch_add(1)) < g.numInfiles;) count_file(acc[(size_t)i], g.infiles[i], t);
+        const int workers = text_workers(g.infiles, g.numInfiles, g.thread < 1 ? 1 : g.thread);
+        text_workers_in_flight() = workers;
+        for (int t = 0; t < workers; ++t)
+            th.emplace_back([&, t] {  // one kt_for worker (klib/kthread.c:34-60) = one thread + one GPU context
+                hpn_ctx *ctx = nullptr;
+                const int rc = hpn_ctx_create(g_dev0 + t % g_ndev, &ctx);
+                if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+                for (long i; (i = next.fetch_add(1)) < g.numInfiles;) count_file(ctx, acc[(size_t)i], g.infiles[i]);
             });
         for (auto &t : th) t.join();
 
@@ -143,5 +145,5 @@ int main(int argc, char *argv[])
         for (int i = 0; i < g.numInfiles; ++i) fclose(acc[i].out);
     }
     fprintf(stderr, "Finished at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
-    return 0;
+    quick_exit_ok();
 }

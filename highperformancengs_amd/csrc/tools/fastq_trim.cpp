@@ -68,10 +68,9 @@ int main(int argc, char *argv[])
         // out -- the carried-over tail, this chunk, whatever the reader has queued -- go to
         // the exact framer below; records before them are unaffected (readNextNode zeroes its
         // buffer per record, fastq_trim.c:97, so framing has no memory across records).
-        const size_t chunk = text_chunk_bytes();
-        TextPump pump(ctx, infile, chunk);
+        TextPump pump(ctx, infile, text_chunk_bytes());
         if (!pump.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
-        const size_t ocap = chunk + 8192 + 64;
+        const size_t ocap = pump.chunk_bytes() + 8192 + 64;
         AsyncWriter writer(ctx, out, ocap);  // chunk k is written while chunk k+1 is on the GPU
         if (!writer.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
         if ((rc = hpn_fastq_text_begin(ctx)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
@@ -147,6 +146,5 @@ int main(int argc, char *argv[])
     fprintf(stderr, "Total_reads: %lu\nFinished in %.3f s\n", reads, (double)(usec() - begin) / CLOCKS_PER_SEC);
     in.close();
     fclose(out);
-    hpn_ctx_destroy(ctx);
-    return 0;
+    quick_exit_ok();
 }
