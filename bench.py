@@ -45,6 +45,25 @@ def parse():
 # --------------------------------------------------------------------------------------
 # CPU baseline leg: the only place bench.py touches oracle/ (reported, never the product)
 # --------------------------------------------------------------------------------------
+def usable_cpus():
+    """CPUs this process can keep busy: affinity mask cut down to the cgroup CPU quota (the GPU
+    boxes show 256 online CPUs under a 16-CPU quota; 256 threads there are 16 cores' worth)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
 def cpu_baseline(read_len, target_s):
     orc_so = os.path.join(ROOT, "oracle", "liborc.so")
     if not os.path.exists(orc_so):
@@ -54,14 +73,14 @@ def cpu_baseline(read_len, target_s):
     L.orc_counts_new.restype = C.c_void_p
     L.orc_counts_free.argtypes = [C.c_void_p]
     L.orc_count_files_threaded.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "fastq_count_kthread")
     kind = "reference" if os.access(ref_bin, os.X_OK) else "port"
     td = tempfile.mkdtemp(prefix="hpn_cpu_")
     # one plain-text shard per core (the reference parallelises per file), bounded to 8 GB
     # and to a quarter of the free space of the temp directory
     budget = min(8 << 30, shutil.disk_usage(td).free // 4)
-    per_shard = int(max(10_000, min(250_000, budget // (cores * (2 * read_len + 16)))))
+    per_shard = int(max(10_000, min(2_000_000, budget // (cores * (2 * read_len + 16)))))
     try:
         paths = [os.path.join(td, f"shard{i}.fq") for i in range(cores)]
         with ThreadPoolExecutor(cores) as ex:  # the C writer releases the GIL
@@ -223,7 +242,7 @@ def main():
             try:
                 line["cpu_baseline"] = cpu_baseline(L, a.cpu_seconds)
             except Exception as e:  # noqa: BLE001  (a reported baseline must not take the GPU line down)
-                line["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": os.cpu_count(), "kind": "port",
+                line["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": usable_cpus(), "kind": "port",
                                         "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:

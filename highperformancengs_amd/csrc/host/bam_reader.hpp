@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "cpus.hpp"
 #include "hpngs.h"
 
 namespace hpn {
@@ -36,7 +37,7 @@ public:
         if (!fp_) return false;
         if (threads <= 0) {
             const char *e = getenv("HPN_BGZF_THREADS");
-            long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+            long n = e ? atol(e) : usable_cpus();
             threads = (int)(n < 1 ? 1 : n > 8 ? 8 : n);
         }
         slots_.resize((size_t)threads * 4);

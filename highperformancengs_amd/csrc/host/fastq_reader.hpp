@@ -23,17 +23,28 @@
 #include <vector>
 
 #include "bam_reader.hpp"  // BgzfReader
+#include "mgz_reader.hpp"
 
 namespace hpn {
 
 constexpr int kLineBuf = 1024;  // fastq_count.c:107
 
+// Files in flight at once (set by the tools): the inflate thread pools and the text chunk
+// size are scaled by it.
+inline int &text_workers_in_flight()
+{
+    static int n = 1;
+    return n;
+}
+
 // A byte source: zlib's gzFile (plain text, gzip, concatenated members -- what the
-// reference reads with), or, for regular files that are BGZF (bgzip output), the
-// threaded block inflater.  Both deliver the same byte stream; only the speed differs.
+// reference reads with), or, for regular files, the threaded inflaters: BGZF blocks
+// (bgzip output) and concatenated gzip members.  All deliver the same byte stream; only
+// the speed differs.
 struct InStream {
     gzFile gz = nullptr;
     std::shared_ptr<BgzfReader> bz;
+    std::shared_ptr<MgzReader> mz;
     // bytes that were already taken from the stream and are to be served again first
     // (the text front end hands an irregular stream back to the exact framer this way)
     std::shared_ptr<const std::vector<char>> pre;
@@ -46,13 +57,14 @@ struct InStream {
             pre_pos += k;
             return (int)k;
         }
-        return bz ? (int)bz->read(dst, n) : gzread(gz, dst, n);
+        return bz ? (int)bz->read(dst, n) : mz ? (int)mz->read(dst, n) : gzread(gz, dst, n);
     }
     void close()
     {
         if (gz) gzclose(gz);
         gz = nullptr;
         bz.reset();
+        mz.reset();
     }
 };
 
@@ -69,13 +81,22 @@ inline InStream open_input_stream(const char *name)
     } else {
         fd = open(name, O_CREAT | O_RDONLY, 0666);
         if (fd == -1) fprintf(stderr, "Failed to create input file (%s)", name);
-        uint8_t h[18];  // BGZF: gzip member with the 'BC' extra subfield first (SAM spec 4.1)
+        uint8_t h[18] = {0};  // BGZF: gzip member with the 'BC' extra subfield first (SAM spec 4.1)
         if (fd != -1 && pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) &&
             h[12] == 'B' && h[13] == 'C' && !getenv("HPN_NO_BGZF")) {
             auto bz = std::make_shared<BgzfReader>();
             if (bz->open(name)) {
                 close(fd);
                 in.bz = bz;
+                return in;
+            }
+        }
+        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_MGZ")) {  // gzip: members inflated in parallel
+            long cpus = usable_cpus() / text_workers_in_flight();
+            auto mz = std::make_shared<MgzReader>();
+            if (mz->open(name, getenv("HPN_GZ_THREADS") ? 0 : (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus))) {
+                close(fd);
+                in.mz = mz;
                 return in;
             }
         }

@@ -35,13 +35,7 @@ inline bool text_path_enabled()
     return !(e && e[0] == '0');
 }
 
-// Files in flight at once (set by the tools): scales the default chunk so that the pinned
-// footprint of a run stays near 100 MB however many workers there are.
-inline int &text_workers_in_flight()
-{
-    static int n = 1;
-    return n;
-}
+// default chunk: the pinned footprint of a run stays near 100 MB however many workers there are
 inline size_t text_chunk_bytes()
 {
     const char *e = getenv("HPN_TEXT_CHUNK");
@@ -114,7 +108,7 @@ public:
             buf_.push_back((uint8_t *)p);
             free_.push_back(i);
         }
-        ok_ = (int)buf_.size() == nbuf && (fd_ >= 0 || in_.gz || in_.bz);
+        ok_ = (int)buf_.size() == nbuf && (fd_ >= 0 || in_.gz || in_.bz || in_.mz);
         if (ok_) th_ = std::thread([this] { loop(); });
     }
     ~TextPump()
@@ -179,7 +173,8 @@ private:
         if (fd_ >= 0) {  // plain file: a few threads pull disjoint pieces out of the page cache
             static const int kThreads = [] {
                 const char *e = getenv("HPN_READ_THREADS");
-                const long n = e ? atol(e) : 4;
+                long n = e ? atol(e) : 4;
+                if (!e && n > usable_cpus() / text_workers_in_flight()) n = usable_cpus() / text_workers_in_flight();
                 return (int)(n < 1 ? 1 : n > 32 ? 32 : n);
             }();
             const size_t piece = (cap_ / (size_t)kThreads + 4095) & ~(size_t)4095;

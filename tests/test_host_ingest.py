@@ -124,3 +124,65 @@ def test_bgzf_fastq_goes_through_the_threaded_inflater(tmp_path):
     rc, a = orc.count_soa(qual, off)
     rc2, b = orc.count_stream(p)
     assert rc == 0 and rc2 == 0 and np.array_equal(a.seqlen, b.seqlen) and np.array_equal(a.quality, b.quality)
+
+
+def _gz_cases(tmp_path):
+    """Concatenated-gzip inputs, sound and damaged: (name, bytes)."""
+    import gzip
+    import zlib
+    text = open(golden_path("fastq", "syn_var_a.fq"), "rb").read()
+    lines = text.split(b"\n")[:-1]
+    recs = [b"\n".join(lines[i:i + 4]) + b"\n" for i in range(0, len(lines), 4)]
+    members = [gzip.compress(b"".join(recs[i:i + 100]), 1) for i in range(0, len(recs), 100)]  # 15 members
+    whole = b"".join(members)
+    cases = {"multi": whole,
+             "single": gzip.compress(text, 6),
+             "empty_members": members[0] + gzip.compress(b"") + members[1] + gzip.compress(b"") + gzip.compress(b""),
+             "trailing_garbage": whole + b"this is not gzip\n" * 3,
+             "trailing_magic": whole + b"\x1f\x8b\x08\x00garbage after a real magic............",
+             "truncated": whole[:len(whole) - len(members[-1]) // 2],
+             "corrupt_middle": b"".join(members[:7]) + members[7][:40] + bytes(20) + members[7][60:] + b"".join(members[8:]),
+             "bad_crc": b"".join(members[:3]) + members[3][:-8] + b"\0\0\0\0" + members[3][-4:] + b"".join(members[4:]),
+             "with_name_field": b"".join(members[:2]) + _gz_with_name(b"".join(recs[200:300])) + b"".join(members[3:]),
+             "magic_inside": gzip.compress(b"@r\n" + b"\x1f\x8b\x08\x00" * 50 + b"\n+\n" + b"I" * 200 + b"\n", 0) + members[0]}
+    out = []
+    for k, v in cases.items():
+        p = tmp_path / f"{k}.fq.gz"
+        p.write_bytes(v)
+        out.append((k, str(p)))
+    return out
+
+
+def _gz_with_name(payload):
+    import struct
+    import zlib
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = c.compress(payload) + c.flush()
+    return (b"\x1f\x8b\x08\x08\0\0\0\0\0\x03" + b"some name.fq\0" + body +
+            struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload) & 0xffffffff))
+
+
+def test_parallel_gzip_member_inflate_equals_zlib(tmp_path):
+    """The speculative member-parallel inflater delivers gzread's bytes on every file zlib reads
+    without a data error (sound, empty members, trailing garbage, truncated, header fields, gzip
+    magic inside the payload).  On a member with a data error zlib drops whatever the failing
+    gzread call had decoded so far (the reference: < 16 KiB with its default buffer); this reader
+    keeps every member before the damaged one and nothing after -- for any thread count."""
+    damaged = {"trailing_magic": 1500, "corrupt_middle": 700, "bad_crc": 300}  # records before the bad member
+    for name, p in _gz_cases(tmp_path):
+        for mode in ("count", "trim"):
+            ref = subprocess.run([DUMP, mode, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                 env={**os.environ, "HPN_NO_MGZ": "1"})
+            outs = []
+            for threads in ("1", "3", "8"):
+                got = subprocess.run([DUMP, mode, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                     env={**os.environ, "HPN_GZ_THREADS": threads})
+                assert got.returncode == 0
+                outs.append(got.stdout)
+            assert outs[0] == outs[1] == outs[2], (name, mode)
+            if name in damaged:
+                assert struct.unpack_from("<Q", outs[0])[0] == damaged[name], (name, mode)
+            else:
+                assert outs[0] == ref.stdout, (name, mode)
+    raw = _dump("count", str(tmp_path / "multi.fq.gz"))
+    assert struct.unpack_from("<Q", raw)[0] == 1500
