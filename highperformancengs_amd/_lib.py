@@ -39,6 +39,14 @@ class TextInfo(C.Structure):
 TEXT_NUL, TEXT_LONG_LINE, TEXT_RAGGED, TEXT_PARTIAL, TEXT_LEN, TEXT_DENSE = 1, 2, 4, 8, 16, 32
 
 
+class Rqc(C.Structure):
+    _fields_ = [("quality", C.POINTER(C.c_int32)), ("nucleotide", C.POINTER(C.c_int32)), ("length", C.POINTER(C.c_int32)),
+                ("gc", C.POINTER(C.c_double))]
+
+
+RQC_MAXLEN = 300
+
+
 class Run(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32)]
 
@@ -71,6 +79,8 @@ SYMBOLS = [
     ("hpn_fastq_tally_dev", _int, [_vp, _vp, _vp, _vp, _u64, _u32]),
     ("hpn_fastq_tally_fetch", _int, [_vp, C.POINTER(Tally)]),
     ("hpn_fastq_tally_devptr", _int, [_vp, C.POINTER(_vp)]),
+    ("hpn_fastq_rqc", _int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(Rqc)]),
+    ("hpn_fastq_read_gc_dev", _int, [_vp, _vp, _vp, _u64, _vp]),
     ("hpn_fastq_trim", _int, [_vp, _vp, _vp, _vp, _u64, _i32, _i32, _vp, _vp, _vp]),
     ("hpn_fastq_trim_dev", _int, [_vp, _vp, _vp, _vp, _u64, _i32, _i32, _vp, _vp, _vp]),
     ("hpn_fastq_qtrim_points", _int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),

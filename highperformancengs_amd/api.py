@@ -120,6 +120,29 @@ class Context:
         self._ck(self.L.hpn_fastq_tally_devptr(self.h, C.byref(p)), "hpn_fastq_tally_devptr")
         return p.value
 
+    # ---- R plugin tally (Rgzfastq_uniq.c) -----------------------------------
+    def fastq_rqc(self, seq, qual, off, out=None):
+        """-> dict(quality int32[300,128] view of [q+128*pos], nucleotide int32[300,5], length int32[300], gc f64[n]);
+        pass the previous dict as `out` to keep adding into the matrices."""
+        seq = np.ascontiguousarray(seq, np.uint8)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        n = len(off) - 1
+        M = _lib.RQC_MAXLEN
+        out = out or {"quality": np.zeros((M, 128), np.int32), "nucleotide": np.zeros((M, 5), np.int32),
+                      "length": np.zeros(M, np.int32)}
+        out["gc"] = np.zeros(max(n, 1), np.float64)
+        r = _lib.Rqc()
+        i32 = C.POINTER(C.c_int32)
+        r.quality, r.nucleotide = out["quality"].ctypes.data_as(i32), out["nucleotide"].ctypes.data_as(i32)
+        r.length, r.gc = out["length"].ctypes.data_as(i32), out["gc"].ctypes.data_as(C.POINTER(C.c_double))
+        self._ck(self.L.hpn_fastq_rqc(self.h, _ptr(seq), _ptr(qual), _ptr(off), n, C.byref(r)), "hpn_fastq_rqc")
+        out["gc"] = out["gc"][:n]
+        return out
+
+    def fastq_read_gc_dev(self, d_seq, d_off, n, d_gc):
+        self._ck(self.L.hpn_fastq_read_gc_dev(self.h, _ptr(d_seq), _ptr(d_off), n, _ptr(d_gc)), "hpn_fastq_read_gc_dev")
+
     # ---- fastq_trim -------------------------------------------------------
     def fastq_trim(self, seq, qual, off, S, E):
         seq = np.ascontiguousarray(seq, np.uint8)

@@ -117,6 +117,32 @@ int hpn_fastq_tally_fetch(hpn_ctx *ctx, hpn_tally *acc);
 #define HPN_TALLY_WORDS (HPN_TALLY_W_NUC + HPN_NUC_CODES * HPN_LEN_BINS)
 int hpn_fastq_tally_devptr(hpn_ctx *ctx, uint64_t **d_acc);
 
+/* ---- Rfastqc tally: the per-read statistics of the R plugin -------------
+ * Rgzfastq_uniq.c: STATSEQ (:50-57), AssignQuality (:42-48), Length (:174), as returned by
+ * qsort_hash_count (:250) in list elements 2..5 -- in the plugin's own layouts:
+ *   quality[q + 128*pos]      += 1 per quality byte q at cycle pos          int[128*300]
+ *   nucleotide[5*pos + code]  += 1 per base (T/U 0, C 1, A 2, G 3, N '.' 4,   int[5*300]
+ *                                 every other byte 0; :97-108)
+ *   length[len - 1]           += 1 per read                                 int[300]
+ *   gc[i]                      = #{'G','C'} / len of read i, as double       double[n]
+ * Adds into quality / nucleotide / length (the plugin callocs them, :37-40) and writes
+ * gc.  Any of the four pointers may be NULL.  The duplicate-count vector (list element
+ * 1: hash of the first 50 bases, qsort) is the dedup family and is not produced here.
+ * Domain (else HPN_E_DOMAIN): 1 <= len <= 300 (MaxLen; the plugin writes out of bounds
+ * otherwise), quality byte < 128. */
+#define HPN_RQC_MAXLEN 300
+typedef struct hpn_rqc {
+    int32_t *quality;
+    int32_t *nucleotide;
+    int32_t *length;
+    double *gc;
+} hpn_rqc;
+int hpn_fastq_rqc(hpn_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off,
+                  uint64_t n_records, hpn_rqc *out);
+/* The GC-fraction part alone, on device-resident arrays (async on the context's stream). */
+int hpn_fastq_read_gc_dev(hpn_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_records,
+                          double *d_gc);
+
 /* ---- fastq_trim: replaces readNextNode's cut --------------------------------------
  * fastq_trim.c:76-77,83-84: out = line[min(S,len) .. min(E,len)) for the sequence
  * and the quality line of every record.  out_off[0] = 0, out_off[i+1] = running

@@ -325,6 +325,79 @@ static char *cut(const char *buf, int S, int E)
     return d;
 }
 
+/* ---- Rgzfastq_uniq.c (PARITY UNPINNED: restated from the source text, R is not in the image) ---- */
+
+static int rqc_ntval(unsigned char b) /* initNtVal, Rgzfastq_uniq.c:97-108 */
+{
+    switch (b) {
+    case 'c': case 'C': return 1;
+    case 'a': case 'A': return 2;
+    case 'g': case 'G': return 3;
+    case '.': case 'N': return 4;
+    default: return 0; /* t T u U and every other byte */
+    }
+}
+
+static int rqc_one(const uint8_t *seq, uint64_t ls, const uint8_t *qual, uint64_t lq, int32_t *quality,
+                   int32_t *nucleotide, int32_t *length, double *gc)
+{
+    if (ls < 1 || ls > ORC_RQC_MAXLEN || lq > ORC_RQC_MAXLEN) return ORC_E_DOMAIN;
+    double GC = 0; /* STATSEQ :50-57 */
+    for (uint64_t L = 0; L < ls; ++L) {
+        if (seq[L] == 'G' || seq[L] == 'C') GC++;
+        if (nucleotide) nucleotide[5 * L + rqc_ntval(seq[L])]++;
+    }
+    GC /= (double)ls;
+    if (gc) *gc = GC;
+    for (uint64_t i = 0; i < lq; ++i) { /* AssignQuality :42-48 */
+        if (qual[i] >= 128) return ORC_E_DOMAIN;
+        if (quality) quality[qual[i] + 128 * i]++;
+    }
+    if (length) length[ls - 1]++; /* :174 */
+    return ORC_OK;
+}
+
+int orc_rqc_soa(const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint64_t n, int32_t *quality,
+                int32_t *nucleotide, int32_t *length, double *gc)
+{
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint64_t len = off[r + 1] - off[r];
+        int rc = rqc_one(seq + off[r], len, qual + off[r], len, quality, nucleotide, length, gc ? gc + r : NULL);
+        if (rc != ORC_OK) return rc;
+    }
+    return ORC_OK;
+}
+
+int orc_rqc_stream(const char *path, int32_t *quality, int32_t *nucleotide, int32_t *length, double *gc,
+                   uint64_t gc_cap, uint64_t *n_reads)
+{
+    gzFile fq = open_in(path);
+    if (!fq) return ORC_E_IO;
+    char *buf = (char *)malloc(ORC_LINE_BUF);
+    uint8_t seq[ORC_LINE_BUF];
+    uint64_t n = 0;
+    int rc = ORC_OK;
+    for (;;) { /* readNextNode :118-137 */
+        char *p = gzgets(fq, buf, ORC_LINE_BUF);
+        if (gzeof(fq) || !p) break;
+        gzgets(fq, buf, ORC_LINE_BUF);
+        chop_last(buf);
+        const size_t ls = strlen(buf);
+        memcpy(seq, buf, ls + 1);
+        gzgets(fq, buf, ORC_LINE_BUF);
+        gzgets(fq, buf, ORC_LINE_BUF);
+        chop_last(buf);
+        rc = rqc_one(seq, ls, (const uint8_t *)buf, strlen(buf), quality, nucleotide, length,
+                     gc && n < gc_cap ? gc + n : NULL);
+        if (rc != ORC_OK) break;
+        ++n;
+    }
+    free(buf);
+    gzclose(fq);
+    if (n_reads) *n_reads = n;
+    return rc;
+}
+
 int orc_trim_stream(const char *path, int S, int E, FILE *out, uint64_t *n_reads)
 {
     if (S < 0 || E < S || S >= ORC_LINE_BUF) return ORC_E_DOMAIN;

@@ -338,3 +338,31 @@ def synth_soa(seed, first, n, len_lo, len_hi):
     seq, qual = np.zeros(max(tot, 1), np.uint8), np.zeros(max(tot, 1), np.uint8)
     L.orc_synth_soa(seed, first, n, len_lo, len_hi, seq, qual, off)
     return seq[:tot], qual[:tot], off
+
+
+# ---- Rgzfastq_uniq.c per-read tally (parity unpinned: R is not in the image) ----------------
+RQC_MAXLEN = 300
+
+
+def _rqc_out(n):
+    return (np.zeros((RQC_MAXLEN, 128), np.int32), np.zeros((RQC_MAXLEN, 5), np.int32), np.zeros(RQC_MAXLEN, np.int32),
+            np.zeros(max(n, 1), np.float64))
+
+
+def rqc_soa(seq, qual, off):
+    L = lib()
+    L.orc_rqc_soa.argtypes = [u8p, u8p, u64p, C.c_uint64, i32p, i32p, i32p, f64p]
+    n = len(off) - 1
+    q, nuc, ln, gc = _rqc_out(n)
+    rc = L.orc_rqc_soa(np.ascontiguousarray(seq, np.uint8), np.ascontiguousarray(qual, np.uint8),
+                       np.ascontiguousarray(off, np.uint64), n, q.reshape(-1), nuc.reshape(-1), ln, gc)
+    return rc, {"quality": q, "nucleotide": nuc, "length": ln, "gc": gc[:n]}
+
+
+def rqc_stream(path, cap=1 << 20):
+    L = lib()
+    L.orc_rqc_stream.argtypes = [C.c_char_p, i32p, i32p, i32p, f64p, C.c_uint64, C.POINTER(C.c_uint64)]
+    q, nuc, ln, gc = _rqc_out(cap)
+    n = C.c_uint64(0)
+    rc = L.orc_rqc_stream(os.fsencode(path), q.reshape(-1), nuc.reshape(-1), ln, gc, cap, C.byref(n))
+    return rc, {"quality": q, "nucleotide": nuc, "length": ln, "gc": gc[:n.value]}
