@@ -30,15 +30,16 @@ namespace hpn {
 
 class BgzfReader {
 public:
-    // threads: inflate workers (0 = min(8, online CPUs), overridable with HPN_BGZF_THREADS)
+    // threads: inflate workers (0 = the usable CPUs minus three -- file reader, decoder, GPU runtime --
+    // overridable with HPN_BGZF_THREADS)
     bool open(const char *path, int threads = 0)
     {
         fp_ = fopen(path, "rb");
         if (!fp_) return false;
         if (threads <= 0) {
             const char *e = getenv("HPN_BGZF_THREADS");
-            long n = e ? atol(e) : usable_cpus();
-            threads = (int)(n < 1 ? 1 : n > 8 ? 8 : n);
+            long n = e ? atol(e) : usable_cpus() - 3;
+            threads = (int)(n < 1 ? 1 : n > 64 ? 64 : n);
         }
         slots_.resize((size_t)threads * 4);
         io_ = std::thread([this] { io_loop(); });
@@ -73,6 +74,14 @@ public:
         }
         return got;
     }
+    // The next n bytes in place (no copy), or nullptr when they straddle a block boundary or
+    // the stream ends first.  The pointer stays valid until the next read / peek call.
+    const uint8_t *peek(size_t n)
+    {
+        if ((!cur_ || pos_ == cur_->data.size()) && !next_block()) return nullptr;
+        return cur_->data.size() - pos_ >= n ? cur_->data.data() + pos_ : nullptr;
+    }
+    void skip(size_t n) { pos_ += n; }  // only what peek() just showed
     const char *error() const { return err_; }
 
 private:
@@ -131,6 +140,9 @@ private:
     }
     void work_loop()
     {
+        z_stream zs;  // one inflate state per worker, reset per block
+        memset(&zs, 0, sizeof zs);
+        const bool zs_ok = inflateInit2(&zs, -15) == Z_OK;
         for (;;) {
             Slot *s = nullptr;
             {
@@ -141,7 +153,7 @@ private:
                         if (x.st == kRaw) return true;
                     return false;
                 });
-                if (stop_) return;
+                if (stop_) break;
                 for (auto &x : slots_)
                     if (x.st == kRaw) {
                         s = &x;
@@ -152,16 +164,13 @@ private:
             s->data.resize(s->isize);
             s->bad = false;
             if (s->isize) {
-                z_stream zs;
-                memset(&zs, 0, sizeof zs);
-                if (inflateInit2(&zs, -15) != Z_OK) s->bad = true;
+                if (!zs_ok || inflateReset(&zs) != Z_OK) s->bad = true;
                 else {
                     zs.next_in = s->raw.data();
                     zs.avail_in = (uInt)(s->raw.size() - 8);
                     zs.next_out = s->data.data();
                     zs.avail_out = s->isize;
                     if (inflate(&zs, Z_FINISH) != Z_STREAM_END) s->bad = true;
-                    inflateEnd(&zs);
                 }
             }
             {
@@ -170,6 +179,7 @@ private:
             }
             cv_.notify_all();
         }
+        if (zs_ok) inflateEnd(&zs);
     }
     bool next_block()
     {
@@ -274,10 +284,7 @@ public:
             append(b, want_seq);
             return true;
         }
-        int32_t block_size;
-        if (z_.read(&block_size, 4) != 4) return false;
-        rec_.resize((size_t)block_size);
-        if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return false;
+        if (!fetch()) return false;
         append(b, want_seq);
         return true;
     }
@@ -285,22 +292,39 @@ public:
     int32_t peek_tid()
     {
         if (!pending_) {
-            int32_t block_size;
-            if (z_.read(&block_size, 4) != 4) return INT32_MIN;
-            rec_.resize((size_t)block_size);
-            if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return INT32_MIN;
+            if (!fetch()) return INT32_MIN;
             pending_ = true;
         }
         int32_t t;
-        memcpy(&t, rec_.data(), 4);
+        memcpy(&t, p_, 4);
         return t;
     }
 
 private:
+    // Next record -> p_ (the bytes after block_size).  A record that lies inside one BGZF block
+    // (all but one per 64 KiB) is parsed where the inflater put it; only a straddling record
+    // is assembled in rec_.
+    bool fetch()
+    {
+        int32_t block_size;
+        if (const uint8_t *h = z_.peek(4)) {
+            memcpy(&block_size, h, 4);
+            if (const uint8_t *q = z_.peek(4 + (size_t)block_size)) {
+                z_.skip(4 + (size_t)block_size);
+                p_ = q + 4;
+                return true;
+            }
+        }
+        if (z_.read(&block_size, 4) != 4) return false;
+        rec_.resize((size_t)block_size);
+        if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return false;
+        p_ = rec_.data();
+        return true;
+    }
     void append(BamBatch &b, bool want_seq)
     {
         // bam1_core_t on disk (bam.h:178-187): refID, pos, bin_mq_nl, flag_nc, l_seq, ...
-        const uint8_t *p = rec_.data();
+        const uint8_t *p = p_;
         int32_t tid, pos, l_seq;
         uint32_t bin_mq_nl, flag_nc;
         memcpy(&tid, p, 4), memcpy(&pos, p + 4, 4), memcpy(&bin_mq_nl, p + 8, 4), memcpy(&flag_nc, p + 12, 4);
@@ -320,6 +344,7 @@ private:
     }
     BgzfReader z_;
     std::vector<uint8_t> rec_;
+    const uint8_t *p_ = nullptr;
     bool pending_ = false;
 };
 

@@ -4,9 +4,18 @@
 #pragma once
 #include <sched.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <unistd.h>
 
 namespace hpn {
+
+inline double wall_s()  // monotonic seconds, for the HPN_TIMING diagnostics
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 inline int usable_cpus()
 {

@@ -22,13 +22,6 @@
 
 namespace hpn {
 
-inline double wall_s()
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-
 inline bool text_path_enabled()
 {
     const char *e = getenv("HPN_TEXT");

@@ -101,6 +101,7 @@ int main(int argc, char *argv[])
         BamBatch batch;
         std::vector<hpn_run> runs(1u << 20);
         std::vector<uint64_t> win;
+        double t_read = 0, t_add = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
         for (int32_t j = 0; j < hdr.n_targets(); ++j) {
             const uint32_t tlen = hdr.target_len[j];
             const char *name = hdr.target_name[j].c_str();
@@ -114,16 +115,21 @@ int main(int argc, char *argv[])
                     t = bam.peek_tid();
                 }
                 batch.clear();
+                t0 = wall_s();
                 while (t == j && batch.n() < (4u << 20)) {
                     bam.next(batch, false);
                     t = bam.peek_tid();
                 }
+                t_read += wall_s() - t0;
                 if (batch.n()) {
+                    t0 = wall_s();
                     hpn_bam_batch v = batch.view();
                     if ((rc = hpn_depth_add(ctx, &v)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
+                    t_add += wall_s() - t0;
                 }
                 if (t != j) break;
             }
+            t0 = wall_s();
             win.assign((size_t)tlen / window + 1, 0);
             uint64_t n_runs = 0;
             rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
@@ -132,14 +138,20 @@ int main(int argc, char *argv[])
                 rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
             }
             if (rc != HPN_OK) die_hpn(ctx, rc, name);
+            t_finish += wall_s() - t0;
+            t0 = wall_s();
             print_bedgraph(bedGraph, name, runs.data(), n_runs);
             print_depth_bins(depth, name, tlen, window, win.data());
             if (wig) {
                 print_wig_bins(WIG, name, tlen, window, win.data());
                 fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
             }
+            t_print += wall_s() - t0;
             fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
         }
+        if (getenv("HPN_TIMING"))
+            fprintf(stderr, "[hpn] inflate+decode %.3f s  copy+scatter %.3f s  scan+fetch runs %.3f s  format+write %.3f s\n", t_read,
+                    t_add, t_finish, t_print);
         fclose(bedGraph);
         fclose(depth);
         if (wig) {

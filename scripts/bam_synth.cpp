@@ -1,0 +1,143 @@
+// bam_synth.cpp -- synthetic coordinate-sorted BAM of the shape SURVEY.md §8(d) asks for, fast
+// enough to make multi-GB inputs on the GPU box (bench / profiling input only, not the product):
+//   g++ -O2 -std=c++17 scripts/bam_synth.cpp -o /tmp/bam_synth -lz -lpthread
+//   /tmp/bam_synth out.bam <reads> <contigs> <contig_len> [threads]
+// 150 bp reads, starts uniform per contig, CIGAR mix 85 % 150M, 5 % 40M2I108M, 5 % 60M5D90M,
+// 5 % 10S140M; flags 90 % {0,16}, 10 % from {4,256,512,1024}; bases ACGT + 1 % N.
+// Writes out.bam and an EMPTY out.bam.bai (our tools only test that the index exists; the
+// reference tools need a real one -- use tests/bam_synth.py + highperformancengs_amd/bamio.py for those).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+static uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30, x *= 0xBF58476D1CE4E5B9ull, x ^= x >> 27, x *= 0x94D049BB133111EBull, x ^= x >> 31;
+    return x;
+}
+static void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+static void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x), v.push_back((uint8_t)(x >> 8)); }
+
+static std::vector<uint8_t> bgzf_block(const uint8_t *src, size_t n)
+{
+    std::vector<uint8_t> out(18 + compressBound(n) + 8);
+    z_stream s;
+    memset(&s, 0, sizeof s);
+    deflateInit2(&s, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    s.next_in = (Bytef *)src, s.avail_in = (uInt)n;
+    s.next_out = out.data() + 18, s.avail_out = (uInt)(out.size() - 18);
+    deflate(&s, Z_FINISH);
+    const size_t clen = s.total_out;
+    deflateEnd(&s);
+    const uint8_t hdr[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+    memcpy(out.data(), hdr, 12);
+    out[12] = 'B', out[13] = 'C', out[14] = 2, out[15] = 0;
+    const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
+    out[16] = (uint8_t)bsize, out[17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), src, (uInt)n);
+    for (int i = 0; i < 4; ++i) out[18 + clen + i] = (uint8_t)(crc >> (8 * i)), out[18 + clen + 4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+    out.resize(18 + clen + 8);
+    return out;
+}
+
+static void write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads)
+{
+    const size_t kIn = 0xff00;
+    const size_t nb = (raw.size() + kIn - 1) / kIn;
+    std::vector<std::vector<uint8_t>> out(nb);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&, t] {
+            for (size_t b = (size_t)t; b < nb; b += (size_t)threads) {
+                const size_t lo = b * kIn, n = raw.size() - lo < kIn ? raw.size() - lo : kIn;
+                out[b] = bgzf_block(raw.data() + lo, n);
+            }
+        });
+    for (auto &t : th) t.join();
+    for (auto &o : out) fwrite(o.data(), 1, o.size(), f);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) return fprintf(stderr, "usage: %s out.bam reads contigs contig_len [threads]\n", argv[0]), 1;
+    const uint64_t reads = (uint64_t)atof(argv[2]);
+    const int contigs = atoi(argv[3]);
+    const uint32_t clen = (uint32_t)atof(argv[4]);
+    const int threads = argc > 5 ? atoi(argv[5]) : 8;
+    FILE *f = fopen(argv[1], "wb");
+    if (!f) return perror(argv[1]), 1;
+    std::vector<uint8_t> raw;
+    {  // header
+        std::string text = "@HD\tVN:1.0\tSO:coordinate\n";
+        for (int c = 0; c < contigs; ++c) text += "@SQ\tSN:chr" + std::to_string(c + 1) + "\tLN:" + std::to_string(clen) + "\n";
+        raw.insert(raw.end(), {'B', 'A', 'M', 1});
+        put32(raw, (uint32_t)text.size());
+        raw.insert(raw.end(), text.begin(), text.end());
+        put32(raw, (uint32_t)contigs);
+        for (int c = 0; c < contigs; ++c) {
+            const std::string nm = "chr" + std::to_string(c + 1);
+            put32(raw, (uint32_t)nm.size() + 1);
+            raw.insert(raw.end(), nm.begin(), nm.end());
+            raw.push_back(0);
+            put32(raw, clen);
+        }
+        write_blocks(f, raw, threads);
+    }
+    const uint64_t per = reads / (uint64_t)contigs, kBatch = 1u << 20;
+    static const uint32_t cig[4][3] = {{150u << 4, 0, 0}, {40u << 4, (2u << 4) | 1, 108u << 4}, {60u << 4, (5u << 4) | 2, 90u << 4}, {(10u << 4) | 4, 140u << 4, 0}};
+    static const int ncig[4] = {1, 3, 3, 2};
+    static const uint32_t odd[4] = {4, 256, 512, 1024};
+    for (int c = 0; c < contigs; ++c)
+        for (uint64_t i0 = 0; i0 < per; i0 += kBatch) {
+            const uint64_t n = per - i0 < kBatch ? per - i0 : kBatch;
+            std::vector<std::vector<uint8_t>> part((size_t)threads);
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; ++t)
+                th.emplace_back([&, t] {
+                    std::vector<uint8_t> &v = part[(size_t)t];
+                    const uint64_t lo = i0 + n * (uint64_t)t / (uint64_t)threads, hi = i0 + n * (uint64_t)(t + 1) / (uint64_t)threads;
+                    v.reserve((hi - lo) * 300);
+                    for (uint64_t i = lo; i < hi; ++i) {
+                        const uint64_t h = mix64(((uint64_t)c << 40) ^ i ^ 0x9E3779B97F4A7C15ull);
+                        const uint32_t pos = (uint32_t)((double)i * (double)(clen - 160) / (double)per);
+                        const int k = (h % 100) < 85 ? 0 : (int)((h % 100 - 85) / 5) + 1;
+                        const uint32_t flag = ((h >> 8) % 10) ? (((h >> 16) & 1) ? 16u : 0u) : odd[(h >> 20) & 3];
+                        char name[32];
+                        const int ln = snprintf(name, sizeof name, "r%llu", (unsigned long long)(c * per + i)) + 1;
+                        const uint32_t bs = 32 + (uint32_t)ln + 4u * (uint32_t)ncig[k > 3 ? 3 : k] + 75 + 150;
+                        const int kk = k > 3 ? 3 : k;
+                        put32(v, bs), put32(v, (uint32_t)c), put32(v, pos);
+                        v.push_back((uint8_t)ln), v.push_back(30), put16(v, 4680);
+                        put16(v, (uint32_t)ncig[kk]), put16(v, flag), put32(v, 150);
+                        put32(v, 0xffffffffu), put32(v, 0xffffffffu), put32(v, 0);
+                        v.insert(v.end(), name, name + ln);
+                        for (int q = 0; q < ncig[kk]; ++q) put32(v, cig[kk][q]);
+                        uint64_t g = h;
+                        for (int b = 0; b < 75; ++b) {
+                            g = mix64(g + (uint64_t)b);
+                            static const uint8_t code[4] = {1, 2, 4, 8};
+                            uint8_t hi4 = code[g & 3], lo4 = code[(g >> 2) & 3];
+                            if ((g >> 8) % 100 == 0) hi4 = 15;
+                            if ((g >> 20) % 100 == 0) lo4 = 15;
+                            v.push_back((uint8_t)(hi4 << 4 | lo4));
+                        }
+                        for (int b = 0; b < 150; ++b) v.push_back((uint8_t)(2 + ((g >> (b & 31)) + (uint64_t)b * 7) % 40));
+                    }
+                });
+            for (auto &t : th) t.join();
+            raw.clear();
+            for (auto &p : part) raw.insert(raw.end(), p.begin(), p.end());
+            write_blocks(f, raw, threads);
+        }
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fwrite(eof, 1, 28, f);
+    fclose(f);
+    fclose(fopen((std::string(argv[1]) + ".bai").c_str(), "wb"));
+    return 0;
+}
