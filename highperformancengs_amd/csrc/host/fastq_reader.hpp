@@ -85,7 +85,8 @@ inline InStream open_input_stream(const char *name)
         if (fd != -1 && pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) &&
             h[12] == 'B' && h[13] == 'C' && !getenv("HPN_NO_BGZF")) {
             auto bz = std::make_shared<BgzfReader>();
-            if (bz->open(name)) {
+            const long share = usable_cpus() / text_workers_in_flight();
+            if (bz->open(name, getenv("HPN_BGZF_THREADS") ? 0 : (int)(share < 1 ? 1 : share > 16 ? 16 : share))) {
                 close(fd);
                 in.bz = bz;
                 return in;
