@@ -36,7 +36,7 @@ class TextInfo(C.Structure):
                 ("irregular", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-TEXT_NUL, TEXT_LONG_LINE, TEXT_RAGGED, TEXT_PARTIAL, TEXT_LEN, TEXT_DENSE = 1, 2, 4, 8, 16, 32
+TEXT_NUL, TEXT_LONG_LINE, TEXT_RAGGED, TEXT_PARTIAL, TEXT_LEN, TEXT_DENSE, TEXT_STALE = 1, 2, 4, 8, 16, 32, 64
 
 
 class Rqc(C.Structure):

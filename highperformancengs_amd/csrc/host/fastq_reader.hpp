@@ -249,7 +249,8 @@ private:
 // character (the '\n', or a real character when the final newline is missing).
 class TrimFramer {
 public:
-    explicit TrimFramer(const InStream &f) : src_(f) {}
+    // S, E: the cut the batch will get.  Only needed for reads shorter than S, see take().
+    explicit TrimFramer(const InStream &f, int S = 0, int E = 0) : src_(f), S_(S < 0 ? 0 : (size_t)S), E_(E < S ? S_ : (size_t)E) {}
 
     bool fill(FastqBatch &b)
     {
@@ -262,8 +263,7 @@ public:
             b.names.emplace_back(buf);
             src_.gets(buf, kLineBuf);
             chop(buf);
-            const size_t ls = strlen(buf);
-            memcpy(b.seq + b.nbytes, buf, ls);
+            const size_t ls = take(b.seq + b.nbytes, buf);
             src_.gets(buf, kLineBuf);
             src_.gets(buf, kLineBuf);
             chop(buf);
@@ -271,9 +271,8 @@ public:
             // strncpy, i.e. up to that line's own NUL; when the two lines differ in
             // length the shorter is NUL-padded to the longer and the writer prints
             // each cut as a C string, which gives the same bytes.
-            const size_t lq = strlen(buf), lr = ls > lq ? ls : lq;
+            const size_t lq = take(b.qual + b.nbytes, buf), lr = ls > lq ? ls : lq;
             memset(b.seq + b.nbytes + ls, 0, lr - ls);
-            memcpy(b.qual + b.nbytes, buf, lq);
             memset(b.qual + b.nbytes + lq, 0, lr - lq);
             b.push(lr);
         }
@@ -286,7 +285,26 @@ private:
         const size_t l = strlen(s);
         if (l) s[l - 1] = 0;  // (the reference writes s[-1] on an empty string)
     }
+    // The line in buf -> dst; returns its length.  strncpy(dst, buf + S, E - S) of the reference
+    // (:76-77, :83-84) starts S bytes into the buffer whether or not the line is that long: past
+    // the line's NUL it finds what the record's earlier, longer lines left there (the buffer
+    // is zeroed per record, so nothing older).  Such a read is handed on as S filler bytes
+    // followed by exactly those bytes, so that the cut [S, E) of the batch yields them.
+    size_t take(uint8_t *dst, const char *buf) const
+    {
+        const size_t l = strlen(buf);
+        if (S_ <= l || S_ >= (size_t)kLineBuf) {  // (S beyond the buffer: the reference reads out of bounds)
+            memcpy(dst, buf, l);
+            return l;
+        }
+        const size_t room = (size_t)kLineBuf - 1 - S_;
+        const size_t k = strnlen(buf + S_, E_ - S_ < room ? E_ - S_ : room);
+        memset(dst, 'x', S_);
+        memcpy(dst + S_, buf + S_, k);
+        return S_ + k;
+    }
     LineSource src_;
+    size_t S_, E_;
 };
 
 }  // namespace hpn

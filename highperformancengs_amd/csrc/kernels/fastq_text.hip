@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__
             const uint32_t len = L2 - 1u;
             if (kTrim) {
                 if (L4 != L2) flags |= HPN_TEXT_RAGGED;
+                if (S > len) flags |= HPN_TEXT_STALE;  // strncpy(buf + S) would run into the earlier lines' bytes
                 uint32_t b;
                 val[k] = L1 + 2u * trim_cut(len, S, E, b) + 4u;
             } else {

@@ -117,7 +117,7 @@ int main(int argc, char *argv[])
         in = open_input_stream(infile);
     }
     if (exact) {
-        TrimFramer framer(in);
+        TrimFramer framer(in, start, end);
         FastqBatch b;
         const size_t kBytes = 64u << 20, kRecs = 1u << 20;
         if (!b.init(kBytes, kRecs, true)) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");

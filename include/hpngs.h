@@ -184,7 +184,7 @@ int hpn_fastq_trim_points_dev(hpn_ctx *ctx, const uint8_t *d_seq, const uint8_t 
  *     the reference then drops nothing it would tally);
  *   - count: the quality line is not shorter than the sequence line (the reference
  *     would tally stale buffer bytes), read length < 512;
- *   - trim: sequence and quality line have the same length.
+ *   - trim: sequence and quality line have the same length, S <= every read's length.
  * Anything else is DETECTED, never mis-framed: the call reports the reasons in
  * info->irregular, adds nothing, and closes the text stream; the caller then frames
  * that input with the exact gzgets emulation (csrc/host/fastq_reader.hpp) and
@@ -209,6 +209,8 @@ typedef struct hpn_text_info {
 #define HPN_TEXT_PARTIAL 8u    /* stream ends inside a record */
 #define HPN_TEXT_LEN 16u       /* read of 512+ bases (count) */
 #define HPN_TEXT_DENSE 32u     /* more than one line per 4 bytes: not worth indexing */
+#define HPN_TEXT_STALE 64u     /* trim: S beyond a read's end (the reference copies what the record's
+                                  earlier lines left in its buffer; the host framer reproduces that) */
 
 int hpn_fastq_text_begin(hpn_ctx *ctx);
 /* count_read's loop: adds into the context's device accumulators exactly like

@@ -106,6 +106,20 @@ def make_fastq_inputs():
     seq = "".join(rnd.choice("ACGT") for _ in range(130))
     qual = "".join(chr(rnd.randint(35, 74)) for _ in range(130))
     w(f"{FQ}/longname.fq", f"@ok\n{seq}\n+\n{qual}\n{longname}\n{seq}\n+\n{qual}\n@ok2\n{seq}\n+\n{qual}\n")
+    # short reads behind long name lines: with -s beyond a read's end fastq_trim copies what the
+    # earlier lines of the record left in its buffer (fastq_trim.c:76-77,83-84)
+    rnd = random.Random(11)
+    recs = []
+    for i in range(40):
+        ln = rnd.randint(0, 22)
+        name = "@read%d:%s" % (i, "".join(rnd.choice("abcdefghijklmnopqrstuvwxyz0123456789:/ ") for _ in range(rnd.randint(0, 70))))
+        sq = "".join(rnd.choice("ACGTN") for _ in range(ln))
+        ql = "".join(chr(rnd.randint(35, 74)) for _ in range(ln))
+        plus = "+" if rnd.random() < 0.5 else "+" + name[1:]
+        if i % 9 == 4:
+            plus = "+" + "".join(rnd.choice("XYZ") for _ in range(rnd.randint(1, 60)))
+        recs.append(f"{name}\n{sq}\n{plus}\n{ql}\n")
+    w(f"{FQ}/stale.fq", "".join(recs))
     # synthetic inputs from the oracle's counter-based generator
     orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
     orc.orc_synth_write_fastq.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64,
@@ -204,6 +218,11 @@ def main():
     run_case("trim_syn_100", "fastq_trim", ["-i", "syn_100.fq.gz", "-s", "0", "-e", "75", "-o", "t100"], [fq("syn_100.fq.gz")])
     run_case("trim_multi", "fastq_trim", ["-i", "multi.fq.gz", "-s", "4", "-e", "9"], [fq("multi.fq.gz")])
     run_case("trim_empty", "fastq_trim", ["-i", "empty.fq", "-e", "9"], [fq("empty.fq")])
+    run_case("trim_stale_8_40", "fastq_trim", ["-i", "stale.fq", "-s", "8", "-e", "40"], [fq("stale.fq")])
+    run_case("trim_stale_15_400", "fastq_trim", ["-i", "stale.fq", "-s", "15", "-e", "400"], [fq("stale.fq")])
+    run_case("trim_stale_30_31", "fastq_trim", ["-i", "stale.fq", "-s", "30", "-e", "31", "-o", "st"], [fq("stale.fq")])
+    run_case("trim_stale_a1", "fastq_trim", ["-i", "t.fq", "-s", "12", "-e", "30"], [fq("t.fq")])
+    run_case("count_stale", "fastq_count", ["-H", "-L", "stale.fq"], [fq("stale.fq")])
     # ---- bam2depth ---------------------------------------------------------
     bm = lambda n: os.path.join(BAM, n)  # noqa: E731
     run_case("depth_a3", "bam2depth", ["-w", "100", "-o", "d", "e.bam"], [bm("e.bam")])

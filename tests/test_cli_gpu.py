@@ -18,7 +18,8 @@ CASES = ["count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "
          "count_len0", "count_allzero", "count_trunc", "count_longname", "count_syn_var_a", "count_syn_var_b",
          "count_syn_100", "count_to_file", "kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty",
          "trim_a1", "trim_a1_default", "trim_a1_file", "trim_nonl", "trim_short", "trim_crlf", "trim_syn_var",
-         "trim_syn_100", "trim_multi", "trim_empty",
+         "trim_syn_100", "trim_multi", "trim_empty", "trim_stale_8_40", "trim_stale_15_400", "trim_stale_30_31",
+         "trim_stale_a1", "count_stale",
          "depth_a3", "depth_a3_wig", "depth_a3_stdout", "depth_rand", "depth_rand_w1000", "depth_two_files",
          "wig_a3", "wig_a3_w7", "wig_rand", "wig_rand_w1000", "wig_rand_w37"]
 

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "highperformancengs_amd", "bin")
 DUMP = os.path.join(BIN, "hpn_ingest_dump")
 FASTQS = ["t.fq", "t.fq.gz", "empty.fq", "nonl.fq", "crlf.fq", "multi.fq.gz", "short.fq", "len0.fq", "allzero.fq",
-          "trunc.fq", "longname.fq", "syn_var_a.fq", "syn_var_b.fq.gz", "syn_100.fq.gz"]
+          "trunc.fq", "longname.fq", "syn_var_a.fq", "syn_var_b.fq.gz", "syn_100.fq.gz", "stale.fq"]
 
 
 def _dump(mode, path):

@@ -111,7 +111,8 @@ def test_threaded_baseline_matches_serial(tmp_path):
 # ---- fastq_trim ---------------------------------------------------------------
 
 @pytest.mark.parametrize("case", ["trim_a1", "trim_a1_default", "trim_a1_file", "trim_nonl", "trim_short",
-                                  "trim_crlf", "trim_syn_var", "trim_syn_100", "trim_multi", "trim_empty"])
+                                  "trim_crlf", "trim_syn_var", "trim_syn_100", "trim_multi", "trim_empty",
+                                  "trim_stale_8_40", "trim_stale_15_400", "trim_stale_30_31", "trim_stale_a1"])
 def test_trim_stream(manifest, case):
     c = manifest[case]
     a = c["args"]
@@ -121,7 +122,10 @@ def test_trim_stream(manifest, case):
     assert rc == 0
     want = expected(case, a[a.index("-o") + 1] + ".trim.fastq") if "-o" in a else expected(case)
     assert text == want
-    assert n == want.count(b"\n") // 4
+    if "stale" in case:  # stale bytes may hold the '\n' of the '+' line, which is not chopped (fastq_trim.c:79)
+        assert n == (5 if case == "trim_stale_a1" else 40)
+    else:
+        assert n == want.count(b"\n") // 4
 
 
 def test_trim_appendix_a1():
