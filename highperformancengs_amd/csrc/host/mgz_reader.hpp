@@ -9,15 +9,19 @@
 //   * candidate starts = byte patterns 1f 8b 08 <flags with the reserved bits clear>, found by
 //     scanning ahead of the consumer in the mmap'ed file;
 //   * a pool of threads inflates candidates (zlib inflate with the gzip wrapper, so header,
-//     CRC32 and ISIZE are checked exactly as gzread checks them);
-//   * the consumer only ever accepts the member that starts where the previous accepted one
+//     CRC32 and ISIZE are checked exactly as gzread checks them) into recycled 4 MiB blocks;
+//   * the consumer only ever takes bytes from the member that starts where the previous one
 //     ended (the first at offset 0), so the bytes delivered are exactly gzread's; candidates
 //     that turn out to lie inside a member are cancelled and dropped.
 //
-// Whatever zlib would treat specially is handed to zlib itself: a member that fails to inflate
-// (corrupt, truncated) is re-read with gzdopen from its first byte on, which reproduces gzread's
-// partial output and error; bytes after the last member that are not a gzip header are trailing
-// garbage, which gzread ignores.  A single-member file simply degenerates to one worker.
+// The member being consumed is streamed block by block while it is still being inflated, and
+// no member may run more than 128 MiB ahead of its consumption: a single-member file of any
+// size degenerates to one worker and a bounded buffer, i.e. to zlib's own behaviour.
+//
+// Whatever zlib would treat specially is handed to zlib itself: when a member fails to inflate
+// (corrupt, truncated), gzdopen re-reads it from its first byte, the bytes already delivered
+// are skipped, and gzread's remaining output and its error take over; bytes after the last
+// member that are not a gzip header are trailing garbage, which gzread ignores.
 #pragma once
 #include <fcntl.h>
 #include <stdint.h>
@@ -41,7 +45,7 @@ namespace hpn {
 
 class MgzReader {
 public:
-    // threads <= 0: HPN_GZ_THREADS, else min(16, online CPUs)
+    // threads <= 0: HPN_GZ_THREADS, else min(16, usable CPUs)
     bool open(const char *path, int threads = 0)
     {
         fd_ = ::open(path, O_RDONLY);
@@ -52,6 +56,7 @@ public:
         void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
         if (m == MAP_FAILED) return fail_open();
         data_ = (const uint8_t *)m;
+        madvise(m, size_, MADV_SEQUENTIAL);
         if (!is_header(0)) return fail_open();
         if (threads <= 0) {
             const char *e = getenv("HPN_GZ_THREADS");
@@ -59,7 +64,6 @@ public:
             threads = (int)(n < 1 ? 1 : n > 16 ? 16 : n);
         }
         max_jobs_ = (size_t)threads + 2;
-        scan_ = 0;
         for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work_loop(); });
         return true;
     }
@@ -69,11 +73,13 @@ public:
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
             for (auto &j : jobs_) j->cancel = true;
+            if (cur_) cur_->cancel = true;
         }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
-        if (cur_) put_blocks(cur_->out);
-        for (auto &j : jobs_) put_blocks(j->out);
+        if (have_.p) free(have_.p);
+        if (cur_) drop_blocks(*cur_);
+        for (auto &j : jobs_) drop_blocks(*j);
         for (Block &b : pool_) free(b.p);
         if (fallback_) gzclose(fallback_);
         if (data_) munmap((void *)data_, size_);
@@ -93,26 +99,22 @@ public:
                 got += (size_t)k;
                 continue;
             }
-            if (cur_ && blk_ < cur_->out.size()) {
-                Block &b = cur_->out[blk_];
-                size_t k = b.n - pos_;
+            if (have_.p && pos_ < have_.n) {
+                size_t k = have_.n - pos_;
                 if (k > n - got) k = n - got;
-                memcpy(out + got, b.p + pos_, k);
-                pos_ += k, got += k;
-                if (pos_ == b.n) ++blk_, pos_ = 0;
+                memcpy(out + got, have_.p + pos_, k);
+                pos_ += k, got += k, delivered_ += k;
                 continue;
             }
-            if (!next_member()) break;
+            if (!next_block()) break;
         }
         return got;
     }
 
 private:
     enum State { kQueued, kRunning, kDone, kFailed };
-    // Inflated bytes live in fixed 4 MiB blocks that are recycled through a pool: after the
-    // first few members no page is ever faulted in again (growing one vector per member made
-    // the workers fight over the address-space lock and ran slower than one thread).
     static constexpr size_t kBlock = (size_t)4 << 20;
+    static constexpr size_t kMaxAhead = 32;  // blocks a member may hold unconsumed (128 MiB)
     struct Block {
         uint8_t *p = nullptr;
         size_t n = 0;
@@ -121,8 +123,10 @@ private:
         uint64_t start = 0, end = 0;
         State st = kQueued;
         std::atomic<bool> cancel{false};
-        std::vector<Block> out;
+        std::deque<Block> out;  // inflated, not yet consumed; guarded by m_
     };
+
+    // ---- block pool: after the first members no page is faulted in again ------------------
     Block get_block()
     {
         {
@@ -141,12 +145,16 @@ private:
         b.p = (uint8_t *)p;
         return b;
     }
-    void put_blocks(std::vector<Block> &v)
+    void put_block(Block b)
     {
+        if (!b.p) return;
         std::lock_guard<std::mutex> lk(pool_m_);
-        for (Block &b : v)
-            if (b.p) pool_.push_back(b);
-        v.clear();
+        pool_.push_back(b);
+    }
+    void drop_blocks(Job &j)  // m_ held (or no other thread left)
+    {
+        for (Block &b : j.out) put_block(b);
+        j.out.clear();
     }
 
     bool fail_open()
@@ -161,34 +169,46 @@ private:
     {
         return p + 18 <= size_ && data_[p] == 0x1f && data_[p + 1] == 0x8b && data_[p + 2] == 8 && !(data_[p + 3] & 0xe0);
     }
-    // next candidate at or after p (size_ if none)
-    uint64_t find_candidate(uint64_t p) const
+    // next candidate in [p, limit) (limit if none)
+    uint64_t find_candidate(uint64_t p, uint64_t limit) const
     {
-        while (p + 18 <= size_) {
-            const uint8_t *q = (const uint8_t *)memchr(data_ + p, 0x1f, size_ - 17 - p);
-            if (!q) return size_;
+        if (limit > size_) limit = size_;
+        while (p + 18 <= limit) {
+            const uint8_t *q = (const uint8_t *)memchr(data_ + p, 0x1f, limit - 17 - p);
+            if (!q) return limit;
             p = (uint64_t)(q - data_);
             if (is_header(p)) return p;
             ++p;
         }
-        return size_;
+        return limit;
     }
-    // with m_ held: keep the queue of speculative jobs filled, in file order
-    void schedule()
+    // Keep the queue of speculative jobs filled, in file order.  Called by the consumer with
+    // m_ held; the scan itself (read-only data, consumer-only cursor) runs unlocked, and looks
+    // at most 256 MiB ahead per call so that a single huge member is not read twice up front.
+    void schedule(std::unique_lock<std::mutex> &lk)
     {
-        while (jobs_.size() < max_jobs_ && scan_ < size_) {
-            uint64_t c = find_candidate(scan_ < expect_ ? expect_ : scan_);
-            if (c >= size_) {
+        uint64_t budget = (uint64_t)256 << 20;
+        while (jobs_.size() + (cur_ ? 1 : 0) < max_jobs_ && scan_ < size_ && budget) {
+            const uint64_t from = scan_ < expect_ ? expect_ : scan_;
+            if (from >= size_) {
                 scan_ = size_;
                 break;
             }
-            scan_ = c + 1;
-            bool have = false;
+            const uint64_t limit = from + budget < size_ ? from + budget : size_;
+            lk.unlock();
+            const uint64_t c = find_candidate(from, limit);
+            lk.lock();
+            const uint64_t reached = c < limit ? c + 1 : limit;
+            budget -= reached - from;
+            scan_ = reached;
+            if (c >= limit) continue;
+            bool have = cur_ && cur_->start == c;
             for (auto &j : jobs_) have |= j->start == c;
             if (have) continue;
             auto j = std::make_shared<Job>();
             j->start = c;
             jobs_.push_back(j);
+            cv_.notify_all();
         }
     }
 
@@ -200,6 +220,10 @@ private:
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [this, &job] {
                     if (stop_) return true;
+                    if (cur_ && cur_->st == kQueued) {
+                        job = cur_;
+                        return true;
+                    }
                     for (auto &j : jobs_)
                         if (j->st == kQueued) {
                             job = j;
@@ -210,144 +234,191 @@ private:
                 if (stop_) return;
                 job->st = kRunning;
             }
-            const bool ok = inflate_member(*job);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                job->st = ok ? kDone : kFailed;
-                if (job->cancel) put_blocks(job->out);  // dropped by the consumer meanwhile
-            }
-            cv_.notify_all();
+            inflate_member(job);
         }
     }
 
-    bool inflate_member(Job &j)
+    // Hand a filled block to the job's queue; wait while the member is too far ahead of its
+    // consumption.  false = cancelled / stopping.
+    bool publish(const std::shared_ptr<Job> &j, Block b)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        j->out.push_back(b);
+        cv_.notify_all();
+        cv_.wait(lk, [&] { return j->out.size() < kMaxAhead || j->cancel || stop_; });
+        return !(j->cancel || stop_);
+    }
+
+    void inflate_member(const std::shared_ptr<Job> &j)
     {
         z_stream s;
         memset(&s, 0, sizeof s);
-        if (inflateInit2(&s, 15 + 16) != Z_OK) return false;
-        uint64_t in_pos = j.start;
+        bool ok = inflateInit2(&s, 15 + 16) == Z_OK;
+        const bool inited = ok;
+        uint64_t in_pos = j->start;
         int rc = Z_OK;
-        bool ok = true;
-        while (rc != Z_STREAM_END) {
-            if (j.cancel.load(std::memory_order_relaxed)) break;
+        Block b;
+        while (ok && rc != Z_STREAM_END) {
+            if (j->cancel.load(std::memory_order_relaxed)) {
+                ok = false;
+                break;
+            }
             if (s.avail_in == 0) {
                 const uint64_t left = size_ - in_pos;
-                if (left == 0) break;  // input exhausted inside the member: truncated file
+                if (left == 0) {  // input exhausted inside the member: truncated file
+                    ok = false;
+                    break;
+                }
                 const uint32_t take = left > ((uint64_t)1 << 30) ? 1u << 30 : (uint32_t)left;
                 s.next_in = (Bytef *)(data_ + in_pos);
                 s.avail_in = take;
                 in_pos += take;
             }
-            if (j.out.empty() || j.out.back().n == kBlock) {
-                Block b = get_block();
+            if (!b.p) {
+                b = get_block();
                 if (!b.p) {
                     ok = false;
                     break;
                 }
-                j.out.push_back(b);
             }
-            Block &b = j.out.back();
             s.next_out = b.p + b.n;
             s.avail_out = (uInt)(kBlock - b.n);
             rc = inflate(&s, Z_NO_FLUSH);
             b.n = kBlock - s.avail_out;
-            if (rc != Z_OK && rc != Z_STREAM_END) break;  // Z_DATA_ERROR, Z_BUF_ERROR, ...
-        }
-        ok = ok && rc == Z_STREAM_END;
-        if (ok) {
-            j.end = in_pos - s.avail_in;
-            if (!j.out.empty() && j.out.back().n == 0) {  // a block taken right before the stream ended
-                std::vector<Block> last(1, j.out.back());
-                j.out.pop_back();
-                put_blocks(last);
+            if (rc != Z_OK && rc != Z_STREAM_END) {  // Z_DATA_ERROR, Z_BUF_ERROR, ...
+                ok = false;
+                break;
             }
-        } else {
-            put_blocks(j.out);
+            if (b.n == kBlock && rc != Z_STREAM_END) {
+                const bool go = publish(j, b);
+                b = Block();
+                if (!go) {
+                    ok = false;
+                    break;
+                }
+            }
         }
-        inflateEnd(&s);
-        return ok;
+        if (inited) inflateEnd(&s);
+        std::lock_guard<std::mutex> lk(m_);
+        if (ok) {
+            if (b.p && b.n) j->out.push_back(b);
+            else put_block(b);
+            j->end = in_pos - s.avail_in;
+            j->st = kDone;
+        } else {
+            put_block(b);  // the partial block of a failed member is never delivered
+            j->st = kFailed;
+        }
+        if (j->cancel) drop_blocks(*j);  // dropped by the consumer meanwhile
+        cv_.notify_all();
     }
 
-    // Advance to the member that starts at expect_.  false = end of the stream.
-    bool next_member()
+    // The consumer ran out of bytes: next block of the current member, or the next member.
+    // false = end of the stream.
+    bool next_block()
     {
+        if (have_.p) {
+            put_block(have_);
+            have_ = Block();
+        }
+        pos_ = 0;
         std::unique_lock<std::mutex> lk(m_);
-        if (cur_) put_blocks(cur_->out);
-        cur_.reset();
-        pos_ = 0, blk_ = 0;
         for (;;) {
-            // everything that starts before expect_ lies inside an accepted member: drop it
+            if (cur_) {
+                cv_.wait(lk, [&] { return !cur_->out.empty() || cur_->st == kDone || cur_->st == kFailed; });
+                if (!cur_->out.empty()) {
+                    have_ = cur_->out.front();
+                    cur_->out.pop_front();
+                    cv_.notify_all();  // the producer may go on
+                    return true;
+                }
+                if (cur_->st == kFailed) return start_fallback(lk);
+                expect_ = cur_->end;  // member complete and fully consumed
+                cur_.reset();
+                delivered_ = 0;
+            }
+            // everything that starts before expect_ lies inside a consumed member: drop it
             for (auto it = jobs_.begin(); it != jobs_.end();) {
                 if ((*it)->start < expect_) {
                     (*it)->cancel = true;
-                    if ((*it)->st == kDone) put_blocks((*it)->out);
+                    if ((*it)->st == kDone || (*it)->st == kFailed) drop_blocks(**it);
                     it = jobs_.erase(it);
                 } else {
                     ++it;
                 }
             }
+            cv_.notify_all();
             if (expect_ >= size_) return false;
-            std::shared_ptr<Job> mine;
-            for (auto &j : jobs_)
-                if (j->start == expect_) mine = j;
-            if (!mine) {
+            for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+                if ((*it)->start == expect_) {
+                    cur_ = *it;
+                    jobs_.erase(it);
+                    break;
+                }
+            if (!cur_) {
                 if (!is_header(expect_)) {
                     // not something this reader speculates on: a gzip magic goes to zlib as it is
                     // (it will report the bad method / flags), anything else is trailing garbage
                     if (data_[expect_] == 0x1f && expect_ + 1 < size_ && data_[expect_ + 1] == 0x8b) return start_fallback(lk);
                     return false;
                 }
-                mine = std::make_shared<Job>();
-                mine->start = expect_;
-                jobs_.push_front(mine);
+                cur_ = std::make_shared<Job>();
+                cur_->start = expect_;
             }
-            schedule();
-            cv_.notify_all();
-            cv_.wait(lk, [&] { return mine->st == kDone || mine->st == kFailed; });
-            if (mine->st == kFailed) return start_fallback(lk);
-            cur_ = mine;
-            expect_ = mine->end;
-            for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
-                if (*it == mine) {
-                    jobs_.erase(it);
-                    break;
-                }
-            schedule();
-            cv_.notify_all();
-            if (!cur_->out.empty()) return true;
-            cur_.reset();  // empty member: go on to the next one
+            cv_.notify_all();  // a waiting producer of this member may go on; a free worker may take it
+            schedule(lk);
         }
     }
 
-    // zlib takes over at expect_ (a gzip magic is there): its output and its error are the reference's.
+    // zlib takes over at the start of the current member (a gzip magic is there): the bytes of it
+    // that were already delivered are skipped, the rest -- and the error -- are gzread's.
     bool start_fallback(std::unique_lock<std::mutex> &lk)
     {
         stop_ = true;
         for (auto &j : jobs_) {
             j->cancel = true;
-            if (j->st == kDone) put_blocks(j->out);
+            if (j->st == kDone || j->st == kFailed) drop_blocks(*j);
         }
         jobs_.clear();
+        const uint64_t at = cur_ ? cur_->start : expect_;
+        if (cur_) {
+            cur_->cancel = true;
+            drop_blocks(*cur_);
+            cur_.reset();
+        }
         lk.unlock();
         cv_.notify_all();
         const int fd = dup(fd_);
-        if (fd < 0 || lseek(fd, (off_t)expect_, SEEK_SET) < 0) return false;
-        fallback_ = gzdopen(fd, "rb");
-        if (!fallback_) return false;
-        gzbuffer(fallback_, 1u << 20);
+        bool ok = fd >= 0 && lseek(fd, (off_t)at, SEEK_SET) >= 0;
+        if (ok) {
+            fallback_ = gzdopen(fd, "rb");
+            ok = fallback_ != nullptr;
+        }
+        if (ok) {
+            gzbuffer(fallback_, 1u << 20);
+            std::vector<uint8_t> sink((size_t)1 << 20);
+            uint64_t skip = delivered_;
+            while (skip) {
+                const int k = gzread(fallback_, sink.data(), (unsigned)(skip < sink.size() ? skip : sink.size()));
+                if (k <= 0) break;
+                skip -= (uint64_t)k;
+            }
+        }
         lk.lock();
-        return true;  // read() continues through gzread
+        return ok;  // read() continues through gzread
     }
 
     int fd_ = -1;
     const uint8_t *data_ = nullptr;
     uint64_t size_ = 0;
-    uint64_t expect_ = 0;  // compressed offset where the next accepted member must start
-    uint64_t scan_ = 0;    // candidates before this offset are already queued
+    uint64_t expect_ = 0;     // compressed offset where the next member must start
+    uint64_t scan_ = 0;       // candidates before this offset are already queued
+    uint64_t delivered_ = 0;  // bytes of the current member handed to the caller
     size_t max_jobs_ = 4;
-    std::deque<std::shared_ptr<Job>> jobs_;
-    std::shared_ptr<Job> cur_;
-    size_t blk_ = 0, pos_ = 0;  // read position in cur_
+    std::deque<std::shared_ptr<Job>> jobs_;  // speculative members, in file order
+    std::shared_ptr<Job> cur_;               // the member being consumed
+    Block have_;                             // the block being read from
+    size_t pos_ = 0;
     std::mutex pool_m_;
     std::vector<Block> pool_;
     std::vector<std::thread> workers_;
