@@ -90,6 +90,7 @@ SYMBOLS = [
     ("hpn_fastq_text_begin", _int, [_vp]),
     ("hpn_fastq_text_count", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_trim", _int, [_vp, _vp, _u64, _int, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
+    ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("hpn_depth_begin", _int, [_vp, _i32, _u32, _u32]),
     ("hpn_depth_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_add_dev", _int, [_vp, C.POINTER(BamBatch)]),

@@ -213,6 +213,11 @@ class Context:
                                             C.byref(info)), "hpn_fastq_text_trim")
         return out[:0 if info.irregular else int(info.n_bytes)].tobytes(), info
 
+    # ---- BGZF inflate on the device ----------------------------------------------
+    def bgzf_inflate_dev(self, d_comp, d_blocks, n_blocks, d_out, d_status):
+        self._ck(self.L.hpn_bgzf_inflate_dev(self.h, _ptr(d_comp), _ptr(d_blocks), n_blocks, _ptr(d_out), _ptr(d_status)),
+                 "hpn_bgzf_inflate_dev")
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

@@ -27,7 +27,7 @@ struct Scratch {
     size_t cap = 0;
 };
 
-enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamText = 4, kFamCount = 5 };
+enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamText = 4, kFamInflate = 5, kFamCount = 6 };
 
 }  // namespace hpn
 

@@ -1,0 +1,402 @@
+// bgzf_inflate.hip -- DEFLATE (RFC 1951) decoding of independent BGZF blocks on gfx950.
+//
+// A BAM / bgzip file is a sequence of gzip members of at most 64 KiB each (SAM spec 4.1);
+// the reference inflates them one after the other on the host (samtools-0.1.19 bgzf.c:214-307
+// inflate_block / bgzf_read_block), which is where bam2depth and bam_sliding_count spend their
+// time once the per-record work is on the GPU.  Blocks are independent, and a file has one per
+// ~20 KB of compressed data, so here every block is decoded by its own wavefront:
+//
+//   * Huffman decoding is serial by nature; the 64 lanes run the decoder redundantly on
+//     wave-uniform state (bit buffer, positions), which keeps control flow scalar;
+//   * the lanes cooperate where there is data parallelism: staging the compressed bytes
+//     through an LDS ring (coalesced 16-byte loads), filling the decode tables, copying an
+//     LZ77 match (lane i copies byte i; an overlapping match is a periodic pattern, so every
+//     source byte already exists), and flushing finished 16 KiB of output (coalesced stores);
+//   * the 32 KiB history window lives in LDS (a match must see bytes written a few cycles
+//     ago), with two-level decode tables (10-bit root for literal/length, 8-bit for distance).
+//
+// LDS per wave: 32 KiB window + 8 KiB tables + 2 KiB input ring: three waves per CU, 768 blocks
+// in flight on the chip.  Bound: latency of the dependent LDS table lookups (~1 symbol per
+// 130 clk per wave), not memory.  Like the reference's reader, the CRC32 of the trailer is not
+// checked; the ISIZE is (the block must produce exactly out_len bytes).
+//
+// Anything malformed sets the block's status word; the host then inflates that file with zlib.
+#include "common.hpp"
+
+namespace hpn {
+
+constexpr uint32_t kWin = 32768;             // DEFLATE window
+constexpr uint32_t kRing = 2048;             // compressed-input ring (bytes)
+constexpr uint32_t kLitRoot = 10, kDistRoot = 8;
+constexpr uint32_t kLitSize = 1024 + 512, kDistSize = 256 + 256;
+constexpr uint32_t kFlush = 16384;           // output is written back in segments of this size
+
+// table entry: [31:16] value, [15:8] extra-bit count (or sub-table index bits), [7:4] kind, [3:0] code bits
+enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kDist = 4, kBad = 15 };
+__device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t kind, uint32_t nbits)
+{
+    return value << 16 | extra << 8 | kind << 4 | nbits;
+}
+
+struct InfLds {
+    uint8_t win[kWin];
+    uint32_t lit[kLitSize];
+    uint32_t dist[kDistSize];
+    uint32_t ring[kRing / 4];
+    uint8_t lens[384];     // code lengths being assembled (19 code-length codes | 286 + 30 lengths from offset 32)
+    uint16_t count[16], first[16], next[16];
+};
+
+struct Bits {  // wave-uniform bit reader over the LDS ring
+    u64 bb = 0;
+    uint32_t bc = 0;       // valid bits in bb
+    uint32_t in_pos = 0;   // compressed bytes moved into bb
+    uint32_t filled = 0;   // compressed bytes staged into the ring
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// stage the next kRing/2 bytes of the block's compressed data (all lanes, 16 B each)
+__device__ __forceinline__ void stage(InfLds &s, Bits &b, const uint8_t *__restrict__ in, uint32_t in_len)
+{
+    const uint32_t at = b.filled + 16u * (uint32_t)lane_id();
+    u32 v = {0, 0, 0, 0};
+    if (at < in_len + 16u) __builtin_memcpy(&v, in + at, 16);  // the buffer is padded by the host
+    *(u32 *)((uint8_t *)s.ring + (at & (kRing - 1))) = v;
+    b.filled += kRing / 2;
+}
+
+__device__ __forceinline__ void refill(InfLds &s, Bits &b, const uint8_t *__restrict__ in, uint32_t in_len)
+{
+    if (b.bc > 32u) return;
+    if (b.filled - b.in_pos < 8u + kRing / 4) {
+        if (b.filled < in_len + 8u) stage(s, b, in, in_len);
+    }
+    const uint32_t p = b.in_pos;
+    const uint32_t w0 = s.ring[(p >> 2) & (kRing / 4 - 1)], w1 = s.ring[((p >> 2) + 1) & (kRing / 4 - 1)];
+    const uint32_t v = uni((uint32_t)((((u64)w1 << 32) | w0) >> (8u * (p & 3u))));
+    b.bb |= (u64)v << b.bc;
+    b.bc += 32u;
+    b.in_pos = p + 4u;
+}
+__device__ __forceinline__ uint32_t peek(const Bits &b, uint32_t n) { return (uint32_t)b.bb & ((1u << n) - 1u); }
+__device__ __forceinline__ void drop(Bits &b, uint32_t n) { b.bb >>= n, b.bc -= n; }
+__device__ __forceinline__ uint32_t take(Bits &b, uint32_t n)
+{
+    const uint32_t v = peek(b, n);
+    drop(b, n);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t rev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32u - len); }
+
+// Canonical Huffman table from s.lens[base .. base+n): root-bit primary table, sub-tables for
+// longer codes sized like zlib's (per prefix, for the longest code under it).  All lanes run
+// this redundantly on uniform values; stores of the same value to the same address by every
+// lane are intended.  payload(sym, nbits) supplies the entry.  false: over-subscribed or
+// (beyond what zlib accepts) incomplete code, or a table that does not fit.
+template <typename F>
+__device__ bool build(InfLds &s, uint32_t *tab, uint32_t tab_size, uint32_t root, uint32_t base, uint32_t n, bool allow_single,
+                      F payload)
+{
+    const int lane = lane_id();
+    if (lane < 16) s.count[lane] = 0;
+    uint32_t maxlen = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t l = s.lens[base + i];
+        if (l) s.count[l] = (uint16_t)(s.count[l] + 1);
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    uint32_t code = 0, left = 1;
+    bool over = false;
+    for (uint32_t l = 1; l <= 15; ++l) {
+        const uint32_t c = s.count[l];
+        left <<= 1;
+        if (c > left) over = true;
+        left -= over ? 0 : c;
+        code = (code + (l > 1 ? s.count[l - 1] : 0)) << 1;
+        s.first[l] = (uint16_t)code;
+        s.next[l] = (uint16_t)code;
+    }
+    if (over) return false;
+    if (left != 0 && !(allow_single && maxlen <= 1)) return false;  // inftrees.c: incomplete only with max == 1 (or no code at all)
+    for (uint32_t i = (uint32_t)lane; i < tab_size; i += kWave) tab[i] = mk(0, 0, kBad, 0);
+    if (maxlen == 0) return true;
+    uint32_t sub_next = 1u << root;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t l = s.lens[base + i];
+        if (!l) continue;
+        const uint32_t c = s.next[l];
+        s.next[l] = (uint16_t)(c + 1);
+        const uint32_t r = rev(c, l);
+        if (l <= root) {
+            const uint32_t e = payload(i, l);
+            for (uint32_t k = r + ((uint32_t)lane << l); k < (1u << root); k += (uint32_t)kWave << l) tab[k] = e;
+        } else {
+            const uint32_t prefix = r & ((1u << root) - 1u), top = c >> (l - root);  // the code's first root bits
+            uint32_t pe = tab[prefix];
+            if (((pe >> 4) & 15u) != kSub) {
+                // codes under one prefix are consecutive in canonical order with non-decreasing
+                // lengths: the sub-table is as wide as the longest length that reaches this prefix
+                uint32_t sb = l - root;
+                for (uint32_t m = maxlen; m > l; --m) {
+                    const uint32_t cnt = s.count[m];
+                    if (cnt && top >= ((uint32_t)s.first[m] >> (m - root)) && top <= (((uint32_t)s.first[m] + cnt - 1u) >> (m - root))) {
+                        sb = m - root;
+                        break;
+                    }
+                }
+                if (sub_next + (1u << sb) > tab_size) return false;
+                pe = mk(sub_next, sb, kSub, root);
+                tab[prefix] = pe;
+                sub_next += 1u << sb;
+            }
+            const uint32_t sb = (pe >> 8) & 255u, so = pe >> 16;
+            const uint32_t e = payload(i, l - root);
+            const uint32_t hi = r >> root, step = 1u << (l - root);
+            for (uint32_t k = hi + ((uint32_t)lane * step); k < (1u << sb); k += (uint32_t)kWave * step) tab[so + k] = e;
+        }
+    }
+    return true;
+}
+
+__device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t lit_payload(uint32_t sym, uint32_t nbits)
+{
+    if (sym < 256u) return mk(sym, 0, kLit, nbits);
+    if (sym == 256u) return mk(0, 0, kEob, nbits);
+    if (sym < 286u) return mk(kLenBase[sym - 257u], kLenExtra[sym - 257u], kLen, nbits);
+    return mk(0, 0, kBad, nbits);
+}
+__device__ __forceinline__ uint32_t dist_payload(uint32_t sym, uint32_t nbits)
+{
+    if (sym < 30u) return mk(kDistBase[sym], kDistExtra[sym], kDist, nbits);
+    return mk(0, 0, kBad, nbits);
+}
+
+__device__ __forceinline__ uint32_t lookup(const uint32_t *tab, uint32_t root, Bits &b)
+{
+    uint32_t e = uni(tab[peek(b, root)]);
+    if (((e >> 4) & 15u) == kSub) {
+        drop(b, root);
+        e = uni(tab[(e >> 16) + peek(b, (e >> 8) & 255u)]);
+    }
+    drop(b, e & 15u);
+    return e;
+}
+
+// write back [from, to) of the block's output (window index = absolute position mod kWin)
+__device__ __forceinline__ void flush(const InfLds &s, uint8_t *__restrict__ out, uint32_t from, uint32_t to)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t body = (from + 15u) & ~15u;  // LDS vectors must be 16-byte aligned (and then never wrap)
+    if (body > to) body = to;
+    for (uint32_t q = from + lane; q < body; q += kWave) out[q] = s.win[q & (kWin - 1)];
+    const uint32_t tail = body + ((to - body) & ~15u);
+    for (uint32_t p = body + 16u * lane; p < tail; p += 16u * kWave) {
+        const u32 v = *(const u32 *)(s.win + (p & (kWin - 1)));
+        __builtin_memcpy(out + p, &v, 16);  // out + p may be unaligned (block offsets are arbitrary)
+    }
+    for (uint32_t q = tail + lane; q < to; q += kWave) out[q] = s.win[q & (kWin - 1)];
+}
+
+struct BgzfBlock {  // = hpn_bgzf_block
+    uint64_t in_off;
+    uint32_t in_len, out_len;
+    uint64_t out_off;
+};
+
+__global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
+                                                        uint32_t n_blocks, uint8_t *__restrict__ outbuf,
+                                                        uint32_t *__restrict__ status)
+{
+    __shared__ InfLds s;
+    const int lane = lane_id();
+    for (uint32_t bi = blockIdx.x; bi < n_blocks; bi += gridDim.x) {
+        const BgzfBlock blk = blocks[bi];
+        const uint8_t *in = comp + blk.in_off;
+        uint8_t *out = outbuf + blk.out_off;
+        const uint32_t in_len = blk.in_len, out_len = blk.out_len;
+        Bits b;
+        stage(s, b, in, in_len);
+        stage(s, b, in, in_len);
+        uint32_t op = 0, flushed = 0, err = 0;
+        bool last = false;
+        while (!last && !err) {
+            refill(s, b, in, in_len);
+            if (b.in_pos - (b.bc >> 3) > in_len) {  // ran past the payload (the ring would only repeat itself)
+                err = 17;
+                break;
+            }
+            last = take(b, 1) != 0;
+            const uint32_t type = take(b, 2);
+            if (type == 0) {  // stored
+                drop(b, b.bc & 7u);
+                refill(s, b, in, in_len);
+                const uint32_t len = take(b, 16);
+                refill(s, b, in, in_len);
+                const uint32_t nlen = take(b, 16);
+                if ((len ^ nlen) != 0xffffu || op + len > out_len) {
+                    err = 1;
+                    break;
+                }
+                // the stored bytes start with what is still in the bit buffer; copy them from
+                // global memory in pieces the window can hold, writing each piece back at once
+                const uint32_t src = b.in_pos - (b.bc >> 3);  // compressed offset of the first stored byte
+                if (src + len > in_len) {
+                    err = 2;
+                    break;
+                }
+                flush(s, out, flushed, op);
+                for (uint32_t c = 0; c < len; c += kFlush) {
+                    const uint32_t step = min(len - c, kFlush);
+                    for (uint32_t i = (uint32_t)lane; i < step; i += kWave) s.win[(op + c + i) & (kWin - 1)] = in[src + c + i];
+                    flush(s, out, op + c, op + c + step);
+                }
+                op += len;
+                flushed = op;
+                // restart the bit reader behind the stored bytes
+                b.bb = 0, b.bc = 0;
+                b.in_pos = src + len;
+                b.filled = b.in_pos & ~(kRing / 2 - 1);
+                stage(s, b, in, in_len);
+                stage(s, b, in, in_len);
+                continue;
+            }
+            if (type == 3) {
+                err = 3;
+                break;
+            }
+            if (type == 1) {  // fixed codes (RFC 1951 3.2.6)
+                for (uint32_t i = (uint32_t)lane; i < 288u; i += kWave) s.lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8;
+                for (uint32_t i = (uint32_t)lane; i < 32u; i += kWave) s.lens[288 + i] = 5;
+                if (!build(s, s.lit, kLitSize, kLitRoot, 0, 288, true, lit_payload) ||
+                    !build(s, s.dist, kDistSize, kDistRoot, 288, 32, true, dist_payload)) {  // 30 used + 2 reserved: complete
+                    err = 4;
+                    break;
+                }
+            } else {  // dynamic codes
+                refill(s, b, in, in_len);
+                const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
+                if (hlit > 286u || hdist > 30u) {
+                    err = 5;
+                    break;
+                }
+                if (lane < 19) s.lens[lane] = 0;
+                for (uint32_t i = 0; i < hclen; ++i) {
+                    refill(s, b, in, in_len);
+                    const uint32_t v = take(b, 3);
+                    s.lens[kClOrder[i]] = (uint8_t)v;
+                }
+                // the code-length code decodes with the distance table's storage (7-bit root is enough)
+                if (!build(s, s.dist, kDistSize, 7, 0, 19, false, [](uint32_t sym, uint32_t nb) { return mk(sym, 0, kLit, nb); })) {
+                    err = 6;
+                    break;
+                }
+                uint32_t i = 0, prev = 0;
+                const uint32_t total = hlit + hdist;
+                while (i < total && !err) {
+                    refill(s, b, in, in_len);
+                    const uint32_t e = lookup(s.dist, 7, b);
+                    if (((e >> 4) & 15u) != kLit) {
+                        err = 7;
+                        break;
+                    }
+                    const uint32_t sym = e >> 16;
+                    uint32_t rep = 1, val = sym;
+                    if (sym == 16u) {
+                        if (i == 0) {
+                            err = 8;
+                            break;
+                        }
+                        rep = 3u + take(b, 2), val = prev;
+                    } else if (sym == 17u) {
+                        rep = 3u + take(b, 3), val = 0;
+                    } else if (sym == 18u) {
+                        rep = 11u + take(b, 7), val = 0;
+                    }
+                    if (i + rep > total) {
+                        err = 9;
+                        break;
+                    }
+                    for (uint32_t k = (uint32_t)lane; k < rep; k += kWave) s.lens[32 + i + k] = (uint8_t)val;
+                    i += rep, prev = val;
+                }
+                if (err) break;
+                if (s.lens[32 + 256] == 0) {  // no end-of-block code
+                    err = 10;
+                    break;
+                }
+                if (!build(s, s.lit, kLitSize, kLitRoot, 32, hlit, true, lit_payload) ||
+                    !build(s, s.dist, kDistSize, kDistRoot, 32 + hlit, hdist, true, dist_payload)) {
+                    err = 11;
+                    break;
+                }
+            }
+            // ---- symbols of this block ------------------------------------------------------
+            for (;;) {
+                refill(s, b, in, in_len);
+                if (b.in_pos - (b.bc >> 3) > in_len + 4u) {
+                    err = 17;
+                    break;
+                }
+                const uint32_t e = lookup(s.lit, kLitRoot, b);
+                const uint32_t kind = (e >> 4) & 15u;
+                if (kind == kLit) {
+                    if (op >= out_len) {
+                        err = 12;
+                        break;
+                    }
+                    s.win[op & (kWin - 1)] = (uint8_t)(e >> 16);
+                    ++op;
+                } else if (kind == kLen) {
+                    const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
+                    refill(s, b, in, in_len);
+                    const uint32_t d = lookup(s.dist, kDistRoot, b);
+                    if (((d >> 4) & 15u) != kDist) {
+                        err = 13;
+                        break;
+                    }
+                    const uint32_t dist = (d >> 16) + take(b, (d >> 8) & 255u);
+                    if (dist > op || op + len > out_len) {
+                        err = 14;
+                        break;
+                    }
+                    const uint32_t start = op - dist;
+                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave)
+                        s.win[(op + i) & (kWin - 1)] = s.win[(start + (i < dist ? i : i % dist)) & (kWin - 1)];
+                    op += len;
+                } else if (kind == kEob) {
+                    break;
+                } else {
+                    err = 15;
+                    break;
+                }
+                if (op - flushed >= kFlush) {  // keep less than 16 KiB + one match unflushed: the ring never overwrites it
+                    flush(s, out, flushed, op);
+                    flushed = op;
+                }
+            }
+        }
+        if (!err && op != out_len) err = 16;
+        if (!err) flush(s, out, flushed, op);
+        if (lane == 0) status[bi] = err;
+    }
+}
+
+hipError_t launch_bgzf_inflate(const uint8_t *d_comp, const void *d_blocks, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_status,
+                               int n_cu, hipStream_t st)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const uint32_t cap = (uint32_t)n_cu * 3u;  // three waves (one LDS image each) per CU
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < cap ? n_blocks : cap), dim3(kWave), 0, st, d_comp, (const BgzfBlock *)d_blocks,
+                       n_blocks, d_out, d_status);
+    return hipGetLastError();
+}
+
+}  // namespace hpn

@@ -63,7 +63,7 @@ const char *hpn_ctx_last_error(const hpn_ctx *ctx);
 /* Milliseconds the device spent in the most recent kernel launch group of the
  * given family, measured with hipEvents on the context's stream (valid after
  * the matching fetch/sync). Families: 0 tally, 1 trim, 2 depth, 3 window,
- * 4 text framing. */
+ * 4 text framing, 5 BGZF inflate. */
 int hpn_ctx_last_kernel_ms(hpn_ctx *ctx, int family, float *ms);
 
 /* ---- memory helpers (thin wrappers; callers may use their own allocator) ---- */
@@ -222,6 +222,23 @@ int hpn_fastq_text_count(hpn_ctx *ctx, const void *text, uint64_t nbytes, int la
  * capacity out_cap; nbytes + 8192 always suffices). */
 int hpn_fastq_text_trim(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, int32_t S, int32_t E,
                         void *out_text, uint64_t out_cap, hpn_text_info *info);
+
+/* ---- BGZF: inflate on the device ------------------------------------------------------------
+ * A BAM / bgzip file is a chain of independent gzip members of at most 64 KiB (SAM spec 4.1);
+ * the reference inflates them one by one on the host (samtools-0.1.19 bgzf.c:214-307).  Here
+ * the host only walks the 18-byte block headers; every block is decoded by one wavefront.
+ * blocks[i]: in_off / in_len = the raw DEFLATE payload inside the compressed buffer (after the
+ * member header, before the 8-byte trailer), out_off / out_len = where its ISIZE bytes go.
+ * d_comp must be readable 64 bytes past the last payload.  d_status[i] = 0 or a decoder error
+ * code (malformed stream, or output != out_len); like the reference's reader the CRC32 is not
+ * checked.  Asynchronous on the context's stream. */
+typedef struct hpn_bgzf_block {
+    uint64_t in_off;
+    uint32_t in_len, out_len;
+    uint64_t out_off;
+} hpn_bgzf_block;
+int hpn_bgzf_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_bgzf_block *d_blocks, uint64_t n_blocks,
+                         uint8_t *d_out, uint32_t *d_status);
 
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),
