@@ -9,27 +9,29 @@
 //   * Huffman decoding is serial by nature; the 64 lanes run the decoder redundantly on
 //     wave-uniform state (bit buffer, positions), which keeps control flow scalar;
 //   * the lanes cooperate where there is data parallelism: staging the compressed bytes
-//     through an LDS ring (coalesced 16-byte loads), filling the decode tables, copying an
+//     through an LDS ring (coalesced 16-byte loads), filling the decode tables, and copying an
 //     LZ77 match (lane i copies byte i; an overlapping match is a periodic pattern, so every
-//     source byte already exists), and flushing finished 16 KiB of output (coalesced stores);
-//   * the 32 KiB history window lives in LDS (a match must see bytes written a few cycles
-//     ago), with two-level decode tables (10-bit root for literal/length, 8-bit for distance).
+//     source byte already exists);
+//   * the output goes straight to global memory, and a match reads its source back from there:
+//     the 32 KiB history window does not have to live in LDS, which leaves two-level decode
+//     tables (10-bit root for literal/length, 8-bit for distance) and a 2 KiB input ring =
+//     10.6 KiB per wave, 14 waves per CU, 3,584 blocks in flight on the chip (with the window in
+//     LDS it was 3 waves per CU and 2.7x slower).  A match whose source overlaps bytes this
+//     wave stored since its last wait first waits for those stores (workgroup-scope fence: the
+//     CU's vector cache is coherent for its own waves, so that is a counter wait only).
 //
-// LDS per wave: 32 KiB window + 8 KiB tables + 2 KiB input ring: three waves per CU, 768 blocks
-// in flight on the chip.  Bound: latency of the dependent LDS table lookups (~1 symbol per
-// 130 clk per wave), not memory.  Like the reference's reader, the CRC32 of the trailer is not
-// checked; the ISIZE is (the block must produce exactly out_len bytes).
+// Bound: instruction issue of the serial symbol loop (dependent LDS table lookups), not memory.
+// Like the reference's reader, the CRC32 of the trailer is not checked; the ISIZE is (the block
+// must produce exactly out_len bytes).
 //
 // Anything malformed sets the block's status word; the host then inflates that file with zlib.
 #include "common.hpp"
 
 namespace hpn {
 
-constexpr uint32_t kWin = 32768;             // DEFLATE window
 constexpr uint32_t kRing = 2048;             // compressed-input ring (bytes)
 constexpr uint32_t kLitRoot = 10, kDistRoot = 8;
 constexpr uint32_t kLitSize = 1024 + 512, kDistSize = 256 + 256;
-constexpr uint32_t kFlush = 16384;           // output is written back in segments of this size
 
 // table entry: [31:16] value, [15:8] extra-bit count (or sub-table index bits), [7:4] kind, [3:0] code bits
 enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kDist = 4, kBad = 15 };
@@ -39,7 +41,6 @@ __device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t 
 }
 
 struct InfLds {
-    uint8_t win[kWin];
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
     uint32_t ring[kRing / 4];
@@ -190,21 +191,6 @@ __device__ __forceinline__ uint32_t lookup(const uint32_t *tab, uint32_t root, B
     return e;
 }
 
-// write back [from, to) of the block's output (window index = absolute position mod kWin)
-__device__ __forceinline__ void flush(const InfLds &s, uint8_t *__restrict__ out, uint32_t from, uint32_t to)
-{
-    const uint32_t lane = (uint32_t)lane_id();
-    uint32_t body = (from + 15u) & ~15u;  // LDS vectors must be 16-byte aligned (and then never wrap)
-    if (body > to) body = to;
-    for (uint32_t q = from + lane; q < body; q += kWave) out[q] = s.win[q & (kWin - 1)];
-    const uint32_t tail = body + ((to - body) & ~15u);
-    for (uint32_t p = body + 16u * lane; p < tail; p += 16u * kWave) {
-        const u32 v = *(const u32 *)(s.win + (p & (kWin - 1)));
-        __builtin_memcpy(out + p, &v, 16);  // out + p may be unaligned (block offsets are arbitrary)
-    }
-    for (uint32_t q = tail + lane; q < to; q += kWave) out[q] = s.win[q & (kWin - 1)];
-}
-
 struct BgzfBlock {  // = hpn_bgzf_block
     uint64_t in_off;
     uint32_t in_len, out_len;
@@ -225,7 +211,7 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
         Bits b;
         stage(s, b, in, in_len);
         stage(s, b, in, in_len);
-        uint32_t op = 0, flushed = 0, err = 0;
+        uint32_t op = 0, safe = 0, err = 0;  // output bytes below `safe` are known to have reached memory
         bool last = false;
         while (!last && !err) {
             refill(s, b, in, in_len);
@@ -252,14 +238,8 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                     err = 2;
                     break;
                 }
-                flush(s, out, flushed, op);
-                for (uint32_t c = 0; c < len; c += kFlush) {
-                    const uint32_t step = min(len - c, kFlush);
-                    for (uint32_t i = (uint32_t)lane; i < step; i += kWave) s.win[(op + c + i) & (kWin - 1)] = in[src + c + i];
-                    flush(s, out, op + c, op + c + step);
-                }
+                for (uint32_t i = (uint32_t)lane; i < len; i += kWave) out[op + i] = in[src + i];
                 op += len;
-                flushed = op;
                 // restart the bit reader behind the stored bytes
                 b.bb = 0, b.bc = 0;
                 b.in_pos = src + len;
@@ -352,7 +332,7 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                         err = 12;
                         break;
                     }
-                    s.win[op & (kWin - 1)] = (uint8_t)(e >> 16);
+                    if (lane == 0) out[op] = (uint8_t)(e >> 16);
                     ++op;
                 } else if (kind == kLen) {
                     const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
@@ -368,8 +348,17 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                         break;
                     }
                     const uint32_t start = op - dist;
-                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave)
-                        s.win[(op + i) & (kWin - 1)] = s.win[(start + (i < dist ? i : i % dist)) & (kWin - 1)];
+                    if (start + (len < dist ? len : dist) > safe) {
+                        // the source reaches into bytes this wave stored a moment ago: wait for those stores
+                        // (workgroup scope = this CU's vector cache: a counter wait, no cache invalidate)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        safe = op;
+                    }
+                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
+                        uint32_t k = i;
+                        if (k >= dist) k %= dist;  // overlapping match = periodic pattern: every source byte exists already
+                        out[op + i] = out[start + k];
+                    }
                     op += len;
                 } else if (kind == kEob) {
                     break;
@@ -377,14 +366,9 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                     err = 15;
                     break;
                 }
-                if (op - flushed >= kFlush) {  // keep less than 16 KiB + one match unflushed: the ring never overwrites it
-                    flush(s, out, flushed, op);
-                    flushed = op;
-                }
             }
         }
         if (!err && op != out_len) err = 16;
-        if (!err) flush(s, out, flushed, op);
         if (lane == 0) status[bi] = err;
     }
 }
@@ -393,7 +377,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *d_comp, const void *d_blocks, uint
                                int n_cu, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
-    const uint32_t cap = (uint32_t)n_cu * 3u;  // three waves (one LDS image each) per CU
+    const uint32_t cap = (uint32_t)n_cu * 14u;  // 14 single-wave workgroups (10.6 KiB of LDS each) per CU
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < cap ? n_blocks : cap), dim3(kWave), 0, st, d_comp, (const BgzfBlock *)d_blocks,
                        n_blocks, d_out, d_status);
     return hipGetLastError();
