@@ -47,6 +47,11 @@ class Rqc(C.Structure):
 RQC_MAXLEN = 300
 
 
+class RawInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("tid_min", C.c_int32), ("tid_max", C.c_int32), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class Run(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32)]
 
@@ -91,6 +96,9 @@ SYMBOLS = [
     ("hpn_fastq_text_count", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_trim", _int, [_vp, _vp, _u64, _int, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    ("hpn_bam_raw_index_dev", _int, [_vp, _vp, _vp, _u64, _u32, _vp, C.POINTER(RawInfo)]),
+    ("hpn_depth_add_raw_dev", _int, [_vp, _vp]),
+    ("hpn_window_add_raw_dev", _int, [_vp, _vp]),
     ("hpn_depth_begin", _int, [_vp, _i32, _u32, _u32]),
     ("hpn_depth_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_add_dev", _int, [_vp, C.POINTER(BamBatch)]),

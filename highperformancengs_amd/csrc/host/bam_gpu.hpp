@@ -1,0 +1,317 @@
+// bam_gpu.hpp -- BAM ingest with the inflate and the record walk on the GPU.
+//
+// The host-side path (bam_reader.hpp) inflates BGZF blocks on a thread pool and decodes records on
+// one thread: 84 % of bam2depth's run time once the per-record work is on the GPU, and capped by
+// the host's cores.  Here the host only moves bytes: a reader thread preads the compressed file
+// into pinned chunks, the 18-byte block headers are walked to build the block table (one hop
+// per ~20 KB), and the device inflates the blocks (hpn_bgzf_inflate_dev) and indexes the records
+// where they lie (hpn_bam_raw_index_dev).  The BAM header is parsed on the host from the first
+// blocks (zlib), which also tells where the first record starts.
+//
+// Works for files whose BGZF blocks start at record boundaries (everything samtools writes,
+// bam.c:238); otherwise, and on any damaged block, next() reports failure and the tool runs
+// the host path instead.
+#pragma once
+#include <zlib.h>
+
+#include <memory>
+
+#include "bam_reader.hpp"
+#include "text_stream.hpp"
+
+namespace hpn {
+
+class BamGpuStream {
+public:
+    ~BamGpuStream()
+    {
+        pump_.reset();
+        if (ctx_) {
+            hpn_dev_free(ctx_, d_comp_), hpn_dev_free(ctx_, d_blocks_), hpn_dev_free(ctx_, d_out_), hpn_dev_free(ctx_, d_status_);
+            hpn_host_free(ctx_, h_blocks_);
+        }
+    }
+
+    // Parses the BAM header (host, zlib) and positions the stream at the first record.
+    bool open(hpn_ctx *ctx, const char *path, BamHeader &hdr)
+    {
+        ctx_ = ctx;
+        FILE *f = fopen(path, "rb");
+        if (!f) return false;
+        std::vector<uint8_t> text, raw;
+        uint64_t file_off = 0;
+        bool ok = false;
+        size_t need = 12;
+        for (;;) {
+            uint8_t h[18];
+            if (fread(h, 1, 18, f) != 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') break;
+            const uint32_t bsize = (h[16] | (h[17] << 8)) + 1u, xlen = h[10] | (h[11] << 8);
+            if (bsize < xlen + 20u || xlen < 6u) break;
+            raw.resize(bsize - 18);
+            if (fread(raw.data(), 1, raw.size(), f) != raw.size()) break;
+            uint32_t isize;
+            memcpy(&isize, raw.data() + raw.size() - 4, 4);
+            const size_t before = text.size();
+            text.resize(before + isize);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) break;
+            zs.next_in = raw.data() + (xlen - 6), zs.avail_in = (uInt)(raw.size() - (xlen - 6) - 8);
+            zs.next_out = text.data() + before, zs.avail_out = isize;
+            const int rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || (isize && zs.avail_out != 0)) break;
+            const int st = parse_header(text, hdr, &need);
+            if (st < 0) break;
+            if (st > 0) {  // complete: the first record is at text[need]
+                ok = true;
+                first_off_ = (uint32_t)(need - before);  // inside this block ...
+                start_ = file_off;                        // ... which starts here in the file
+                if (need == text.size()) first_off_ = 0, start_ = file_off + bsize;  // the header ends with its block
+                break;
+            }
+            file_off += bsize;
+        }
+        fclose(f);
+        if (!ok) return false;
+        chunk_ = (size_t)64 << 20;
+        if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
+        pump_.reset(new TextPump(ctx, path, chunk_, 3, true));
+        if (!pump_->ok()) return false;
+        skip_ = start_;
+        return true;
+    }
+
+    const uint8_t *d_raw() const { return (const uint8_t *)d_out_; }
+
+    // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
+    // be empty), 0 = end of file, -1 = not decodable here (the caller switches to the host path).
+    int next(hpn_raw_info *info)
+    {
+        memset(info, 0, sizeof *info);
+        for (;;) {
+            TextPump::Chunk c;
+            if (eof_ || !pump_->next(c)) return carry_.empty() ? 0 : -1;  // a partial block at the end: truncated file
+            if (c.eof) eof_ = true;
+            size_t at = 0;
+            if (skip_) {  // chunks before the first record's block
+                const size_t k = skip_ < c.n ? (size_t)skip_ : c.n;
+                skip_ -= k, at = k;
+            }
+            if (at == c.n) {
+                pump_->recycle(c);
+                if (eof_) return carry_.empty() ? 0 : -1;
+                continue;
+            }
+            const int r = submit(c, at, info);
+            pump_->recycle(c);
+            return r;
+        }
+    }
+
+private:
+    // 0 = need more bytes, 1 = complete (*need = header length), -1 = not BAM
+    static int parse_header(const std::vector<uint8_t> &t, BamHeader &h, size_t *need)
+    {
+        if (t.size() < 8) return 0;
+        if (memcmp(t.data(), "BAM\1", 4)) return -1;
+        int32_t l_text, n_ref;
+        memcpy(&l_text, t.data() + 4, 4);
+        size_t p = 8 + (size_t)l_text;
+        if (t.size() < p + 4) return 0;
+        memcpy(&n_ref, t.data() + p, 4);
+        p += 4;
+        h.target_name.clear(), h.target_len.clear();
+        for (int32_t i = 0; i < n_ref; ++i) {
+            if (t.size() < p + 4) return 0;
+            int32_t l_name, l_ref;
+            memcpy(&l_name, t.data() + p, 4);
+            if (t.size() < p + 4 + (size_t)l_name + 4) return 0;
+            h.target_name.emplace_back((const char *)t.data() + p + 4);
+            memcpy(&l_ref, t.data() + p + 4 + l_name, 4);
+            h.target_len.push_back((uint32_t)l_ref);
+            p += 8 + (size_t)l_name;
+        }
+        *need = p;
+        return 1;
+    }
+
+    template <typename T>
+    bool reserve(void *&p, size_t &cap, size_t n)
+    {
+        if (n * sizeof(T) <= cap) return true;
+        if (p) hpn_dev_free(ctx_, p);
+        p = nullptr, cap = 0;
+        const size_t want = n * sizeof(T) + n * sizeof(T) / 4 + 4096;
+        if (hpn_dev_malloc(ctx_, want, &p) != HPN_OK) return false;
+        cap = want;
+        return true;
+    }
+
+    // Blocks of carry_ + chunk[at..): table on the host, bytes and table to the device, inflate, index.
+    int submit(const TextPump::Chunk &c, size_t at, hpn_raw_info *info)
+    {
+        const uint8_t *p = c.p + at;
+        const size_t n = c.n - at;
+        size_t done = 0;
+        blocks_.clear();
+        uint64_t out = 0, in = 0;
+        size_t carry_used = 0;
+        if (!carry_.empty()) {  // complete the block the previous chunk ended in
+            while (carry_.size() < 18 && done < n) carry_.push_back(p[done++]);
+            if (carry_.size() < 18) return eof_ ? -1 : 1;
+            const uint32_t bsize = (carry_[16] | (carry_[17] << 8)) + 1u;
+            const size_t more = bsize > carry_.size() ? bsize - carry_.size() : 0;
+            if (more > n - done) {
+                carry_.insert(carry_.end(), p + done, p + n);
+                return eof_ ? -1 : 1;
+            }
+            carry_.insert(carry_.end(), p + done, p + done + more);
+            done += more;
+            if (!add_block(carry_.data(), 0, bsize, &out)) return -1;
+            carry_used = in = bsize;
+        }
+        const size_t body = done;  // chunk bytes [body, stop) go to the device behind the carried block
+        size_t q = done;
+        while (q + 18 <= n) {
+            const uint32_t bsize = (p[q + 16] | (p[q + 17] << 8)) + 1u;
+            if (q + bsize > n) break;
+            if (!add_block(p + q, in + (q - body), bsize, &out)) return -1;
+            q += bsize;
+        }
+        const size_t stop = q;
+        std::vector<uint8_t> tail(p + stop, p + n);  // a partial block: kept for the next chunk
+        const size_t nb = blocks_.size();
+        const size_t comp_bytes = carry_used + (stop - body);
+        if (nb) {
+            if (!reserve<uint8_t>(d_comp_, cap_comp_, comp_bytes + 64) || !reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) ||
+                !reserve<uint8_t>(d_out_, cap_out_, out + 64) || !reserve<uint32_t>(d_status_, cap_status_, nb))
+                return -1;
+            if (nb > h_blocks_cap_) {
+                if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
+                h_blocks_cap_ = nb + nb / 2 + 1024;
+                if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
+            }
+            memcpy(h_blocks_, blocks_.data(), nb * sizeof(hpn_bgzf_block));
+            if (carry_used) {
+                if (hpn_memcpy_h2d(ctx_, d_comp_, carry_.data(), carry_used) != HPN_OK) return -1;
+                if (hpn_ctx_sync(ctx_) != HPN_OK) return -1;  // carry_ is pageable and replaced below
+            }
+            if (stop > body && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + carry_used, p + body, stop - body) != HPN_OK) return -1;
+            if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
+            if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
+                                     (uint32_t *)d_status_) != HPN_OK)
+                return -1;
+            // the sync inside the index call also covers the copies out of the pinned chunk
+            if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
+                                      (const uint32_t *)d_status_, info) != HPN_OK)
+                return -1;
+            first_off_ = 0;
+            if (info->flags) return -1;
+        }
+        carry_.swap(tail);
+        if (eof_ && !carry_.empty()) return -1;
+        return 1;
+    }
+
+    bool add_block(const uint8_t *h, uint64_t in_off, uint32_t bsize, uint64_t *out)
+    {
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') return false;
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (bsize < xlen + 20u) return false;
+        hpn_bgzf_block b;
+        b.in_off = in_off + 12u + xlen;
+        b.in_len = bsize - xlen - 20u;
+        memcpy(&b.out_len, h + bsize - 4, 4);
+        if (b.out_len > 65536u) return false;
+        b.out_off = *out;
+        *out += b.out_len;
+        blocks_.push_back(b);
+        return true;
+    }
+
+    hpn_ctx *ctx_ = nullptr;
+    std::unique_ptr<TextPump> pump_;
+    size_t chunk_ = 0;
+    uint64_t start_ = 0, skip_ = 0;  // file offset of the block holding the first record
+    uint32_t first_off_ = 0;         // ... and the record's offset inside it
+    bool eof_ = false;
+    std::vector<uint8_t> carry_;
+    std::vector<hpn_bgzf_block> blocks_;
+    void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr;
+    size_t cap_comp_ = 0, cap_blocks_ = 0, cap_out_ = 0, cap_status_ = 0, h_blocks_cap_ = 0;
+};
+
+inline bool bam_gpu_enabled()
+{
+    const char *e = getenv("HPN_BAM_GPU");
+    return !(e && e[0] == '0');
+}
+
+// All records of one target into the open depth accumulation, from whichever ingest is active.
+class DepthFeeder {
+public:
+    // try_gpu: device inflate + record walk (feed() returns 1 when the file turns out not to be decodable there)
+    bool open(hpn_ctx *ctx, const char *path, BamHeader &hdr, bool try_gpu)
+    {
+        ctx_ = ctx;
+        if (try_gpu) {
+            gpu_.reset(new BamGpuStream());
+            if (gpu_->open(ctx, path, hdr)) return true;
+            gpu_.reset();
+            hdr = BamHeader();
+        }
+        return host_.open(path, hdr);
+    }
+    bool on_gpu() const { return (bool)gpu_; }
+
+    // HPN_OK, an hpn_status, or 1 = the GPU ingest gave up (re-run the file with try_gpu = false)
+    int feed(int32_t j)
+    {
+        if (gpu_) {
+            for (;;) {
+                if (!have_) {
+                    const int r = gpu_->next(&info_);
+                    if (r == 0) return HPN_OK;
+                    if (r < 0) return 1;
+                    have_ = true;
+                }
+                if (info_.n_records && info_.tid_min <= j && j <= info_.tid_max) {
+                    const int rc = hpn_depth_add_raw_dev(ctx_, gpu_->d_raw());
+                    if (rc != HPN_OK) return rc;
+                }
+                if (info_.n_records && info_.tid_max > j) return HPN_OK;  // the batch also holds later targets
+                have_ = false;
+            }
+        }
+        for (;;) {  // the target's records are contiguous in a coordinate-sorted file
+            int32_t t = host_.peek_tid();
+            while (t != INT32_MIN && t >= 0 && t < j) {  // out of order: not reachable through the index either
+                batch_.clear();
+                host_.next(batch_, false);
+                t = host_.peek_tid();
+            }
+            batch_.clear();
+            while (t == j && batch_.n() < (4u << 20)) {
+                host_.next(batch_, false);
+                t = host_.peek_tid();
+            }
+            if (batch_.n()) {
+                hpn_bam_batch v = batch_.view();
+                const int rc = hpn_depth_add(ctx_, &v);
+                if (rc != HPN_OK) return rc;
+            }
+            if (t != j) return HPN_OK;
+        }
+    }
+
+private:
+    hpn_ctx *ctx_ = nullptr;
+    std::unique_ptr<BamGpuStream> gpu_;
+    BamReader host_;
+    BamBatch batch_;
+    hpn_raw_info info_;
+    bool have_ = false;
+};
+
+}  // namespace hpn

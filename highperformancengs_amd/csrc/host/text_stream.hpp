@@ -72,7 +72,8 @@ public:
         int idx = -1;
     };
 
-    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3) : ctx_(ctx), cap_(chunk)
+    // raw: deliver the file's own bytes whatever they are (compressed BGZF for the device inflater)
+    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false) : ctx_(ctx), cap_(chunk)
     {
         struct stat sb;
         uint8_t magic[2] = {0, 0};
@@ -81,7 +82,7 @@ public:
             const int fd = open(path, O_RDONLY);
             if (fd >= 0) {
                 const ssize_t k = pread(fd, magic, 2, 0);
-                if (k < 2 || magic[0] != 0x1f || magic[1] != 0x8b) {  // zlib would copy it through unchanged
+                if (raw || k < 2 || magic[0] != 0x1f || magic[1] != 0x8b) {  // zlib would copy it through unchanged
                     fd_ = fd;
                 } else {
                     close(fd);

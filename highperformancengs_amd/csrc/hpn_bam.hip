@@ -16,6 +16,14 @@ hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uin
                              const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
                              u64 *n_count, uint32_t *bad, int n_cu, hipStream_t st);
+hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
+                            uint32_t *counts, u64 *bases, int32_t *info, hipStream_t st);
+hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *counts,
+                            const u64 *bases, uint64_t *rec_off, hipStream_t st);
+hipError_t launch_raw_fields(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t *tid, int32_t *pos, uint32_t *flag,
+                             int32_t *l_qseq, uint64_t *seq_off, int n_cu, hipStream_t st);
+hipError_t launch_depth_scatter_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask,
+                                    int32_t *diff, uint64_t slots, uint32_t *bad, int n_cu, hipStream_t st);
 }  // namespace hpn
 
 using namespace hpn;
@@ -145,6 +153,81 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
         HPN_HIP(c, hipMemcpyAsync(runs, c->d_runs.p, head.n_runs * sizeof(hpn_run), hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
     return HPN_OK;
+}
+
+// ---- records in place in inflated BGZF blocks -------------------------------------------------
+
+int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block *d_blocks, uint64_t n_blocks, uint32_t first_off,
+                          const uint32_t *d_status, hpn_raw_info *info)
+{
+    if (!c || !info || (n_blocks && (!d_raw || !d_blocks || !d_status)) || n_blocks > 0xffffffffull) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    memset(info, 0, sizeof *info);
+    c->r_n = 0, c->r_fields = false;
+    if (n_blocks == 0) return HPN_OK;
+    int rc;
+    if ((rc = scratch_reserve(c, c->r_counts, n_blocks * sizeof(uint32_t))) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->r_bases, (n_blocks + 1) * sizeof(u64))) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->r_info, 64)) != HPN_OK) return rc;
+    const int32_t init[4] = {0, INT32_MAX, INT32_MIN, 0};
+    HPN_HIP(c, hipMemcpyAsync(c->r_info.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HPN_HIP(c, launch_raw_count(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_status, (uint32_t *)c->r_counts.p, (u64 *)c->r_bases.p,
+                                (int32_t *)c->r_info.p, c->stream));
+    int32_t h[4];
+    u64 total = 0;
+    HPN_HIP(c, hipMemcpyAsync(h, c->r_info.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(&total, (const u64 *)c->r_bases.p + n_blocks, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    info->flags = (uint32_t)h[0];
+    info->n_records = total;
+    info->tid_min = total ? h[1] : 0, info->tid_max = total ? h[2] : -1;
+    if (info->flags || total == 0) return HPN_OK;  // nothing indexed: the caller decodes this file on the host
+    if ((rc = scratch_reserve(c, c->r_off, total * sizeof(uint64_t))) != HPN_OK) return rc;
+    HPN_HIP(c, launch_raw_index(d_raw, d_blocks, (uint32_t)n_blocks, first_off, (const uint32_t *)c->r_counts.p, (const u64 *)c->r_bases.p,
+                                (uint64_t *)c->r_off.p, c->stream));
+    c->r_n = total;
+    return HPN_OK;
+}
+
+int hpn_depth_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
+{
+    if (!c || (c->r_n && !d_raw)) return HPN_E_ARG;
+    if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_add before hpn_depth_begin");
+    HPN_HIP(c, hipSetDevice(c->device));
+    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
+    HPN_HIP(c, launch_depth_scatter_raw(d_raw, (const uint64_t *)c->r_off.p, c->r_n, c->depth_tid, c->depth_mask, (int32_t *)c->d_diff.p,
+                                        c->depth_slots, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
+    c->ev_valid[kFamDepth] = true;
+    c->depth_scanned = false;
+    return HPN_OK;
+}
+
+static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b);
+
+int hpn_window_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
+{
+    if (!c || (c->r_n && !d_raw)) return HPN_E_ARG;
+    if (!c->win_open) return fail(c, HPN_E_STATE, "hpn_window_add before hpn_window_begin");
+    HPN_HIP(c, hipSetDevice(c->device));
+    const uint64_t n = c->r_n;
+    if (n == 0) return HPN_OK;
+    int rc;
+    if (!c->r_fields) {
+        if ((rc = scratch_reserve(c, c->r_tid, n * 4)) != HPN_OK || (rc = scratch_reserve(c, c->r_pos, n * 4)) != HPN_OK ||
+            (rc = scratch_reserve(c, c->r_flag, n * 4)) != HPN_OK || (rc = scratch_reserve(c, c->r_lq, n * 4)) != HPN_OK ||
+            (rc = scratch_reserve(c, c->r_soff, n * 8)) != HPN_OK)
+            return rc;
+        HPN_HIP(c, launch_raw_fields(d_raw, (const uint64_t *)c->r_off.p, n, (int32_t *)c->r_tid.p, (int32_t *)c->r_pos.p,
+                                     (uint32_t *)c->r_flag.p, (int32_t *)c->r_lq.p, (uint64_t *)c->r_soff.p, c->n_cu, c->stream));
+        c->r_fields = true;
+    }
+    hpn_bam_batch b;
+    memset(&b, 0, sizeof b);
+    b.n = n;
+    b.tid = (const int32_t *)c->r_tid.p, b.pos = (const int32_t *)c->r_pos.p, b.flag = (const uint32_t *)c->r_flag.p;
+    b.l_qseq = (const int32_t *)c->r_lq.p, b.seq_off = (const uint64_t *)c->r_soff.p, b.seq4 = d_raw;
+    return window_add_common(c, &b);
 }
 
 // ---- bam_sliding_count -------------------------------------------------------------------

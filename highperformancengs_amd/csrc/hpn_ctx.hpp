@@ -65,6 +65,10 @@ struct hpn_ctx {
     bool t_open = false;
     int t_cur = 0;
     uint32_t t_carry = 0, t_tail = 0;  // carry bytes and where they start in slot[t_cur ^ 1]
+    // records indexed in place in inflated BGZF blocks (hpn_bam_raw_*)
+    hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info;
+    uint64_t r_n = 0;
+    bool r_fields = false;  // the SoA view of the current index has been gathered
     // RCCL
     void *comm = nullptr;
     char err[512] = {0};

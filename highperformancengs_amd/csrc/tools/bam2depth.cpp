@@ -13,6 +13,7 @@
 #include <getopt.h>
 #include <libgen.h>
 
+#include "../host/bam_gpu.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
 
@@ -79,9 +80,12 @@ int main(int argc, char *argv[])
 
     char suffix[64];
     for (int i = 0; i < n_in; ++i) {
-        BamReader bam;
+      // first with the BGZF inflate and the record walk on the GPU; a file that cannot be decoded
+      // there (records straddling blocks, damaged block) is done again with the host reader
+      for (int pass = bam_gpu_enabled() ? 0 : 1; pass < 2; ++pass) {
+        DepthFeeder bam;
         BamHeader hdr;
-        if (!bam.open(infiles[i], hdr)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        if (!bam.open(ctx, infiles[i], hdr, pass == 0)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
         std::string nm = infiles[i];
         snprintf(suffix, sizeof suffix, ".%u.bedGraph", i + 1);
         FILE *bedGraph = fcreat_outfile(basename(&nm[0]), suffix);
@@ -98,37 +102,22 @@ int main(int argc, char *argv[])
             fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
             exit(1);
         }
-        BamBatch batch;
         std::vector<hpn_run> runs(1u << 20);
         std::vector<uint64_t> win;
-        double t_read = 0, t_add = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
-        for (int32_t j = 0; j < hdr.n_targets(); ++j) {
+        double t_feed = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
+        bool redo = false;
+        for (int32_t j = 0; j < hdr.n_targets() && !redo; ++j) {
             const uint32_t tlen = hdr.target_len[j];
             const char *name = hdr.target_name[j].c_str();
             if ((rc = hpn_depth_begin(ctx, j, tlen, BAM_DEF_MASK)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");
-            // the target's records are contiguous in a coordinate-sorted file
-            for (;;) {
-                int32_t t = bam.peek_tid();
-                while (t != INT32_MIN && t >= 0 && t < j) {  // out of order: not reachable through the index either
-                    batch.clear();
-                    bam.next(batch, false);
-                    t = bam.peek_tid();
-                }
-                batch.clear();
-                t0 = wall_s();
-                while (t == j && batch.n() < (4u << 20)) {
-                    bam.next(batch, false);
-                    t = bam.peek_tid();
-                }
-                t_read += wall_s() - t0;
-                if (batch.n()) {
-                    t0 = wall_s();
-                    hpn_bam_batch v = batch.view();
-                    if ((rc = hpn_depth_add(ctx, &v)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
-                    t_add += wall_s() - t0;
-                }
-                if (t != j) break;
+            t0 = wall_s();
+            rc = bam.feed(j);
+            t_feed += wall_s() - t0;
+            if (rc == 1) {
+                redo = true;
+                break;
             }
+            if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
             t0 = wall_s();
             win.assign((size_t)tlen / window + 1, 0);
             uint64_t n_runs = 0;
@@ -150,15 +139,17 @@ int main(int argc, char *argv[])
             fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
         }
         if (getenv("HPN_TIMING"))
-            fprintf(stderr, "[hpn] inflate+decode %.3f s  copy+scatter %.3f s  scan+fetch runs %.3f s  format+write %.3f s\n", t_read,
-                    t_add, t_finish, t_print);
+            fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  format+write %.3f s%s\n",
+                    bam.on_gpu() ? "GPU" : "host", t_feed, t_finish, t_print, redo ? "  (abandoned: not decodable on the GPU)" : "");
         fclose(bedGraph);
         fclose(depth);
         if (wig) {
             fclose(WIG);
             fclose(chrSize);
         }
-        fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
+        if (!redo) break;  // else: the outputs are re-created (truncated) by the host pass
+      }
+      fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
     }
     quick_exit_ok();
 }

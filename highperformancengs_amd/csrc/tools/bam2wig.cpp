@@ -10,6 +10,7 @@
 #include <err.h>
 #include <getopt.h>
 
+#include "../host/bam_gpu.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
 
@@ -72,9 +73,10 @@ int main(int argc, char *argv[])
 
     char suffix[64];
     for (int i = 0; i < n_in; ++i) {
-        BamReader bam;
+      for (int pass = bam_gpu_enabled() ? 0 : 1; pass < 2; ++pass) {  // GPU ingest first, host reader if the file needs it
+        DepthFeeder bam;
         BamHeader hdr;
-        if (!bam.open(infiles[i], hdr)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        if (!bam.open(ctx, infiles[i], hdr, pass == 0)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
         snprintf(suffix, sizeof suffix, ".%u.wig", i + 1);
         FILE *wig = fcreat_outfile(outfile, suffix);
         snprintf(suffix, sizeof suffix, ".%u.chromSize.txt", i + 1);
@@ -83,31 +85,19 @@ int main(int argc, char *argv[])
             fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
             exit(1);
         }
-        BamBatch batch;
         std::vector<hpn_run> runs(1u << 20);
         std::vector<double> bins;
+        bool redo = false;
         for (int32_t j = 0; j < hdr.n_targets(); ++j) {
             const uint32_t tlen = hdr.target_len[j];
             const char *name = hdr.target_name[j].c_str();
             if ((rc = hpn_depth_begin(ctx, j, tlen, BAM_FUNMAP)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");
-            for (;;) {  // the target's records are contiguous in a coordinate-sorted file
-                int32_t t = bam.peek_tid();
-                while (t != INT32_MIN && t >= 0 && t < j) {
-                    batch.clear();
-                    bam.next(batch, false);
-                    t = bam.peek_tid();
-                }
-                batch.clear();
-                while (t == j && batch.n() < (4u << 20)) {
-                    bam.next(batch, false);
-                    t = bam.peek_tid();
-                }
-                if (batch.n()) {
-                    hpn_bam_batch v = batch.view();
-                    if ((rc = hpn_depth_add(ctx, &v)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
-                }
-                if (t != j) break;
+            rc = bam.feed(j);
+            if (rc == 1) {
+                redo = true;
+                break;
             }
+            if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
             uint64_t n_runs = 0;
             rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, nullptr);
             if (rc == HPN_E_CAPACITY) {
@@ -123,7 +113,9 @@ int main(int argc, char *argv[])
         }
         fclose(wig);
         fclose(chrSize);
-        fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
+        if (!redo) break;
+      }
+      fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
     }
     quick_exit_ok();
 }

@@ -293,6 +293,26 @@ int hpn_window_add_dev(hpn_ctx *ctx, const hpn_bam_batch *dev_batch);
 int hpn_window_finish(hpn_ctx *ctx, uint32_t *bins, uint64_t *gc, uint32_t *len, uint8_t *touched,
                       uint64_t *n_count);
 
+/* ---- BAM records in place in inflated BGZF blocks -----------------------------------------
+ * bam_read1 (samtools-0.1.19 bam.c:191) on the device: after hpn_bgzf_inflate_dev the records
+ * are indexed where they lie.  samtools never lets a record straddle a BGZF block (bam.c:238
+ * bgzf_flush_try; the header ends with a flush), so every block starts at a record boundary and
+ * is walked independently; `first_off` is the offset of the first record inside block 0 (the
+ * block the BAM header ends in).  info->flags: 1 = some block's record chain does not end at
+ * the block's end (a file written otherwise), 2 = a block failed to inflate -- in both cases
+ * nothing is indexed and the caller decodes the file on the host.  Synchronous (returns the
+ * record count and the refID range of the batch).  The two add calls then run the depth /
+ * window kernels over the indexed records, like hpn_depth_add_dev / hpn_window_add_dev. */
+typedef struct hpn_raw_info {
+    uint64_t n_records;
+    int32_t tid_min, tid_max;
+    uint32_t flags, reserved;
+} hpn_raw_info;
+int hpn_bam_raw_index_dev(hpn_ctx *ctx, const uint8_t *d_raw, const hpn_bgzf_block *d_blocks, uint64_t n_blocks,
+                          uint32_t first_off, const uint32_t *d_status, hpn_raw_info *info);
+int hpn_depth_add_raw_dev(hpn_ctx *ctx, const uint8_t *d_raw);
+int hpn_window_add_raw_dev(hpn_ctx *ctx, const uint8_t *d_raw);
+
 /* ---- multi-GPU reduction of count vectors -----------------------------------
  * One RCCL communicator per context; `unique_id` is the 128-byte ncclUniqueId
  * produced by hpn_comm_unique_id on rank 0 and handed to every rank by the host

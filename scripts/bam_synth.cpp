@@ -1,7 +1,7 @@
 // bam_synth.cpp -- synthetic coordinate-sorted BAM of the shape SURVEY.md §8(d) asks for, fast
 // enough to make multi-GB inputs on the GPU box (bench / profiling input only, not the product):
 //   g++ -O2 -std=c++17 scripts/bam_synth.cpp -o /tmp/bam_synth -lz -lpthread
-//   /tmp/bam_synth out.bam <reads> <contigs> <contig_len> [threads]
+//   /tmp/bam_synth out.bam <reads> <contigs> <contig_len> [threads] [packed]
 // 150 bp reads, starts uniform per contig, CIGAR mix 85 % 150M, 5 % 40M2I108M, 5 % 60M5D90M,
 // 5 % 10S140M; flags 90 % {0,16}, 10 % from {4,256,512,1024}; bases ACGT + 1 % N.
 // Writes out.bam and an EMPTY out.bam.bai (our tools only test that the index exists; the
@@ -46,18 +46,31 @@ static std::vector<uint8_t> bgzf_block(const uint8_t *src, size_t n)
     return out;
 }
 
-static void write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads)
+// records = true: `raw` is a run of whole BAM records and no record may straddle two blocks
+// (what samtools' bam_write1 guarantees through bgzf_flush_try, bam.c:238)
+static void write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads, bool records)
 {
     const size_t kIn = 0xff00;
-    const size_t nb = (raw.size() + kIn - 1) / kIn;
+    std::vector<size_t> cut{0};
+    if (records) {
+        size_t p = 0, start = 0;
+        while (p < raw.size()) {
+            uint32_t bs;
+            memcpy(&bs, raw.data() + p, 4);
+            if (p + 4 + bs - start > kIn && p > start) cut.push_back(p), start = p;
+            p += 4 + (size_t)bs;
+        }
+    } else {
+        for (size_t p = kIn; p < raw.size(); p += kIn) cut.push_back(p);
+    }
+    cut.push_back(raw.size());
+    const size_t nb = cut.size() - 1;
     std::vector<std::vector<uint8_t>> out(nb);
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t)
         th.emplace_back([&, t] {
-            for (size_t b = (size_t)t; b < nb; b += (size_t)threads) {
-                const size_t lo = b * kIn, n = raw.size() - lo < kIn ? raw.size() - lo : kIn;
-                out[b] = bgzf_block(raw.data() + lo, n);
-            }
+            for (size_t b = (size_t)t; b < nb; b += (size_t)threads)
+                if (cut[b + 1] > cut[b]) out[b] = bgzf_block(raw.data() + cut[b], cut[b + 1] - cut[b]);
         });
     for (auto &t : th) t.join();
     for (auto &o : out) fwrite(o.data(), 1, o.size(), f);
@@ -87,7 +100,7 @@ int main(int argc, char **argv)
             raw.push_back(0);
             put32(raw, clen);
         }
-        write_blocks(f, raw, threads);
+        write_blocks(f, raw, threads, false);
     }
     const uint64_t per = reads / (uint64_t)contigs, kBatch = 1u << 20;
     static const uint32_t cig[4][3] = {{150u << 4, 0, 0}, {40u << 4, (2u << 4) | 1, 108u << 4}, {60u << 4, (5u << 4) | 2, 90u << 4}, {(10u << 4) | 4, 140u << 4, 0}};
@@ -133,7 +146,7 @@ int main(int argc, char **argv)
             for (auto &t : th) t.join();
             raw.clear();
             for (auto &p : part) raw.insert(raw.end(), p.begin(), p.end());
-            write_blocks(f, raw, threads);
+            write_blocks(f, raw, threads, argc <= 6);  // a 7th argument: pack records across blocks instead
         }
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, 28, f);

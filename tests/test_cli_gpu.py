@@ -68,6 +68,54 @@ def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
         assert open(tmp_path / f, "rb").read() == expected(case, f), f
 
 
+# The BAM tools inflate BGZF blocks and walk the records on the GPU when every block starts at a
+# record boundary (as samtools writes them), else on the host: both routes, and compressed
+# chunks that cut blocks every 64 KiB, must give the reference's bytes.
+@pytest.mark.parametrize("env", [{"HPN_BAM_GPU": "0"}, {"HPN_BAM_CHUNK": "65600"}], ids=["host-ingest", "chunk64k"])
+@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("depth_", "wig_"))])
+def test_drop_in_bam_routes(manifest, case, env, tmp_path):
+    c = manifest[case]
+    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, env)
+    assert p.returncode == c["returncode"], p.stderr.decode()
+    assert p.stdout == expected(case), p.stderr.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+
+
+def test_bam_gpu_ingest_is_used_and_falls_back(tmp_path):
+    """HPN_TIMING names the ingest: golden BAMs (record-aligned blocks) decode on the GPU; the same
+    records packed across block boundaries are detected and decoded by the host reader."""
+    import zlib
+    src = golden_path("bam", "rand.bam")
+    p, _ = _run("bam2depth", ["-o", "d", "rand.bam"], [src], tmp_path, {"HPN_TIMING": "1"})
+    assert p.returncode == 0 and b"[hpn] GPU ingest" in p.stderr and b"abandoned" not in p.stderr
+    want = open(tmp_path / "rand.bam.1.bedGraph", "rb").read()
+    # re-block the same uncompressed stream in fixed 20000-byte pieces: records now straddle blocks
+    raw, o, data = open(src, "rb").read(), 0, b""
+    while o < len(raw):
+        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+        xlen = int.from_bytes(raw[o + 10:o + 12], "little")
+        data += zlib.decompress(raw[o + 12 + xlen:o + bsize - 8], -15)
+        o += bsize
+    d2 = tmp_path / "packed"
+    d2.mkdir()
+    with open(d2 / "rand.bam", "wb") as fh:
+        for i in range(0, len(data), 20000):
+            piece = data[i:i + 20000]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = co.compress(piece) + co.flush()
+            fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
+                     (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
+        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    shutil.copy(src + ".bai", d2 / "rand.bam.bai")
+    p = subprocess.run([os.path.join(BIN, "bam2depth"), "-o", "d", "rand.bam"], cwd=d2, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "HPN_TIMING": "1"})
+    assert p.returncode == 0, p.stderr.decode()
+    assert b"abandoned" in p.stderr and b"[hpn] host ingest" in p.stderr
+    assert open(d2 / "rand.bam.1.bedGraph", "rb").read() == want
+
+
 def test_fastq_trim_reports_total_reads(tmp_path):
     p, _ = _run("fastq_trim", ["-i", "t.fq", "-s", "2", "-e", "8"], [golden_path("fastq", "t.fq")], tmp_path)
     assert p.stderr.startswith(b"Total_reads: 5\nFinished in ")
