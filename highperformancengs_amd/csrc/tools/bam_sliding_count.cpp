@@ -12,6 +12,7 @@
 
 #include <cctype>
 
+#include "../host/bam_gpu.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
 
@@ -127,8 +128,27 @@ int main(int argc, char *argv[])
             }
             fprintf(stdout, "%s\t%d\t%d\n", hdr.target_name[ref].c_str(), beg, end);
         }
+        // Whole-file mode: BGZF inflate and record walk on the GPU when the file allows it (every block
+        // starts at a record boundary, as samtools writes them); else, and for -r, the host reader.
+        bool on_gpu = false;
+        if (whole && bam_gpu_enabled()) {
+            BamGpuStream gs;
+            BamHeader h2;
+            if (gs.open(ctx, infiles[i], h2)) {
+                hpn_raw_info info;
+                int r;
+                while ((r = gs.next(&info)) == 1)
+                    if (info.n_records && (rc = hpn_window_add_raw_dev(ctx, gs.d_raw())) != HPN_OK) die_hpn(ctx, rc, "hpn_window_add");
+                on_gpu = r == 0;
+                if (!on_gpu) {  // start over on the host: forget what was added
+                    if ((rc = hpn_window_begin(ctx, hdr.n_targets() > 0 ? hdr.n_targets() : 1, off.data(), (uint32_t)window)) != HPN_OK)
+                        die_hpn(ctx, rc, "hpn_window_begin");
+                }
+            }
+        }
+        if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] %s ingest\n", on_gpu ? "GPU" : "host");
         BamBatch batch, one;
-        bool more = true;
+        bool more = !on_gpu;
         while (more) {
             batch.clear();
             while (batch.n() < (2u << 20)) {
