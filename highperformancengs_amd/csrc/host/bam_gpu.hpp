@@ -74,7 +74,7 @@ public:
         }
         fclose(f);
         if (!ok) return false;
-        chunk_ = (size_t)64 << 20;
+        chunk_ = (size_t)88 << 20;  // ~4,500 blocks: one full round of the inflate kernel's 4,608 wave slots
         if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
         pump_.reset(new TextPump(ctx, path, chunk_, 3, true));
         if (!pump_->ok()) return false;

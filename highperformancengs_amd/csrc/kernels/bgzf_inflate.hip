@@ -15,8 +15,8 @@
 //   * the output goes straight to global memory, and a match reads its source back from there:
 //     the 32 KiB history window does not have to live in LDS, which leaves two-level decode
 //     tables (10-bit root for literal/length, 8-bit for distance) and a 2 KiB input ring =
-//     10.6 KiB per wave, 14 waves per CU, 3,584 blocks in flight on the chip (with the window in
-//     LDS it was 3 waves per CU and 2.7x slower).  A match whose source overlaps bytes this
+//     8.7 KiB per wave, 18 waves per CU, 4,608 blocks in flight on the chip (with the window in
+//     LDS it was 3 waves per CU and 2.9x slower).  A match whose source overlaps bytes this
 //     wave stored since its last wait first waits for those stores (workgroup-scope fence: the
 //     CU's vector cache is coherent for its own waves, so that is a counter wait only).
 //
@@ -29,12 +29,12 @@
 
 namespace hpn {
 
-constexpr uint32_t kRing = 2048;             // compressed-input ring (bytes)
+constexpr uint32_t kRing = 1024;             // compressed-input ring (bytes), refilled by halves
 constexpr uint32_t kLitRoot = 10, kDistRoot = 8;
-constexpr uint32_t kLitSize = 1024 + 512, kDistSize = 256 + 256;
+constexpr uint32_t kLitSize = 1024 + 384, kDistSize = 256 + 144;  // root + sub-tables (inftrees.c ENOUGH: 1332 for a 10-bit root)
 
 // table entry: [31:16] value, [15:8] extra-bit count (or sub-table index bits), [7:4] kind, [3:0] code bits
-enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kDist = 4, kBad = 15 };
+enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kDist = 4, kLit2 = 5, kBad = 15 };
 __device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t kind, uint32_t nbits)
 {
     return value << 16 | extra << 8 | kind << 4 | nbits;
@@ -57,13 +57,15 @@ struct Bits {  // wave-uniform bit reader over the LDS ring
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// stage the next kRing/2 bytes of the block's compressed data (all lanes, 16 B each)
+// stage the next kRing/2 bytes of the block's compressed data (16 B per lane)
 __device__ __forceinline__ void stage(InfLds &s, Bits &b, const uint8_t *__restrict__ in, uint32_t in_len)
 {
     const uint32_t at = b.filled + 16u * (uint32_t)lane_id();
-    u32 v = {0, 0, 0, 0};
-    if (at < in_len + 16u) __builtin_memcpy(&v, in + at, 16);  // the buffer is padded by the host
-    *(u32 *)((uint8_t *)s.ring + (at & (kRing - 1))) = v;
+    if (16u * (uint32_t)lane_id() < kRing / 2) {
+        u32 v = {0, 0, 0, 0};
+        if (at < in_len + 16u) __builtin_memcpy(&v, in + at, 16);  // the buffer is padded by the host
+        *(u32 *)((uint8_t *)s.ring + (at & (kRing - 1))) = v;
+    }
     b.filled += kRing / 2;
 }
 
@@ -191,6 +193,29 @@ __device__ __forceinline__ uint32_t lookup(const uint32_t *tab, uint32_t root, B
     return e;
 }
 
+// Two literals per lookup: where a root-table index starts with a literal code of l1 bits and the
+// remaining root - l1 bits hold a whole second literal code, the entry delivers both
+// ([23:16] first, [31:24] second, [15:8] l1, code bits = l1 + l2).  The decoder is bound by the
+// latency of its dependent table lookups, and most of a BAM block's symbols are literals
+// (qualities, names); this halves the lookups for them.  In place: an entry that was already
+// paired still shows its first literal and l1, so the pass can run on all entries at once.
+__device__ __forceinline__ void pair_literals(uint32_t *tab, uint32_t root)
+{
+    for (uint32_t i = (uint32_t)lane_id(); i < (1u << root); i += kWave) {
+        const uint32_t e1 = tab[i], k1 = (e1 >> 4) & 15u;
+        if (k1 != kLit) continue;
+        const uint32_t l1 = e1 & 15u, rest = root - l1;
+        if (rest == 0) continue;
+        const uint32_t e2 = tab[i >> l1], k2 = (e2 >> 4) & 15u;  // the second code sees the remaining bits, zero-extended
+        uint32_t l2, lit2;
+        if (k2 == kLit) l2 = e2 & 15u, lit2 = e2 >> 16;
+        else if (k2 == kLit2) l2 = (e2 >> 8) & 255u, lit2 = (e2 >> 16) & 255u;
+        else continue;
+        if (l2 > rest) continue;  // its code would need bits beyond the index
+        tab[i] = mk((e1 >> 16) | lit2 << 8, l1, kLit2, l1 + l2);
+    }
+}
+
 struct BgzfBlock {  // = hpn_bgzf_block
     uint64_t in_off;
     uint32_t in_len, out_len;
@@ -260,6 +285,7 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                     err = 4;
                     break;
                 }
+                pair_literals(s.lit, kLitRoot);
             } else {  // dynamic codes
                 refill(s, b, in, in_len);
                 const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
@@ -317,6 +343,7 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                     err = 11;
                     break;
                 }
+                pair_literals(s.lit, kLitRoot);
             }
             // ---- symbols of this block ------------------------------------------------------
             for (;;) {
@@ -334,6 +361,13 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                     }
                     if (lane == 0) out[op] = (uint8_t)(e >> 16);
                     ++op;
+                } else if (kind == kLit2) {
+                    if (op + 2u > out_len) {
+                        err = 12;
+                        break;
+                    }
+                    if (lane == 0) out[op] = (uint8_t)(e >> 16), out[op + 1u] = (uint8_t)(e >> 24);
+                    op += 2u;
                 } else if (kind == kLen) {
                     const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
                     refill(s, b, in, in_len);
@@ -377,7 +411,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *d_comp, const void *d_blocks, uint
                                int n_cu, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
-    const uint32_t cap = (uint32_t)n_cu * 14u;  // 14 single-wave workgroups (10.6 KiB of LDS each) per CU
+    const uint32_t cap = (uint32_t)n_cu * 18u;  // 18 single-wave workgroups (8.7 KiB of LDS each) per CU
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < cap ? n_blocks : cap), dim3(kWave), 0, st, d_comp, (const BgzfBlock *)d_blocks,
                        n_blocks, d_out, d_status);
     return hipGetLastError();
