@@ -82,6 +82,19 @@ public:
         return true;
     }
 
+    // bgzip-compressed text (a .fastq.gz written by bgzip): batches of inflated bytes on the device,
+    // no records to index.  next() then fills only info->n_records with the batch's byte count.
+    bool open_text(hpn_ctx *ctx, const char *path)
+    {
+        ctx_ = ctx;
+        text_mode_ = true;
+        chunk_ = (size_t)88 << 20;
+        if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
+        pump_.reset(new TextPump(ctx, path, chunk_, 3, true));
+        return pump_->ok();
+    }
+    bool at_eof() const { return eof_ && carry_.empty(); }
+
     const uint8_t *d_raw() const { return (const uint8_t *)d_out_; }
 
     // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
@@ -202,6 +215,16 @@ private:
             if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
                                      (uint32_t *)d_status_) != HPN_OK)
                 return -1;
+            if (text_mode_) {  // no records: wait, check every block's status
+                status_.resize(nb);
+                if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
+                for (uint32_t st : status_)
+                    if (st) return -1;
+                info->n_records = out;
+                carry_.swap(tail);
+                if (eof_ && !carry_.empty()) return -1;
+                return 1;
+            }
             // the sync inside the index call also covers the copies out of the pinned chunk
             if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
                                       (const uint32_t *)d_status_, info) != HPN_OK)
@@ -235,7 +258,8 @@ private:
     size_t chunk_ = 0;
     uint64_t start_ = 0, skip_ = 0;  // file offset of the block holding the first record
     uint32_t first_off_ = 0;         // ... and the record's offset inside it
-    bool eof_ = false;
+    bool eof_ = false, text_mode_ = false;
+    std::vector<uint32_t> status_;
     std::vector<uint8_t> carry_;
     std::vector<hpn_bgzf_block> blocks_;
     void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr;

@@ -6,6 +6,7 @@
 // while the GPU copies and scans batch k, the host frames batch k+1.
 #pragma once
 #include "../host/fastq_reader.hpp"
+#include "../host/bam_gpu.hpp"
 #include "../host/text_stream.hpp"
 #include "hpngs.h"
 
@@ -104,10 +105,64 @@ inline int tally_text_stream(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
     return hpn_fastq_tally_fetch(ctx, acc);
 }
 
+// bgzip-compressed FASTQ: compressed bytes to the GPU, BGZF blocks inflated there, the text framed
+// and tallied where it lands -- the host never sees the text.  *unusable: a damaged block or a
+// stream that is not regular FASTQ; nothing is added to acc and the caller takes another route.
+inline bool is_bgzf_file(const char *path)
+{
+    uint8_t h[18] = {0};
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    const bool ok = pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
+    close(fd);
+    return ok;
+}
+inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *unusable)
+{
+    *unusable = false;
+    BamGpuStream gs;
+    if (!gs.open_text(ctx, path)) {
+        *unusable = true;
+        return HPN_OK;
+    }
+    const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
+    int rc = hpn_fastq_text_begin(ctx);
+    bool sent_last = false;
+    while (rc == HPN_OK && !*unusable) {
+        hpn_raw_info bi;
+        const int r = gs.next(&bi);
+        if (r < 0) {
+            *unusable = true;
+            break;
+        }
+        hpn_text_info info;
+        const bool last = r == 0 || gs.at_eof();
+        rc = hpn_fastq_text_count(ctx, gs.d_raw(), r == 0 ? 0 : bi.n_records, last, flags, &info);
+        if (rc == HPN_OK && info.irregular) *unusable = true;
+        if (last) {
+            sent_last = true;
+            break;
+        }
+    }
+    (void)sent_last;
+    if (*unusable || rc != HPN_OK) {
+        hpn_tally scratch;
+        memset(&scratch, 0, sizeof scratch);
+        (void)hpn_fastq_tally_fetch(ctx, &scratch);
+        return rc;
+    }
+    return hpn_fastq_tally_fetch(ctx, acc);
+}
+
 // One input file of fastq_count / fastq_count_kthread (count_read, fastq_count.c:106-133).
 inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_long)
 {
     const bool is_stdin = strncmp(path, "-", 1) == 0 || !strcmp(path, "");
+    if (text_path_enabled() && !is_stdin && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(path)) {
+        bool unusable = false;
+        const int rc = tally_bgzf_on_gpu(ctx, path, acc, &unusable);
+        if (!unusable) return rc;
+    }
     if (text_path_enabled() && !is_stdin) {  // an irregular stream is framed again from its first byte
         bool irregular = false;
         const int rc = tally_text_stream(ctx, path, acc, &irregular);

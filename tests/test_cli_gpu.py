@@ -116,6 +116,35 @@ def test_bam_gpu_ingest_is_used_and_falls_back(tmp_path):
     assert open(d2 / "rand.bam.1.bedGraph", "rb").read() == want
 
 
+def test_bgzipped_fastq_is_inflated_on_the_gpu(tmp_path):
+    """bgzip-style FASTQ: compressed blocks go to the GPU, are inflated there and framed where they land;
+    the report equals the one for the same text read through zlib on the host."""
+    from highperformancengs_amd.bamio import _Bgzf
+    text = open(golden_path("fastq", "syn_var_a.fq"), "rb").read() * 30
+    with open(tmp_path / "s.fq.gz", "wb") as fh:
+        z = _Bgzf(fh)
+        for i in range(0, len(text), 40000):
+            z.write(text[i:i + 40000])
+        z.close()
+    outs = []
+    for env in ({}, {"HPN_BAM_CHUNK": "70000"}, {"HPN_NO_BGZF": "1", "HPN_NO_MGZ": "1", "HPN_TEXT": "0"}):
+        p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "s.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env={**os.environ, **env})
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append(p.stdout)
+    assert outs[0] == outs[1] == outs[2]
+    want = orc.fastq_count_report([str(tmp_path / "s.fq.gz")], names=["s.fq.gz"], header=True, length_detail=True)
+    assert outs[0] == want
+    # the same bytes with a damaged block in the middle: the GPU route gives up, zlib's verdict stands
+    raw = bytearray(open(tmp_path / "s.fq.gz", "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    open(tmp_path / "bad.fq.gz", "wb").write(raw)
+    a = subprocess.run([os.path.join(BIN, "fastq_count"), "bad.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    b = subprocess.run([os.path.join(BIN, "fastq_count"), "bad.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "HPN_BAM_GPU": "0"})
+    assert a.returncode == b.returncode and a.stdout == b.stdout
+
+
 def test_fastq_trim_reports_total_reads(tmp_path):
     p, _ = _run("fastq_trim", ["-i", "t.fq", "-s", "2", "-e", "8"], [golden_path("fastq", "t.fq")], tmp_path)
     assert p.stderr.startswith(b"Total_reads: 5\nFinished in ")
