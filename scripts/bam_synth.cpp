@@ -78,6 +78,21 @@ static void write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads, 
 
 int main(int argc, char **argv)
 {
+    if (argc >= 4 && !strcmp(argv[1], "--bgzip")) {  // bam_synth --bgzip in out [threads]: what `bgzip -c in > out` does
+        FILE *in = fopen(argv[2], "rb"), *out = fopen(argv[3], "wb");
+        if (!in || !out) return perror("bgzip"), 1;
+        const int threads = argc > 4 ? atoi(argv[4]) : 8;
+        std::vector<uint8_t> buf((size_t)0xff00 * 4096);
+        size_t n;
+        while ((n = fread(buf.data(), 1, buf.size(), in)) > 0) {
+            std::vector<uint8_t> piece(buf.begin(), buf.begin() + n);
+            write_blocks(out, piece, threads, false);
+        }
+        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        fwrite(eof, 1, 28, out);
+        fclose(in), fclose(out);
+        return 0;
+    }
     if (argc < 5) return fprintf(stderr, "usage: %s out.bam reads contigs contig_len [threads]\n", argv[0]), 1;
     const uint64_t reads = (uint64_t)atof(argv[2]);
     const int contigs = atoi(argv[3]);
