@@ -163,22 +163,28 @@ __device__ bool build(InfLds &s, uint32_t *tab, uint32_t tab_size, uint32_t root
     return true;
 }
 
-__device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ uint32_t lit_payload(uint32_t sym, uint32_t nbits)
 {
     if (sym < 256u) return mk(sym, 0, kLit, nbits);
     if (sym == 256u) return mk(0, 0, kEob, nbits);
-    if (sym < 286u) return mk(kLenBase[sym - 257u], kLenExtra[sym - 257u], kLen, nbits);
+    if (sym < 286u) {  // RFC 1951 3.2.5, in closed form (a table in global memory would cost a load per symbol)
+        const uint32_t k = sym - 257u;
+        if (k < 8u) return mk(3u + k, 0, kLen, nbits);
+        if (k == 28u) return mk(258u, 0, kLen, nbits);
+        const uint32_t xb = (k - 4u) >> 2;
+        return mk(3u + ((4u + (k & 3u)) << xb), xb, kLen, nbits);
+    }
     return mk(0, 0, kBad, nbits);
 }
 __device__ __forceinline__ uint32_t dist_payload(uint32_t sym, uint32_t nbits)
 {
-    if (sym < 30u) return mk(kDistBase[sym], kDistExtra[sym], kDist, nbits);
+    if (sym < 30u) {
+        if (sym < 4u) return mk(1u + sym, 0, kDist, nbits);
+        const uint32_t xb = (sym - 2u) >> 1;
+        return mk(1u + ((2u + (sym & 1u)) << xb), xb, kDist, nbits);
+    }
     return mk(0, 0, kBad, nbits);
 }
 
