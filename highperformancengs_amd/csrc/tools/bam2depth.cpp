@@ -13,6 +13,8 @@
 #include <getopt.h>
 #include <libgen.h>
 
+#include <thread>
+
 #include "../host/bam_gpu.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
@@ -102,8 +104,11 @@ int main(int argc, char *argv[])
             fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
             exit(1);
         }
-        std::vector<hpn_run> runs(1u << 20);
-        std::vector<uint64_t> win;
+        // two result buffers: target j is formatted and written by a thread of its own while the GPU
+        // already ingests target j + 1 (the writers run one after the other, so the files stay in order)
+        std::vector<hpn_run> runs_buf[2] = {std::vector<hpn_run>(1u << 20), std::vector<hpn_run>(1u << 20)};
+        std::vector<uint64_t> win_buf[2];
+        std::thread printer;
         double t_feed = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
         bool redo = false;
         for (int32_t j = 0; j < hdr.n_targets() && !redo; ++j) {
@@ -119,6 +124,8 @@ int main(int argc, char *argv[])
             }
             if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_depth_add");
             t0 = wall_s();
+            std::vector<hpn_run> &runs = runs_buf[j & 1];
+            std::vector<uint64_t> &win = win_buf[j & 1];
             win.assign((size_t)tlen / window + 1, 0);
             uint64_t n_runs = 0;
             rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
@@ -129,17 +136,23 @@ int main(int argc, char *argv[])
             if (rc != HPN_OK) die_hpn(ctx, rc, name);
             t_finish += wall_s() - t0;
             t0 = wall_s();
-            print_bedgraph(bedGraph, name, runs.data(), n_runs);
-            print_depth_bins(depth, name, tlen, window, win.data());
-            if (wig) {
-                print_wig_bins(WIG, name, tlen, window, win.data());
-                fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
-            }
+            if (printer.joinable()) printer.join();
+            printer = std::thread([=, &runs, &win] {
+                print_bedgraph(bedGraph, name, runs.data(), n_runs);
+                print_depth_bins(depth, name, tlen, window, win.data());
+                if (wig) {
+                    print_wig_bins(WIG, name, tlen, window, win.data());
+                    fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
+                }
+            });
             t_print += wall_s() - t0;
             fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
         }
+        t0 = wall_s();
+        if (printer.joinable()) printer.join();
+        t_print += wall_s() - t0;
         if (getenv("HPN_TIMING"))
-            fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  format+write %.3f s%s\n",
+            fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  waiting for the writer %.3f s%s\n",
                     bam.on_gpu() ? "GPU" : "host", t_feed, t_finish, t_print, redo ? "  (abandoned: not decodable on the GPU)" : "");
         fclose(bedGraph);
         fclose(depth);
