@@ -34,7 +34,7 @@ constexpr uint32_t kLitRoot = 10, kDistRoot = 8;
 constexpr uint32_t kLitSize = 1024 + 384, kDistSize = 256 + 144;  // root + sub-tables (inftrees.c ENOUGH: 1332 for a 10-bit root)
 
 // table entry: [31:16] value, [15:8] extra-bit count (or sub-table index bits), [7:4] kind, [3:0] code bits
-enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kDist = 4, kLit2 = 5, kBad = 15 };
+enum { kLit = 0, kLit2 = 1, kLen = 2, kEob = 3, kSub = 4, kDist = 5, kBad = 15 };  // literal kinds first: one compare
 __device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t kind, uint32_t nbits)
 {
     return value << 16 | extra << 8 | kind << 4 | nbits;
@@ -352,29 +352,28 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                 pair_literals(s.lit, kLitRoot);
             }
             // ---- symbols of this block ------------------------------------------------------
+            // (every pass emits at least one byte -- bounded by out_len -- or leaves, so the loop ends on any
+            // input; running past the payload is caught per block above)
             for (;;) {
                 refill(s, b, in, in_len);
-                if (b.in_pos - (b.bc >> 3) > in_len + 4u) {
-                    err = 17;
-                    break;
+                uint32_t e = lookup(s.lit, kLitRoot, b);
+                uint32_t kind = (e >> 4) & 15u;
+                // literal run: a loop of its own, so that the common case carries none of the match path's state;
+                // every lane stores the same byte(s) to the same address (no exec masking)
+                while (kind <= kLit2) {
+                    if (op + kind + 1u > out_len) {
+                        err = 12;
+                        break;
+                    }
+                    out[op] = (uint8_t)(e >> 16);
+                    if (kind) out[op + 1u] = (uint8_t)(e >> 24);
+                    op += kind + 1u;
+                    refill(s, b, in, in_len);
+                    e = lookup(s.lit, kLitRoot, b);
+                    kind = (e >> 4) & 15u;
                 }
-                const uint32_t e = lookup(s.lit, kLitRoot, b);
-                const uint32_t kind = (e >> 4) & 15u;
-                if (kind == kLit) {
-                    if (op >= out_len) {
-                        err = 12;
-                        break;
-                    }
-                    if (lane == 0) out[op] = (uint8_t)(e >> 16);
-                    ++op;
-                } else if (kind == kLit2) {
-                    if (op + 2u > out_len) {
-                        err = 12;
-                        break;
-                    }
-                    if (lane == 0) out[op] = (uint8_t)(e >> 16), out[op + 1u] = (uint8_t)(e >> 24);
-                    op += 2u;
-                } else if (kind == kLen) {
+                if (err) break;
+                if (kind == kLen) {
                     const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
                     refill(s, b, in, in_len);
                     const uint32_t d = lookup(s.dist, kDistRoot, b);
