@@ -270,6 +270,31 @@ class Context:
                  "hpn_window_finish")
         return bins, gc, ln, touched, nc.value
 
+    # ---- BAM records in place in inflated BGZF blocks ------------------------------
+    def bam_raw_index_dev(self, d_raw, d_blocks, n_blocks, first_off, d_status):
+        info = _lib.RawInfo()
+        self._ck(self.L.hpn_bam_raw_index_dev(self.h, _ptr(d_raw), _ptr(d_blocks), n_blocks, first_off, _ptr(d_status),
+                                              C.byref(info)), "hpn_bam_raw_index_dev")
+        return info
+
+    def depth_target_raw(self, d_raw, tid, target_len, W, flag_mask=0x704):
+        self._ck(self.L.hpn_depth_begin(self.h, tid, target_len, flag_mask), "hpn_depth_begin")
+        self._ck(self.L.hpn_depth_add_raw_dev(self.h, _ptr(d_raw)), "hpn_depth_add_raw_dev")
+        return self.depth_finish(target_len, W)
+
+    def window_counts_raw(self, d_raw, win_off, W):
+        win_off = np.ascontiguousarray(win_off, np.uint64)
+        nt = len(win_off) - 1
+        self._ck(self.L.hpn_window_begin(self.h, nt, _ptr(win_off), W), "hpn_window_begin")
+        self._ck(self.L.hpn_window_add_raw_dev(self.h, _ptr(d_raw)), "hpn_window_add_raw_dev")
+        tot = int(win_off[-1])
+        bins, gc, ln = np.zeros(tot, np.uint32), np.zeros(tot, np.uint64), np.zeros(tot, np.uint32)
+        touched = np.zeros(nt, np.uint8)
+        nc = C.c_uint64(0)
+        self._ck(self.L.hpn_window_finish(self.h, _ptr(bins), _ptr(gc), _ptr(ln), _ptr(touched), C.byref(nc)),
+                 "hpn_window_finish")
+        return bins, gc, ln, touched, nc.value
+
     # ---- collectives / synthetic -----------------------------------------
     def comm_init(self, rank, n_ranks, unique_id: bytes):
         buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)

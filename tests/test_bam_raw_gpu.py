@@ -1,0 +1,115 @@
+"""GPU parity through the C ABI: BAM files taken as they are -- BGZF blocks inflated on the device
+(hpn_bgzf_inflate_dev), records indexed in place (hpn_bam_raw_index_dev), depth / window kernels
+run on the raw records -- against the oracle's dense model fed by the Python BAM decoder."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import golden_path
+from highperformancengs_amd import bamio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available()
+    import highperformancengs_amd as hp
+    c = hp.Context(0)
+    yield c
+    c.close()
+
+
+def _blocks(raw):
+    """BGZF member chain -> list of (payload_off, payload_len, isize)"""
+    out, o = [], 0
+    while o < len(raw):
+        xlen = struct.unpack_from("<H", raw, o + 10)[0]
+        bsize = struct.unpack_from("<H", raw, o + 16)[0] + 1
+        out.append((o + 12 + xlen, bsize - xlen - 20, struct.unpack_from("<I", raw, o + bsize - 4)[0]))
+        o += bsize
+    return out
+
+
+def _header_len(text):
+    l_text = struct.unpack_from("<i", text, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", text, p)[0]
+    p += 4
+    for _ in range(n_ref):
+        p += 8 + struct.unpack_from("<i", text, p)[0]
+    return p
+
+
+def _to_device(ctx, raw, skip_header=True):
+    """-> (d_raw, info, keepalive) with the blocks from the one holding the first record on"""
+    import torch
+    blks = _blocks(raw)
+    text = b"".join(zlib.decompress(raw[a:a + n], -15) for a, n, _ in blks[:4])
+    hl = _header_len(text)
+    first, acc = 0, 0
+    while acc + blks[first][2] <= hl and first < len(blks) - 1:  # the block the header ends in (or the next one)
+        acc += blks[first][2]
+        first += 1
+    blks = blks[first:]
+    table = np.zeros((len(blks), 3), np.uint64)
+    outo = 0
+    for i, (a, n, isz) in enumerate(blks):
+        table[i] = (a, n | (isz << 32), outo)
+        outo += isz
+    d_comp = torch.from_numpy(np.frombuffer(raw + bytes(64), np.uint8).copy()).cuda()
+    d_blocks = torch.from_numpy(table.view(np.int64)).cuda()
+    d_out = torch.zeros(outo + 64, dtype=torch.uint8, device="cuda")
+    d_status = torch.zeros(len(blks), dtype=torch.int32, device="cuda")
+    ctx.bgzf_inflate_dev(d_comp, d_blocks, len(blks), d_out, d_status)
+    info = ctx.bam_raw_index_dev(d_out, d_blocks, len(blks), hl - acc, d_status)
+    return d_out, info, (d_comp, d_blocks, d_status)
+
+
+@pytest.mark.parametrize("bam", ["e.bam", "rand.bam"])
+def test_index_depth_and_window_on_raw_records(ctx, bam):
+    raw = open(golden_path("bam", bam), "rb").read()
+    soa = bamio.read_bam_records(golden_path("bam", bam))
+    d_raw, info, keep = _to_device(ctx, raw)
+    assert info.flags == 0 and info.n_records == len(soa.tid)
+    assert info.tid_min == int(soa.tid.min()) and info.tid_max == int(soa.tid.max())
+    for W in (100, 20000):
+        for tid, (name, tlen) in enumerate(soa.refs):
+            for mask in (0x704, 0x4):
+                runs, win = ctx.depth_target_raw(d_raw, tid, tlen, W, mask)
+                rc, wruns, wbins = orc.depth_target(soa, tid, W, mask)
+                assert rc == 0 and np.array_equal(runs, wruns) and np.array_equal(win.astype(np.float64), wbins), (name, W, mask)
+        off = orc.window_offsets(soa.refs, W)
+        got = ctx.window_counts_raw(d_raw, off, W)
+        want = orc.window_counts(soa, W)  # rc, off, bins, gc, len, touched, n_count
+        assert want[0] == 0
+        for g, w in zip(got[:4], want[2:6]):
+            assert np.array_equal(np.asarray(g), np.asarray(w))
+        assert got[4] == want[6]
+
+
+def test_records_straddling_blocks_are_flagged(ctx):
+    raw = open(golden_path("bam", "rand.bam"), "rb").read()
+    data = b"".join(zlib.decompress(raw[a:a + n], -15) for a, n, _ in _blocks(raw))
+    packed = b""
+    for i in range(0, len(data), 20000):  # fixed-size blocks: records now cross block boundaries
+        piece = data[i:i + 20000]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(piece) + co.flush()
+        packed += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
+                   (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
+    _, info, _ = _to_device(ctx, packed)
+    assert info.flags & 1 and info.flags & 2 == 0
+
+
+def test_damaged_block_is_flagged(ctx):
+    raw = bytearray(open(golden_path("bam", "rand.bam"), "rb").read())
+    a, n, _ = _blocks(bytes(raw))[-3]  # a data block behind the ones the helper reads the header from
+    for k in range(a + 10, a + 40):
+        raw[k] ^= 0xa5
+    _, info, _ = _to_device(ctx, bytes(raw))
+    assert info.flags & 2
