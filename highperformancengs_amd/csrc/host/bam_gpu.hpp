@@ -1,4 +1,4 @@
-// bam_gpu.hpp -- BAM ingest with the inflate and the record walk on the GPU.
+// bam_gpu.hpp -- BGZF ingest (BAM, bgzip-compressed FASTQ) with the inflate and the record walk on the GPU.
 //
 // The host-side path (bam_reader.hpp) inflates BGZF blocks on a thread pool and decodes records on
 // one thread: 84 % of bam2depth's run time once the per-record work is on the GPU, and capped by
@@ -21,9 +21,9 @@
 
 namespace hpn {
 
-class BamGpuStream {
+class BgzfGpuStream {
 public:
-    ~BamGpuStream()
+    ~BgzfGpuStream()
     {
         pump_.reset();
         if (ctx_) {
@@ -280,7 +280,7 @@ public:
     {
         ctx_ = ctx;
         if (try_gpu) {
-            gpu_.reset(new BamGpuStream());
+            gpu_.reset(new BgzfGpuStream());
             if (gpu_->open(ctx, path, hdr)) return true;
             gpu_.reset();
             hdr = BamHeader();
@@ -331,7 +331,7 @@ public:
 
 private:
     hpn_ctx *ctx_ = nullptr;
-    std::unique_ptr<BamGpuStream> gpu_;
+    std::unique_ptr<BgzfGpuStream> gpu_;
     BamReader host_;
     BamBatch batch_;
     hpn_raw_info info_;

@@ -120,7 +120,7 @@ inline bool is_bgzf_file(const char *path)
 inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *unusable)
 {
     *unusable = false;
-    BamGpuStream gs;
+    BgzfGpuStream gs;
     if (!gs.open_text(ctx, path)) {
         *unusable = true;
         return HPN_OK;

@@ -132,7 +132,7 @@ int main(int argc, char *argv[])
         // starts at a record boundary, as samtools writes them); else, and for -r, the host reader.
         bool on_gpu = false;
         if (whole && bam_gpu_enabled()) {
-            BamGpuStream gs;
+            BgzfGpuStream gs;
             BamHeader h2;
             if (gs.open(ctx, infiles[i], h2)) {
                 hpn_raw_info info;
