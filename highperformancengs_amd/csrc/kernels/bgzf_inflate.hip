@@ -393,10 +393,10 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         safe = op;
                     }
-                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
-                        uint32_t k = i;
-                        if (k >= dist) k %= dist;  // overlapping match = periodic pattern: every source byte exists already
-                        out[op + i] = out[start + k];
+                    if (dist >= len) {  // the usual case: source and destination do not overlap
+                        for (uint32_t i = (uint32_t)lane; i < len; i += kWave) out[op + i] = out[start + i];
+                    } else {  // overlapping match = periodic pattern: every source byte exists already
+                        for (uint32_t i = (uint32_t)lane; i < len; i += kWave) out[op + i] = out[start + i % dist];
                     }
                     op += len;
                 } else if (kind == kEob) {
