@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "cpus.hpp"
+#include "fast_inflate.hpp"
 #include "hpngs.h"
 
 namespace hpn {
@@ -143,6 +144,8 @@ private:
         z_stream zs;  // one inflate state per worker, reset per block
         memset(&zs, 0, sizeof zs);
         const bool zs_ok = inflateInit2(&zs, -15) == Z_OK;
+        FastInflate fi;
+        const bool fast_ok = !(getenv("HPN_FAST_INFLATE") && getenv("HPN_FAST_INFLATE")[0] == '0');
         for (;;) {
             Slot *s = nullptr;
             {
@@ -161,9 +164,16 @@ private:
                     }
                 s->st = kBusy;
             }
-            s->data.resize(s->isize);
             s->bad = false;
-            if (s->isize) {
+            bool done = false;
+            if (s->isize && fast_ok) {  // the quick decoder first; zlib below if it declines
+                s->data.resize((size_t)s->isize + 1 + FastInflate::kOvershoot);
+                uint8_t *d = s->data.data();
+                fi.begin(s->raw.data(), s->raw.data() + s->raw.size() - 8);
+                done = fi.run(d, s->data.data() + s->isize + 1, s->data.data()) == FastInflate::kDone && d == s->data.data() + s->isize;
+            }
+            s->data.resize(s->isize);
+            if (s->isize && !done) {
                 if (!zs_ok || inflateReset(&zs) != Z_OK) s->bad = true;
                 else {
                     zs.next_in = s->raw.data();

@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "cpus.hpp"
+#include "fast_inflate.hpp"
 
 namespace hpn {
 
@@ -249,7 +250,106 @@ private:
         return !(j->cancel || stop_);
     }
 
+    // The quick decoder first (fast_inflate.hpp), with gzread's own checks of the trailer; zlib when it
+    // declines before anything was handed out; the consumer's zlib fallback when it fails later.
     void inflate_member(const std::shared_ptr<Job> &j)
+    {
+        static const bool use_fast = [] {
+            const char *e = getenv("HPN_FAST_INFLATE");
+            return !(e && e[0] == '0');
+        }();
+        if (use_fast) {
+            const int r = inflate_member_fast(j);
+            if (r != 0) return;
+        }
+        inflate_member_zlib(j);
+    }
+
+    // 1 = member done, -1 = failed after output was published (state set), 0 = declined, nothing published
+    int inflate_member_fast(const std::shared_ptr<Job> &j)
+    {
+        // gzip header (RFC 1952): magic, CM, FLG, MTIME(4), XFL, OS, then optional fields
+        const uint8_t *p = data_ + j->start, *lim = data_ + size_;
+        if (lim - p < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return 0;
+        const uint32_t flg = p[3];
+        p += 10;
+        if (flg & 4) {  // FEXTRA
+            if (lim - p < 2) return 0;
+            const size_t xl = p[0] | p[1] << 8;
+            if ((size_t)(lim - p) < 2 + xl) return 0;
+            p += 2 + xl;
+        }
+        for (int f = 8; f <= 16; f <<= 1)  // FNAME, FCOMMENT: zero-terminated
+            if (flg & f) {
+                const void *z = memchr(p, 0, (size_t)(lim - p));
+                if (!z) return 0;
+                p = (const uint8_t *)z + 1;
+            }
+        if (flg & 2) {  // FHCRC
+            if (lim - p < 2) return 0;
+            p += 2;
+        }
+        constexpr size_t kHist = 32768, kChunk = kBlock - 512;
+        static thread_local std::vector<uint8_t> buf;
+        buf.resize(kHist + kChunk + FastInflate::kOvershoot);
+        FastInflate fi;
+        fi.begin(p, lim);
+        uint8_t *const base = buf.data() + kHist;
+        uint8_t *cur = base;
+        const uint8_t *hist = base;
+        uint32_t crc = 0;
+        uint64_t total = 0;
+        bool published = false;
+        for (;;) {
+            if (j->cancel.load(std::memory_order_relaxed)) break;
+            const int r = fi.run(cur, base + kChunk, hist);
+            const size_t n = (size_t)(cur - base);
+            if (r == FastInflate::kError) break;
+            if (n) {
+                crc = crc32_fast(crc, base, n);
+                total += n;
+                if (r == FastInflate::kDone) {  // the trailer decides before the last block goes out
+                    const uint8_t *t = fi.in_pos();
+                    uint32_t want_crc, want_size;
+                    if (lim - t < 8) break;
+                    memcpy(&want_crc, t, 4), memcpy(&want_size, t + 4, 4);
+                    if (want_crc != crc || want_size != (uint32_t)total) break;
+                }
+                Block b = get_block();
+                if (!b.p) break;
+                memcpy(b.p, base, n);
+                b.n = n;
+                published = true;
+                if (!publish(j, b)) break;
+            } else if (r == FastInflate::kDone) {  // empty member (or nothing new): still check the trailer
+                const uint8_t *t = fi.in_pos();
+                uint32_t want_crc, want_size;
+                if (lim - t < 8) break;
+                memcpy(&want_crc, t, 4), memcpy(&want_size, t + 4, 4);
+                if (want_crc != crc || want_size != (uint32_t)total) break;
+            }
+            if (r == FastInflate::kDone) {
+                std::lock_guard<std::mutex> lk(m_);
+                j->end = (uint64_t)(fi.in_pos() + 8 - data_);
+                j->st = kDone;
+                if (j->cancel) drop_blocks(*j);
+                cv_.notify_all();
+                return 1;
+            }
+            const size_t keep = n < kHist ? n + (size_t)(base - hist) > kHist ? kHist : n + (size_t)(base - hist) : kHist;
+            memmove(base - keep, cur - keep, keep);  // the last `keep` bytes of history + new output stay in front
+            hist = base - keep;
+            cur = base;
+        }
+        if (!published && !j->cancel) return 0;
+        std::lock_guard<std::mutex> lk(m_);
+        j->st = kFailed;
+        if (j->cancel) drop_blocks(*j);
+        cv_.notify_all();
+        return -1;
+    }
+
+    void inflate_member_zlib(const std::shared_ptr<Job> &j)
     {
         z_stream s;
         memset(&s, 0, sizeof s);

@@ -4,6 +4,8 @@
 //
 //   hpn_ingest_dump count FILE   -> u64 n, u64 off[n+1], u8 qual[off[n]], u8 seq[off[n]]
 //   hpn_ingest_dump trim  FILE   -> u64 n, u64 off[n+1], u8 seq[..], u8 qual[..], then n NUL-terminated names
+//   hpn_ingest_dump cat   FILE   -> the decompressed byte stream as the tools' readers deliver it
+//   hpn_ingest_dump crc   FILE   -> crc32_fast and zlib's crc32 of the file's bytes in odd-sized pieces (hex, must agree)
 //   hpn_ingest_dump bam   FILE   -> u64 n, i32 tid[n], i32 pos[n], u32 flag[n], i32 l_qseq[n],
 //                                   u32 cigar_off[n+1], u32 cigar[..], u64 seq_off[n+1], u8 seq4[..]
 #include <stdio.h>
@@ -22,7 +24,7 @@ static void put(const std::vector<T> &v)
 int main(int argc, char **argv)
 {
     if (argc != 3) {
-        fprintf(stderr, "usage: %s count|trim|bam FILE\n", argv[0]);
+        fprintf(stderr, "usage: %s count|trim|cat|crc|bam FILE\n", argv[0]);
         return 1;
     }
     const std::string mode = argv[1];
@@ -57,6 +59,37 @@ int main(int argc, char **argv)
             for (auto &s : names) fwrite(s.c_str(), 1, s.size() + 1, stdout);
         }
         return 0;
+    }
+    if (mode == "cat") {
+        InStream f = open_input_stream(argv[2]);
+        std::vector<uint8_t> buf(1u << 20);
+        for (;;) {
+            const int n = f.read(buf.data(), (unsigned)buf.size());
+            if (n <= 0) break;
+            fwrite(buf.data(), 1, (size_t)n, stdout);
+        }
+        f.close();
+        return 0;
+    }
+    if (mode == "crc") {
+        FILE *fp = fopen(argv[2], "rb");
+        if (!fp) return 2;
+        std::vector<uint8_t> all;
+        uint8_t tmp[65536];
+        size_t k;
+        while ((k = fread(tmp, 1, sizeof tmp, fp)) > 0) all.insert(all.end(), tmp, tmp + k);
+        fclose(fp);
+        uint32_t a = 0, b = 0;
+        size_t o = 0, step = 1;
+        while (o < all.size()) {  // pieces of 1, 3, 7, 15 ... bytes, capped: every alignment and the short-tail path
+            const size_t n = step < all.size() - o ? step : all.size() - o;
+            a = crc32_fast(a, all.data() + o, n);
+            b = (uint32_t)crc32(b, all.data() + o, (uInt)n);
+            o += n;
+            step = step * 2 + 1 > 300000 ? 1 : step * 2 + 1;
+        }
+        printf("%08x %08x %08x\n", a, b, crc32_fast(0, all.data(), all.size()));
+        return a == b ? 0 : 5;
     }
     if (mode == "bam") {
         BamReader r;

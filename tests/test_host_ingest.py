@@ -186,3 +186,57 @@ def test_parallel_gzip_member_inflate_equals_zlib(tmp_path):
                 assert outs[0] == ref.stdout, (name, mode)
     raw = _dump("count", str(tmp_path / "multi.fq.gz"))
     assert struct.unpack_from("<Q", raw)[0] == 1500
+
+
+def _gzip_member(data, level, strategy, wbits=15, mem=8):
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, 16 + wbits, mem, strategy)
+    return c.compress(data) + c.flush()
+
+
+def test_fast_inflate_and_crc_equal_zlib(tmp_path):
+    """The quick DEFLATE decoder + carry-less-multiply CRC-32 of the gzip readers (fast_inflate.hpp): every
+    level, strategy and window size zlib can emit, stored / fixed / dynamic blocks, overlapping and
+    32 KiB-distant matches, members larger than the 4 MiB streaming buffer -- the delivered stream is the
+    input, for 1 and 4 inflate threads, and equal to the zlib-only readers' on damaged files."""
+    import zlib
+    rng = np.random.default_rng(11)
+    fq = open(golden_path("fastq", "syn_var_a.fq"), "rb").read()
+    payloads = [fq, rng.integers(0, 256, 200000, dtype=np.uint8).tobytes(), bytes(300000), (b"ACGT" * 100000)[:333333],
+                (rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()) * 6, b"", b"x", fq * 40,  # 12 MB: several buffer rounds
+                bytes(rng.integers(33, 75, 5_000_000, dtype=np.uint8))]
+    members, want = [], b""
+    k = 0
+    for data in payloads:
+        for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (5, zlib.Z_HUFFMAN_ONLY), (7, zlib.Z_RLE), (4, zlib.Z_FILTERED)):
+            if len(data) > 1_000_000 and level not in (1, 6):
+                continue
+            members.append(_gzip_member(data, level, strategy, wbits=9 + k % 7, mem=1 + k % 9))
+            want += data
+            k += 1
+    p = tmp_path / "all.gz"
+    p.write_bytes(b"".join(members))
+    import hashlib
+    h = hashlib.md5(want).hexdigest()
+    for env in ({"HPN_GZ_THREADS": "1"}, {"HPN_GZ_THREADS": "4"}, {"HPN_FAST_INFLATE": "0", "HPN_GZ_THREADS": "3"}, {"HPN_NO_MGZ": "1"}):
+        r = subprocess.run([DUMP, "cat", str(p)], stdout=subprocess.PIPE, env={**os.environ, **env}, check=True)
+        assert len(r.stdout) == len(want) and hashlib.md5(r.stdout).hexdigest() == h, env
+    # CRC-32: odd-sized pieces of a file, against zlib's
+    r = subprocess.run([DUMP, "crc", str(p)], stdout=subprocess.PIPE, check=True)
+    a, b, c = r.stdout.split()
+    assert a == b == c == b"%08x" % (zlib.crc32(p.read_bytes()) & 0xffffffff)
+    # damage: the quick decoder may give up earlier or later than zlib, the delivered stream may not differ
+    raw = bytearray(p.read_bytes())
+    for trial in range(12):
+        bad = bytearray(raw)
+        for _ in range(3):
+            pos = int(rng.integers(0, len(bad)))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        if trial % 3 == 0:
+            del bad[int(rng.integers(len(bad) // 2, len(bad))):]
+        q = tmp_path / f"bad{trial}.gz"
+        q.write_bytes(bad)
+        outs = [subprocess.run([DUMP, "cat", str(q)], stdout=subprocess.PIPE, env={**os.environ, **env}).stdout
+                for env in ({"HPN_GZ_THREADS": "4"}, {"HPN_FAST_INFLATE": "0", "HPN_GZ_THREADS": "4"})]
+        assert outs[0] == outs[1], trial
