@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Host-side inflate: the quick decoder vs zlib in the tools, same session (fastq_count on single-/multi-member gzip,
+bam2depth with host ingest), against the reference on the same files."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN, REF = os.path.join(ROOT, "highperformancengs_amd", "bin"), os.path.join(ROOT, "oracle", "_ref")
+L = C.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
+L.orc_synth_write_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+reads, rl = int(float(sys.argv[1])) if len(sys.argv) > 1 else 4_000_000, 150
+td = tempfile.mkdtemp(prefix="hpn_e2e_")
+one, many = os.path.join(td, "one.fq.gz"), os.path.join(td, "many.fq.gz")
+L.orc_synth_write_fastq(one.encode(), 5, 0, reads, rl, rl, 1)
+L.orc_synth_write_fastq(many.encode(), 5, 0, reads, rl, rl, 40)
+
+
+def t(cmd, env):
+    best, out = 1e9, b""
+    for _ in range(2):
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **env})
+        best = min(best, time.perf_counter() - t0)
+        out = p.stdout
+    return best, out
+
+
+for label, f in (("single-member gzip", one), ("40-member gzip", many)):
+    outs = []
+    for who, exe, env in (("reference", os.path.join(REF, "fastq_count"), {}), ("hpngs quick decoder", os.path.join(BIN, "fastq_count"), {}),
+                          ("hpngs zlib", os.path.join(BIN, "fastq_count"), {"HPN_FAST_INFLATE": "0"})):
+        if not os.access(exe, os.X_OK):
+            continue
+        dt, out = t([exe, f], env)
+        outs.append(out)
+        print(f"{label:20s} {who:20s} {dt:7.3f} s  {reads*rl/dt/1e9:6.3f} Gbases/s", flush=True)
+    print("   reports identical:", len(set(outs)) == 1)
+subprocess.run(["rm", "-rf", td])
