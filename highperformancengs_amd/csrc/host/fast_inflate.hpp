@@ -95,24 +95,36 @@ inline uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len)
 }
 
 // ---- DEFLATE ------------------------------------------------------------------------------------------
-class FastInflate {
+// T = uint8_t: bytes.  T = uint16_t: the same decoder writing one 16-bit symbol per byte, so that a
+// caller who does not know the 32 KiB of history yet can put placeholders (values >= 256) in front
+// of the buffer and have the match copies carry them along (pgz_reader.hpp).
+template <class T>
+class FastInflateT {
 public:
-    enum { kNeedOutput = 1, kDone = 0, kError = -1 };
-    static constexpr size_t kOvershoot = 320;  // run() may write this far past dst_end (one match + word copy)
+    enum { kBlockEnd = 2, kNeedOutput = 1, kDone = 0, kError = -1 };
+    static constexpr size_t kOvershoot = 320;  // run() may write this many elements past dst_end (one match + word copy)
 
-    // raw DEFLATE starting at `in`; nothing at or beyond `limit` is read
-    void begin(const uint8_t *in, const uint8_t *limit)
+    // raw DEFLATE starting `bit` bits (0..7) into `in`; nothing at or beyond `limit` is read.
+    // stop_blocks: run() also returns (kBlockEnd) after every non-final block.
+    void begin(const uint8_t *in, const uint8_t *limit, uint32_t bit = 0, bool stop_blocks = false)
     {
         in_ = in, limit_ = limit;
         bb_ = 0, bc_ = 0;
-        state_ = kHeader, last_ = false, stored_ = 0;
+        state_ = kHeader, last_ = false, stored_ = 0, stop_blocks_ = stop_blocks;
+        if (bit) {
+            refill();
+            if (bc_ >= bit) drop(bit);
+            else in_ = limit_, bb_ = 0, bc_ = 0;
+        }
     }
     // first input byte not consumed (valid after kDone)
     const uint8_t *in_pos() const { return in_ - (bc_ >> 3); }
+    // bit offset from `base` of the next unread bit (valid whenever run() has returned)
+    uint64_t bit_pos(const uint8_t *base) const { return (uint64_t)(in_ - base) * 8 - bc_; }
 
     // Decode into [dst, dst_end) (+ kOvershoot of slack).  Bytes [hist, dst) are the history (earlier
     // output, up to 32 KiB of it is looked at).  Advances dst.
-    int run(uint8_t *&dst, uint8_t *dst_end, const uint8_t *hist)
+    int run(T *&dst, T *dst_end, const T *hist)
     {
         for (;;) {
             if (state_ == kHeader) {
@@ -146,83 +158,124 @@ public:
                     if (dst >= dst_end) return kNeedOutput;
                     size_t k = (size_t)(dst_end - dst) < stored_ ? (size_t)(dst_end - dst) : stored_;
                     if ((size_t)(limit_ - in_) < k) return kError;
-                    memcpy(dst, in_, k);
+                    if constexpr (sizeof(T) == 1) memcpy(dst, in_, k);
+                    else
+                        for (size_t i = 0; i < k; ++i) dst[i] = in_[i];
                     dst += k, in_ += k, stored_ -= (uint32_t)k;
                 }
                 state_ = kHeader;
                 continue;
             }
             // ---- kSymbols ----
+            // The decoder state lives in locals here: byte stores through `out` may alias any member, and
+            // the compiler would otherwise reload and spill the bit buffer around every literal.
+            const uint8_t *in = in_;
+            uint64_t bb = bb_;
+            uint32_t bc = bc_;
+            T *out = dst;
+            const uint32_t *const lit = lit_, *const dtab = dist_;
+            const uint8_t *const limit = limit_;
+            auto leave = [&](int rc) {
+                in_ = in, bb_ = bb, bc_ = bc, dst = out;
+                return rc;
+            };
+            auto fill = [&]() {
+                if (__builtin_expect(limit - in >= 8, 1)) {  // one unaligned load; the bits above bc are real and are loaded again
+                    uint64_t v;
+                    memcpy(&v, in, 8);
+                    bb |= v << bc;
+                    in += (63 - bc) >> 3;
+                    bc |= 56;
+                } else {
+                    while (bc <= 56 && in < limit) bb |= (uint64_t)*in++ << bc, bc += 8;
+                }
+            };
+            auto put = [&](uint32_t e) {  // a literal entry: store both bytes, advance by one or two, consume its bits
+                out[0] = (uint8_t)(e >> 16), out[1] = (T)(e >> 24);
+                out += 1 + kind(e);
+                bb >>= (e & 15), bc -= (e & 15);
+            };
+            constexpr uint32_t kLitMask = (1u << kLitRoot) - 1;
             for (;;) {
-                if (dst >= dst_end) return kNeedOutput;
-                refill();
-                uint32_t e = lit_[bb_ & ((1u << kLitRoot) - 1)];
-                // up to two more literals out of the same 56+ bits (a literal code is at most 15 bits long)
-                if (kind(e) == kLit && bc_ >= 48) {
-                    drop(e & 15);
-                    *dst++ = (uint8_t)(e >> 16);
-                    e = lit_[bb_ & ((1u << kLitRoot) - 1)];
-                    if (kind(e) == kLit) {
-                        drop(e & 15);
-                        *dst++ = (uint8_t)(e >> 16);
-                        e = lit_[bb_ & ((1u << kLitRoot) - 1)];
+                if (out >= dst_end) return leave(kNeedOutput);
+                fill();
+                uint32_t e = lit[bb & kLitMask];
+                // Literal entries carry one or two bytes (two where both codes fit in the root index).  Up to
+                // three such entries per refill: each uses at most 11 of the 56+ buffered bits.
+                if (kind(e) <= kLit2 && bc >= 48) {
+                    put(e);
+                    e = lit[bb & kLitMask];
+                    if (kind(e) <= kLit2) {
+                        put(e);
+                        e = lit[bb & kLitMask];
+                        if (kind(e) <= kLit2) {
+                            put(e);
+                            continue;
+                        }
                     }
                 }
                 if (kind(e) == kSub) {
-                    if (bc_ < kLitRoot) return kError;
-                    drop(kLitRoot);
-                    e = lit_[(e >> 16) + ((uint32_t)bb_ & ((1u << ((e >> 8) & 255)) - 1))];
+                    if (bc < kLitRoot) return leave(kError);
+                    bb >>= kLitRoot, bc -= kLitRoot;
+                    e = lit[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 8) & 255)) - 1))];
                 }
-                if ((e & 15) > bc_) return kError;  // the stream ends inside a code
-                drop(e & 15);
+                if ((e & 15) > bc) return leave(kError);  // the stream ends inside a code
+                bb >>= (e & 15), bc -= (e & 15);
                 const uint32_t k = kind(e);
-                if (k == kLit) {
-                    *dst++ = (uint8_t)(e >> 16);
+                if (k <= kLit2) {
+                    out[0] = (uint8_t)(e >> 16), out[1] = (T)(e >> 24);
+                    out += 1 + k;
                     continue;
                 }
                 if (k == kEob) {
                     state_ = kHeader;
+                    if (stop_blocks_ && !last_) return leave(kBlockEnd);
                     break;
                 }
-                if (k != kLen) return kError;
+                if (k != kLen) return leave(kError);
                 uint32_t xb = (e >> 8) & 255;
-                if (bc_ < xb) return kError;
-                const uint32_t len = (e >> 16) + ((uint32_t)bb_ & ((1u << xb) - 1));
-                drop(xb);
-                if (bc_ < 28) refill();  // a distance code and its extra bits: up to 15 + 13
-                uint32_t d = dist_[bb_ & ((1u << kDistRoot) - 1)];
+                if (bc < xb) return leave(kError);
+                const uint32_t len = (e >> 16) + ((uint32_t)bb & ((1u << xb) - 1));
+                bb >>= xb, bc -= xb;
+                if (bc < 28) fill();  // a distance code and its extra bits: up to 15 + 13
+                uint32_t d = dtab[bb & ((1u << kDistRoot) - 1)];
                 if (kind(d) == kSub) {
-                    if (bc_ < kDistRoot) return kError;
-                    drop(kDistRoot);
-                    d = dist_[(d >> 16) + ((uint32_t)bb_ & ((1u << ((d >> 8) & 255)) - 1))];
+                    if (bc < kDistRoot) return leave(kError);
+                    bb >>= kDistRoot, bc -= kDistRoot;
+                    d = dtab[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 8) & 255)) - 1))];
                 }
-                if (kind(d) != kDist || (d & 15) > bc_) return kError;
-                drop(d & 15);
+                if (kind(d) != kDist || (d & 15) > bc) return leave(kError);
+                bb >>= (d & 15), bc -= (d & 15);
                 xb = (d >> 8) & 255;
-                if (bc_ < xb) return kError;
-                const size_t distance = (d >> 16) + ((uint32_t)bb_ & ((1u << xb) - 1));
-                drop(xb);
-                if (distance > (size_t)(dst - hist)) return kError;
-                const uint8_t *src = dst - distance;
-                uint8_t *end = dst + len;
-                if (distance >= 8) {  // word-wise, may run up to 7 bytes past `end` (slack / overwritten next)
+                if (bc < xb) return leave(kError);
+                const size_t distance = (d >> 16) + ((uint32_t)bb & ((1u << xb) - 1));
+                bb >>= xb, bc -= xb;
+                if (distance > (size_t)(out - hist)) return leave(kError);
+                const T *src = out - distance;
+                T *end = out + len;
+                constexpr size_t kWord = 8 / sizeof(T);
+                if (distance >= kWord) {  // word-wise, may run up to 7 bytes past `end` (slack / overwritten next)
                     do {
-                        memcpy(dst, src, 8);
-                        dst += 8, src += 8;
-                    } while (dst < end);
+                        memcpy(out, src, 8);
+                        out += kWord, src += kWord;
+                    } while (out < end);
                 } else if (distance == 1) {
-                    memset(dst, *src, len);
+                    const T v = *src;
+                    if constexpr (sizeof(T) == 1) memset(out, v, len);
+                    else
+                        while (out < end) *out++ = v;
                 } else {
-                    while (dst < end) *dst++ = *src++;
+                    while (out < end) *out++ = *src++;
                 }
-                dst = end;
+                out = end;
             }
+            leave(0);
         }
     }
 
 private:
     enum { kHeader, kStored, kSymbols };
-    enum { kLit = 0, kLen = 1, kEob = 2, kSub = 3, kDist = 4, kBad = 15 };
+    enum { kLit = 0, kLit2 = 1, kLen = 2, kEob = 3, kSub = 4, kDist = 5, kBad = 15 };  // literal kinds first: one compare
     static constexpr uint32_t kLitRoot = 11, kDistRoot = 8;
     static constexpr uint32_t kLitSize = 2048 + 512, kDistSize = 256 + 256;
     static uint32_t mk(uint32_t value, uint32_t extra, uint32_t kd, uint32_t nbits) { return value << 16 | extra << 8 | kd << 4 | nbits; }
@@ -329,12 +382,33 @@ private:
         }
         return true;
     }
+    // two literals per root entry where both codes fit in the index (in place: a paired entry still shows
+    // its first literal and that literal's code length in the extra field)
+    void pair_literals()
+    {
+        for (uint32_t i = 0; i < (1u << kLitRoot); ++i) {
+            const uint32_t e1 = lit_[i];
+            if (kind(e1) != kLit) continue;
+            const uint32_t l1 = e1 & 15, rest = kLitRoot - l1;
+            if (!rest) continue;
+            const uint32_t e2 = lit_[i >> l1];
+            uint32_t l2, b2;
+            if (kind(e2) == kLit) l2 = e2 & 15, b2 = (e2 >> 16) & 255;
+            else if (kind(e2) == kLit2) l2 = (e2 >> 8) & 255, b2 = (e2 >> 16) & 255;
+            else continue;
+            if (l2 > rest) continue;
+            lit_[i] = mk(((e1 >> 16) & 255) | b2 << 8, l1, kLit2, l1 + l2);
+        }
+    }
     bool fixed_tables()
     {
         uint8_t lens[320];
         for (uint32_t i = 0; i < 288; ++i) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
         for (uint32_t i = 0; i < 32; ++i) lens[288 + i] = 5;
-        return build(lit_, kLitSize, kLitRoot, lens, 288, true, lit_payload) && build(dist_, kDistSize, kDistRoot, lens + 288, 32, true, dist_payload);
+        if (!build(lit_, kLitSize, kLitRoot, lens, 288, true, lit_payload) || !build(dist_, kDistSize, kDistRoot, lens + 288, 32, true, dist_payload))
+            return false;
+        pair_literals();
+        return true;
     }
     bool dynamic_tables()
     {
@@ -374,17 +448,22 @@ private:
             i += rep, prev = val;
         }
         if (lens[256] == 0) return false;  // no end-of-block code
-        return build(lit_, kLitSize, kLitRoot, lens, hlit, true, lit_payload) &&
-               build(dist_, kDistSize, kDistRoot, lens + hlit, hdist, true, dist_payload);
+        if (!build(lit_, kLitSize, kLitRoot, lens, hlit, true, lit_payload) ||
+            !build(dist_, kDistSize, kDistRoot, lens + hlit, hdist, true, dist_payload))
+            return false;
+        pair_literals();
+        return true;
     }
 
     const uint8_t *in_ = nullptr, *limit_ = nullptr;
     uint64_t bb_ = 0;
     uint32_t bc_ = 0;
     int state_ = kHeader;
-    bool last_ = false;
+    bool last_ = false, stop_blocks_ = false;
     uint32_t stored_ = 0;
     uint32_t lit_[kLitSize], dist_[kDistSize];
 };
+
+using FastInflate = FastInflateT<uint8_t>;
 
 }  // namespace hpn
