@@ -13,6 +13,8 @@
 #pragma once
 #include <fcntl.h>
 #include <stdint.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -24,6 +26,7 @@
 
 #include "bam_reader.hpp"  // BgzfReader
 #include "mgz_reader.hpp"
+#include "pgz_reader.hpp"
 
 namespace hpn {
 
@@ -45,6 +48,7 @@ struct InStream {
     gzFile gz = nullptr;
     std::shared_ptr<BgzfReader> bz;
     std::shared_ptr<MgzReader> mz;
+    std::shared_ptr<PgzReader> pz;
     // bytes that were already taken from the stream and are to be served again first
     // (the text front end hands an irregular stream back to the exact framer this way)
     std::shared_ptr<const std::vector<char>> pre;
@@ -57,7 +61,7 @@ struct InStream {
             pre_pos += k;
             return (int)k;
         }
-        return bz ? (int)bz->read(dst, n) : mz ? (int)mz->read(dst, n) : gzread(gz, dst, n);
+        return bz ? (int)bz->read(dst, n) : mz ? (int)mz->read(dst, n) : pz ? (int)pz->read(dst, n) : gzread(gz, dst, n);
     }
     void close()
     {
@@ -65,8 +69,47 @@ struct InStream {
         gz = nullptr;
         bz.reset();
         mz.reset();
+        pz.reset();
     }
 };
+
+// Does a second gzip member start within the first 64 MiB (or the file is small: < 4 MiB)?  Such files go to
+// the member-parallel reader.  A member start is the header pattern followed by a deflate block header that
+// parses (a dynamic header is a complete prefix code twice over: compressed data does not look like that).
+inline bool gzip_has_second_member(int fd)
+{
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return true;
+    if (getenv("HPN_PGZ_FORCE")) return false;  // tests: any gzip file through the two-pass reader
+    if (sb.st_size < (4 << 20)) return true;  // not worth the threads
+    const size_t n = (size_t)sb.st_size < ((size_t)64 << 20) ? (size_t)sb.st_size : (size_t)64 << 20;
+    void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return true;
+    const uint8_t *d = (const uint8_t *)m, *lim = d + n;
+    bool second = false;
+    for (const uint8_t *p = d + 18; !second && p + 18 < lim;) {
+        p = (const uint8_t *)memchr(p, 0x1f, (size_t)(lim - 18 - p));
+        if (!p) break;
+        const uint8_t *body = gzip_header_end(p, lim);
+        if (body && body + 8 < lim) {
+            const uint32_t type = (body[0] >> 1) & 3;
+            if (type == 2) {
+                FastInflateT<uint16_t> fi;
+                static thread_local std::vector<uint16_t> out(32768 + 4096 + FastInflateT<uint16_t>::kOvershoot);
+                uint16_t *o = out.data() + 32768;
+                fi.begin(body, lim, 0, true);
+                second = fi.run(o, o + 4096, out.data()) != FastInflateT<uint16_t>::kError;
+            } else if (type == 1) {
+                second = true;  // fixed codes: tiny members
+            } else if (type == 0) {
+                second = (uint16_t)(body[1] | body[2] << 8) == (uint16_t) ~(body[3] | body[4] << 8);
+            }
+        }
+        ++p;
+    }
+    munmap(m, n);
+    return second;
+}
 
 // open_input_stream (IO_stream.h:122-136): a name starting with '-' (or empty) is
 // stdin; anything else is open()+gzdopen(fd,"rb"), which reads plain files, gzip
@@ -92,8 +135,17 @@ inline InStream open_input_stream(const char *name)
                 return in;
             }
         }
+        long cpus = usable_cpus() / text_workers_in_flight();
+        // gzip with no second member in sight: one deflate stream, inflated in parallel by the two-pass reader
+        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_PGZ") && !getenv("HPN_NO_MGZ") && (cpus >= 2 || getenv("HPN_PGZ_FORCE")) && !gzip_has_second_member(fd)) {
+            auto pz = std::make_shared<PgzReader>();
+            if (pz->open(name, getenv("HPN_GZ_THREADS") ? 0 : (int)(cpus > 16 ? 16 : cpus))) {
+                close(fd);
+                in.pz = pz;
+                return in;
+            }
+        }
         if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_MGZ")) {  // gzip: members inflated in parallel
-            long cpus = usable_cpus() / text_workers_in_flight();
             auto mz = std::make_shared<MgzReader>();
             if (mz->open(name, getenv("HPN_GZ_THREADS") ? 0 : (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus))) {
                 close(fd);

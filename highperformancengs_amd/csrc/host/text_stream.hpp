@@ -102,7 +102,7 @@ public:
             buf_.push_back((uint8_t *)p);
             free_.push_back(i);
         }
-        ok_ = (int)buf_.size() == nbuf && (fd_ >= 0 || in_.gz || in_.bz || in_.mz);
+        ok_ = (int)buf_.size() == nbuf && (fd_ >= 0 || in_.gz || in_.bz || in_.mz || in_.pz);
         if (ok_) th_ = std::thread([this] { loop(); });
     }
     ~TextPump()

@@ -240,3 +240,81 @@ def test_fast_inflate_and_crc_equal_zlib(tmp_path):
         outs = [subprocess.run([DUMP, "cat", str(q)], stdout=subprocess.PIPE, env={**os.environ, **env}).stdout
                 for env in ({"HPN_GZ_THREADS": "4"}, {"HPN_FAST_INFLATE": "0", "HPN_GZ_THREADS": "4"})]
         assert outs[0] == outs[1], trial
+
+
+def _cat(path, **env):
+    r = subprocess.run([DUMP, "cat", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "HPN_READER_STATS": "1", **env})
+    assert r.returncode == 0
+    stats = dict(kv.split("=") for kv in r.stderr.decode().split() if "=" in kv)
+    return r.stdout, stats
+
+
+def test_two_pass_parallel_inflate_of_one_member_equals_zlib(tmp_path):
+    """pgz_reader.hpp: ONE deflate stream cut into chunks of compressed bytes, block starts found by trial,
+    chunks inflated with the 32 KiB of history unknown (16-bit symbols), histories resolved in order.  The
+    delivered stream is zlib's for every level / strategy / chunk size / thread count, the chunks really are
+    used (accepted > 1, no fallback), and what the trial decoder cannot place goes back to zlib."""
+    import gzip
+    import hashlib
+    import zlib
+    rng = np.random.default_rng(5)
+    fq = open(golden_path("fastq", "syn_var_a.fq"), "rb").read() * 8          # 1.9 MB of FASTQ, repeats beyond the window
+    n = 20000
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n, 100))
+    qual = rng.integers(35, 74, (n, 100), dtype=np.uint8)
+    big = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, seq[i].tobytes(), qual[i].tobytes()) for i in range(n))  # 4.3 MB, random
+    for name, data, level, strategy in (("fq6", fq, 6, zlib.Z_DEFAULT_STRATEGY), ("fq1", fq, 1, zlib.Z_DEFAULT_STRATEGY),
+                                        ("big9", big, 9, zlib.Z_DEFAULT_STRATEGY), ("big6", big, 6, zlib.Z_DEFAULT_STRATEGY),
+                                        ("bigfilt", big, 4, zlib.Z_FILTERED), ("bighuff", big, 5, zlib.Z_HUFFMAN_ONLY)):
+        p = tmp_path / f"{name}.fq.gz"
+        p.write_bytes(_gzip_member(data, level, strategy))
+        want = hashlib.md5(data).hexdigest()
+        for chunk, threads in (("4096", "3"), ("50000", "1"), ("50000", "8"), ("400000", "4")):
+            out, st = _cat(str(p), HPN_PGZ_FORCE="1", HPN_PGZ_CHUNK=chunk, HPN_GZ_THREADS=threads)
+            assert hashlib.md5(out).hexdigest() == want, (name, chunk, threads)
+            assert st["reader"] == "pgz" and st["fallback"] == "0" and st["crc_failed"] == "0", (name, st)
+            assert int(st["accepted"]) > 2, (name, chunk, st)
+    # what it has to hand back or walk through serially: stored / fixed blocks, binary data, huge expansion,
+    # several members (header fields, empty members), trailing garbage, a bad CRC
+    odd = {"stored": _gzip_member(big[:600000], 0, zlib.Z_DEFAULT_STRATEGY),
+           "fixed": _gzip_member(big[:600000], 6, zlib.Z_FIXED),
+           "binary": gzip.compress(rng.integers(0, 256, 500000, dtype=np.uint8).tobytes() + bytes(300000), 6),
+           "zeros": gzip.compress(bytes(30_000_000), 6),
+           "members": gzip.compress(big[:900000], 6) + _gz_with_name(fq[:500000]) + gzip.compress(b"") + gzip.compress(fq[:70000], 1),
+           "garbage": gzip.compress(big[:900000], 6) + b"not gzip at all\n" * 5,
+           "empty": gzip.compress(b""),
+           "tiny": gzip.compress(b"@r\nA\n+\nI\n")}
+    bad_crc = bytearray(gzip.compress(big[:900000], 6))
+    bad_crc[-8] ^= 0x55
+    odd["bad_crc"] = bytes(bad_crc)
+    for name, blob in odd.items():
+        p = tmp_path / f"{name}.gz"
+        p.write_bytes(blob)
+        ref, st0 = _cat(str(p), HPN_NO_MGZ="1")
+        assert st0["reader"] == "zlib"
+        for chunk, threads in (("30000", "4"), ("3000", "2")):
+            out, st = _cat(str(p), HPN_PGZ_FORCE="1", HPN_PGZ_CHUNK=chunk, HPN_GZ_THREADS=threads)
+            assert st["reader"] == "pgz", (name, st)
+            if name == "bad_crc":   # gzread reports it after the data (and drops the bytes of the failing call): flagged here
+                assert st["crc_failed"] == "1" and out == big[:900000] and out.startswith(ref)
+            else:
+                assert out == ref and st["crc_failed"] == "0", (name, chunk, st)
+    # damage and truncation: zlib delivers what decodes (right or wrong) up to the gzread call that fails; this reader
+    # delivers the same bytes, cut within one read / one chunk of the same place, for every thread count
+    good = _gzip_member(big, 6, zlib.Z_DEFAULT_STRATEGY)
+    for trial in range(8):
+        bad = bytearray(good)
+        pos = int(rng.integers(len(bad) // 4, len(bad) - 8))
+        if trial % 2:
+            del bad[pos:]
+        else:
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        q = tmp_path / f"bad{trial}.gz"
+        q.write_bytes(bad)
+        ref, _ = _cat(str(q), HPN_NO_MGZ="1")
+        outs = [_cat(str(q), HPN_PGZ_FORCE="1", HPN_PGZ_CHUNK="100000", HPN_GZ_THREADS=t)[0] for t in ("1", "5")]
+        assert outs[0] == outs[1], trial
+        short, long_ = sorted((outs[0], ref), key=len)
+        assert long_.startswith(short) and len(long_) - len(short) <= (1 << 20) + 400000, (trial, len(ref), len(outs[0]))
+        assert len(outs[0]) >= len(big) * (pos - 200000) // len(good) - (1 << 20), trial
