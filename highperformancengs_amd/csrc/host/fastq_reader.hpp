@@ -137,7 +137,7 @@ inline InStream open_input_stream(const char *name)
         }
         long cpus = usable_cpus() / text_workers_in_flight();
         // gzip with no second member in sight: one deflate stream, inflated in parallel by the two-pass reader
-        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_PGZ") && !getenv("HPN_NO_MGZ") && (cpus >= 2 || getenv("HPN_PGZ_FORCE")) && !gzip_has_second_member(fd)) {
+        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_PGZ") && !getenv("HPN_NO_MGZ") && (cpus >= 3 || getenv("HPN_PGZ_FORCE"))  /* the symbolic decode costs ~1.6x the plain one */ && !gzip_has_second_member(fd)) {
             auto pz = std::make_shared<PgzReader>();
             if (pz->open(name, getenv("HPN_GZ_THREADS") ? 0 : (int)(cpus > 16 ? 16 : cpus))) {
                 close(fd);
