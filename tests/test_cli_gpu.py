@@ -52,8 +52,9 @@ def test_drop_in(manifest, case, tmp_path):
 # The FASTQ tools frame regular text on the GPU (hpn_fastq_text_*) and everything else with
 # the exact gzgets emulation on the host: both routes, and a chunk size that cuts records
 # every few bytes, must give the reference's bytes.
-@pytest.mark.parametrize("env", [{"HPN_TEXT": "0"}, {"HPN_TEXT_CHUNK": "100"}, {"HPN_TEXT_CHUNK": "4099"}],
-                         ids=["host-framer", "chunk100", "chunk4099"])
+@pytest.mark.parametrize("env", [{"HPN_TEXT": "0"}, {"HPN_TEXT_CHUNK": "100"}, {"HPN_TEXT_CHUNK": "4099"},
+                                 {"HPN_PGZ_FORCE": "1", "HPN_PGZ_CHUNK": "1500", "HPN_GZ_THREADS": "3"}],
+                         ids=["host-framer", "chunk100", "chunk4099", "two-pass-gzip"])
 @pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("count_", "kthread_", "trim_"))])
 def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
     c = manifest[case]
