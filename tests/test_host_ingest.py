@@ -275,6 +275,14 @@ def test_two_pass_parallel_inflate_of_one_member_equals_zlib(tmp_path):
             assert hashlib.md5(out).hexdigest() == want, (name, chunk, threads)
             assert st["reader"] == "pgz" and st["fallback"] == "0" and st["crc_failed"] == "0", (name, st)
             assert int(st["accepted"]) > 2, (name, chunk, st)
+    # pigz-style output: one member, an empty stored block (sync / full flush) after every 128 KiB of input
+    for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)
+        blob = b"".join(c.compress(big[i:i + 131072]) + c.flush(flush) for i in range(0, len(big), 131072)) + c.flush()
+        p = tmp_path / f"flush{flush}.fq.gz"
+        p.write_bytes(blob)
+        out, st = _cat(str(p), HPN_PGZ_FORCE="1", HPN_PGZ_CHUNK="60000", HPN_GZ_THREADS="4")
+        assert out == big and st["fallback"] == "0" and int(st["accepted"]) > 10, st
     # what it has to hand back or walk through serially: stored / fixed blocks, binary data, huge expansion,
     # several members (header fields, empty members), trailing garbage, a bad CRC
     odd = {"stored": _gzip_member(big[:600000], 0, zlib.Z_DEFAULT_STRATEGY),
