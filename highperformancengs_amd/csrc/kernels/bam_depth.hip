@@ -57,9 +57,14 @@ __global__ __launch_bounds__(kScatThreads) void k_depth_scatter(
 // ---------------------------------------------------------------------------
 // K4
 // ---------------------------------------------------------------------------
-constexpr int kDsThreads = 256;
+// Tile size: a look-back hop resolves at most 64 tiles (one per lane) and takes ~0.8 us of agent-scope
+// round trips, and with every resident workgroup waiting on the same chain the prefix can only advance by
+// that much per hop -- measured 12 ns per tile on top of a 0.8 ms streaming floor for chr1, whatever the
+// ticket or the dispatch order (a persistent grid and ticket-free tiles changed nothing).  Hence few, large
+// tiles: 256 x 16 -> 1.55 ms, 512 x 16 -> 1.26, 1024 x 16 -> 1.00 (1024 x 20 and up spill).
+constexpr int kDsThreads = 1024;
 constexpr int kDsPer = 16;                       // positions per lane, four 16-byte loads
-constexpr int kDsTile = kDsThreads * kDsPer;     // 4096 positions = 16 KiB per workgroup
+constexpr int kDsTile = kDsThreads * kDsPer;     // 16384 positions = 64 KiB per workgroup
 
 struct DepthOut {
     hpn_run *runs;
