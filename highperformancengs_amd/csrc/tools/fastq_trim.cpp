@@ -9,7 +9,9 @@
 // empty line there).
 #include <getopt.h>
 
+#include "../host/bam_gpu.hpp"
 #include "../host/fastq_reader.hpp"
+#include "../host/tally_stream.hpp"
 #include "../host/text_stream.hpp"
 #include "../host/report.hpp"
 
@@ -62,7 +64,59 @@ int main(int argc, char *argv[])
     const long long begin = usec();
     InStream in;
     bool exact = !text_path_enabled();
-    if (!exact) {
+    bool done = false;
+    // bgzip-compressed input, output to a file: the BGZF blocks are inflated on the GPU (as for BAM) and the text
+    // is framed and cut where it lands; the host moves compressed bytes in and trimmed text out.  A damaged block
+    // or irregular text: the output is emptied and the file goes through the paths below from its first byte.
+    const bool to_file = !(strncmp(outfile, "-", 1) == 0 || !strcmp(outfile, ""));
+    const bool from_file = !(strncmp(infile, "-", 1) == 0 || !strcmp(infile, ""));
+    if (!exact && to_file && from_file && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(infile)) {
+        BgzfGpuStream gs;
+        bool usable = gs.open_text(ctx, infile);
+        if (usable) {
+            const size_t slice = (size_t)64 << 20, ocap = slice + 8192 + 64;
+            AsyncWriter writer(ctx, out, ocap);
+            if (!writer.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
+            if ((rc = hpn_fastq_text_begin(ctx)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
+            for (bool fin = false; usable && !fin;) {
+                hpn_raw_info bi;
+                const int r = gs.next(&bi);
+                if (r < 0) {
+                    usable = false;
+                    break;
+                }
+                fin = r == 0 || gs.at_eof();
+                const uint64_t total = r == 0 ? 0 : bi.n_records;  // text mode: bytes inflated
+                for (uint64_t at = 0; at < total || (fin && total == 0);) {
+                    const uint64_t k = total - at < slice ? total - at : slice;
+                    hpn_text_info info;
+                    int oi;
+                    void *obuf = writer.acquire(&oi);
+                    rc = hpn_fastq_text_trim(ctx, gs.d_raw() + at, k, fin && at + k == total, start, end, obuf, ocap, &info);
+                    if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_text_trim");
+                    if (info.irregular) {
+                        writer.submit(oi, 0);
+                        usable = false;
+                        break;
+                    }
+                    writer.submit(oi, info.n_bytes);
+                    reads += info.n_records;
+                    at += k;
+                    if (total == 0) break;
+                }
+            }
+            writer.finish();
+        }
+        if (usable) {
+            done = true;
+        } else {  // start over
+            fflush(out);
+            if (ftruncate(fileno(out), 0) != 0 || fseek(out, 0, SEEK_SET) != 0) die_hpn(ctx, HPN_E_STATE, "fastq_trim: cannot rewind the output");
+            reads = 0;
+        }
+    }
+    if (done) {
+    } else if (!exact) {
         // Fast path: raw text to the GPU, trimmed text back (framing, cut and formatting on the
         // device).  At the first chunk that is not regular FASTQ the bytes not yet written
         // out -- the carried-over tail, this chunk, whatever the reader has queued -- go to
@@ -116,7 +170,7 @@ int main(int argc, char *argv[])
     } else {
         in = open_input_stream(infile);
     }
-    if (exact) {
+    if (exact && !done) {
         TrimFramer framer(in, start, end);
         FastqBatch b;
         const size_t kBytes = 64u << 20, kRecs = 1u << 20;
