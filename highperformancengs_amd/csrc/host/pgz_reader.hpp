@@ -32,6 +32,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -163,6 +164,10 @@ public:
     uint64_t chunks_accepted() const { return n_accepted_; }
     uint64_t gaps_decoded() const { return n_gaps_; }
     bool fell_back() const { return fallback_ != nullptr; }
+    // seconds of thread time spent searching block starts / decoding / translating (+CRC), over all workers
+    double seconds_find() const { return t_find_.load() * 1e-9; }
+    double seconds_decode() const { return t_decode_.load() * 1e-9; }
+    double seconds_translate() const { return t_translate_.load() * 1e-9; }
 
 private:
     static constexpr size_t kHist = 32768;
@@ -189,6 +194,12 @@ private:
         uint32_t want_crc = 0, want_size = 0;
     };
 
+    struct Stopwatch {  // adds its lifetime (ns) to a counter
+        std::atomic<uint64_t> &acc;
+        const double t0;
+        explicit Stopwatch(std::atomic<uint64_t> &a) : acc(a), t0(wall_s()) {}
+        ~Stopwatch() { acc.fetch_add((uint64_t)((wall_s() - t0) * 1e9), std::memory_order_relaxed); }
+    };
     bool fail_open()
     {
         if (data_) munmap((void *)data_, size_);
@@ -248,6 +259,7 @@ private:
     // first bit position in [lo, hi) where two dynamic blocks in a row decode to text
     uint64_t find_start(uint64_t lo, uint64_t hi, uint16_t *scratch, size_t cap)
     {
+        const Stopwatch sw(t_find_);
         const uint8_t *lim = data_ + size_;
         if (hi > (size_ - 8) * 8) hi = (size_ - 8) * 8;  // the trailer is not deflate data
         FastInflateT<uint16_t> fi;
@@ -313,6 +325,7 @@ private:
     }
     void decode(Chunk &c)
     {
+        const Stopwatch sw(t_decode_);
         FastInflateT<uint16_t> fi;
         fi.begin(data_ + (c.start >> 3), data_ + size_, (uint32_t)(c.start & 7), true);
         uint16_t *out = c.sym;
@@ -340,13 +353,17 @@ private:
     {
         size_t i = 0;
 #if defined(__x86_64__)
-        const __m128i hi = _mm_set1_epi16((short)0xff00);
+        // low bytes of 16 symbols packed at once; the (few) placeholders among them are patched from the history
+        const __m128i low = _mm_set1_epi16(0x00ff), zero = _mm_setzero_si128();
         for (; i + 16 <= n; i += 16) {
             const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
-            if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b), hi), _mm_setzero_si128())) == 0xffff) {
-                _mm_storeu_si128((__m128i *)(out + i), _mm_packus_epi16(a, b));
-            } else {
-                for (size_t k = i; k < i + 16; ++k) out[k] = s[k] < 256 ? (uint8_t)s[k] : window[s[k] - 256];
+            _mm_storeu_si128((__m128i *)(out + i), _mm_packus_epi16(_mm_and_si128(a, low), _mm_and_si128(b, low)));
+            const __m128i high = _mm_packus_epi16(_mm_srli_epi16(a, 8), _mm_srli_epi16(b, 8));
+            uint32_t m = ~(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(high, zero)) & 0xffffu;
+            while (m) {
+                const uint32_t k = (uint32_t)__builtin_ctz(m);
+                out[i + k] = window[s[i + k] - 256];
+                m &= m - 1;
             }
         }
 #endif
@@ -365,6 +382,7 @@ private:
                 c->bytes = get_bytes();
                 lk.unlock();
                 if (c->bytes) {
+                    const Stopwatch sw(t_translate_);
                     translate(c->sym, c->nsym, c->window.data(), c->bytes);
                     c->crc = crc32_fast(0, c->bytes, c->nsym);
                 }
@@ -591,6 +609,7 @@ private:
     size_t next_take_ = 0, stitch_idx_ = 0;
     bool stop_ = false, failed_ = false, done_ = false;
     uint64_t n_accepted_ = 0, n_gaps_ = 0;
+    std::atomic<uint64_t> t_find_{0}, t_decode_{0}, t_translate_{0};
 
     // consumer side
     std::shared_ptr<Chunk> have_;
