@@ -52,6 +52,11 @@ class RawInfo(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class GzInfo(C.Structure):
+    _fields_ = [("n_bytes", C.c_uint64), ("end_bit", C.c_uint64), ("status", C.c_uint32), ("bad_chunk", C.c_uint32),
+                ("final_chunk", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Run(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("depth", C.c_int32)]
 
@@ -96,6 +101,7 @@ SYMBOLS = [
     ("hpn_fastq_text_count", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_trim", _int, [_vp, _vp, _u64, _int, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    ("hpn_gz_inflate_dev", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
     ("hpn_bam_raw_index_dev", _int, [_vp, _vp, _vp, _u64, _u32, _vp, C.POINTER(RawInfo)]),
     ("hpn_depth_add_raw_dev", _int, [_vp, _vp]),
     ("hpn_window_add_raw_dev", _int, [_vp, _vp]),

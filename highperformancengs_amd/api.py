@@ -218,6 +218,16 @@ class Context:
         self._ck(self.L.hpn_bgzf_inflate_dev(self.h, _ptr(d_comp), _ptr(d_blocks), n_blocks, _ptr(d_out), _ptr(d_status)),
                  "hpn_bgzf_inflate_dev")
 
+    # ---- one gzip member on the device (two passes) -------------------------------
+    def gz_inflate_dev(self, d_comp, d_chunks, n_chunks, sym_cap, d_text, text_cap, d_window_in=None, d_window_out=None):
+        """hpn_gz_inflate_dev; returns hpn_gz_info (status != 0: a stretch could not be decoded as given)."""
+        info = _lib.GzInfo()
+        self._ck(self.L.hpn_gz_inflate_dev(self.h, _ptr(d_comp), _ptr(d_chunks), n_chunks, sym_cap,
+                                           _ptr(d_window_in) if d_window_in is not None else None, _ptr(d_text) if d_text is not None else None,
+                                           text_cap, _ptr(d_window_out) if d_window_out is not None else None, C.byref(info)),
+                 "hpn_gz_inflate_dev")
+        return info
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

@@ -67,6 +67,7 @@ struct hpn_ctx {
     uint32_t t_carry = 0, t_tail = 0;  // carry bytes and where they start in slot[t_cur ^ 1]
     // records indexed in place in inflated BGZF blocks (hpn_bam_raw_*)
     hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info;
+    hpn::Scratch g_sym, g_meta, g_windows, g_summary;  // single-member gzip: symbols, per-stretch results, histories
     uint64_t r_n = 0;
     bool r_fields = false;  // the SoA view of the current index has been gathered
     // RCCL

@@ -1,0 +1,63 @@
+// hpn_gz.hip -- C ABI of the device-side single-member gzip inflater (kernels/gz_inflate.hip).
+#include <string.h>
+
+#include "hpn_ctx.hpp"
+
+namespace hpn {
+hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, uint32_t n_chunks, uint16_t *d_sym, uint32_t sym_cap,
+                                 void *d_meta, int n_cu, hipStream_t st);
+hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
+                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, hipStream_t st);
+hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
+                               uint8_t *d_text, hipStream_t st);
+}
+
+using namespace hpn;
+
+extern "C" {
+
+int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks, uint32_t sym_cap,
+                       const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap, uint8_t *d_window_out, hpn_gz_info *info)
+{
+    if (!c || !info || (n_chunks && (!d_comp || !d_chunks))) return HPN_E_ARG;
+    memset(info, 0, sizeof *info);
+    if (n_chunks > 65535u || (sym_cap & 7u) || (n_chunks && !sym_cap)) return fail(c, HPN_E_ARG, "hpn_gz_inflate_dev: n_chunks <= 65535, sym_cap a multiple of 8");
+    HPN_HIP(c, hipSetDevice(c->device));
+    if (n_chunks == 0) {
+        if (d_window_out && d_window_in) HPN_HIP(c, hipMemcpyAsync(d_window_out, d_window_in, 32768, hipMemcpyDeviceToDevice, c->stream));
+        else if (d_window_out) HPN_HIP(c, hipMemsetAsync(d_window_out, 0, 32768, c->stream));
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+        return HPN_OK;
+    }
+    int rc;
+    if ((rc = scratch_reserve(c, c->g_sym, (size_t)n_chunks * sym_cap * sizeof(uint16_t) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->g_meta, (size_t)n_chunks * 32)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->g_windows, (size_t)n_chunks * 32768)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->g_summary, 64)) != HPN_OK) return rc;
+    uint16_t *sym = (uint16_t *)c->g_sym.p;
+    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamInflate], c->stream));
+    HPN_HIP(c, launch_gz_sym_inflate(d_comp, d_chunks, n_chunks, sym, sym_cap, c->g_meta.p, c->n_cu, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_end[kFamInflate], c->stream));
+    c->ev_valid[kFamInflate] = true;
+    HPN_HIP(c, launch_gz_windows(sym, sym_cap, c->g_meta.p, n_chunks, d_window_in, (uint8_t *)c->g_windows.p, d_window_out,
+                                 (u64 *)c->g_summary.p, c->stream));
+    u64 summary[4] = {0, 0, 0, 0};
+    HPN_HIP(c, hipMemcpyAsync(summary, c->g_summary.p, sizeof summary, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    info->n_bytes = summary[0];
+    info->status = (uint32_t)summary[1], info->bad_chunk = (uint32_t)summary[2], info->final_chunk = (uint32_t)summary[3];
+    if (info->final_chunk) {  // where that stretch stopped: the member's trailer
+        struct { uint32_t n_out, status, final_block, reserved; uint64_t end_bit, text_off; } m;
+        HPN_HIP(c, hipMemcpyAsync(&m, (const uint8_t *)c->g_meta.p + (size_t)(info->final_chunk - 1) * 32, 32, hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+        info->end_bit = m.end_bit;
+    }
+    if (info->status) return HPN_OK;  // reported, not an API failure: the caller takes another route
+    if (info->n_bytes > text_cap) return fail(c, HPN_E_CAPACITY, "hpn_gz_inflate_dev: %llu bytes of text, capacity %llu", (unsigned long long)info->n_bytes, (unsigned long long)text_cap);
+    if (info->n_bytes && !d_text) return HPN_E_ARG;
+    HPN_HIP(c, launch_gz_translate(sym, sym_cap, c->g_meta.p, n_chunks, (const uint8_t *)c->g_windows.p, d_text, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    return HPN_OK;
+}
+
+}  // extern "C"

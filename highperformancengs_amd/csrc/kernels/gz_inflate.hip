@@ -1,0 +1,324 @@
+// gz_inflate.hip -- ONE gzip member (the usual .fastq.gz) inflated on gfx950, two passes.
+//
+// A gzip member is a single DEFLATE stream in which every byte may refer to the 32 KiB before it;
+// the reference reads it through gzread on one host thread (fastq_count.c:112-118 via gzgets).
+// host/pgz_reader.hpp does the two-pass parallel decode on the host cores; this is the same
+// scheme with the heavy passes on the device (the host only finds where deflate blocks start):
+//
+//   k_gz_sym_inflate  one wavefront per stretch [block start, next stretch's start): the decoder of
+//                     bgzf_inflate.hip writing 16-bit symbols -- a byte value, or 256 + i for
+//                     "byte i of the 32 KiB of history before this stretch", which a match that
+//                     reaches in front of the stretch's own output produces.  The stretch must end
+//                     on its given end bit exactly at a block boundary (or at the final block),
+//                     which is what makes the next stretch's start a proven block boundary.
+//   k_gz_windows      one workgroup walks the stretches in order: the resolved last 32 KiB of a
+//                     stretch are the history of the next (LDS ping-pong); also the running text
+//                     offsets.
+//   k_gz_translate    symbols -> bytes through each stretch's history, compacted into one text.
+//
+// Bounds: k_gz_sym_inflate is bound by the scalar issue of the serial symbol loop like
+// k_bgzf_inflate; the other two are small streaming passes.  CRC-32 is not checked here (ISIZE is,
+// by the caller); anything malformed sets a status and the host readers take the file.
+#include "common.hpp"
+#include "inflate_core.hpp"
+
+namespace hpn {
+
+struct GzChunk {  // = hpn_gz_chunk
+    uint64_t in_off;   // byte of the compressed buffer that holds the stretch's first bit
+    uint64_t end_bit;  // where the stretch ends, in bits from in_off * 8; ~0: at the final block
+    uint32_t in_len;   // bytes that may be read from in_off on
+    uint32_t start_bit;
+};
+struct GzMeta {
+    uint32_t n_out, status, final_block, reserved;
+    uint64_t end_bit;   // bit position reached (byte-aligned after a final block), from in_off * 8
+    uint64_t text_off;  // filled by k_gz_windows
+};
+
+constexpr uint32_t kGzHist = 32768;
+
+__global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
+                                                          uint32_t n_chunks, uint16_t *__restrict__ symbuf, uint32_t sym_cap,
+                                                          GzMeta *__restrict__ meta)
+{
+    __shared__ InfLds s;
+    const int lane = lane_id();
+    for (uint32_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
+        const GzChunk ck = chunks[ci];
+        const uint8_t *in = comp + ck.in_off;
+        uint16_t *out = symbuf + (uint64_t)ci * sym_cap;
+        const uint32_t in_len = ck.in_len, out_len = sym_cap;
+        const uint64_t end_bit = ck.end_bit;
+        Bits b;
+        stage(s, b, in, in_len);
+        stage(s, b, in, in_len);
+        refill(s, b, in, in_len);
+        drop(b, ck.start_bit);
+        uint32_t op = 0, safe = 0, err = 0;  // symbols below `safe` are known to have reached memory
+        bool last = false, arrived = false;
+        while (!last && !err) {
+            const uint64_t pos = (uint64_t)b.in_pos * 8u - b.bc;  // a block boundary
+            if (pos >= end_bit) {
+                if (pos == end_bit) arrived = true;
+                else err = 20;  // the given end is not a block boundary of this stream
+                break;
+            }
+            refill(s, b, in, in_len);
+            if (b.in_pos - (b.bc >> 3) > in_len) {
+                err = 17;
+                break;
+            }
+            last = take(b, 1) != 0;
+            const uint32_t type = take(b, 2);
+            if (type == 0) {  // stored
+                drop(b, b.bc & 7u);
+                refill(s, b, in, in_len);
+                const uint32_t len = take(b, 16);
+                refill(s, b, in, in_len);
+                const uint32_t nlen = take(b, 16);
+                if ((len ^ nlen) != 0xffffu || op + len > out_len) {
+                    err = 1;
+                    break;
+                }
+                const uint32_t src = b.in_pos - (b.bc >> 3);
+                if (src + len > in_len) {
+                    err = 2;
+                    break;
+                }
+                for (uint32_t i = (uint32_t)lane; i < len; i += kWave) out[op + i] = in[src + i];
+                op += len;
+                b.bb = 0, b.bc = 0;
+                b.in_pos = src + len;
+                b.filled = b.in_pos & ~(kRing / 2 - 1);
+                stage(s, b, in, in_len);
+                stage(s, b, in, in_len);
+                continue;
+            }
+            if (type == 3) {
+                err = 3;
+                break;
+            }
+            if (type == 1) {  // fixed codes
+                for (uint32_t i = (uint32_t)lane; i < 288u; i += kWave) s.lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8;
+                for (uint32_t i = (uint32_t)lane; i < 32u; i += kWave) s.lens[288 + i] = 5;
+                if (!build(s, s.lit, kLitSize, kLitRoot, 0, 288, true, lit_payload) ||
+                    !build(s, s.dist, kDistSize, kDistRoot, 288, 32, true, dist_payload)) {
+                    err = 4;
+                    break;
+                }
+            } else {  // dynamic codes
+                refill(s, b, in, in_len);
+                const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
+                if (hlit > 286u || hdist > 30u) {
+                    err = 5;
+                    break;
+                }
+                if (lane < 19) s.lens[lane] = 0;
+                for (uint32_t i = 0; i < hclen; ++i) {
+                    refill(s, b, in, in_len);
+                    const uint32_t v = take(b, 3);
+                    s.lens[kClOrder[i]] = (uint8_t)v;
+                }
+                if (!build(s, s.dist, kDistSize, 7, 0, 19, false, [](uint32_t sym, uint32_t nb) { return mk(sym, 0, kLit, nb); })) {
+                    err = 6;
+                    break;
+                }
+                uint32_t i = 0, prev = 0;
+                const uint32_t total = hlit + hdist;
+                while (i < total && !err) {
+                    refill(s, b, in, in_len);
+                    const uint32_t e = lookup(s.dist, 7, b);
+                    if (((e >> 4) & 15u) != kLit) {
+                        err = 7;
+                        break;
+                    }
+                    const uint32_t sym = e >> 16;
+                    uint32_t rep = 1, val = sym;
+                    if (sym == 16u) {
+                        if (i == 0) {
+                            err = 8;
+                            break;
+                        }
+                        rep = 3u + take(b, 2), val = prev;
+                    } else if (sym == 17u) {
+                        rep = 3u + take(b, 3), val = 0;
+                    } else if (sym == 18u) {
+                        rep = 11u + take(b, 7), val = 0;
+                    }
+                    if (i + rep > total) {
+                        err = 9;
+                        break;
+                    }
+                    for (uint32_t k = (uint32_t)lane; k < rep; k += kWave) s.lens[32 + i + k] = (uint8_t)val;
+                    i += rep, prev = val;
+                }
+                if (err) break;
+                if (s.lens[32 + 256] == 0) {
+                    err = 10;
+                    break;
+                }
+                if (!build(s, s.lit, kLitSize, kLitRoot, 32, hlit, true, lit_payload) ||
+                    !build(s, s.dist, kDistSize, kDistRoot, 32 + hlit, hdist, true, dist_payload)) {
+                    err = 11;
+                    break;
+                }
+            }
+            // ---- symbols of this block ----
+            for (;;) {
+                refill(s, b, in, in_len);
+                uint32_t e = lookup(s.lit, kLitRoot, b);
+                uint32_t kind = (e >> 4) & 15u;
+                while (kind == kLit) {  // every lane stores the same symbol to the same address
+                    if (op + 1u > out_len) {
+                        err = 12;
+                        break;
+                    }
+                    out[op] = (uint16_t)((e >> 16) & 255u);
+                    op += 1u;
+                    refill(s, b, in, in_len);
+                    e = lookup(s.lit, kLitRoot, b);
+                    kind = (e >> 4) & 15u;
+                }
+                if (err) break;
+                if (kind == kLen) {
+                    const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
+                    refill(s, b, in, in_len);
+                    const uint32_t d = lookup(s.dist, kDistRoot, b);
+                    if (((d >> 4) & 15u) != kDist) {
+                        err = 13;
+                        break;
+                    }
+                    const uint32_t dist = (d >> 16) + take(b, (d >> 8) & 255u);
+                    if (dist > op + kGzHist || op + len > out_len) {
+                        err = 14;
+                        break;
+                    }
+                    const int32_t start = (int32_t)op - (int32_t)dist;  // negative: in the history before this stretch
+                    if (start + (int32_t)(len < dist ? len : dist) > (int32_t)safe) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        safe = op;
+                    }
+                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
+                        const int32_t idx = start + (int32_t)(dist >= len ? i : i % dist);
+                        out[op + i] = idx < 0 ? (uint16_t)(256 + (int32_t)kGzHist + idx) : out[idx];
+                    }
+                    op += len;
+                } else if (kind == kEob) {
+                    break;
+                } else {
+                    err = 15;
+                    break;
+                }
+            }
+        }
+        uint64_t pos = (uint64_t)b.in_pos * 8u - b.bc;
+        if (!err && last) pos = (pos + 7u) & ~(uint64_t)7u;          // the trailer is byte-aligned
+        if (!err && !last && !arrived) err = 21;                      // cannot happen: the loop only leaves on one of these
+        if (lane == 0) {
+            GzMeta m;
+            m.n_out = op, m.status = err, m.final_block = last ? 1u : 0u, m.reserved = 0;
+            m.end_bit = pos, m.text_off = 0;
+            meta[ci] = m;
+        }
+    }
+}
+
+// One workgroup: histories in stream order.  windows + k * 32768 = the 32 KiB before stretch k.
+constexpr int kGzWinThreads = 1024;
+__global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
+                                                              GzMeta *__restrict__ meta, uint32_t n_chunks,
+                                                              const uint8_t *__restrict__ window_in, uint8_t *__restrict__ windows,
+                                                              uint8_t *__restrict__ window_out, u64 *__restrict__ summary)
+{
+    __shared__ uint8_t w[2][kGzHist];
+    const int tid = threadIdx.x;
+    for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) w[0][j] = window_in ? window_in[j] : 0;
+    __syncthreads();
+    u64 text = 0;
+    uint32_t bad = 0, bad_at = 0, fin = 0;
+    int cur = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t n = meta[k].n_out, st = meta[k].status;
+        if (st && !bad) bad = st, bad_at = k;
+        if (meta[k].final_block) fin = k + 1u;
+        if (tid == 0) meta[k].text_off = text;
+        text += n;
+        const uint16_t *sym = symbuf + (uint64_t)k * sym_cap;
+        uint8_t *wk = windows + (uint64_t)k * kGzHist;
+        for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) {
+            wk[j] = w[cur][j];
+            const int64_t p = (int64_t)n - (int64_t)kGzHist + (int64_t)j;
+            uint8_t v;
+            if (p >= 0) {
+                const uint32_t sv = sym[p];
+                v = sv < 256u ? (uint8_t)sv : w[cur][sv - 256u];
+            } else {
+                v = w[cur][(int64_t)kGzHist + p];
+            }
+            w[cur ^ 1][j] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (window_out)
+        for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) window_out[j] = w[cur][j];
+    if (tid == 0) summary[0] = text, summary[1] = bad, summary[2] = bad_at, summary[3] = fin;
+}
+
+// symbols -> bytes: blockIdx.y = stretch, the x blocks stride over its symbols (8 per thread and step)
+constexpr int kGzTrThreads = 256;
+__global__ __launch_bounds__(kGzTrThreads) void k_gz_translate(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
+                                                               const GzMeta *__restrict__ meta, const uint8_t *__restrict__ windows,
+                                                               uint8_t *__restrict__ text)
+{
+    const uint32_t k = blockIdx.y;
+    const uint32_t n = meta[k].n_out;
+    const uint16_t *sym = symbuf + (uint64_t)k * sym_cap;  // 16-byte aligned when sym_cap % 8 == 0
+    const uint8_t *wk = windows + (uint64_t)k * kGzHist;
+    uint8_t *dst = text + meta[k].text_off;
+    const uint32_t groups = n / 8u;
+    for (uint32_t g = blockIdx.x * kGzTrThreads + threadIdx.x; g < groups; g += gridDim.x * kGzTrThreads) {
+        const u32 v = *reinterpret_cast<const u32 *>(sym + (uint64_t)g * 8u);
+        uint8_t o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t a = v[q] & 0xffffu, c = v[q] >> 16;
+            o[2 * q] = a < 256u ? (uint8_t)a : wk[a - 256u];
+            o[2 * q + 1] = c < 256u ? (uint8_t)c : wk[c - 256u];
+        }
+        __builtin_memcpy(dst + (uint64_t)g * 8u, o, 8);  // dst is not aligned in general
+    }
+    if (blockIdx.x == 0)
+        for (uint32_t i = groups * 8u + threadIdx.x; i < n; i += kGzTrThreads) {
+            const uint32_t a = sym[i];
+            dst[i] = a < 256u ? (uint8_t)a : wk[a - 256u];
+        }
+}
+
+hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, uint32_t n_chunks, uint16_t *d_sym, uint32_t sym_cap,
+                                 void *d_meta, int n_cu, hipStream_t st)
+{
+    if (n_chunks == 0) return hipSuccess;
+    const uint32_t cap = (uint32_t)n_cu * 18u;
+    hipLaunchKernelGGL(k_gz_sym_inflate, dim3(n_chunks < cap ? n_chunks : cap), dim3(kWave), 0, st, d_comp, (const GzChunk *)d_chunks,
+                       n_chunks, d_sym, sym_cap, (GzMeta *)d_meta);
+    return hipGetLastError();
+}
+hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
+                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(kGzWinThreads), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in,
+                       d_windows, d_window_out, d_summary);
+    return hipGetLastError();
+}
+hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
+                               uint8_t *d_text, hipStream_t st)
+{
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gz_translate, dim3(64, n_chunks), dim3(kGzTrThreads), 0, st, d_sym, sym_cap, (const GzMeta *)d_meta, d_windows,
+                       d_text);
+    return hipGetLastError();
+}
+
+}  // namespace hpn

@@ -240,6 +240,39 @@ typedef struct hpn_bgzf_block {
 int hpn_bgzf_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_bgzf_block *d_blocks, uint64_t n_blocks,
                          uint8_t *d_out, uint32_t *d_status);
 
+/* ---- one gzip member inflated on the device (two passes) -------------------------------------
+ * gzread behind the 4 x gzgets loops (fastq_count.c:112-118, IO_stream.h:122-136) on a single-
+ * member .fastq.gz: one DEFLATE stream, every byte of which may refer to the 32 KiB before it.
+ * The host cuts the stream into stretches that start at deflate block boundaries (it finds them,
+ * csrc/host/pgz_reader.hpp find_start); here every stretch is inflated by one wavefront with the
+ * history unknown (16-bit symbols, placeholders for history bytes), the histories are resolved in
+ * stream order, and the symbols are translated into one contiguous text.
+ * chunks[i]: in_off = byte of d_comp holding the stretch's first bit, start_bit = 0..7, in_len =
+ * bytes readable from in_off (d_comp must be readable 64 bytes beyond), end_bit = where the
+ * stretch must end in bits from in_off * 8 (the next stretch's first bit), ~0 for "at the final
+ * block".  A stretch that does not end exactly there on a block boundary is an error: that is what
+ * proves every start.  sym_cap (multiple of 8) = symbols of scratch per stretch; n_chunks <= 65535.
+ * d_window_in / d_window_out (32768 bytes, may be NULL): the history before the first stretch /
+ * after the last, for streams inflated in several calls.  info: n_bytes = text produced (if it
+ * exceeds text_cap: HPN_E_CAPACITY, nothing written), status = 0 or the first failing stretch's
+ * decoder code (bad_chunk says which), final_chunk = 1 + index of the stretch that ended at a
+ * final block (0: none), end_bit = bit position that stretch reached (the member trailer).
+ * Synchronous.  CRC-32 is not checked (ISIZE is the caller's to check). */
+typedef struct hpn_gz_chunk {
+    uint64_t in_off;
+    uint64_t end_bit;
+    uint32_t in_len;
+    uint32_t start_bit;
+} hpn_gz_chunk;
+typedef struct hpn_gz_info {
+    uint64_t n_bytes;
+    uint64_t end_bit;
+    uint32_t status, bad_chunk, final_chunk, reserved;
+} hpn_gz_info;
+int hpn_gz_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks,
+                       uint32_t sym_cap, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap,
+                       uint8_t *d_window_out, hpn_gz_info *info);
+
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),
  * flattened to SoA by the host decoder: core fields, CIGAR words (len<<4|op,

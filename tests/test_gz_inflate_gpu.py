@@ -1,0 +1,150 @@
+"""GPU: one DEFLATE stream inflated in stretches with the history unknown (hpn_gz_inflate_dev).
+
+zlib is the oracle (it is what the reference's gzread calls).  The stretches are cut where the
+bit position of a block boundary is known without a search: after a Z_FULL_FLUSH / Z_SYNC_FLUSH
+marker the stream is byte-aligned at a block start.  (The tools find arbitrary block starts with
+host/pgz_reader.hpp's trial decoder; tests/test_cli_gpu.py covers that route end to end.)"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = np.dtype([("in_off", "<u8"), ("end_bit", "<u8"), ("in_len", "<u4"), ("start_bit", "<u4")])
+NONE = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available()
+    import highperformancengs_amd as hp
+    c = hp.Context(0)
+    yield c
+    c.close()
+
+
+def _stream(pieces, level=6, flush=zlib.Z_SYNC_FLUSH, strategy=zlib.Z_DEFAULT_STRATEGY):
+    """raw deflate of the concatenated pieces; returns (bytes, [byte offset where piece i starts])."""
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    out, starts = b"", []
+    for k, p in enumerate(pieces):
+        starts.append(len(out))
+        out += c.compress(p)
+        out += c.flush(flush) if k + 1 < len(pieces) else c.flush()
+    return out, starts
+
+
+def _run(ctx, comp, starts, want, sym_cap=None, window=None, start_bits=None):
+    n = len(starts)
+    tab = np.zeros(n, CHUNK)
+    for k in range(n):
+        tab[k]["in_off"] = starts[k]
+        tab[k]["start_bit"] = 0 if start_bits is None else start_bits[k]
+        tab[k]["in_len"] = len(comp) - starts[k]
+        tab[k]["end_bit"] = (starts[k + 1] - starts[k]) * 8 if k + 1 < n else NONE
+    d_comp = torch.from_numpy(np.frombuffer(comp + bytes(128), np.uint8).copy()).cuda()
+    d_tab = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+    cap = sym_cap or (max(len(w) for w in want) + 8 + 7) // 8 * 8
+    total = sum(len(w) for w in want)
+    d_text = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    d_wout = torch.zeros(32768, dtype=torch.uint8, device="cuda")
+    d_win = torch.from_numpy(np.frombuffer(window, np.uint8).copy()).cuda() if window is not None else None
+    info = ctx.gz_inflate_dev(d_comp, d_tab, n, cap, d_text, total + 64, d_win, d_wout)
+    return info, d_text[:int(info.n_bytes)].cpu().numpy().tobytes() if not info.status else b"", d_wout.cpu().numpy().tobytes()
+
+
+def _fastq(rng, n, L=100):
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n, L))
+    qual = rng.integers(35, 74, (n, L), dtype=np.uint8)
+    return b"".join(b"@read%d/1\n%s\n+\n%s\n" % (i, seq[i].tobytes(), qual[i].tobytes()) for i in range(n))
+
+
+@pytest.mark.parametrize("level,strategy", [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (6, zlib.Z_FIXED), (5, zlib.Z_HUFFMAN_ONLY), (7, zlib.Z_RLE), (0, zlib.Z_DEFAULT_STRATEGY)])
+def test_stretches_with_unknown_history_equal_zlib(ctx, level, strategy):
+    rng = np.random.default_rng(level * 10 + strategy)
+    text = _fastq(rng, 6000)
+    cuts = sorted(int(x) for x in rng.integers(1, len(text), 11))
+    pieces = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+    comp, starts = _stream(pieces, level, zlib.Z_SYNC_FLUSH, strategy)   # sync flush: later pieces refer back into earlier ones
+    assert zlib.decompress(comp, -15) == text
+    info, got, wout = _run(ctx, comp, starts, pieces)
+    assert info.status == 0 and info.final_chunk == len(pieces)
+    assert got == text
+    assert wout == text[-32768:]
+    assert info.end_bit == (len(comp) - starts[-1]) * 8   # the final block ends with the stream (byte-aligned)
+
+
+def test_history_handed_in_and_out_across_calls(ctx):
+    """A stream inflated in two calls: the first call's window_out is the second's window_in."""
+    rng = np.random.default_rng(3)
+    text = _fastq(rng, 4000)
+    pieces = [text[i:i + 90000] for i in range(0, len(text), 90000)]
+    comp, starts = _stream(pieces, 6, zlib.Z_SYNC_FLUSH)
+    half = len(pieces) // 2
+    # first call: stretches [0, half) -- the last one must stop at the start of stretch `half`
+    n1 = starts[half]
+    tab_want = pieces[:half]
+    info1, got1, w1 = _run_partial(ctx, comp, starts[:half], n1, tab_want)
+    assert info1.status == 0 and info1.final_chunk == 0 and got1 == b"".join(pieces[:half])
+    info2, got2, w2 = _run(ctx, comp[n1:], [s - n1 for s in starts[half:]], pieces[half:], window=w1)
+    assert info2.status == 0 and got2 == b"".join(pieces[half:])
+    assert w2 == text[-32768:]
+
+
+def _run_partial(ctx, comp, starts, stop, want):
+    n = len(starts)
+    tab = np.zeros(n, CHUNK)
+    for k in range(n):
+        tab[k]["in_off"] = starts[k]
+        tab[k]["in_len"] = len(comp) - starts[k]
+        tab[k]["end_bit"] = ((starts[k + 1] if k + 1 < n else stop) - starts[k]) * 8
+    d_comp = torch.from_numpy(np.frombuffer(comp + bytes(128), np.uint8).copy()).cuda()
+    d_tab = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+    cap = (max(len(w) for w in want) + 15) // 8 * 8
+    total = sum(len(w) for w in want)
+    d_text = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    d_wout = torch.zeros(32768, dtype=torch.uint8, device="cuda")
+    info = ctx.gz_inflate_dev(d_comp, d_tab, n, cap, d_text, total + 64, None, d_wout)
+    return info, d_text[:int(info.n_bytes)].cpu().numpy().tobytes(), d_wout.cpu().numpy().tobytes()
+
+
+def test_payload_shapes(ctx):
+    """Long matches, distance-1 runs, matches reaching exactly 32768 back, binary bytes, tiny and empty stretches."""
+    rng = np.random.default_rng(9)
+    block = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    pieces = [block, block, b"", b"x", bytes(100000), (b"ACGT" * 30000)[:77777], block[:100] * 50, rng.integers(0, 4, 50000, dtype=np.uint8).tobytes(),
+              block]
+    comp, starts = _stream(pieces, 9, zlib.Z_SYNC_FLUSH)
+    info, got, wout = _run(ctx, comp, starts, pieces)
+    text = b"".join(pieces)
+    assert info.status == 0 and got == text and wout == text[-32768:]
+
+
+def test_wrong_ends_and_damage_are_reported(ctx):
+    rng = np.random.default_rng(4)
+    text = _fastq(rng, 3000)
+    pieces = [text[i:i + 100000] for i in range(0, len(text), 100000)]
+    comp, starts = _stream(pieces, 6, zlib.Z_SYNC_FLUSH)
+    # an end that is not a block boundary of the stream
+    bad_starts = list(starts)
+    bad_starts[2] += 3
+    info, _, _ = _run(ctx, comp, bad_starts, pieces)
+    assert info.status != 0 and info.bad_chunk in (1, 2)
+    # too little room for the symbols
+    info, _, _ = _run(ctx, comp, starts, pieces, sym_cap=4096)
+    assert info.status != 0
+    # flipped bits: either some stretch reports, or the text differs from the original exactly as zlib's does
+    for trial in range(6):
+        raw = bytearray(comp)
+        pos = int(rng.integers(0, len(raw)))
+        raw[pos] ^= 1 << int(rng.integers(0, 8))
+        info, got, _ = _run(ctx, bytes(raw), starts, pieces, sym_cap=(len(text) + 15) // 8 * 8)
+        try:
+            want = zlib.decompress(bytes(raw), -15)
+        except zlib.error:
+            want = None
+        if info.status == 0:
+            assert want is not None and got == want, trial
