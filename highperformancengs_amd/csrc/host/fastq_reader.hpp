@@ -75,13 +75,13 @@ struct InStream {
 
 // Does a second gzip member start within the first 64 MiB (or the file is small: < 4 MiB)?  Such files go to
 // the member-parallel reader.  A member start is the header pattern followed by a deflate block header that
-// parses (a dynamic header is a complete prefix code twice over: compressed data does not look like that).
-inline bool gzip_has_second_member(int fd)
+// parses (decoded strictly, with no history to refer to: compressed data that looks like a header does not get far).
+inline bool gzip_has_second_member(int fd, bool any_size = false)
 {
     struct stat sb;
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return true;
     if (getenv("HPN_PGZ_FORCE")) return false;  // tests: any gzip file through the two-pass reader
-    if (sb.st_size < (4 << 20)) return true;  // not worth the threads
+    if (sb.st_size < (4 << 20) && !any_size) return true;  // not worth the threads
     const size_t n = (size_t)sb.st_size < ((size_t)64 << 20) ? (size_t)sb.st_size : (size_t)64 << 20;
     void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     if (m == MAP_FAILED) return true;
@@ -91,19 +91,19 @@ inline bool gzip_has_second_member(int fd)
         p = (const uint8_t *)memchr(p, 0x1f, (size_t)(lim - 18 - p));
         if (!p) break;
         const uint8_t *body = gzip_header_end(p, lim);
-        if (body && body + 8 < lim) {
-            const uint32_t type = (body[0] >> 1) & 3;
-            if (type == 2) {
-                FastInflateT<uint16_t> fi;
-                static thread_local std::vector<uint16_t> out(32768 + 4096 + FastInflateT<uint16_t>::kOvershoot);
-                uint16_t *o = out.data() + 32768;
-                fi.begin(body, lim, 0, true);
-                second = fi.run(o, o + 4096, out.data()) != FastInflateT<uint16_t>::kError;
-            } else if (type == 1) {
-                second = true;  // fixed codes: tiny members
-            } else if (type == 0) {
-                second = (uint16_t)(body[1] | body[2] << 8) == (uint16_t) ~(body[3] | body[4] << 8);
-            }
+        // A member start: the header (XFL is 0, 2 or 4 from every deflate writer) and a deflate stream that decodes
+        // from there WITHOUT any history -- compressed bytes that merely look like a header fail that within a few
+        // symbols (a match reaching in front of the stream's first byte), and what decodes must be text.
+        if (body && body + 8 < lim && (p[8] == 0 || p[8] == 2 || p[8] == 4)) {
+            FastInflate fi;
+            static thread_local std::vector<uint8_t> out(4096 + FastInflate::kOvershoot);
+            uint8_t *o = out.data();
+            fi.begin(body, lim, 0, true);
+            const int r = fi.run(o, out.data() + 4096, out.data());
+            bool texty = r != FastInflate::kError;
+            for (const uint8_t *q = out.data(); texty && q < o && q < out.data() + 4096; ++q)
+                texty = (*q >= 32 && *q < 127) || *q == '\n' || *q == '\r' || *q == '\t';
+            second = texty;
         }
         ++p;
     }

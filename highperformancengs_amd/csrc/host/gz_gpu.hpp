@@ -1,0 +1,304 @@
+// gz_gpu.hpp -- a single-member .fastq.gz inflated on the GPU (hpn_gz_inflate_dev), host side.
+//
+// host/pgz_reader.hpp inflates ONE deflate stream in parallel on the host cores (two passes:
+// symbolic decode with unknown history, histories resolved in order); the decode is 3/4 of
+// that thread time.  Here the host keeps only what is cheap per megabyte: finding where
+// deflate blocks start (gz_find_block_start: ~1 ms per stretch on one core) and moving the
+// compressed bytes into pinned chunks and on to the device.  The device inflates every stretch
+// with one wavefront, resolves the histories and writes one contiguous text per batch, which the
+// caller frames where it lies (hpn_fastq_text_count / _trim take device text).
+//
+// Exactness is by construction as in the host reader: stretch 0 starts at the member's first
+// block, and the device accepts a stretch only if it ends on the next one's first bit at a block
+// boundary.  The member must end the file (trailer + nothing else) and its ISIZE must match.
+// Anything else -- several members, trailing bytes, a block start the trial decoder got wrong,
+// more than 8x expansion, damage -- makes next() return -1 and the caller reads the file
+// through the host readers from its first byte.
+#pragma once
+#include <atomic>
+#include <thread>
+
+#include "pgz_reader.hpp"
+#include "text_stream.hpp"
+
+namespace hpn {
+
+inline bool gz_gpu_enabled()
+{
+    const char *e = getenv("HPN_GZ_GPU");
+    return !(e && e[0] == '0');
+}
+
+class GzGpuStream {
+public:
+    ~GzGpuStream()
+    {
+        pump_.reset();
+        if (ctx_) {
+            hpn_dev_free(ctx_, d_comp_), hpn_dev_free(ctx_, d_chunks_), hpn_dev_free(ctx_, d_text_), hpn_dev_free(ctx_, d_win_[0]),
+                hpn_dev_free(ctx_, d_win_[1]);
+            if (h_chunks_) hpn_host_free(ctx_, h_chunks_);
+        }
+        if (data_) munmap((void *)data_, size_);
+        if (fd_ >= 0) close(fd_);
+    }
+
+    // threads: block-start searchers.  max_stretches: per device call.  stretch_bytes 0: HPN_GZ_STRETCH, else the file
+    // size / max_stretches within 256 KiB .. 2 MiB (the search costs ~0.4 ms per stretch).
+    bool open(hpn_ctx *ctx, const char *path, int threads, uint32_t max_stretches, size_t stretch_bytes = 0)
+    {
+        ctx_ = ctx;
+        fd_ = ::open(path, O_RDONLY);
+        if (fd_ < 0) return give_up("cannot open");
+        struct stat sb;
+        if (fstat(fd_, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) return give_up("not a regular file");
+        size_ = (uint64_t)sb.st_size;
+        void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) return give_up("mmap failed");
+        data_ = (const uint8_t *)m;
+        const uint8_t *body = gzip_header_end(data_, data_ + size_);
+        if (!body) return give_up("no gzip header");
+        threads_ = threads < 1 ? 1 : threads;
+        max_stretches_ = max_stretches < 1 ? 1 : max_stretches > 65535u ? 65535u : max_stretches;
+        if (!stretch_bytes) {
+            // as many stretches as the device call may hold, so that one call fills the chip: a wavefront inflates ~4.5 MB
+            // of text per second whatever the stretch size, so only the number of waves in flight matters
+            const char *e = getenv("HPN_GZ_STRETCH");
+            stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / max_stretches_ + 65536) & ~(uint64_t)65535);
+            if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
+            if (!e && stretch_bytes > ((size_t)2 << 20)) stretch_bytes = (size_t)2 << 20;
+        }
+        if (stretch_bytes < 4096) stretch_bytes = 4096;
+        stretch_ = stretch_bytes;
+        // symbols of scratch per stretch: from the expansion of the member's first megabytes (FASTQ is homogeneous; a
+        // stretch that needs more is decoded again with twice the room)
+        {
+            std::vector<uint8_t> probe(((size_t)4 << 20) + FastInflate::kOvershoot);
+            FastInflate fi;
+            fi.begin(body, data_ + size_);
+            uint8_t *o = probe.data();
+            const int r = fi.run(o, probe.data() + ((size_t)4 << 20), probe.data());
+            if (r == FastInflate::kError) return give_up("the stream does not decode");
+            const double in = (double)(fi.in_pos() - body) + 1, out = (double)(o - probe.data()) + 1;
+            ratio_ = out / in < 1.0 ? 1.0 : out / in;
+        }
+        sym_cap_ = cap_for(ratio_ * 1.4);
+        first_bit_ = (uint64_t)(body - data_) * 8;
+        next_start_ = first_bit_;
+        // the compressed bytes reach the device through pinned chunks read in parallel (the page cache is not pinned)
+        pump_.reset(new TextPump(ctx, path, (size_t)32 << 20, 3, true));
+        if (!pump_->ok()) return give_up("reader not available");
+        if (hpn_dev_malloc(ctx_, 32768, &d_win_[0]) != HPN_OK || hpn_dev_malloc(ctx_, 32768, &d_win_[1]) != HPN_OK) return give_up("device memory");
+        return true;
+    }
+    const uint8_t *d_text() const { return (const uint8_t *)d_text_; }
+    const char *why() const { return why_; }  // what made open() / next() give up
+    double seconds_find() const { return t_find_; }
+    double seconds_upload() const { return t_upload_; }
+    double seconds_device() const { return t_device_; }
+    bool at_end() const { return done_; }
+
+    // Next batch of text on the device: 1 = ok (*n_bytes of it at d_text()), 0 = end of the member (checked), -1 = not
+    // decodable here.
+    int next(uint64_t *n_bytes)
+    {
+        *n_bytes = 0;
+        if (done_) return 0;
+        // ---- the batch's stretches: starts found in [lo, hi) slices of the compressed file, by the pool, while this
+        // thread moves the batch's compressed bytes to the device ----
+        const uint64_t base_byte = next_start_ >> 3;
+        const uint64_t left = (size_ - base_byte + stretch_ - 1) / stretch_;
+        const uint64_t calls = (left + max_stretches_ - 1) / max_stretches_;
+        uint64_t slices = (left + calls - 1) / calls;  // even shares: no call is left with a sliver
+        bool last_batch = calls <= 1;
+        if (last_batch) slices = left;
+        const double t0 = wall_s();
+        std::vector<uint64_t> found((size_t)slices + 1, kGzNone);
+        found[0] = next_start_;
+        std::atomic<uint64_t> take{1};
+        auto work = [&] {
+            for (;;) {
+                const uint64_t k = take.fetch_add(1);
+                if (k > slices || (k == slices && last_batch)) return;
+                const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
+                found[(size_t)k] = gz_find_block_start(data_, size_, lo, hi < size_ * 8 ? hi : size_ * 8, gz_find_scratch(), kGzFindScratch);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads_; ++t) pool.emplace_back(work);
+        const uint64_t body_end = last_batch || base_byte + slices * stretch_ > size_ ? size_ : base_byte + slices * stretch_;
+        bool up_ok = reserve(d_comp_, cap_comp_, (size_t)((slices + 3) * stretch_ + 8192 + 256));
+        if (up_ok) up_ok = upload(base_byte, body_end, base_byte);
+        t_upload_ += wall_s() - t0;
+        for (auto &t : pool) t.join();
+        if (!up_ok) return give_up("upload failed") - 1;
+        // the slice after the batch tells where its last stretch ends; nothing found there: one more slice ...
+        uint64_t end_bit = kGzNone;
+        if (!last_batch) {
+            uint64_t k = slices;
+            end_bit = found[(size_t)slices];
+            while (end_bit == kGzNone && k < slices + 1 && (base_byte + (k + 1) * stretch_) < size_) {  // (a slice without a dynamic block)
+                ++k;
+                const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
+                end_bit = gz_find_block_start(data_, size_, lo, hi < size_ * 8 ? hi : size_ * 8, gz_find_scratch(), kGzFindScratch);
+            }
+            if (end_bit == kGzNone) {
+                if ((base_byte + (k + 1) * stretch_) < size_) return give_up("no block start where one is expected") - 1;
+                last_batch = true;  // ... or, at the end of the file, run to the final block
+            }
+        }
+        t_find_ += wall_s() - t0;
+        starts_.clear();
+        for (uint64_t k = 0; k < slices; ++k)
+            if (found[(size_t)k] != kGzNone) starts_.push_back(found[(size_t)k]);
+        const uint32_t n = (uint32_t)starts_.size();
+        // ---- the rest of the compressed bytes, up to a little beyond the batch's end ----
+        const uint64_t stop_byte = last_batch ? size_ : ((end_bit >> 3) + 4096 < size_ ? (end_bit >> 3) + 4096 : size_);
+        const uint64_t comp_bytes = stop_byte - base_byte;
+        if (comp_bytes + 256 > cap_comp_) return give_up("a stretch without a block start") - 1;
+        if (stop_byte > body_end && !upload(body_end, stop_byte, base_byte)) return give_up("upload failed") - 1;
+        // ---- stretch table ----
+        if (n > h_chunks_cap_) {
+            if (h_chunks_) hpn_host_free(ctx_, h_chunks_);
+            h_chunks_cap_ = n + n / 2 + 64;
+            void *p = nullptr;
+            if (hpn_host_malloc(ctx_, h_chunks_cap_ * sizeof(hpn_gz_chunk), &p) != HPN_OK) return give_up("pinned memory") - 1;
+            h_chunks_ = (hpn_gz_chunk *)p;
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            hpn_gz_chunk &c = h_chunks_[k];
+            const uint64_t s = starts_[k], e = k + 1 < n ? starts_[k + 1] : end_bit;
+            c.in_off = (s >> 3) - base_byte;
+            c.start_bit = (uint32_t)(s & 7);
+            c.end_bit = e == kGzNone ? kGzNone : e - (s & ~(uint64_t)7);
+            const uint64_t room = stop_byte - (s >> 3);
+            c.in_len = room > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)room;
+        }
+        if (!reserve(d_chunks_, cap_chunks_, (size_t)n * sizeof(hpn_gz_chunk))) return give_up("device memory") - 1;
+        if (hpn_memcpy_h2d(ctx_, d_chunks_, h_chunks_, (size_t)n * sizeof(hpn_gz_chunk)) != HPN_OK) return give_up("copy failed") - 1;
+        const double t2 = wall_s();
+        // ---- inflate, resolve, translate ----
+        uint64_t want = (uint64_t)((double)comp_bytes * ratio_ * 1.25) + ((uint64_t)8 << 20);
+        hpn_gz_info info;
+        for (int attempt = 0;; ++attempt) {
+            if (!reserve(d_text_, cap_text_, want + 64)) return give_up("device memory (text)") - 1;
+            const int rc = hpn_gz_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
+                                              batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
+                                              (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
+            if (rc == HPN_E_CAPACITY && attempt == 0) {  // more text than guessed: once more with room for it
+                want = info.n_bytes;
+                continue;
+            }
+            if (rc != HPN_OK) return give_up(hpn_ctx_last_error(ctx_)) - 1;
+            break;
+        }
+        t_device_ += wall_s() - t2;
+        if ((info.status == 12 || info.status == 14 || info.status == 1) && !grown_) {  // out of room: once more with twice as much
+            grown_ = true;
+            sym_cap_ = cap_for(ratio_ * 3.0);
+            const int rc = hpn_gz_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
+                                              batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
+                                              (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
+            if (rc != HPN_OK) return give_up(hpn_ctx_last_error(ctx_)) - 1;
+        }
+        if (info.status) {
+            snprintf(why_buf_, sizeof why_buf_, "stretch %u of %u: decoder status %u", info.bad_chunk, n, info.status);
+            return give_up(why_buf_) - 1;
+        }
+        ++batch_;
+        total_ += info.n_bytes;
+        *n_bytes = info.n_bytes;
+        if (last_batch) {
+            // the member must end the file: final block in the last stretch, 8-byte trailer, nothing behind, ISIZE right
+            if (info.final_chunk != n) return give_up("the member ends before the file does") - 1;
+            const uint64_t trailer = ((starts_[n - 1] & ~(uint64_t)7) + info.end_bit) >> 3;
+            if (trailer + 8 != size_) return give_up("bytes behind the member") - 1;
+            uint32_t isize;
+            memcpy(&isize, data_ + trailer + 4, 4);
+            if (isize != (uint32_t)total_) return give_up("ISIZE mismatch") - 1;
+            done_ = true;
+        } else {
+            if (info.final_chunk) return give_up("the member ends inside the file") - 1;  // more members or garbage follow
+            next_start_ = end_bit;
+        }
+        return 1;
+    }
+
+private:
+    uint32_t cap_for(double ratio) const  // symbols per stretch: its compressed bytes + a block or two, expanded
+    {
+        const double c = ((double)stretch_ + 131072.0) * ratio + 65536.0;
+        return (uint32_t)(((uint64_t)c + 7) & ~(uint64_t)7);
+    }
+    bool give_up(const char *why)  // false (callers returning int subtract 1)
+    {
+        why_ = why;
+        return false;
+    }
+    bool reserve(void *&p, size_t &cap, size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) hpn_dev_free(ctx_, p);
+        p = nullptr, cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (hpn_dev_malloc(ctx_, want, &p) != HPN_OK) return false;
+        cap = want;
+        return true;
+    }
+    // file bytes [from, to) -> d_comp_[0 ..).  The pump delivers the file once, in order, in pinned chunks; a chunk that
+    // reaches beyond `to` stays current for the next batch.  Batches overlap by a few KiB at their seams (a stretch may be
+    // read a little past its end): bytes the pump has already let go of are taken from the mapped file.
+    bool upload(uint64_t from, uint64_t to, uint64_t origin)
+    {
+        uint64_t at = from;
+        if (at < pump_off_) {
+            const uint64_t e = to < pump_off_ ? to : pump_off_;
+            if (hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + (at - origin), data_ + at, e - at) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return false;
+            at = e;
+        }
+        while (at < to) {
+            if (!have_chunk_) {
+                if (!pump_->next(cur_)) return false;
+                have_chunk_ = true;
+            }
+            const uint64_t c0 = pump_off_, c1 = pump_off_ + cur_.n;
+            const uint64_t b = at >= c1 ? at : (to < c1 ? to : c1);
+            if (b > at && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + (at - origin), cur_.p + (at - c0), b - at) != HPN_OK) return false;
+            at = b;
+            if (at >= c1) {  // used up: back to the reader once the copy out of it is done
+                if (hpn_ctx_sync(ctx_) != HPN_OK) return false;
+                const bool eof = cur_.eof;
+                pump_->recycle(cur_);
+                have_chunk_ = false;
+                pump_off_ = c1;
+                if (eof && at < to) return false;  // the file is shorter than its size said
+            }
+        }
+        return hpn_ctx_sync(ctx_) == HPN_OK;
+    }
+
+    hpn_ctx *ctx_ = nullptr;
+    int fd_ = -1;
+    const uint8_t *data_ = nullptr;
+    uint64_t size_ = 0;
+    size_t stretch_ = 0;
+    int threads_ = 1;
+    uint32_t max_stretches_ = 0, sym_cap_ = 0, batch_ = 0;
+    uint64_t first_bit_ = 0, next_start_ = 0, total_ = 0;
+    bool done_ = false, grown_ = false;
+    double ratio_ = 4.0;
+    const char *why_ = "";
+    char why_buf_[96];
+    double t_find_ = 0, t_upload_ = 0, t_device_ = 0;
+    std::unique_ptr<TextPump> pump_;
+    TextPump::Chunk cur_;
+    bool have_chunk_ = false;
+    uint64_t pump_off_ = 0;  // file offset of cur_'s first byte
+    std::vector<uint64_t> starts_;
+    void *d_comp_ = nullptr, *d_chunks_ = nullptr, *d_text_ = nullptr, *d_win_[2] = {nullptr, nullptr};
+    size_t cap_comp_ = 0, cap_chunks_ = 0, cap_text_ = 0;
+    hpn_gz_chunk *h_chunks_ = nullptr;
+    size_t h_chunks_cap_ = 0;
+};
+
+}  // namespace hpn

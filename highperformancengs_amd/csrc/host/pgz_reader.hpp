@@ -74,6 +74,70 @@ inline const uint8_t *gzip_header_end(const uint8_t *p, const uint8_t *lim)
     return p;
 }
 
+// ---- where does a deflate block start? (shared with the device path, host/gz_gpu.hpp) ---------------
+constexpr size_t kGzFindHist = 32768, kGzFindScratch = (size_t)1 << 20;  // history placeholders; two candidate blocks of symbols
+constexpr uint64_t kGzNone = ~(uint64_t)0;
+
+inline bool gz_texty(const uint16_t *s, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t v = s[i];
+        if (v < 256 && !(v >= 32 && v < 127) && v != '\n' && v != '\r' && v != '\t') return false;
+    }
+    return true;
+}
+inline uint16_t *gz_find_scratch()  // per thread: kGzFindScratch symbols behind the placeholder history
+{
+    static thread_local std::vector<uint16_t> store;
+    if (store.empty()) {
+        store.resize(kGzFindHist + kGzFindScratch + FastInflateT<uint16_t>::kOvershoot);
+        for (size_t i = 0; i < kGzFindHist; ++i) store[i] = (uint16_t)(256 + i);
+    }
+    return store.data() + kGzFindHist;
+}
+// First bit position in [lo, hi) of data[0..size) where two dynamic-Huffman blocks in a row decode to text; kGzNone if
+// there is none.  Per candidate position, cheapest test first: BFINAL = 0 / BTYPE = 2 / HLIT <= 29 / HDIST <= 29
+// (RFC 1951 3.2.7); then the code-length code (HCLEN + 4 three-bit lengths) must be a complete prefix code or zlib's
+// inftrees rejects it -- Kraft sum = 1, ~20 operations that turn away ~99 % of what got this far; only then tables are
+// built and blocks decoded.
+inline uint64_t gz_find_block_start(const uint8_t *data, uint64_t size, uint64_t lo, uint64_t hi, uint16_t *scratch, size_t cap)
+{
+    const uint8_t *lim = data + size;
+    if (size < 8) return kGzNone;
+    if (hi > (size - 8) * 8) hi = (size - 8) * 8;  // the trailer is not deflate data
+    FastInflateT<uint16_t> fi;
+    for (uint64_t byte = lo >> 3; byte * 8 < hi; ++byte) {
+        const uint8_t *b = data + byte;
+        uint64_t w0 = 0, w1 = 0;
+        if (lim - b >= 16) {
+            memcpy(&w0, b, 8), memcpy(&w1, b + 8, 8);
+        } else {
+            memcpy(&w0, b, lim - b >= 8 ? 8 : (size_t)(lim - b));
+            if (lim - b > 8) memcpy(&w1, b + 8, (size_t)(lim - b - 8));
+        }
+        for (uint32_t sh = 0; sh < 8; ++sh) {
+            const uint64_t v0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+            if ((v0 & 7) != 4 || ((v0 >> 3) & 31) > 29 || ((v0 >> 8) & 31) > 29) continue;
+            const uint64_t p = byte * 8 + sh;
+            if (p < lo || p >= hi) continue;
+            const uint32_t hclen = (uint32_t)(v0 >> 13 & 15) + 4;
+            uint64_t x = (v0 >> 17) | ((w1 >> sh) << 47);
+            uint32_t kraft = 0;
+            for (uint32_t i = 0; i < hclen; ++i, x >>= 3) kraft += (128u >> (x & 7)) & 127u;  // length 0: unused
+            if (kraft != 128) continue;
+            fi.begin(b, lim, sh, true);
+            uint16_t *out = scratch;
+            int r = fi.run(out, scratch + cap, scratch - kGzFindHist);
+            if (r != FastInflateT<uint16_t>::kBlockEnd || out == scratch || !gz_texty(scratch, (size_t)(out - scratch))) continue;
+            uint16_t *mid = out;
+            r = fi.run(out, scratch + cap, scratch - kGzFindHist);
+            if ((r != FastInflateT<uint16_t>::kBlockEnd && r != FastInflateT<uint16_t>::kDone) || !gz_texty(mid, (size_t)(out - mid))) continue;
+            return p;
+        }
+    }
+    return kGzNone;
+}
+
 class PgzReader {
 public:
     // threads <= 0: HPN_GZ_THREADS, else min(16, usable CPUs).  chunk_bytes 0: HPN_PGZ_CHUNK, else 2 MiB.
@@ -239,61 +303,11 @@ private:
     }
 
     // ---- pass 1: where does a block start? ----------------------------------------------------------
-    static bool texty(const uint16_t *s, size_t n)
-    {
-        for (size_t i = 0; i < n; ++i) {
-            const uint16_t v = s[i];
-            if (v < 256 && !(v >= 32 && v < 127) && v != '\n' && v != '\r' && v != '\t') return false;
-        }
-        return true;
-    }
-    static uint16_t *scratch()  // per thread: kScratch symbols behind the placeholder history
-    {
-        static thread_local std::vector<uint16_t> store;
-        if (store.empty()) {
-            store.resize(kHist + kScratch + FastInflateT<uint16_t>::kOvershoot);
-            for (size_t i = 0; i < kHist; ++i) store[i] = (uint16_t)(256 + i);
-        }
-        return store.data() + kHist;
-    }
-    // first bit position in [lo, hi) where two dynamic blocks in a row decode to text
+    static uint16_t *scratch() { return gz_find_scratch(); }
     uint64_t find_start(uint64_t lo, uint64_t hi, uint16_t *scratch, size_t cap)
     {
         const Stopwatch sw(t_find_);
-        const uint8_t *lim = data_ + size_;
-        if (hi > (size_ - 8) * 8) hi = (size_ - 8) * 8;  // the trailer is not deflate data
-        FastInflateT<uint16_t> fi;
-        for (uint64_t p = lo; p < hi; ++p) {
-            // BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29 (RFC 1951 3.2.7) before anything is built
-            const uint8_t *b = data_ + (p >> 3);
-            uint32_t w = 0;
-            memcpy(&w, b, lim - b >= 4 ? 4 : (size_t)(lim - b));
-            w >>= p & 7;
-            if ((w & 7) != 4 || ((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
-            // ... and the code-length code (HCLEN + 4 three-bit lengths) must be a complete prefix code, or zlib's
-            // inftrees rejects it: Kraft sum = 1.  This turns away ~99 % of what got this far for ~20 operations
-            // instead of a table build (the search went from 24 ms to ~1 ms per chunk).
-            if (lim - b >= 16) {
-                uint64_t lo, hi;
-                memcpy(&lo, b, 8), memcpy(&hi, b + 8, 8);
-                const uint32_t sh = (uint32_t)(p & 7);
-                const uint64_t v0 = sh ? (lo >> sh) | (hi << (64 - sh)) : lo, v1 = hi >> sh;
-                const uint32_t hclen = (uint32_t)(v0 >> 13 & 15) + 4;
-                uint64_t x = (v0 >> 17) | (v1 << 47);
-                uint32_t kraft = 0;
-                for (uint32_t i = 0; i < hclen; ++i, x >>= 3) kraft += (128u >> (x & 7)) & 127u;  // length 0: unused
-                if (kraft != 128) continue;
-            }
-            fi.begin(b, lim, (uint32_t)(p & 7), true);
-            uint16_t *out = scratch;
-            int r = fi.run(out, scratch + cap, scratch - kHist);
-            if (r != FastInflateT<uint16_t>::kBlockEnd || out == scratch || !texty(scratch, (size_t)(out - scratch))) continue;
-            uint16_t *mid = out;
-            r = fi.run(out, scratch + cap, scratch - kHist);
-            if ((r != FastInflateT<uint16_t>::kBlockEnd && r != FastInflateT<uint16_t>::kDone) || !texty(mid, (size_t)(out - mid))) continue;
-            return p;
-        }
-        return kNone;
+        return gz_find_block_start(data_, size_, lo, hi, scratch, cap);
     }
 
     // ---- pass 2: decode a stretch with unknown history -------------------------------------------
@@ -589,7 +603,7 @@ private:
         return true;
     }
 
-    static constexpr size_t kScratch = (size_t)1 << 20;  // two candidate blocks of symbols
+    static constexpr size_t kScratch = kGzFindScratch;
 
     int fd_ = -1;
     const uint8_t *data_ = nullptr;

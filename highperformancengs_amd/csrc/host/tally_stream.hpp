@@ -7,6 +7,7 @@
 #pragma once
 #include "../host/fastq_reader.hpp"
 #include "../host/bam_gpu.hpp"
+#include "../host/gz_gpu.hpp"
 #include "../host/text_stream.hpp"
 #include "hpngs.h"
 
@@ -154,6 +155,68 @@ inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
     return hpn_fastq_tally_fetch(ctx, acc);
 }
 
+// A single-member .fastq.gz: block starts found on the host, the stretches inflated on the device (host/gz_gpu.hpp),
+// the text framed and tallied where it lands.  *unusable as above.
+inline bool is_plain_gzip_file(const char *path)  // gzip, not BGZF, one member as far as a look at the first 64 MiB tells
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    uint8_t h[18] = {0};
+    struct stat sb;
+    const bool gz = pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 &&
+                    !((h[3] & 4) && h[12] == 'B' && h[13] == 'C') && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    const bool force = getenv("HPN_GZ_GPU_FORCE") != nullptr;  // tests: small files too
+    const bool ok = gz && (force || sb.st_size >= (8 << 20)) && !gzip_has_second_member(fd, force);
+    close(fd);
+    return ok;
+}
+inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *unusable)
+{
+    *unusable = false;
+    GzGpuStream gs;
+    const long cpus = usable_cpus() / text_workers_in_flight();
+    uint32_t per_call = (uint32_t)(4608 / text_workers_in_flight());  // the chip runs 4,608 stretches at a time
+    if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);  // (tests: several device calls per file)
+    const double t0 = wall_s();
+    if (!gs.open(ctx, path, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call)) {
+        if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] gzip route on the GPU not taken: %s\n", gs.why());
+        *unusable = true;
+        return HPN_OK;
+    }
+    const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
+    int rc = hpn_fastq_text_begin(ctx);
+    const uint64_t slice = (uint64_t)256 << 20;
+    while (rc == HPN_OK && !*unusable) {
+        uint64_t n = 0;
+        const int r = gs.next(&n);
+        if (r < 0) {
+            *unusable = true;
+            break;
+        }
+        const bool fin = r == 0 || gs.at_end();
+        for (uint64_t at = 0; rc == HPN_OK && !*unusable && (at < n || (fin && n == 0));) {
+            const uint64_t k = n - at < slice ? n - at : slice;
+            hpn_text_info info;
+            rc = hpn_fastq_text_count(ctx, gs.d_text() + at, k, fin && at + k == n, flags, &info);
+            if (rc == HPN_OK && info.irregular) *unusable = true;
+            at += k;
+            if (n == 0) break;
+        }
+        if (fin) break;
+    }
+    if (*unusable || rc != HPN_OK) {
+        hpn_tally scratch;
+        memset(&scratch, 0, sizeof scratch);
+        (void)hpn_fastq_tally_fetch(ctx, &scratch);
+        if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] gzip route on the GPU abandoned after %.3f s: %s\n", wall_s() - t0, gs.why());
+        return rc;
+    }
+    if (getenv("HPN_TIMING"))
+        fprintf(stderr, "[hpn] gzip on the GPU: inflate + frame + tally %.3f s (block starts %.3f s, upload %.3f s, device inflate %.3f s)\n",
+                wall_s() - t0, gs.seconds_find(), gs.seconds_upload(), gs.seconds_device());
+    return hpn_fastq_tally_fetch(ctx, acc);
+}
+
 // One input file of fastq_count / fastq_count_kthread (count_read, fastq_count.c:106-133).
 inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_long)
 {
@@ -161,6 +224,11 @@ inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_
     if (text_path_enabled() && !is_stdin && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(path)) {
         bool unusable = false;
         const int rc = tally_bgzf_on_gpu(ctx, path, acc, &unusable);
+        if (!unusable) return rc;
+    }
+    if (text_path_enabled() && !is_stdin && gz_gpu_enabled() && !getenv("HPN_NO_MGZ") && !getenv("HPN_NO_PGZ") && is_plain_gzip_file(path)) {
+        bool unusable = false;
+        const int rc = tally_gz_on_gpu(ctx, path, acc, &unusable);
         if (!unusable) return rc;
     }
     if (text_path_enabled() && !is_stdin) {  // an irregular stream is framed again from its first byte

@@ -1,5 +1,8 @@
 // hpn_gz.hip -- C ABI of the device-side single-member gzip inflater (kernels/gz_inflate.hip).
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "hpn_ctx.hpp"
 
@@ -29,12 +32,16 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
         HPN_HIP(c, hipStreamSynchronize(c->stream));
         return HPN_OK;
     }
+    const bool dbg = getenv("HPN_GZ_DEBUG") != nullptr;
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    const double t0 = now();
     int rc;
     if ((rc = scratch_reserve(c, c->g_sym, (size_t)n_chunks * sym_cap * sizeof(uint16_t) + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->g_meta, (size_t)n_chunks * 32)) != HPN_OK) return rc;
-    if ((rc = scratch_reserve(c, c->g_windows, (size_t)n_chunks * 32768)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->g_windows, ((size_t)n_chunks + 1) * 32768)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->g_summary, 64)) != HPN_OK) return rc;
     uint16_t *sym = (uint16_t *)c->g_sym.p;
+    const double t1 = now();
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamInflate], c->stream));
     HPN_HIP(c, launch_gz_sym_inflate(d_comp, d_chunks, n_chunks, sym, sym_cap, c->g_meta.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamInflate], c->stream));
@@ -44,6 +51,7 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     u64 summary[4] = {0, 0, 0, 0};
     HPN_HIP(c, hipMemcpyAsync(summary, c->g_summary.p, sizeof summary, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
+    const double t2 = now();
     info->n_bytes = summary[0];
     info->status = (uint32_t)summary[1], info->bad_chunk = (uint32_t)summary[2], info->final_chunk = (uint32_t)summary[3];
     if (info->final_chunk) {  // where that stretch stopped: the member's trailer
@@ -57,6 +65,12 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     if (info->n_bytes && !d_text) return HPN_E_ARG;
     HPN_HIP(c, launch_gz_translate(sym, sym_cap, c->g_meta.p, n_chunks, (const uint8_t *)c->g_windows.p, d_text, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
+    if (dbg) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev_beg[kFamInflate], c->ev_end[kFamInflate]);
+        fprintf(stderr, "[hpn_gz] %u stretches: scratch %.3f s, inflate + histories %.3f s (inflate kernel %.1f ms), translate %.3f s, %.1f MB of text\n",
+                n_chunks, t1 - t0, t2 - t1, ms, now() - t2, info->n_bytes / 1e6);
+    }
     return HPN_OK;
 }
 

@@ -11,9 +11,8 @@
 //                     reaches in front of the stretch's own output produces.  The stretch must end
 //                     on its given end bit exactly at a block boundary (or at the final block),
 //                     which is what makes the next stretch's start a proven block boundary.
-//   k_gz_windows      one workgroup walks the stretches in order: the resolved last 32 KiB of a
-//                     stretch are the history of the next (LDS ping-pong); also the running text
-//                     offsets.
+//   k_gz_windows      one small workgroup walks the stretches in order: the resolved last 32 KiB of a
+//                     stretch are the history of the next; also the running text offsets.
 //   k_gz_translate    symbols -> bytes through each stretch's history, compacted into one text.
 //
 // Bounds: k_gz_sym_inflate is bound by the scalar issue of the serial symbol loop like
@@ -224,20 +223,22 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
     }
 }
 
-// One workgroup: histories in stream order.  windows + k * 32768 = the 32 KiB before stretch k.
-constexpr int kGzWinThreads = 1024;
+// One small workgroup: histories in stream order.  windows + k * 32768 = the 32 KiB before stretch k (n_chunks + 1 of
+// them: the last is the history after the batch).  The histories live in global memory, not LDS, and the workgroup is 4
+// waves: it has to find room on a chip whose CUs are packed with inflate waves of other contexts (18 x 8.7 KiB of LDS),
+// and with a 64 KiB LDS image it waited for up to a whole stretch time (0.17 s) to be placed.  Each step reads a region
+// that was written in the step before (never read earlier, so no stale cache line), behind a barrier.
+constexpr int kGzWinThreads = 256;
 __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
                                                               GzMeta *__restrict__ meta, uint32_t n_chunks,
-                                                              const uint8_t *__restrict__ window_in, uint8_t *__restrict__ windows,
+                                                              const uint8_t *__restrict__ window_in, uint8_t *windows,
                                                               uint8_t *__restrict__ window_out, u64 *__restrict__ summary)
 {
-    __shared__ uint8_t w[2][kGzHist];
     const int tid = threadIdx.x;
-    for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) w[0][j] = window_in ? window_in[j] : 0;
+    for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) windows[j] = window_in ? window_in[j] : 0;
     __syncthreads();
     u64 text = 0;
     uint32_t bad = 0, bad_at = 0, fin = 0;
-    int cur = 0;
     for (uint32_t k = 0; k < n_chunks; ++k) {
         const uint32_t n = meta[k].n_out, st = meta[k].status;
         if (st && !bad) bad = st, bad_at = k;
@@ -245,24 +246,31 @@ __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__
         if (tid == 0) meta[k].text_off = text;
         text += n;
         const uint16_t *sym = symbuf + (uint64_t)k * sym_cap;
-        uint8_t *wk = windows + (uint64_t)k * kGzHist;
-        for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) {
-            wk[j] = w[cur][j];
-            const int64_t p = (int64_t)n - (int64_t)kGzHist + (int64_t)j;
-            uint8_t v;
-            if (p >= 0) {
-                const uint32_t sv = sym[p];
-                v = sv < 256u ? (uint8_t)sv : w[cur][sv - 256u];
-            } else {
-                v = w[cur][(int64_t)kGzHist + p];
+        const uint8_t *cur = windows + (uint64_t)k * kGzHist;
+        uint8_t *nxt = windows + (uint64_t)(k + 1) * kGzHist;
+        // 128 positions per thread, 16 at a time: 16 independent symbol loads, then 16 independent history look-ups
+        // (one position after the other this step took 67 us -- two dependent global loads x 128 -- and the whole walk
+        // 0.2 s for 2,800 stretches)
+        constexpr int kBatch = 16;
+        for (uint32_t j0 = (uint32_t)tid; j0 < kGzHist; j0 += kGzWinThreads * kBatch) {
+            uint32_t sv[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const int64_t p = (int64_t)n - (int64_t)kGzHist + (int64_t)(j0 + (uint32_t)q * kGzWinThreads);
+                sv[q] = p >= 0 ? (uint32_t)sym[p] : 256u + (uint32_t)((int64_t)kGzHist + p);  // before the stretch: the history itself
             }
-            w[cur ^ 1][j] = v;
+            uint8_t v[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) v[q] = sv[q] < 256u ? (uint8_t)sv[q] : cur[sv[q] - 256u];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) nxt[j0 + (uint32_t)q * kGzWinThreads] = v[q];
         }
         __syncthreads();
-        cur ^= 1;
     }
-    if (window_out)
-        for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) window_out[j] = w[cur][j];
+    if (window_out) {
+        const uint8_t *last = windows + (uint64_t)n_chunks * kGzHist;
+        for (uint32_t j = (uint32_t)tid; j < kGzHist; j += kGzWinThreads) window_out[j] = last[j];
+    }
     if (tid == 0) summary[0] = text, summary[1] = bad, summary[2] = bad_at, summary[3] = fin;
 }
 

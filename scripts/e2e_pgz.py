@@ -32,16 +32,20 @@ def t(cmd, env):
 for tool, args in (("fastq_count", []), ("fastq_count", ["-L"]), ("fastq_trim", ["-s", "5", "-e", "120", "-o", "t", "-i"])):
     outs = []
     for who, exe, env in (("reference", os.path.join(REF, tool), {}),
-                          ("hpngs two-pass parallel", os.path.join(BIN, tool), {}),
-                          ("hpngs 4 inflate threads", os.path.join(BIN, tool), {"HPN_GZ_THREADS": "4"}),
+                          ("hpngs GPU two-pass inflate", os.path.join(BIN, tool), {}),
+                          ("hpngs host two-pass (16 thr)", os.path.join(BIN, tool), {"HPN_GZ_GPU": "0"}),
+                          ("hpngs host two-pass, 4 thr", os.path.join(BIN, tool), {"HPN_GZ_GPU": "0", "HPN_GZ_THREADS": "4"}),
                           ("hpngs serial decoder", os.path.join(BIN, tool), {"HPN_NO_PGZ": "1"}),
                           ("hpngs zlib", os.path.join(BIN, tool), {"HPN_NO_PGZ": "1", "HPN_FAST_INFLATE": "0"})):
         if not os.access(exe, os.X_OK):
             continue
         dt, out = t([exe] + args + [one], env)
+        if "GPU" in who:
+            p = subprocess.run([exe] + args + [one], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **env, "HPN_TIMING": "1"})
+            print("      " + " | ".join(l for l in p.stderr.decode().splitlines() if "gzip" in l), flush=True)
         if tool == "fastq_trim":
             out = subprocess.run("md5sum < t.trim.fastq", shell=True, cwd=td, stdout=subprocess.PIPE).stdout
         outs.append(out)
-        print(f"{tool + ' ' + ' '.join(args):34s} {who:24s} {dt:7.3f} s  {reads*rl/dt/1e9:6.3f} Gbases/s", flush=True)
+        print(f"{tool + ' ' + ' '.join(args):34s} {who:30s} {dt:7.3f} s  {reads*rl/dt/1e9:6.3f} Gbases/s", flush=True)
     print("   outputs identical:", len(set(outs)) == 1, flush=True)
 subprocess.run(["rm", "-rf", td])

@@ -4,6 +4,7 @@ import os
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 import orc
@@ -165,6 +166,42 @@ def test_bgzipped_fastq_is_inflated_on_the_gpu(tmp_path):
         else:
             assert outs[0] == outs[1] == outs[2] == outs[3], name
             assert outs[0][1].startswith(b"Total_reads: ") and len(outs[0][0]) > 100000
+
+
+def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
+    """A plain .fastq.gz (one member): the host finds deflate block starts, the GPU inflates the stretches with the
+    history unknown, resolves it and frames the text; the report equals zlib's route for several stretch sizes and
+    batch splits.  Files the route must hand back: two members, trailing bytes, damage, non-FASTQ text."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(8)
+    n = 30000
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n, 100))
+    qual = rng.integers(35, 74, (n, 100), dtype=np.uint8)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, seq[i].tobytes(), qual[i].tobytes()) for i in range(n))   # 6.4 MB
+    files = {"one.fq.gz": gzip.compress(text, 6), "lvl1.fq.gz": gzip.compress(text, 1),
+             "two.fq.gz": gzip.compress(text[:len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 6),
+             "tail.fq.gz": gzip.compress(text, 6) + b"trailing bytes\n",
+             "ragged.fq.gz": gzip.compress(text + b"@x\nACGT\n+\nII\n" + text[:3000], 6)}
+    bad = bytearray(files["one.fq.gz"])
+    bad[len(bad) // 2] ^= 0x10
+    files["bad.fq.gz"] = bytes(bad)
+    for name, blob in files.items():
+        (tmp_path / name).write_bytes(blob)
+        ref = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", name], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             env={**os.environ, "HPN_NO_MGZ": "1", "HPN_NO_BGZF": "1"})
+        for env in ({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "7"}):
+            p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", name], cwd=tmp_path, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, env={**os.environ, "HPN_TIMING": "1", **env})
+            assert p.returncode == ref.returncode, p.stderr.decode()
+            if name != "bad.fq.gz":   # (what survives a damaged stream depends on the reader)
+                assert p.stdout == ref.stdout, (name, env)
+            used = b"[hpn] gzip on the GPU" in p.stderr
+            assert used == (name in ("one.fq.gz", "lvl1.fq.gz")), (name, env, p.stderr)
+    want = orc.fastq_count_report([str(tmp_path / "one.fq.gz")], names=["one.fq.gz"], header=True, length_detail=True)
+    assert ref is not None and subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "one.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,
+                                              env={**os.environ, "HPN_GZ_GPU_FORCE": "1"}).stdout == want
 
 
 def test_fastq_trim_reports_total_reads(tmp_path):
