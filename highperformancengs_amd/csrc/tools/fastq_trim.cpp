@@ -70,11 +70,36 @@ int main(int argc, char *argv[])
     // or irregular text: the output is emptied and the file goes through the paths below from its first byte.
     const bool to_file = !(strncmp(outfile, "-", 1) == 0 || !strcmp(outfile, ""));
     const bool from_file = !(strncmp(infile, "-", 1) == 0 || !strcmp(infile, ""));
+    // device text -> trimmed text, in 64 MB slices (each with its own pinned output buffer); false: irregular text
+    const size_t slice = (size_t)64 << 20, ocap = slice + 8192 + 64;
+    auto cut_device_text = [&](AsyncWriter &writer, const uint8_t *d_text, uint64_t total, bool fin) {
+        for (uint64_t at = 0; at < total || (fin && total == 0);) {
+            const uint64_t k = total - at < slice ? total - at : slice;
+            hpn_text_info info;
+            int oi;
+            void *obuf = writer.acquire(&oi);
+            rc = hpn_fastq_text_trim(ctx, d_text + at, k, fin && at + k == total, start, end, obuf, ocap, &info);
+            if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_text_trim");
+            if (info.irregular) {
+                writer.submit(oi, 0);
+                return false;
+            }
+            writer.submit(oi, info.n_bytes);
+            reads += info.n_records;
+            at += k;
+            if (total == 0) break;
+        }
+        return true;
+    };
+    auto start_over = [&] {
+        fflush(out);
+        if (ftruncate(fileno(out), 0) != 0 || fseek(out, 0, SEEK_SET) != 0) die_hpn(ctx, HPN_E_STATE, "fastq_trim: cannot rewind the output");
+        reads = 0;
+    };
     if (!exact && to_file && from_file && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(infile)) {
         BgzfGpuStream gs;
         bool usable = gs.open_text(ctx, infile);
         if (usable) {
-            const size_t slice = (size_t)64 << 20, ocap = slice + 8192 + 64;
             AsyncWriter writer(ctx, out, ocap);
             if (!writer.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
             if ((rc = hpn_fastq_text_begin(ctx)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
@@ -86,34 +111,55 @@ int main(int argc, char *argv[])
                     break;
                 }
                 fin = r == 0 || gs.at_eof();
-                const uint64_t total = r == 0 ? 0 : bi.n_records;  // text mode: bytes inflated
-                for (uint64_t at = 0; at < total || (fin && total == 0);) {
-                    const uint64_t k = total - at < slice ? total - at : slice;
-                    hpn_text_info info;
-                    int oi;
-                    void *obuf = writer.acquire(&oi);
-                    rc = hpn_fastq_text_trim(ctx, gs.d_raw() + at, k, fin && at + k == total, start, end, obuf, ocap, &info);
-                    if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_text_trim");
-                    if (info.irregular) {
-                        writer.submit(oi, 0);
-                        usable = false;
-                        break;
-                    }
-                    writer.submit(oi, info.n_bytes);
-                    reads += info.n_records;
-                    at += k;
-                    if (total == 0) break;
-                }
+                usable = cut_device_text(writer, gs.d_raw(), r == 0 ? 0 : bi.n_records, fin);  // text mode: n_records = bytes inflated
             }
             writer.finish();
         }
-        if (usable) {
-            done = true;
-        } else {  // start over
-            fflush(out);
-            if (ftruncate(fileno(out), 0) != 0 || fseek(out, 0, SEEK_SET) != 0) die_hpn(ctx, HPN_E_STATE, "fastq_trim: cannot rewind the output");
-            reads = 0;
+        if (usable) done = true;
+        else start_over();
+    }
+    // a plain .fastq.gz (one member): block starts found here, the stretches inflated on the GPU (host/gz_gpu.hpp)
+    // Writing the trimmed text is as slow as the host's own two-pass inflate on 16 cores (1.1 s vs 1.25 s on 3 GB), so
+    // this route is taken when the host has few cores (or when asked for: HPN_GZ_GPU=1)
+    const char *want_gz_gpu = getenv("HPN_GZ_GPU");
+    const bool gz_on_gpu = gz_gpu_enabled() && (usable_cpus() <= 8 || (want_gz_gpu && want_gz_gpu[0] == '1') || getenv("HPN_GZ_GPU_FORCE"));
+    if (!done && !exact && to_file && from_file && gz_on_gpu && !getenv("HPN_NO_MGZ") && !getenv("HPN_NO_PGZ") &&
+        is_plain_gzip_file(infile)) {
+        GzGpuStream gs;
+        const long cpus = usable_cpus();
+        uint32_t per_call = 4608;
+        if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
+        // several device calls per file, so that the writer thread has text to write while the next part is inflated:
+        // a quarter of the file per call, in stretches small enough to fill the chip each time
+        size_t stretch = 0;
+        struct stat sb;
+        if (!getenv("HPN_GZ_STRETCH") && stat(infile, &sb) == 0) {
+            stretch = ((size_t)sb.st_size / 4 / 4608 + 65536) & ~(size_t)65535;
+            stretch = stretch < ((size_t)256 << 10) ? (size_t)256 << 10 : stretch > ((size_t)2 << 20) ? (size_t)2 << 20 : stretch;
         }
+        bool usable = gs.open(ctx, infile, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call, stretch);
+        if (usable) {
+            AsyncWriter writer(ctx, out, ocap);
+            if (!writer.ok()) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
+            if ((rc = hpn_fastq_text_begin(ctx)) != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
+            for (bool fin = false; usable && !fin;) {
+                uint64_t n = 0;
+                const int r = gs.next(&n);
+                if (r < 0) {
+                    usable = false;
+                    break;
+                }
+                fin = r == 0 || gs.at_end();
+                usable = cut_device_text(writer, gs.d_text(), n, fin);
+            }
+            writer.finish();
+            if (getenv("HPN_TIMING"))
+                fprintf(stderr, usable ? "[hpn] gzip on the GPU: block starts %.3f s, upload %.3f s, device inflate %.3f s\n"
+                                       : "[hpn] gzip route on the GPU abandoned (%.3f / %.3f / %.3f s)\n",
+                        gs.seconds_find(), gs.seconds_upload(), gs.seconds_device());
+        }
+        if (usable) done = true;
+        else start_over();
     }
     if (done) {
     } else if (!exact) {

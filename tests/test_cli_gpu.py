@@ -199,6 +199,18 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
                 assert p.stdout == ref.stdout, (name, env)
             used = b"[hpn] gzip on the GPU" in p.stderr
             assert used == (name in ("one.fq.gz", "lvl1.fq.gz")), (name, env, p.stderr)
+    # fastq_trim to a file takes the same route; whatever it has to hand back (here also: a read shorter than -s) starts over
+    for name in ("one.fq.gz", "two.fq.gz", "ragged.fq.gz", "tail.fq.gz"):
+        outs = []
+        for k, env in enumerate(({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "90000", "HPN_GZ_BATCH": "11"},
+                                 {"HPN_GZ_GPU": "0"}, {"HPN_NO_MGZ": "1", "HPN_TEXT": "0"})):
+            p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", name, "-o", f"t{k}", "-s", "5", "-e", "60"], cwd=tmp_path,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "HPN_TIMING": "1", **env})
+            assert p.returncode == 0, p.stderr.decode()
+            outs.append((open(tmp_path / f"t{k}.trim.fastq", "rb").read(), [l for l in p.stderr.split(b"\n") if l.startswith(b"Total_reads")]))
+            if k < 2:
+                assert (b"[hpn] gzip on the GPU" in p.stderr) == (name == "one.fq.gz"), (name, p.stderr)
+        assert outs[0] == outs[1] == outs[2] == outs[3], name
     want = orc.fastq_count_report([str(tmp_path / "one.fq.gz")], names=["one.fq.gz"], header=True, length_detail=True)
     assert ref is not None and subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "one.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,
                                               env={**os.environ, "HPN_GZ_GPU_FORCE": "1"}).stdout == want
