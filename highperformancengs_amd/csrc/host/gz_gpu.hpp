@@ -44,7 +44,7 @@ public:
     }
 
     // threads: block-start searchers.  max_stretches: per device call.  stretch_bytes 0: HPN_GZ_STRETCH, else the file
-    // size / max_stretches within 256 KiB .. 2 MiB (the search costs ~0.4 ms per stretch).
+    // size / max_stretches within 256 KiB .. 1 MiB (the search costs ~0.4 ms per stretch).
     bool open(hpn_ctx *ctx, const char *path, int threads, uint32_t max_stretches, size_t stretch_bytes = 0)
     {
         ctx_ = ctx;
@@ -66,7 +66,7 @@ public:
             const char *e = getenv("HPN_GZ_STRETCH");
             stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / max_stretches_ + 65536) & ~(uint64_t)65535);
             if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
-            if (!e && stretch_bytes > ((size_t)2 << 20)) stretch_bytes = (size_t)2 << 20;
+            if (!e && stretch_bytes > ((size_t)1 << 20)) stretch_bytes = (size_t)1 << 20;  // (symbol scratch: ~12 bytes per compressed byte in flight)
         }
         if (stretch_bytes < 4096) stretch_bytes = 4096;
         stretch_ = stretch_bytes;
@@ -152,6 +152,9 @@ public:
         for (uint64_t k = 0; k < slices; ++k)
             if (found[(size_t)k] != kGzNone) starts_.push_back(found[(size_t)k]);
         const uint32_t n = (uint32_t)starts_.size();
+        // text compressed the usual way has a block start in every slice; a file where most slices show none is not
+        // what this route is for (one wavefront would crawl through megabytes)
+        if (slices >= 8 && (uint64_t)n * 2 < slices) return give_up("hardly any block starts found: not gzip'ed text") - 1;
         // ---- the rest of the compressed bytes, up to a little beyond the batch's end ----
         const uint64_t stop_byte = last_batch ? size_ : ((end_bit >> 3) + 4096 < size_ ? (end_bit >> 3) + 4096 : size_);
         const uint64_t comp_bytes = stop_byte - base_byte;

@@ -135,7 +135,7 @@ int main(int argc, char *argv[])
         struct stat sb;
         if (!getenv("HPN_GZ_STRETCH") && stat(infile, &sb) == 0) {
             stretch = ((size_t)sb.st_size / 4 / 4608 + 65536) & ~(size_t)65535;
-            stretch = stretch < ((size_t)256 << 10) ? (size_t)256 << 10 : stretch > ((size_t)2 << 20) ? (size_t)2 << 20 : stretch;
+            stretch = stretch < ((size_t)256 << 10) ? (size_t)256 << 10 : stretch > ((size_t)1 << 20) ? (size_t)1 << 20 : stretch;
         }
         bool usable = gs.open(ctx, infile, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call, stretch);
         if (usable) {
