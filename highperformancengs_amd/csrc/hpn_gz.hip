@@ -10,7 +10,7 @@ namespace hpn {
 hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, uint32_t n_chunks, uint16_t *d_sym, uint32_t sym_cap,
                                  void *d_meta, int n_cu, hipStream_t st);
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
-                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, hipStream_t st);
+                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st);
 hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
                                uint8_t *d_text, hipStream_t st);
 }
@@ -47,7 +47,7 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamInflate], c->stream));
     c->ev_valid[kFamInflate] = true;
     HPN_HIP(c, launch_gz_windows(sym, sym_cap, c->g_meta.p, n_chunks, d_window_in, (uint8_t *)c->g_windows.p, d_window_out,
-                                 (u64 *)c->g_summary.p, c->stream));
+                                 (u64 *)c->g_summary.p, c->n_cu, c->stream));
     u64 summary[4] = {0, 0, 0, 0};
     HPN_HIP(c, hipMemcpyAsync(summary, c->g_summary.p, sizeof summary, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));

@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
 // waves: it has to find room on a chip whose CUs are packed with inflate waves of other contexts (18 x 8.7 KiB of LDS),
 // and with a 64 KiB LDS image it waited for up to a whole stretch time (0.17 s) to be placed.  Each step reads a region
 // that was written in the step before (never read earlier, so no stale cache line), behind a barrier.
-constexpr int kGzWinThreads = 256;
+// (kGzWinThreads = 1024 when the call holds enough stretches to have had the chip to itself: 32 positions per thread and step.)
+template <int kGzWinThreads>
 __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
                                                               GzMeta *__restrict__ meta, uint32_t n_chunks,
                                                               const uint8_t *__restrict__ window_in, uint8_t *windows,
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__
         // 128 positions per thread, 16 at a time: 16 independent symbol loads, then 16 independent history look-ups
         // (one position after the other this step took 67 us -- two dependent global loads x 128 -- and the whole walk
         // 0.2 s for 2,800 stretches)
-        constexpr int kBatch = 16;
+        constexpr int kBatch = kGzWinThreads >= 1024 ? 8 : 16;
         for (uint32_t j0 = (uint32_t)tid; j0 < kGzHist; j0 += kGzWinThreads * kBatch) {
             uint32_t sv[kBatch];
 #pragma unroll
@@ -314,10 +315,14 @@ hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, ui
     return hipGetLastError();
 }
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
-                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, hipStream_t st)
+                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_gz_windows, dim3(1), dim3(kGzWinThreads), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in,
-                       d_windows, d_window_out, d_summary);
+    if (n_chunks > (uint32_t)n_cu * 6u)
+        hipLaunchKernelGGL(k_gz_windows<1024>, dim3(1), dim3(1024), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in,
+                           d_windows, d_window_out, d_summary);
+    else
+        hipLaunchKernelGGL(k_gz_windows<256>, dim3(1), dim3(256), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in,
+                           d_windows, d_window_out, d_summary);
     return hipGetLastError();
 }
 hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
