@@ -175,7 +175,7 @@ public:
             c.start_bit = (uint32_t)(s & 7);
             c.end_bit = e == kGzNone ? kGzNone : e - (s & ~(uint64_t)7);
             const uint64_t room = stop_byte - (s >> 3);
-            c.in_len = room > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)room;
+            c.in_len = room > 0x7fffff00ull ? 0x7fffff00u : (uint32_t)room;  // (the kernel adds small constants to it in 32 bits)
         }
         if (!reserve(d_chunks_, cap_chunks_, (size_t)n * sizeof(hpn_gz_chunk))) return give_up("device memory") - 1;
         if (hpn_memcpy_h2d(ctx_, d_chunks_, h_chunks_, (size_t)n * sizeof(hpn_gz_chunk)) != HPN_OK) return give_up("copy failed") - 1;
