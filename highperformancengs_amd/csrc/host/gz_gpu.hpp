@@ -61,10 +61,11 @@ public:
         threads_ = threads < 1 ? 1 : threads;
         max_stretches_ = max_stretches < 1 ? 1 : max_stretches > 65535u ? 65535u : max_stretches;
         if (!stretch_bytes) {
-            // as many stretches as the device call may hold, so that one call fills the chip: a wavefront inflates ~4.5 MB
+            // as many stretches as the device calls may hold, so that every call fills the chip: a wavefront inflates ~4.5 MB
             // of text per second whatever the stretch size, so only the number of waves in flight matters
             const char *e = getenv("HPN_GZ_STRETCH");
-            stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / max_stretches_ + 65536) & ~(uint64_t)65535);
+            const uint64_t calls = (size_ + ((uint64_t)max_stretches_ << 20) - 1) / ((uint64_t)max_stretches_ << 20);  // at 1 MiB per stretch
+            stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 65536) & ~(uint64_t)65535);
             if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
             if (!e && stretch_bytes > ((size_t)1 << 20)) stretch_bytes = (size_t)1 << 20;  // (symbol scratch: ~12 bytes per compressed byte in flight)
         }
