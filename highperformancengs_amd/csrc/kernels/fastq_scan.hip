@@ -178,7 +178,10 @@ hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint6
     const char *ev = getenv("HPN_K1_VARIANT"), *eg = getenv("HPN_K1_WG_PER_CU");
     const int variant = ev ? atoi(ev) : 811;
     const int unroll = variant / 100;
-    const uint64_t per_cu = eg ? (uint64_t)atoi(eg) : 4;  // 4 workgroups of 4 waves per CU (sweep: 4 >= 8 >= 16)
+    // workgroups (4 waves each) per CU.  Long launches: 2 -- same-session sweep over 158 GB: 2 -> 24.01 ms, 3 -> 24.35,
+    // 4 -> 24.51, 6 -> 24.63, 8/16 slower still (profiles/r01e/k1_sweep_wg.txt; a loads-only kernel reads 6.6-6.9 TB/s
+    // with 2 per CU, 6.3-6.4 with 4: profiles/r01e/hbm_read_ubench.txt).  Short launches keep 4 for the latency.
+    const uint64_t per_cu = eg ? (uint64_t)atoi(eg) : (approx_bytes >= (1ull << 30) ? 2 : 4);
     if (unroll <= 0) return hipErrorInvalidValue;
     const uint64_t tiles = approx_bytes / (16ull * kScanThreads * unroll) + n / (2 * kPairTile) + 2;
     const uint64_t want = (variant % 10) ? (tiles + kChunkTiles - 1) / kChunkTiles : tiles;

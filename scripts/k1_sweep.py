@@ -17,7 +17,8 @@ do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
 ctx.synth_fastq_dev(1, 0, n, L, dq, None, do)
 ctx.sync()
 alg = n * L + (n + 1) * 8
-variants = [(v, wg) for v in (410, 411, 800, 801, 810, 811, 1610, 1611) for wg in (4, 8, 16)]
+wgs = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (4, 8, 16)
+variants = [(v, wg) for v in (410, 411, 800, 801, 810, 811, 1610, 1611) for wg in wgs]
 times = {v: [] for v in variants}
 ref = None
 for r in range(rounds + 1):
