@@ -26,6 +26,42 @@ __global__ __launch_bounds__(256) void k_read(const u32x4 *__restrict__ p, size_
     sink[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// the same loads, but a workgroup's U rows of 4 KiB are ADJACENT (one 4*U KiB tile per step, tiles grid-strided): K1's layout
+template <int U>
+__global__ __launch_bounds__(256) void k_read_tile(const u32x4 *__restrict__ p, size_t n_vec, u32x4 *__restrict__ sink)
+{
+    const size_t tile = (size_t)U * 256, n_tiles = n_vec / tile;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const u32x4 *q = p + t * tile + threadIdx.x;
+        u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = __builtin_nontemporal_load(q + k * 256);
+#pragma unroll
+        for (int k = 0; k < U; ++k) acc |= v[k];
+    }
+    sink[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+template <int U>
+static double run_tile(const u32x4 *d, size_t n_vec, u32x4 *sink, int grid, int reps)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    hipLaunchKernelGGL((k_read_tile<U>), dim3(grid), dim3(256), 0, 0, d, n_vec, sink);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL((k_read_tile<U>), dim3(grid), dim3(256), 0, 0, d, n_vec, sink);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
 template <int U, bool NT>
 static double run(const u32x4 *d, size_t n_vec, u32x4 *sink, int grid, int reps)
 {
@@ -58,12 +94,15 @@ int main(int argc, char **argv)
     hipMemset(d, 0x5a, bytes);
     hipDeviceSynchronize();
     printf("%s, %d CUs, %.1f GB read per launch (best of 5)\n", prop.name, n_cu, bytes / 1e9);
-    for (int wg = 2; wg <= 16; wg *= 2) {
+    for (int wg = 1; wg <= 16; wg = wg < 4 ? wg + 1 : wg * 2) {
         const int grid = n_cu * wg;
         const double t4 = run<4, true>(d, n_vec, sink, grid, 5), t8 = run<8, true>(d, n_vec, sink, grid, 5), t16 = run<16, true>(d, n_vec, sink, grid, 5),
                      p8 = run<8, false>(d, n_vec, sink, grid, 5);
         printf("wg/cu=%2d  nt x4 %7.3f ms %7.1f GB/s | nt x8 %7.3f ms %7.1f GB/s | nt x16 %7.3f ms %7.1f GB/s | plain x8 %7.3f ms %7.1f GB/s\n", wg, t4,
                bytes / t4 / 1e6, t8, bytes / t8 / 1e6, t16, bytes / t16 / 1e6, p8, bytes / p8 / 1e6);
+        const double c4 = run_tile<4>(d, n_vec, sink, grid, 5), c8 = run_tile<8>(d, n_vec, sink, grid, 5), c16 = run_tile<16>(d, n_vec, sink, grid, 5);
+        printf("          adjacent rows (tile per workgroup): x4 %7.3f ms %7.1f GB/s | x8 %7.3f ms %7.1f GB/s | x16 %7.3f ms %7.1f GB/s\n", c4,
+               bytes / c4 / 1e6, c8, bytes / c8 / 1e6, c16, bytes / c16 / 1e6);
     }
     return 0;
 }
