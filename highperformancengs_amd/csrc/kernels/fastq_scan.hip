@@ -91,16 +91,32 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
         }
         const uint64_t e_tail = e0 + 2 * (wbase + (uint64_t)(kPairPerThread - 1) * kWave) + 2;
         const uint64_t tail = (lane_id() == kWave - 1 && e_tail <= n) ? off[e_tail] : 0;
+        uint32_t la[kPairPerThread], lb[kPairPerThread];
 #pragma unroll
         for (int k = 0; k < kPairPerThread; ++k) {
-            const uint64_t p = wbase + (uint64_t)k * kWave;
-            const uint64_t e = e0 + 2 * p;
             const uint64_t from_next = __shfl_down(v[k][0], 1, kWave);
             const uint64_t next_row = k + 1 < kPairPerThread ? __shfl(v[k + 1 < kPairPerThread ? k + 1 : k][0], 0, kWave) : tail;
             const uint64_t after = lane_id() == kWave - 1 ? next_row : from_next;
             const uint64_t l0 = v[k][1] - v[k][0], l1 = after - v[k][1];
-            hist_len(s_hist, p < npair && e < n, l0 < HPN_LEN_BINS ? (uint32_t)l0 : (uint32_t)HPN_LEN_BINS);
-            hist_len(s_hist, p < npair && e + 1 < n, l1 < HPN_LEN_BINS ? (uint32_t)l1 : (uint32_t)HPN_LEN_BINS);
+            la[k] = l0 < HPN_LEN_BINS ? (uint32_t)l0 : (uint32_t)HPN_LEN_BINS;
+            lb[k] = l1 < HPN_LEN_BINS ? (uint32_t)l1 : (uint32_t)HPN_LEN_BINS;
+        }
+        // the whole span valid and of one length (fixed-length reads, every tile but the last): ONE add for its 1024 records
+        const uint64_t p_last = wbase + (uint64_t)(kPairPerThread - 1) * kWave;
+        const uint32_t first = (uint32_t)__shfl((int)la[0], 0, kWave);
+        bool same = p_last < npair && e0 + 2 * p_last + 1 < n;
+#pragma unroll
+        for (int k = 0; k < kPairPerThread; ++k) same = same && la[k] == first && lb[k] == first;
+        if (__ballot(!same) == 0) {
+            if (lane_id() == 0) atomicAdd(&s_hist[first], (uint32_t)(2 * kWave * kPairPerThread));
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < kPairPerThread; ++k) {
+            const uint64_t p = wbase + (uint64_t)k * kWave;
+            const uint64_t e = e0 + 2 * p;
+            hist_len(s_hist, p < npair && e < n, la[k]);
+            hist_len(s_hist, p < npair && e + 1 < n, lb[k]);
         }
     };
     auto do_tile = [&](uint64_t t) {  // (spreading the offset tiles among the byte tiles instead was no faster)
