@@ -5,8 +5,8 @@
 // simply be cut into pieces.  What can be done (the published "pugz" idea, restated here):
 //
 //   1. cut the COMPRESSED file into chunks; in each chunk find the first deflate block that starts
-//      there -- try every bit position, keep the one where a dynamic-Huffman header parses, two
-//      blocks in a row decode, and everything they produce is text;
+//      there -- try every bit position, keep the one where a dynamic-Huffman header parses, the
+//      block and the beginning of the next one decode, and everything they produce is text;
 //   2. inflate every chunk from its block start with the 32 KiB of history UNKNOWN: the output is
 //      16-bit symbols, a byte value or "whatever byte history[i] turns out to be" (256 + i); match
 //      copies move the placeholders along like any other symbol (fast_inflate.hpp, T = uint16_t);
@@ -95,7 +95,7 @@ inline uint16_t *gz_find_scratch()  // per thread: kGzFindScratch symbols behind
     }
     return store.data() + kGzFindHist;
 }
-// First bit position in [lo, hi) of data[0..size) where two dynamic-Huffman blocks in a row decode to text; kGzNone if
+// First bit position in [lo, hi) of data[0..size) where a dynamic-Huffman block and the start of the next decode to text; kGzNone if
 // there is none.  Per candidate position, cheapest test first: BFINAL = 0 / BTYPE = 2 / HLIT <= 29 / HDIST <= 29
 // (RFC 1951 3.2.7); then the code-length code (HCLEN + 4 three-bit lengths) must be a complete prefix code or zlib's
 // inftrees rejects it -- Kraft sum = 1, ~20 operations that turn away ~99 % of what got this far; only then tables are
@@ -129,9 +129,13 @@ inline uint64_t gz_find_block_start(const uint8_t *data, uint64_t size, uint64_t
             uint16_t *out = scratch;
             int r = fi.run(out, scratch + cap, scratch - kGzFindHist);
             if (r != FastInflateT<uint16_t>::kBlockEnd || out == scratch || !gz_texty(scratch, (size_t)(out - scratch))) continue;
+            // ... and the next block must at least begin like one (header parses, tables build, the first symbols decode
+            // to text).  Decoding it to its end as well would double the cost of a search for nothing: whoever uses the
+            // start proves it anyway (a stretch has to arrive exactly there from a proven start).
             uint16_t *mid = out;
-            r = fi.run(out, scratch + cap, scratch - kGzFindHist);
-            if ((r != FastInflateT<uint16_t>::kBlockEnd && r != FastInflateT<uint16_t>::kDone) || !gz_texty(mid, (size_t)(out - mid))) continue;
+            uint16_t *const stop = out + 256 < scratch + cap ? out + 256 : scratch + cap;
+            r = fi.run(out, stop, scratch - kGzFindHist);
+            if (r == FastInflateT<uint16_t>::kError || !gz_texty(mid, (size_t)((out < stop ? out : stop) - mid))) continue;
             return p;
         }
     }
