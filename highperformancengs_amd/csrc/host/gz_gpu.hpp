@@ -94,6 +94,8 @@ public:
     }
     const uint8_t *d_text() const { return (const uint8_t *)d_text_; }
     const char *why() const { return why_; }  // what made open() / next() give up
+    double ratio() const { return ratio_; }     // text bytes per compressed byte over the member's first megabytes
+    uint64_t file_bytes() const { return size_; }
     double seconds_find() const { return t_find_; }
     double seconds_upload() const { return t_upload_; }
     double seconds_device() const { return t_device_; }
