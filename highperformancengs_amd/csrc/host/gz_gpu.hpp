@@ -44,7 +44,7 @@ public:
     }
 
     // threads: block-start searchers.  max_stretches: per device call.  stretch_bytes 0: HPN_GZ_STRETCH, else the file
-    // size / max_stretches within 256 KiB .. 1 MiB (the search costs ~0.4 ms per stretch).
+    // size / max_stretches within 256 KiB .. 1.5 MiB (the search costs ~0.4 ms per stretch).
     bool open(hpn_ctx *ctx, const char *path, int threads, uint32_t max_stretches, size_t stretch_bytes = 0)
     {
         ctx_ = ctx;
@@ -64,10 +64,11 @@ public:
             // as many stretches as the device calls may hold, so that every call fills the chip: a wavefront inflates ~4.5 MB
             // of text per second whatever the stretch size, so only the number of waves in flight matters
             const char *e = getenv("HPN_GZ_STRETCH");
-            const uint64_t calls = (size_ + ((uint64_t)max_stretches_ << 20) - 1) / ((uint64_t)max_stretches_ << 20);  // at 1 MiB per stretch
+            const uint64_t kMaxStretch = (uint64_t)3 << 19;  // 1.5 MiB: ~0.5 s of one wavefront; the search is per stretch, so few and long
+            const uint64_t calls = (size_ + max_stretches_ * kMaxStretch - 1) / (max_stretches_ * kMaxStretch);
             stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 65536) & ~(uint64_t)65535);
             if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
-            if (!e && stretch_bytes > ((size_t)1 << 20)) stretch_bytes = (size_t)1 << 20;  // (symbol scratch: ~12 bytes per compressed byte in flight)
+            if (!e && stretch_bytes > kMaxStretch) stretch_bytes = (size_t)kMaxStretch;  // (symbol scratch: ~12 bytes per compressed byte in flight)
         }
         if (stretch_bytes < 4096) stretch_bytes = 4096;
         stretch_ = stretch_bytes;
