@@ -60,18 +60,6 @@ public:
         if (!body) return give_up("no gzip header");
         threads_ = threads < 1 ? 1 : threads;
         max_stretches_ = max_stretches < 1 ? 1 : max_stretches > 65535u ? 65535u : max_stretches;
-        if (!stretch_bytes) {
-            // as many stretches as the device calls may hold, so that every call fills the chip: a wavefront inflates ~4.5 MB
-            // of text per second whatever the stretch size, so only the number of waves in flight matters
-            const char *e = getenv("HPN_GZ_STRETCH");
-            const uint64_t kMaxStretch = (uint64_t)3 << 19;  // 1.5 MiB: ~0.5 s of one wavefront; the search is per stretch, so few and long
-            const uint64_t calls = (size_ + max_stretches_ * kMaxStretch - 1) / (max_stretches_ * kMaxStretch);
-            stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 65536) & ~(uint64_t)65535);
-            if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
-            if (!e && stretch_bytes > kMaxStretch) stretch_bytes = (size_t)kMaxStretch;  // (symbol scratch: ~12 bytes per compressed byte in flight)
-        }
-        if (stretch_bytes < 4096) stretch_bytes = 4096;
-        stretch_ = stretch_bytes;
         // symbols of scratch per stretch: from the expansion of the member's first megabytes (FASTQ is homogeneous; a
         // stretch that needs more is decoded again with twice the room)
         {
@@ -84,6 +72,21 @@ public:
             const double in = (double)(fi.in_pos() - body) + 1, out = (double)(o - probe.data()) + 1;
             ratio_ = out / in < 1.0 ? 1.0 : out / in;
         }
+        if (!stretch_bytes) {
+            // as many stretches as the device calls may hold, so that every call fills the chip: a wavefront inflates ~4.5 MB
+            // of text per second whatever the stretch size, so only the number of waves in flight matters
+            const char *e = getenv("HPN_GZ_STRETCH");
+            // at most 1.5 MiB (~0.5 s of one wavefront; the search is per stretch, so few and long), less for text that
+            // expands a lot: the symbol scratch is ~3 bytes per byte of text in flight
+            uint64_t kMaxStretch = (uint64_t)((double)((uint64_t)3 << 19) * (ratio_ > 2.0 ? 2.0 / ratio_ : 1.0));
+            if (kMaxStretch < ((uint64_t)512 << 10)) kMaxStretch = (uint64_t)512 << 10;
+            const uint64_t calls = (size_ + max_stretches_ * kMaxStretch - 1) / (max_stretches_ * kMaxStretch);
+            stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 65536) & ~(uint64_t)65535);
+            if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
+            if (!e && stretch_bytes > kMaxStretch) stretch_bytes = (size_t)kMaxStretch;  // (symbol scratch: ~12 bytes per compressed byte in flight)
+        }
+        if (stretch_bytes < 4096) stretch_bytes = 4096;
+        stretch_ = stretch_bytes;
         sym_cap_ = cap_for(ratio_ * 1.4);
         first_bit_ = (uint64_t)(body - data_) * 8;
         next_start_ = first_bit_;
