@@ -257,7 +257,9 @@ int hpn_bgzf_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_bgzf_blo
  * exceeds text_cap: HPN_E_CAPACITY, nothing written), status = 0 or the first failing stretch's
  * decoder code (bad_chunk says which), final_chunk = 1 + index of the stretch that ended at a
  * final block (0: none), end_bit = bit position that stretch reached (the member trailer).
- * Synchronous.  CRC-32 is not checked (ISIZE is the caller's to check). */
+ * Synchronous.  CRC-32 is not checked (ISIZE is the caller's to check).  in_len < 2^31.
+ * status codes: 1-11 malformed block header or code tables, 12/14 out of symbol scratch (sym_cap), 13/15 invalid
+ * code in the data, 17 ran past in_len, 20 the stretch did not end on end_bit at a block boundary. */
 typedef struct hpn_gz_chunk {
     uint64_t in_off;
     uint64_t end_bit;
