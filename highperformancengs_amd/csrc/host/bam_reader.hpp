@@ -317,19 +317,38 @@ private:
     bool fetch()
     {
         int32_t block_size;
+        bool have = false;
+        if (corrupt_) return false;
         if (const uint8_t *h = z_.peek(4)) {
             memcpy(&block_size, h, 4);
+            if (block_size < 32) return corrupt();
             if (const uint8_t *q = z_.peek(4 + (size_t)block_size)) {
                 z_.skip(4 + (size_t)block_size);
                 p_ = q + 4;
-                return true;
+                have = true;
             }
         }
-        if (z_.read(&block_size, 4) != 4) return false;
-        rec_.resize((size_t)block_size);
-        if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return false;
-        p_ = rec_.data();
+        if (!have) {
+            if (z_.read(&block_size, 4) != 4) return false;
+            if (block_size < 32) return corrupt();
+            rec_.resize((size_t)block_size);
+            if (z_.read(rec_.data(), rec_.size()) != rec_.size()) return false;
+            p_ = rec_.data();
+        }
+        // bam_read1 (bam.c:191) trusts l_read_name / n_cigar_op / l_seq and the reference's callbacks then read
+        // past the record; here a record whose fields do not fit its block_size ends the file with a message
+        uint32_t bin_mq_nl, flag_nc, l_seq;
+        memcpy(&bin_mq_nl, p_ + 8, 4), memcpy(&flag_nc, p_ + 12, 4), memcpy(&l_seq, p_ + 16, 4);
+        if (l_seq > 0x7fffffffu || 32ull + (bin_mq_nl & 0xff) + 4ull * (flag_nc & 0xffff) + (((uint64_t)l_seq + 1) >> 1) + l_seq >
+                                       (uint64_t)block_size)
+            return corrupt();
         return true;
+    }
+    bool corrupt()
+    {
+        if (!corrupt_) fprintf(stderr, "[hpn] corrupt BAM record (fields do not fit block_size): reading stops here\n");
+        corrupt_ = true;
+        return false;
     }
     void append(BamBatch &b, bool want_seq)
     {
@@ -356,6 +375,7 @@ private:
     std::vector<uint8_t> rec_;
     const uint8_t *p_ = nullptr;
     bool pending_ = false;
+    bool corrupt_ = false;
 };
 
 }  // namespace hpn

@@ -61,6 +61,14 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_count(const uint8_t *__rest
             broken = true;
             break;
         }
+        // the variable-length fields must fit the record (bam_read1 trusts them, bam.c:191; the later kernels
+        // read name, CIGAR and sequence in place, so a record that lies about them is caught here)
+        const uint32_t l_name = p[at + 12u], n_cigar = ld16(p + at + 16u), l_seq = ld32(p + at + 20u);
+        if (l_seq > 0x7fffffffu ||
+            32ull + l_name + 4ull * n_cigar + (((uint64_t)l_seq + 1u) >> 1) + (uint64_t)l_seq > (uint64_t)bs) {
+            broken = true;
+            break;
+        }
         const int32_t tid = (int32_t)ld32(p + at + 4u);
         lo = tid < lo ? tid : lo, hi = tid > hi ? tid : hi;
         at += 4u + bs;

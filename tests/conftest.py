@@ -27,5 +27,11 @@ def golden_path(*parts):
 
 
 def expected(case, name="stdout"):
-    with open(os.path.join(GOLDEN, "expected", case, name), "rb") as f:
+    """Bytes the reference tool produced; reports over 1 MiB are stored gzip-compressed."""
+    path = os.path.join(GOLDEN, "expected", case, name)
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        import gzip
+        with gzip.open(path + ".gz", "rb") as f:
+            return f.read()
+    with open(path, "rb") as f:
         return f.read()

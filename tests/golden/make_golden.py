@@ -156,6 +156,20 @@ def make_bam_inputs():
     recs.append(bamio.BamRecord(tid=1, pos=49990, flag=0, cigar=bamio.parse_cigar("100M"), seq="C" * 100, name="over"))
     recs.append(bamio.BamRecord(tid=-1, pos=-1, flag=4, cigar=[], seq="ACGT", name="unm"))
     bamio.write_bam(f"{BAM}/rand.bam", refs, recs)
+    # bam_sliding_count's window index is an unsigned short (bam_sliding_count.c:117): a contig with
+    # len/W >= 65536 windows makes reads beyond window 65535 land in window (pos/W) mod 65536
+    rnd = random.Random(65536)
+    refs = [("w1", 200000), ("w2", 1000)]
+    recs = []
+    pos = sorted([0, 2, 3, 196605, 196607, 196608, 196609, 196610, 196611, 199990] +
+                 [rnd.randrange(0, 199900) for _ in range(150)])
+    for i, p in enumerate(pos):
+        ln = rnd.choice([1, 2, 7, 50, 75])
+        seq = "".join(rnd.choice("ACGTN" if rnd.random() < .1 else "ACGT") for _ in range(ln))
+        recs.append(bamio.BamRecord(tid=0, pos=p, flag=rnd.choice([0, 16, 1024, 256]),
+                                    cigar=bamio.parse_cigar(f"{ln}M"), seq=seq, name=f"w{i}"))
+    recs.append(bamio.BamRecord(tid=1, pos=10, flag=0, cigar=bamio.parse_cigar("5M"), seq="GGCCA", name="w2a"))
+    bamio.write_bam(f"{BAM}/wrap.bam", refs, recs)
 
 
 CASES = []
@@ -175,9 +189,14 @@ def run_case(name, tool, args, inputs, cwd_outputs=True):
         p = subprocess.run([os.path.join(REF, tool)] + args, cwd=td, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE)
         w(os.path.join(out_dir, "stdout"), p.stdout)
-        files = sorted(set(os.listdir(td)) - before)
+        # bam_sliding_count also plots <bam>_hits.png (draw_hits, libgd): not part of the scan path, not recorded
+        files = sorted(f for f in set(os.listdir(td)) - before if not f.endswith("_hits.png"))
         for f in files:
-            shutil.copy(os.path.join(td, f), os.path.join(out_dir, f))
+            if os.path.getsize(os.path.join(td, f)) > (1 << 20):   # large reports are stored gzip-compressed
+                with open(os.path.join(td, f), "rb") as fh:
+                    gz(os.path.join(out_dir, f + ".gz"), fh.read(), 9)
+            else:
+                shutil.copy(os.path.join(td, f), os.path.join(out_dir, f))
     CASES.append({"name": name, "tool": tool, "args": args,
                   "inputs": [os.path.relpath(i, HERE) for i in inputs],
                   "returncode": p.returncode, "files": files})
@@ -237,6 +256,19 @@ def main():
     run_case("wig_rand", "bam2wig", ["-o", "w", "rand.bam"], [bm("rand.bam")])
     run_case("wig_rand_w1000", "bam2wig", ["-w", "1000", "-o", "w", "rand.bam"], [bm("rand.bam")])
     run_case("wig_rand_w37", "bam2wig", ["-w", "37", "-o", "w", "e.bam", "rand.bam"], [bm("e.bam"), bm("rand.bam")])
+    # ---- bam_sliding_count (built with the reference's vendored libgd + libpng) ---------------
+    run_case("sliding_a3", "bam_sliding_count", ["-w", "100", "-o", "s", "e.bam"], [bm("e.bam")])
+    run_case("sliding_rand", "bam_sliding_count", ["rand.bam"], [bm("rand.bam")])             # -w 20000, out.txt
+    run_case("sliding_rand_w700", "bam_sliding_count", ["-w", "700", "-o", "s", "rand.bam"], [bm("rand.bam")])
+    run_case("sliding_rand_w37", "bam_sliding_count", ["-w", "37", "-o", "s", "rand.bam"], [bm("rand.bam")])
+    run_case("sliding_region", "bam_sliding_count", ["-w", "1000", "-r", "chr2:1,001-20000", "-o", "reg", "rand.bam"],
+             [bm("rand.bam")])
+    run_case("sliding_region_chr", "bam_sliding_count", ["-w", "5000", "-r", "chr1", "-o", "reg", "rand.bam"], [bm("rand.bam")])
+    run_case("sliding_two_files", "bam_sliding_count", ["-w", "500", "-o", "two", "e.bam", "rand.bam"],
+             [bm("e.bam"), bm("rand.bam")])                                                  # only file 0 is reported (:416)
+    run_case("sliding_two_files_rev", "bam_sliding_count", ["-w", "5000", "-o", "two", "rand.bam", "e.bam"],
+             [bm("rand.bam"), bm("e.bam")])
+    run_case("sliding_wrap", "bam_sliding_count", ["-w", "3", "-o", "wr", "wrap.bam"], [bm("wrap.bam")])
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "reference_tools": "oracle/_ref (compiled from /root/reference by oracle/Makefile)",

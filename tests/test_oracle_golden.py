@@ -195,16 +195,51 @@ def test_bam2wig_text(case, bam, W, n):
 
 
 # ---- bam_sliding_count ------------------------------------------------------------
-# The reference tool needs libgd headers (gd.h, gdfontg.h) that this image lacks,
-# so it cannot be compiled here; the only pin is SURVEY.md Appendix A.3.
+# expected/sliding_* are the bytes of the real tool, built by oracle/Makefile with the libgd and libpng
+# the reference vendors (gd-2.1.1.tar.gz, libpng-1.6.17.tar.gz).
+
+SLIDING = [("sliding_a3", "e.bam", 100, "s.txt"), ("sliding_rand", "rand.bam", 20000, "out.txt"),
+           ("sliding_rand_w700", "rand.bam", 700, "s.txt"), ("sliding_rand_w37", "rand.bam", 37, "s.txt"),
+           ("sliding_two_files", "e.bam", 500, "two.txt"),          # only the first input file is reported
+           ("sliding_two_files_rev", "rand.bam", 5000, "two.txt"),
+           ("sliding_wrap", "wrap.bam", 3, "wr.txt")]               # 66,667 windows: the unsigned-short index wraps
+
+
+@pytest.mark.parametrize("case,bam,W,out", SLIDING)
+def test_sliding_count_report(manifest, case, bam, W, out):
+    c = manifest[case]
+    assert c["inputs"][0].endswith(bam) and c["files"] == [out] and c["returncode"] == 0
+    assert ("-w" in c["args"] and int(c["args"][c["args"].index("-w") + 1]) == W) or W == 20000
+    soa = bamio.read_bam_records(BAM(bam))
+    assert orc.window_report(soa, W) == expected(case, out)
+
+
+@pytest.mark.parametrize("case,tid,beg,end,W,line", [("sliding_region", 1, 1000, 20000, 1000, b"chr2\t1000\t20000\n"),
+                                                     ("sliding_region_chr", 0, 0, 1 << 29, 5000, b"chr1\t0\t536870912\n")])
+def test_sliding_count_region(case, tid, beg, end, W, line):
+    assert expected(case) == line          # bam_sliding_count.c:405
+    soa = bamio.read_bam_records(BAM("rand.bam"))
+    assert orc.window_report(orc.region_subset(soa, tid, beg, end), W) == expected(case, "reg.txt")
+
+
+def test_sliding_count_wrap_is_recorded():
+    # the golden case really exercises (unsigned short)(pos/W): a read at 196,608 = 65536*3 is counted in window 1
+    rows = expected("sliding_wrap", "wr.txt").split(b"\n")
+    r = rows[1].split(b"\t")
+    assert r[0] == b"w1" and len(r) == 6 + 3 * 66667
+    soa = bamio.read_bam_records(BAM("wrap.bam"))
+    hi = soa.pos[(soa.tid == 0) & (soa.pos >= 65536 * 3)]
+    assert len(hi) >= 5
+    assert all(r[6 + 3 * k + 1] == b"0" for k in range(65536, 66667))      # nothing is ever counted beyond window 65535
+    want0 = int(((soa.tid == 0) & ((soa.pos // 3) % 65536 == 0)).sum())
+    assert int(r[7]) == want0 and want0 > int(((soa.tid == 0) & (soa.pos // 3 == 0)).sum())
+
 
 def test_sliding_count_appendix_a3():
-    soa = bamio.read_bam_records(BAM("e.bam"))
-    text = orc.window_report(soa, 100).split(b"\n")
-    assert text[0].startswith(b"#chr\tchr_len\tchr_sum_read_count\tchr_sum_base\tchr_mean_cov\tchr_mean_GC%\t1\tcount\tGC%")
-    assert text[0].count(b"\tcount\t") == 11
-    r1 = text[1].split(b"\t")
-    r2 = text[2].split(b"\t")
+    rows = expected("sliding_a3", "s.txt").split(b"\n")
+    assert rows[0].startswith(b"#chr\tchr_len\tchr_sum_read_count\tchr_sum_base\tchr_mean_cov\tchr_mean_GC%\t1\tcount\tGC%")
+    assert rows[0].count(b"\tcount\t") == 11
+    r1, r2 = rows[1].split(b"\t"), rows[2].split(b"\t")
     assert r1[:12] == b"c1\t1000\t7\t60\t0.060000\t53.333336\t1\t5\t48.888889\t2\t1\t100.000000".split(b"\t")
     assert r2[:12] == b"c2\t500\t3\t30\t0.060000\t56.666668\t1\t3\t56.666668\t2\t0\t0.000000".split(b"\t")
     assert len(r1) == 6 + 3 * 11 and len(r2) == 6 + 3 * 6
