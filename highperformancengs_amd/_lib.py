@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhpngs.so")
+LIB_PATH = os.environ.get("HPN_LIB") or os.path.join(HERE, "libhpngs.so")   # HPN_LIB: A/B runs of a variant build
 
 LEN_BINS, QUAL_ROWS, NUC_CODES = 512, 128, 5
 W_SEQLEN, W_TOTAL, W_Q20, W_Q30, W_BAD, W_QUAL = 0, 512, 513, 514, 515, 516

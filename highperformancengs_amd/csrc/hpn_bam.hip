@@ -6,11 +6,16 @@
 #include "hpn_ctx.hpp"
 
 namespace hpn {
-hipError_t launch_depth_scatter(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
-                                const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
-                                uint64_t slots, uint32_t *bad, int n_cu, hipStream_t st);
-uint64_t depth_scan_tiles(uint64_t slots);
-hipError_t launch_depth_scan(const int32_t *diff, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
+hipError_t launch_depth_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
+                            const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots,
+                            void *ws, uint32_t *bad, int n_cu, hipStream_t st);
+hipError_t launch_depth_add_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
+                                uint64_t slots, void *ws, uint32_t *bad, int n_cu, hipStream_t st);
+size_t depth_index_bytes(uint64_t slots);
+hipError_t depth_index_reset(void *ws, uint64_t slots, hipStream_t st);
+const uint32_t *depth_written(void *ws, uint64_t slots);
+size_t depth_scan_bytes(uint64_t slots);
+hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
                              uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st);
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
                              const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint32_t W, int32_t n_targets,
@@ -22,8 +27,6 @@ hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_b
                             const u64 *bases, uint64_t *rec_off, hipStream_t st);
 hipError_t launch_raw_fields(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t *tid, int32_t *pos, uint32_t *flag,
                              int32_t *l_qseq, uint64_t *seq_off, int n_cu, hipStream_t st);
-hipError_t launch_depth_scatter_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask,
-                                    int32_t *diff, uint64_t slots, uint32_t *bad, int n_cu, hipStream_t st);
 }  // namespace hpn
 
 using namespace hpn;
@@ -56,9 +59,11 @@ int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_
     if (slots > kPosLimit) slots = kPosLimit;
     int rc = scratch_reserve(c, c->d_diff, slots * sizeof(int32_t) + 64);
     if (rc != HPN_OK) return rc;
-    if ((rc = scratch_reserve(c, c->d_ws, 16 + 2 * depth_scan_tiles(slots) * sizeof(u64) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->d_ws, depth_scan_bytes(slots) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->d_tidx, depth_index_bytes(slots) + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->w_misc, 64)) != HPN_OK) return rc;
-    HPN_HIP(c, hipMemsetAsync(c->d_diff.p, 0, slots * sizeof(int32_t), c->stream));
+    // the 1 GB array is NOT cleared: K3 writes whole tiles and a per-tile word says which ones hold data
+    HPN_HIP(c, depth_index_reset(c->d_tidx.p, slots, c->stream));
     HPN_HIP(c, hipMemsetAsync(c->w_misc.p, 0, 64, c->stream));  // word 0: domain flag of the scatter
     c->depth_open = true;
     c->depth_tid = tid;
@@ -71,9 +76,10 @@ int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_
 
 static int depth_add_common(hpn_ctx *c, const hpn_bam_batch *b)
 {
+    if (b->n > 0xfffffff0ull) return fail(c, HPN_E_ARG, "more than 2^32 records in one hpn_depth_add call");
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
-    HPN_HIP(c, launch_depth_scatter(b->tid, b->pos, b->flag, b->cigar_off, b->cigar, b->n, c->depth_tid, c->depth_mask,
-                                    (int32_t *)c->d_diff.p, c->depth_slots, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
+    HPN_HIP(c, launch_depth_add(b->tid, b->pos, b->flag, b->cigar_off, b->cigar, b->n, c->depth_tid, c->depth_mask,
+                                (int32_t *)c->d_diff.p, c->depth_slots, c->d_tidx.p, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
     c->ev_valid[kFamDepth] = true;
     c->depth_scanned = false;
@@ -124,8 +130,8 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
         const uint64_t dev_cap = c->d_runs.cap / sizeof(hpn_run);
         HPN_HIP(c, hipMemsetAsync(c->d_win.p, 0, windows * sizeof(u64), c->stream));
         HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
-        HPN_HIP(c, launch_depth_scan((const int32_t *)c->d_diff.p, c->depth_slots, c->depth_len, W, (hpn_run *)c->d_runs.p,
-                                     dev_cap, (u64 *)c->d_win.p, c->d_ws.p, c->stream));
+        HPN_HIP(c, launch_depth_scan((const int32_t *)c->d_diff.p, depth_written(c->d_tidx.p, c->depth_slots), c->depth_slots,
+                                     c->depth_len, W, (hpn_run *)c->d_runs.p, dev_cap, (u64 *)c->d_win.p, c->d_ws.p, c->stream));
         HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
         c->ev_valid[kFamDepth] = true;
         HPN_HIP(c, hipMemcpyAsync(&head, c->d_ws.p, sizeof head, hipMemcpyDeviceToHost, c->stream));
@@ -135,7 +141,8 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
             return fail(c, HPN_E_DOMAIN, "a CIGAR M block ends at or beyond position %llu (2^28 key limit of the reference, "
                         "or more than %llu bases past the contig end)", (unsigned long long)c->depth_slots,
                         (unsigned long long)kOverhang);
-        if (head.err) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
+        if (head.err & 1u) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
+        if (head.err & 2u) return fail(c, HPN_E_DOMAIN, "coverage of 2^30 or more on this target");
         if (head.n_runs <= dev_cap) break;
         // device buffer too small for this chromosome: grow it and redo the pass (diff is read-only)
         if ((rc = scratch_reserve(c, c->d_runs, head.n_runs * sizeof(hpn_run))) != HPN_OK) return rc;
@@ -154,6 +161,7 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
     HPN_HIP(c, hipStreamSynchronize(c->stream));
     return HPN_OK;
 }
+
 
 // ---- records in place in inflated BGZF blocks -------------------------------------------------
 
@@ -195,8 +203,9 @@ int hpn_depth_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
     if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_add before hpn_depth_begin");
     HPN_HIP(c, hipSetDevice(c->device));
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
-    HPN_HIP(c, launch_depth_scatter_raw(d_raw, (const uint64_t *)c->r_off.p, c->r_n, c->depth_tid, c->depth_mask, (int32_t *)c->d_diff.p,
-                                        c->depth_slots, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
+    if (c->r_n > 0xfffffff0ull) return fail(c, HPN_E_ARG, "more than 2^32 records in one batch");
+    HPN_HIP(c, launch_depth_add_raw(d_raw, (const uint64_t *)c->r_off.p, c->r_n, c->depth_tid, c->depth_mask, (int32_t *)c->d_diff.p,
+                                    c->depth_slots, c->d_tidx.p, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
     c->ev_valid[kFamDepth] = true;
     c->depth_scanned = false;

@@ -1,55 +1,283 @@
 // bam_depth.hip -- gfx950 kernels behind hpn_depth_* (include/hpngs.h).
 //
 // Replaces, for one target (chromosome) at a time:
-//   fetch_func      (reference bam2depth.c:86-110)  -> k_depth_scatter (K3)
-//   hash2BedGraph   (bam2depth.c:203-236) + overlap (:132-176) -> k_depth_scan (K4)
+//   fetch_func      (reference bam2depth.c:86-110)  -> K3: k_depth_index + k_depth_tiles (+ k_depth_fill, k_depth_far)
+//   hash2BedGraph   (bam2depth.c:203-236) + overlap (:132-176) -> K4: k_depth_scan
 //
-// The reference keeps two string-keyed hash tables (Start/End breakpoints), sorts
-// the union of keys and sweeps it.  Here the breakpoints live in a dense
-// difference array diff[0 .. target_len + slack) of int32 in HBM:
-//   K3: one lane per record: filter, walk the (short) CIGAR, atomicAdd +1 / -1.
-//   K4: ONE pass over diff: inclusive prefix sum = coverage (never materialised),
-//       change points -> runs (start, end, depth) of depth > 0 written in order,
-//       per-window sums of coverage.  Two decoupled look-back chains (scan.hpp)
-//       carry the coverage prefix and the run count between workgroups.
-// Bounds: K3 atomic rate (2 x 4 B per M block); K4 HBM read of 4 B per position,
-// + 12 B per run + 8 B per window written.
+// The reference keeps two string-keyed hash tables (Start/End breakpoints), sorts the union of keys and
+// sweeps it.  Here the breakpoints live in a dense difference array diff[0 .. target_len + slack) of int32
+// in HBM, cut into tiles of 16384 positions (64 KiB), the unit of both kernels.
+//
+// K3.  bam2depth needs an index, so its input is coordinate-sorted, and a sorted batch turns the scatter
+// into a gather: a workgroup OWNS one tile of positions, looks up which records can put a breakpoint
+// into it (a contiguous range of the batch: pos in [tile start - kReach, tile end)), walks their CIGARs,
+// adds +1 / -1 into an LDS image of the tile and writes the tile with plain coalesced 16-byte stores.
+// No global atomic, no zero-fill of the 1 GB array beforehand: a per-tile `written` word says whether the
+// tile holds data (then the flush adds to it) or has never been touched (then the scan reads it as zeros
+// without loading it).  The per-record atomics this replaces ran at the memory-side atomic rate with 64
+// lanes in ~20 different 64-byte segments (1.86 ms per 5e7 records).
+//   k_depth_index   one pass over (tid, pos): is the batch sorted by (tid, pos)?  where do the records of
+//                   the wanted target start and end, and for every tile threshold inside their position
+//                   range: the first record at or beyond it (two lattices: tile start, tile start - kReach).
+//   k_depth_tiles   the gather described above.  A breakpoint further than kReach behind its record's
+//                   pos (long D / N operations) is "far": the tile that owns the record's pos counts it
+//                   and marks the target tile as needed, k_depth_fill zero-fills needed tiles that were never
+//                   written and k_depth_far adds the far breakpoints with global atomics (it returns at
+//                   once when there are none).  An unsorted batch takes the same two kernels for ALL its
+//                   breakpoints: the per-record atomic scatter of round 1.
+// K4.  ONE pass over diff: prefix sum = coverage (never materialised), change points -> runs (start, end,
+// depth) of depth > 0 written in order, per-window sums of coverage.  ONE decoupled look-back chain
+// carries (coverage, runs started): see DepthSum.
+// Bounds: HBM.  K3 reads 16 B + 4 B x n_cigar per record (x 1.125 for the reach overlap) and writes 4 B per
+// position of the tiles it touches; K4 reads 4 B per written position and writes 12 B per run + 8 B per window.
 #include <stdlib.h>
 
 #include "scan.hpp"
 
 namespace hpn {
 
+// Tile shapes were swept in one session (profiles/r02/k3_k4_sweeps.txt): K3 runs at 0.59-0.62 ms per 5e7 records for
+// tiles of 4096 .. 16384 positions and any unroll (it moves 2.2 GB at 4.7 TB/s, reads and writes mixed).
+constexpr int kTile = 16384;                // positions per K3 tile = granularity of the `written` words
+constexpr int kTileThreads = kTile / 16;    // 16 positions per lane in the flush
+constexpr uint32_t kReach = 2048;           // breakpoints up to this far behind pos are gathered by the owner tile
+constexpr int kTileUnroll = 4;              // records per lane in flight in k_depth_tiles
+
+// ---- record accessors: SoA batch (hpn_bam_batch) or records in place in inflated BGZF blocks ----------
+struct SoaRecs {
+    const int32_t *tid, *pos;
+    const uint32_t *flag, *cigar_off, *cigar;
+    __device__ __forceinline__ void key(uint64_t r, int32_t &t, uint32_t &p) const { t = tid[r], p = (uint32_t)pos[r]; }
+    __device__ __forceinline__ bool open(uint64_t r, int32_t want, uint32_t mask, uint32_t &p, const uint32_t *&cig, uint32_t &n) const
+    {
+        const int32_t t = tid[r];                                 // all five loads issue together
+        const uint32_t f = flag[r], c0 = cigar_off[r], c1 = cigar_off[r + 1];
+        p = (uint32_t)pos[r];                                     // unsigned int temp_start = c->pos (:93)
+        cig = cigar + c0, n = c1 - c0;
+        return t == want && !(f & mask);                          // bam2depth.c:90
+    }
+    static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k) { return cig[k]; }
+};
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// bam1_core_t on disk behind block_size (bam.h:178-187): refID @4, pos @8, l_read_name @12, n_cigar_op @16, flag @18
+struct RawRecs {
+    const uint8_t *raw;
+    const uint64_t *rec_off;
+    __device__ __forceinline__ void key(uint64_t r, int32_t &t, uint32_t &p) const
+    {
+        const uint8_t *q = raw + rec_off[r];
+        t = (int32_t)ld32u(q + 4), p = ld32u(q + 8);
+    }
+    __device__ __forceinline__ bool open(uint64_t r, int32_t want, uint32_t mask, uint32_t &p, const uint32_t *&cig, uint32_t &n) const
+    {
+        const uint8_t *q = raw + rec_off[r];
+        const uint32_t flag_nc = ld32u(q + 16), t = ld32u(q + 4), l_name = q[12];
+        p = ld32u(q + 8);
+        cig = reinterpret_cast<const uint32_t *>(q + 36u + l_name);
+        n = flag_nc & 0xffffu;
+        return (int32_t)t == want && !((flag_nc >> 16) & mask);
+    }
+    static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k)
+    {
+        return ld32u(reinterpret_cast<const uint8_t *>(cig) + 4u * k);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // K3
 // ---------------------------------------------------------------------------
-constexpr int kScatThreads = 256;
+// head[]: per-add state, cleared before k_depth_index
+enum { kHdFlags = 0, kHdFar = 1, kHdR0 = 2, kHdR1 = 3, kHdPmin = 4, kHdPmax = 5, kHdWords = 8 };
+constexpr uint32_t kUnsorted = 1u;
 
-__global__ __launch_bounds__(kScatThreads) void k_depth_scatter(
-    const int32_t *__restrict__ rec_tid, const int32_t *__restrict__ rec_pos, const uint32_t *__restrict__ rec_flag,
-    const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, uint64_t n, int32_t tid,
-    uint32_t flag_mask, int32_t *__restrict__ diff, uint64_t slots, uint32_t *__restrict__ bad)
+struct TileIndex {
+    uint32_t *head;       // [kHdWords]
+    uint32_t *first_hi;   // [ntiles + 1]  first record with pos >= t * kTile          (valid for pmin < threshold <= pmax)
+    uint32_t *first_lo;   // [ntiles + 1]  first record with pos >= t * kTile - kReach (valid likewise)
+    uint32_t *written;    // [ntiles]      the tile holds data
+    uint32_t *need;       // [ntiles]      a far breakpoint targets the tile
+    uint32_t ntiles;
+};
+
+constexpr int kIdxThreads = 256;
+
+template <typename Recs>
+__global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t n, int32_t want, TileIndex ix)
 {
-    for (uint64_t r = (uint64_t)blockIdx.x * kScatThreads + threadIdx.x; r < n;
-         r += (uint64_t)gridDim.x * kScatThreads) {
-        // bam2depth.c:90: flag & BAM_DEF_MASK or tid < 0 -> skipped; other targets are not ours
-        if (rec_tid[r] != tid || tid < 0 || (rec_flag[r] & flag_mask)) continue;
-        uint64_t p = (uint32_t)rec_pos[r];  // unsigned int temp_start = c->pos (:93)
-        const uint32_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
-        for (uint32_t k = c0; k < c1; ++k) {
-            const uint32_t w = cigar[k], op = w & 0xfu, len = w >> 4;
-            if (op == 2u || op == 3u) {          // D, N: advance only
-                p += len;
-            } else if (op == 0u) {               // M: +1 at the block start, -1 one past its end
-                const uint64_t e = p + len;
-                if (e >= slots) {                // breakpoint beyond the dense array (>= 2^28 or huge overhang)
+    for (uint64_t i = (uint64_t)blockIdx.x * kIdxThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kIdxThreads) {
+        int32_t t, tp = 0, tn = 0;
+        uint32_t p, pp = 0, pn = 0;
+        recs.key(i, t, p);
+        if (i) {
+            recs.key(i - 1, tp, pp);
+            // sort order of a BAM: refID as unsigned (unmapped, -1, last), then pos
+            const u64 ka = ((u64)(uint32_t)tp << 32) | pp, kb = ((u64)(uint32_t)t << 32) | p;
+            if (ka > kb) atomicOr(&ix.head[kHdFlags], kUnsorted);
+        }
+        if (t != want) continue;
+        const bool first = i == 0 || tp != want;
+        bool last = i + 1 == n;
+        if (!last) {
+            recs.key(i + 1, tn, pn);
+            last = tn != want;
+        }
+        if (first) ix.head[kHdR0] = (uint32_t)i, ix.head[kHdPmin] = p;
+        if (last) ix.head[kHdR1] = (uint32_t)i + 1u, ix.head[kHdPmax] = p;
+        if (!first && pp < p) {
+            // thresholds in (pp, p]: this is the first record at or beyond them
+            for (u64 k = (u64)pp / kTile + 1; k <= (u64)p / kTile && k <= ix.ntiles; ++k) ix.first_hi[k] = (uint32_t)i;
+            for (u64 k = ((u64)pp + kReach) / kTile + 1; k <= ((u64)p + kReach) / kTile && k <= ix.ntiles; ++k)
+                ix.first_lo[k] = (uint32_t)i;
+        }
+    }
+}
+
+// first record of the wanted target with pos >= thr (thr in positions), from the index
+__device__ __forceinline__ uint32_t first_at(const uint32_t *table, uint32_t k, u64 thr, const uint32_t *head)
+{
+    if (head[kHdR0] == head[kHdR1] || thr <= head[kHdPmin]) return head[kHdR0];
+    if (thr > head[kHdPmax]) return head[kHdR1];
+    return table[k];
+}
+
+template <typename Recs>
+__global__ __launch_bounds__(kTileThreads) void k_depth_tiles(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff,
+                                                             uint64_t slots, TileIndex ix, uint32_t *__restrict__ bad)
+{
+    __shared__ int32_t s_d[kTile];
+    const uint32_t t = blockIdx.x;
+    if (ix.head[kHdFlags] & kUnsorted) return;   // k_depth_far does the whole batch
+    const u64 lo = (u64)t * kTile, hi = lo + kTile;
+    const uint32_t r_first = first_at(ix.first_lo, t, lo > kReach ? lo - kReach : 0, ix.head);
+    const uint32_t r_home = first_at(ix.first_hi, t, lo, ix.head);
+    const uint32_t r_end = t + 1 == ix.ntiles ? ix.head[kHdR1] : first_at(ix.first_hi, t + 1, hi, ix.head);
+    if (r_first >= r_end) return;                // nothing can land here: the tile is not touched
+    const int tid = threadIdx.x;
+    const bool add = ix.written[t] != 0;         // read by every wave before the first barrier; set again after the flush
+    {
+        u32 *z = reinterpret_cast<u32 *>(s_d);
+#pragma unroll
+        for (int k = 0; k < kTile / 4 / kTileThreads; ++k) z[k * kTileThreads + tid] = u32{0, 0, 0, 0};
+    }
+    __syncthreads();
+    uint32_t far = 0;
+    // kTileUnroll records per lane at a time: their fields and first CIGAR words are loaded side by side
+    // (one record after the other is a chain of four dependent loads, ~25 us per tile at 30x)
+    for (uint32_t base = r_first; base < r_end; base += kTileUnroll * kTileThreads) {
+        uint32_t p[kTileUnroll], n[kTileUnroll], w0[kTileUnroll], w1[kTileUnroll];
+        const uint32_t *cig[kTileUnroll];
+        bool home[kTileUnroll];
+#pragma unroll
+        for (int u = 0; u < kTileUnroll; ++u) {
+            const uint32_t r = base + u * kTileThreads + tid;
+            n[u] = 0, p[u] = 0, cig[u] = nullptr;
+            if (r < r_end && !recs.open(r, want, flag_mask, p[u], cig[u], n[u])) n[u] = 0;
+            home[u] = r >= r_home;               // the tile that owns pos answers for the record's far breakpoints
+        }
+#pragma unroll
+        for (int u = 0; u < kTileUnroll; ++u) {
+            w0[u] = n[u] > 0 ? Recs::word(cig[u], 0) : 0u;
+            w1[u] = n[u] > 1 ? Recs::word(cig[u], 1) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kTileUnroll; ++u) {
+            u64 q = p[u];
+            for (uint32_t k = 0; k < n[u]; ++k) {
+                const uint32_t w = k == 0 ? w0[u] : k == 1 ? w1[u] : Recs::word(cig[u], k), op = w & 0xfu, len = w >> 4;
+                if (op == 2u || op == 3u) {          // D, N: advance only
+                    q += len;
+                } else if (op == 0u) {               // M: +1 at the block start, -1 one past its end
+                    const u64 e = q + len;
+                    if (e >= slots) {                // breakpoint beyond the dense array (>= 2^28 or huge overhang)
+                        if (home[u]) atomicOr(bad, 1u);
+                        break;
+                    }
+                    if (q - p[u] <= kReach) {
+                        if (q >= lo && q < hi) __hip_atomic_fetch_add(&s_d[q - lo], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (home[u]) {
+                        ++far, ix.need[q / kTile] = 1u;
+                    }
+                    if (e - p[u] <= kReach) {
+                        if (e >= lo && e < hi) __hip_atomic_fetch_add(&s_d[e - lo], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (home[u]) {
+                        ++far, ix.need[e / kTile] = 1u;
+                    }
+                    q = e;
+                }                                    // I, S, H, P, =, X: neither counted nor advanced (:94-107)
+            }
+        }
+    }
+    far = wave_sum(far);
+    if (far && lane_id() == 0) atomicAdd(&ix.head[kHdFar], far);
+    __syncthreads();
+    // flush: consecutive lanes write consecutive 16 bytes, so every store instruction of a wave covers whole lines
+    // (a lane writing its own 64 bytes leaves each line to four instructions: partial-line stores)
+    if (hi <= slots) {
+        u32 *g = reinterpret_cast<u32 *>(diff + lo);
+        const u32 *sv = reinterpret_cast<const u32 *>(s_d);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u32 v = sv[k * kTileThreads + tid];
+            if (add) v += g[k * kTileThreads + tid];
+            g[k * kTileThreads + tid] = v;
+        }
+    } else {
+        for (u64 q = lo + tid; q < slots; q += kTileThreads) diff[q] = s_d[q - lo] + (add ? diff[q] : 0);
+    }
+    if (tid == 0) ix.written[t] = 1u;
+}
+
+// tiles a far breakpoint targets (or every tile, for an unsorted batch) that have never been written: zero them
+__global__ __launch_bounds__(256) void k_depth_fill(int32_t *__restrict__ diff, uint64_t slots, TileIndex ix)
+{
+    const uint32_t t = blockIdx.x;
+    const bool all = ix.head[kHdFlags] & kUnsorted;
+    if (ix.written[t] || !(all || ix.need[t])) return;
+    const u64 lo = (u64)t * kTile;
+    for (int k = threadIdx.x * 4; k < kTile; k += 256 * 4) {
+        if (lo + k + 4 <= slots) *reinterpret_cast<u32 *>(diff + lo + k) = u32{0, 0, 0, 0};
+        else
+            for (int j = 0; j < 4 && lo + k + j < slots; ++j) diff[lo + k + j] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ix.written[t] = 1u, ix.need[t] = 0u;
+}
+
+// the breakpoints k_depth_tiles left out (far ones; all of them for an unsorted batch), with global atomics:
+// fetch_func's loop one lane per record, as in round 1
+constexpr int kFarThreads = 256;
+template <typename Recs>
+__global__ __launch_bounds__(kFarThreads) void k_depth_far(Recs recs, uint64_t n, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff,
+                                                          uint64_t slots, TileIndex ix, uint32_t *__restrict__ bad)
+{
+    const bool all = ix.head[kHdFlags] & kUnsorted;
+    if (!all && ix.head[kHdFar] == 0) return;
+    for (uint64_t r = (uint64_t)blockIdx.x * kFarThreads + threadIdx.x; r < n; r += (uint64_t)gridDim.x * kFarThreads) {
+        uint32_t p, nc;
+        const uint32_t *cig;
+        if (!recs.open(r, want, flag_mask, p, cig, nc)) continue;
+        u64 q = p;
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t w = Recs::word(cig, k), op = w & 0xfu, len = w >> 4;
+            if (op == 2u || op == 3u) {
+                q += len;
+            } else if (op == 0u) {
+                const u64 e = q + len;
+                if (e >= slots) {
                     atomicOr(bad, 1u);
                     break;
                 }
-                atomicAdd(&diff[p], 1);
-                atomicAdd(&diff[e], -1);
-                p = e;
-            }                                    // I, S, H, P, =, X: neither counted nor advanced (:94-107)
+                if (all || q - p > kReach) atomicAdd(&diff[q], 1);
+                if (all || e - p > kReach) atomicAdd(&diff[e], -1);
+                q = e;
+            }
         }
     }
 }
@@ -57,14 +285,123 @@ __global__ __launch_bounds__(kScatThreads) void k_depth_scatter(
 // ---------------------------------------------------------------------------
 // K4
 // ---------------------------------------------------------------------------
-// Tile size: a look-back hop resolves at most 64 tiles (one per lane) and takes ~0.8 us of agent-scope
-// round trips, and with every resident workgroup waiting on the same chain the prefix can only advance by
-// that much per hop -- measured 12 ns per tile on top of a 0.8 ms streaming floor for chr1, whatever the
-// ticket or the dispatch order (a persistent grid and ticket-free tiles changed nothing).  Hence few, large
-// tiles: 256 x 16 -> 1.55 ms, 512 x 16 -> 1.26, 1024 x 16 -> 1.00 (1024 x 20 and up spill).
+// What a stretch of positions tells whoever comes after it, with the coverage c_in at its start unknown:
+//   s   sum of its differences (coverage after it = c_in + s)
+//   m   smallest inclusive prefix inside it
+//   z   positions with a non-zero difference whose inclusive prefix equals m
+//   nz  positions with a non-zero difference
+// Coverage is never negative, so c_in + m >= 0, and a change point lands on coverage 0 only where the prefix
+// equals m and c_in == -m.  Runs started inside the stretch = nz - (c_in == -m ? z : 0).  Two stretches
+// compose associatively, so ONE look-back chain carries both the coverage prefix and the number of runs
+// started (round 1 ran two chains, one after the other: the second needs the first's result).
+struct DepthSum {
+    int32_t s, m;
+    uint32_t z, nz;
+};
+constexpr int32_t kMInf = 0x3fffffff;   // m of the empty stretch; |s| < 2^30 keeps s + kMInf inside int32
+
+__device__ __forceinline__ DepthSum ds_identity() { return DepthSum{0, kMInf, 0u, 0u}; }
+__device__ __forceinline__ DepthSum ds_compose(const DepthSum &a, const DepthSum &b)   // a first, then b
+{
+    const int32_t mb = a.s + b.m, m = a.m < mb ? a.m : mb;
+    return DepthSum{a.s + b.s, m, (a.m == m ? a.z : 0u) + (mb == m ? b.z : 0u), a.nz + b.nz};
+}
+__device__ __forceinline__ DepthSum ds_shfl_up(const DepthSum &v, int o)
+{
+    return DepthSum{__shfl_up(v.s, o, kWave), __shfl_up(v.m, o, kWave), __shfl_up(v.z, o, kWave), __shfl_up(v.nz, o, kWave)};
+}
+__device__ __forceinline__ DepthSum ds_shfl_down(const DepthSum &v, int o)
+{
+    return DepthSum{__shfl_down(v.s, o, kWave), __shfl_down(v.m, o, kWave), __shfl_down(v.z, o, kWave), __shfl_down(v.nz, o, kWave)};
+}
+__device__ __forceinline__ uint32_t ds_starts(const DepthSum &v, int64_t c_in) { return v.nz - ((int64_t)v.m == -c_in ? v.z : 0u); }
+
+constexpr int kLook = 1;       // tiles per lane per look-back hop (2, 4, 8 were slower: more polling loads, same one hop)
+constexpr int kStStride = 8;   // u64 words between the status entries of consecutive tiles: two entries per 128-byte line
+                               // (0.85 -> 0.80 ms against packed entries: fewer pollers per line)
+
+
+// Chain status: 16 bytes per tile = two 8-byte granules {flag:2, a:31, b:31}, (s, m) and (z, nz), each written and
+// read with one agent-scope relaxed access (scan.hpp); a reader takes a tile only when both flags agree.
+__device__ __forceinline__ void ds_publish(u64 *status, uint64_t tile, u64 flag, const DepthSum &v)
+{
+    const u64 h0 = (flag << 62) | ((u64)((uint32_t)v.s & 0x7fffffffu) << 31) | (u64)((uint32_t)v.m & 0x7fffffffu);
+    const u64 h1 = (flag << 62) | ((u64)(v.z & 0x7fffffffu) << 31) | (u64)(v.nz & 0x7fffffffu);
+    __hip_atomic_store(&status[kStStride * tile], h0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&status[kStStride * tile + 1], h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int32_t sext31(uint32_t x) { return (int32_t)(x << 1) >> 1; }
+
+// All lanes of wave 0.  Returns the composition of tiles 0 .. tile-1 and publishes this tile's inclusive prefix.
+__device__ __forceinline__ DepthSum ds_lookback(u64 *status, uint64_t tile, const DepthSum &aggregate, uint32_t *err)
+{
+    if (tile == 0) {
+        if (lane_id() == 0) ds_publish(status, 0, kScanPrefix, aggregate);
+        return ds_identity();
+    }
+    if (lane_id() == 0) ds_publish(status, tile, kScanAggregate, aggregate);
+    DepthSum exclusive = ds_identity();           // of the tiles looked at so far (the newest ones)
+    int64_t idx = (int64_t)tile - 1;              // lane L inspects tiles idx - kLook L - j, j = 0 .. kLook-1
+    // One hop is one round trip (~1 us) whatever it inspects, and every resident workgroup waits on the same chain: with
+    // one tile per lane the prefix advanced 64 tiles per round trip = 16 ns per tile, the floor of the whole kernel.
+    // kLook tiles per lane: 256 per hop, as many as there are resident workgroups.
+    for (;;) {
+        u64 h0[kLook], h1[kLook];
+        uint32_t spins = 0;
+        for (;;) {
+            bool ready = true;
+#pragma unroll
+            for (int j = 0; j < kLook; ++j) {
+                const int64_t t = idx - (int64_t)lane_id() * kLook - j;
+                h0[j] = h1[j] = kScanPrefix << 62;   // tiles before 0: the empty prefix
+                if (t >= 0) {
+                    h0[j] = __hip_atomic_load(&status[kStStride * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h1[j] = __hip_atomic_load(&status[kStStride * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kLook; ++j) ready = ready && (h0[j] >> 62) != kScanInvalid && (h0[j] >> 62) == (h1[j] >> 62);
+            if (__ballot(!ready) == 0) break;
+            if (++spins > kScanSpinLimit) {
+                if (lane_id() == 0) atomicOr(err, 1u);
+                return exclusive;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        // this lane's tiles, oldest first, from its nearest full prefix on (a prefix already holds everything older)
+        DepthSum v = ds_identity();
+        bool mine_prefix = false;
+#pragma unroll
+        for (int j = 0; j < kLook; ++j) {
+            if (mine_prefix) continue;
+            const int64_t t = idx - (int64_t)lane_id() * kLook - j;
+            if (t >= 0)
+                v = ds_compose(DepthSum{sext31((uint32_t)(h0[j] >> 31) & 0x7fffffffu), sext31((uint32_t)h0[j] & 0x7fffffffu),
+                                        (uint32_t)(h1[j] >> 31) & 0x7fffffffu, (uint32_t)h1[j] & 0x7fffffffu}, v);
+            mine_prefix = (h0[j] >> 62) == kScanPrefix;
+        }
+        const u64 has_prefix = __ballot(mine_prefix);
+        const int stop = has_prefix ? __builtin_ctzll(has_prefix) : kWave;   // lane holding the nearest full prefix
+        if (lane_id() > stop) v = ds_identity();
+        // ordered reduction: higher lanes hold older tiles and come first
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const DepthSum older = ds_shfl_down(v, o);
+            if (lane_id() + o < kWave) v = ds_compose(older, v);
+        }
+        const DepthSum win{__shfl(v.s, 0, kWave), __shfl(v.m, 0, kWave), __shfl(v.z, 0, kWave), __shfl(v.nz, 0, kWave)};
+        exclusive = ds_compose(win, exclusive);
+        if (has_prefix) break;
+        idx -= kWave * kLook;
+    }
+    if (lane_id() == 0) ds_publish(status, tile, kScanPrefix, ds_compose(exclusive, aggregate));
+    return exclusive;
+}
+
 constexpr int kDsThreads = 1024;
 constexpr int kDsPer = 16;                       // positions per lane, four 16-byte loads
-constexpr int kDsTile = kDsThreads * kDsPer;     // 16384 positions = 64 KiB per workgroup
+constexpr int kDsTile = kDsThreads * kDsPer;     // positions per workgroup
+static_assert((kDsTile % kTile == 0 || kTile % kDsTile == 0) && kTile % kDsPer == 0, "a lane's positions lie in one K3 tile");
 
 struct DepthOut {
     hpn_run *runs;
@@ -73,13 +410,12 @@ struct DepthOut {
     u64 *win_sum;         // [target_len / W + 1]
 };
 
-__global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__restrict__ diff, uint64_t slots,
-                                                          uint32_t target_len, uint32_t W, DepthOut out,
-                                                          u64 *__restrict__ st_cov, u64 *__restrict__ st_cnt,
-                                                          uint32_t *__restrict__ ticket, uint32_t *__restrict__ err)
+__global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__restrict__ diff, const uint32_t *__restrict__ written,
+                                                          uint64_t slots, uint32_t target_len, uint32_t W, DepthOut out,
+                                                          u64 *__restrict__ status, uint32_t *__restrict__ ticket,
+                                                          uint32_t *__restrict__ err)
 {
-    __shared__ u64 s_w[kDsThreads / kWave];
-    __shared__ u64 s_x;
+    __shared__ DepthSum s_w[kDsThreads / kWave];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
@@ -88,7 +424,11 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     const uint64_t p0 = tile * kDsTile + (uint64_t)tid * kDsPer;  // this lane's first position
 
     int32_t d[kDsPer];
-    if (p0 + kDsPer <= slots) {
+    const bool have = p0 < slots && written[p0 / kTile] != 0;
+    if (!have) {                                 // never touched by K3: zeros, nothing to load
+#pragma unroll
+        for (int k = 0; k < kDsPer; ++k) d[k] = 0;
+    } else if (p0 + kDsPer <= slots) {
         const u32 *v = reinterpret_cast<const u32 *>(diff + p0);
 #pragma unroll
         for (int k = 0; k < kDsPer / 4; ++k) {
@@ -100,58 +440,60 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
         for (int k = 0; k < kDsPer; ++k) d[k] = p0 + k < slots ? diff[p0 + k] : 0;
     }
 
-    // ---- chain 1: coverage prefix ------------------------------------------------
-    int64_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < kDsPer; ++k) mine += d[k];
-    u64 wtot;
-    const u64 wex = wave_excl_scan((u64)mine, wtot);
-    if (lane_id() == kWave - 1) s_w[wave_id()] = wtot;
-    __syncthreads();
-    u64 before = 0, agg = 0;
-#pragma unroll
-    for (int w = 0; w < kDsThreads / kWave; ++w) {
-        if (w < wave_id()) before += s_w[w];
-        agg += s_w[w];
-    }
-    if (wave_id() == 0) {
-        const u64 ex = scan_lookback(st_cov, tile, agg, err);
-        if (lane_id() == 0) s_x = ex;
-    }
-    __syncthreads();
-    // coverage just before this lane's first position (true value is >= 0 and small: the
-    // 62-bit modular arithmetic of the chain is exact for it)
-    const int64_t cov_in = (int64_t)((s_x + before + wex) & kScanValueMask);
-    __syncthreads();  // s_w / s_x are reused below
-
-    // ---- change points, run starts, window sums -------------------------------------
-    int32_t cov[kDsPer];
-    uint32_t starts = 0;
+    // ---- this lane's stretch, then lanes -> waves -> tile -> chain ----------------------
+    DepthSum mine;
     {
-        int64_t c = cov_in;
+        int32_t pre = 0, m = INT32_MAX;
+        uint32_t nz = 0;
 #pragma unroll
         for (int k = 0; k < kDsPer; ++k) {
-            c += d[k];
-            cov[k] = (int32_t)c;
-            starts += (d[k] != 0 && c > 0);  // coverage changed here to a positive depth: a run starts
+            pre += d[k];
+            m = pre < m ? pre : m;
+            nz += d[k] != 0;
         }
-    }
-    // ---- chain 2: number of runs started before each lane ------------------------------
-    const u64 wex2 = wave_excl_scan((u64)starts, wtot);
-    if (lane_id() == kWave - 1) s_w[wave_id()] = wtot;
-    __syncthreads();
-    before = 0, agg = 0;
+        uint32_t z = 0;
+        pre = 0;
 #pragma unroll
-    for (int w = 0; w < kDsThreads / kWave; ++w) {
-        if (w < wave_id()) before += s_w[w];
-        agg += s_w[w];
+        for (int k = 0; k < kDsPer; ++k) {
+            pre += d[k];
+            z += (d[k] != 0 && pre == m);
+        }
+        mine = DepthSum{pre, m, z, nz};
     }
+    DepthSum inc = mine;                          // inclusive scan across the wave
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const DepthSum t = ds_shfl_up(inc, o);
+        if (lane_id() >= o) inc = ds_compose(t, inc);
+    }
+    DepthSum lanes_before = ds_shfl_up(inc, 1);
+    if (lane_id() == 0) lanes_before = ds_identity();
+    if (lane_id() == kWave - 1) s_w[wave_id()] = inc;
+    __syncthreads();
+    // wave 0: the waves' totals -> what lies before each wave inside the tile, the tile's aggregate, the chain
     if (wave_id() == 0) {
-        const u64 ex = scan_lookback(st_cnt, tile, agg, err);
-        if (lane_id() == 0) s_x = ex;
+        constexpr int kWaves = kDsThreads / kWave;
+        DepthSum w = lane_id() < kWaves ? s_w[lane_id()] : ds_identity();
+        const DepthSum own = w;
+#pragma unroll
+        for (int o = 1; o < kWaves; o <<= 1) {
+            const DepthSum t = ds_shfl_up(w, o);
+            if (lane_id() >= o) w = ds_compose(t, w);
+        }
+        const DepthSum agg{__shfl(w.s, kWaves - 1, kWave), __shfl(w.m, kWaves - 1, kWave), __shfl(w.z, kWaves - 1, kWave),
+                           __shfl(w.nz, kWaves - 1, kWave)};
+        DepthSum excl = ds_shfl_up(w, 1);              // waves before this lane's wave
+        if (lane_id() == 0) excl = ds_identity();
+        (void)own;
+        const DepthSum ex = ds_lookback(status, tile, agg, err);
+        if (lane_id() < kWaves) s_w[lane_id()] = ds_compose(ex, excl);   // everything before wave `lane`
     }
     __syncthreads();
-    u64 idx = ((s_x & kScanValueMask) + before + wex2);  // runs started before this lane's first position
+    const DepthSum before = ds_compose(s_w[wave_id()], lanes_before);   // everything before this lane
+    const int64_t cov_in = before.s;             // coverage just before this lane's first position
+    u64 idx = ds_starts(before, 0);              // runs started before it (the target starts at coverage 0)
+
+    // ---- change points -> runs ------------------------------------------------------------
     // A run [s, e) of depth c: at s coverage becomes c > 0; at e it changes again.  With idx = number
     // of runs started before position p: a start at p is run idx, a run ending at p is run idx-1.
     // At 30x nearly every run starts and ends inside one lane's 16 positions: such a run is
@@ -159,11 +501,15 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     // pieces ({start, -, depth} here, `end` by the lane that sees the next change point).
     {
         typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
-        int64_t prev = cov_in;
+        int64_t c = cov_in;
         bool pending = false;  // a run started in this lane and not yet closed
         int32_t rs = 0, rd = 0;
+        uint32_t over = 0;
 #pragma unroll
         for (int k = 0; k < kDsPer; ++k) {
+            const int64_t prev = c;
+            c += d[k];
+            over |= (uint32_t)(c >> 30);         // coverage >= 2^30 (or negative): outside the chain's 31-bit fields
             if (d[k] != 0) {
                 const int32_t p = (int32_t)(p0 + k);
                 if (prev > 0 && idx - 1 < out.runs_cap) {
@@ -171,23 +517,22 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                     else out.runs[idx - 1].end = p;
                 }
                 pending = false;
-                if (cov[k] > 0) {
-                    rs = p, rd = cov[k], pending = true;
+                if (c > 0) {
+                    rs = p, rd = (int32_t)c, pending = true;
                     ++idx;
                 }
             }
-            prev = cov[k];
         }
         if (pending && idx - 1 < out.runs_cap) {
             out.runs[idx - 1].start = rs;
             out.runs[idx - 1].depth = rd;
         }
+        if (over) atomicOr(err, 2u);
     }
     // ---- window sums (overlap(), bam2depth.c:132-176): sum of coverage per window, clipped at
-    // target_len.  Done last, so that these atomics do not sit in front of the look-back loads in
-    // the wave's vmcnt queue.  A wave covers 1024 consecutive positions: when those touch at most
-    // two windows (W >= 1024, the tool's default is 20000) it reduces both partial sums and issues
-    // at most two atomics; per-lane atomics on one address cost ~4 ms per chr1-sized pass.
+    // target_len.  A wave covers 1024 consecutive positions: when those touch at most two windows
+    // (W >= 1024, the tool's default is 20000) it reduces both partial sums and issues at most two
+    // atomics; per-lane atomics on one address cost ~4 ms per chr1-sized pass.
     if (W) {
         const uint32_t q0 = (uint32_t)p0;                                   // positions are < 2^28
         const uint32_t wave_lo = (uint32_t)(tile * kDsTile) + (uint32_t)wave_id() * (kWave * kDsPer);
@@ -197,15 +542,25 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
             const uint32_t nb = (w0 + 1) * W;                                // first position of window w0+1
             if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
                 u64 sa = 0, sb = 0;
+                int64_t c = cov_in;
 #pragma unroll
                 for (int k = 0; k < kDsPer; ++k) {
                     const uint32_t p = q0 + k;
-                    const u64 c = p < target_len ? (u64)(uint32_t)cov[k] : 0;
-                    if (p < nb) sa += c;
-                    else sb += c;
+                    c += d[k];
+                    const u64 cc = p < target_len ? (u64)c : 0;
+                    if (p < nb) sa += cc;
+                    else sb += cc;
                 }
+                // coverage below 2^21 everywhere under the wave (always, outside pile-ups): the 1024-position sums fit 32 bits
+                if (__ballot((sa | sb) >> 25) == 0) {
+                    uint32_t a32 = (uint32_t)sa, b32 = (uint32_t)sb;
 #pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) sa += __shfl_xor(sa, o, kWave), sb += __shfl_xor(sb, o, kWave);
+                    for (int o = kWave / 2; o > 0; o >>= 1) a32 += __shfl_xor(a32, o, kWave), b32 += __shfl_xor(b32, o, kWave);
+                    sa = a32, sb = b32;
+                } else {
+#pragma unroll
+                    for (int o = kWave / 2; o > 0; o >>= 1) sa += __shfl_xor(sa, o, kWave), sb += __shfl_xor(sb, o, kWave);
+                }
                 if (lane_id() == 0) {
                     if (sa) atomicAdd(&out.win_sum[w0], sa);
                     if (sb) atomicAdd(&out.win_sum[w0 + 1], sb);
@@ -214,6 +569,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                 u64 s = 0;
                 uint32_t w = q0 / W;
                 uint32_t nbl = (w + 1) * W;
+                int64_t c = cov_in;
 #pragma unroll
                 for (int k = 0; k < kDsPer; ++k) {
                     const uint32_t p = q0 + k;
@@ -222,7 +578,8 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                         if (s) atomicAdd(&out.win_sum[w], s);
                         s = 0, ++w, nbl += W;
                     }
-                    s += (u64)(uint32_t)cov[k];
+                    c += d[k];
+                    s += (u64)c;
                 }
                 if (s) atomicAdd(&out.win_sum[w], s);
             }
@@ -231,33 +588,81 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     if (tile == (slots - 1) / kDsTile && tid == kDsThreads - 1) *out.n_runs = idx;
 }
 
-hipError_t launch_depth_scatter(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
-                                const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
-                                uint64_t slots, uint32_t *bad, int n_cu, hipStream_t st)
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+uint64_t depth_tiles(uint64_t slots) { return (slots + kTile - 1) / kTile; }
+static uint64_t scan_tiles(uint64_t slots) { return (slots + kDsTile - 1) / kDsTile; }
+
+// bytes of the per-target index: head | first_hi | first_lo | written | need
+size_t depth_index_bytes(uint64_t slots)
 {
-    if (n == 0) return hipSuccess;
-    uint64_t want = (n + kScatThreads - 1) / kScatThreads;
+    const uint64_t nt = depth_tiles(slots);
+    return sizeof(uint32_t) * (kHdWords + 2 * (nt + 1) + 2 * nt);
+}
+
+static TileIndex tile_index(void *ws, uint64_t slots)
+{
+    const uint32_t nt = (uint32_t)depth_tiles(slots);
+    uint32_t *w = (uint32_t *)ws;
+    return TileIndex{w, w + kHdWords, w + kHdWords + (nt + 1), w + kHdWords + 2 * (nt + 1), w + kHdWords + 2 * (nt + 1) + nt, nt};
+}
+
+// hpn_depth_begin: no tile has been written, none is needed
+hipError_t depth_index_reset(void *ws, uint64_t slots, hipStream_t st)
+{
+    const TileIndex ix = tile_index(ws, slots);
+    return hipMemsetAsync(ix.written, 0, 2 * sizeof(uint32_t) * (size_t)ix.ntiles, st);
+}
+
+const uint32_t *depth_written(void *ws, uint64_t slots) { return tile_index(ws, slots).written; }
+
+template <typename Recs>
+static hipError_t depth_add(const Recs &recs, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots, void *ws,
+                            uint32_t *bad, int n_cu, hipStream_t st)
+{
+    if (n == 0 || tid < 0) return hipSuccess;    // tid < 0 never matches (bam2depth.c:90)
+    const TileIndex ix = tile_index(ws, slots);
+    hipError_t e = hipMemsetAsync(ix.head, 0, kHdWords * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     const uint64_t cap = (uint64_t)n_cu * 8;
-    hipLaunchKernelGGL(k_depth_scatter, dim3((unsigned)(want < cap ? want : cap)), dim3(kScatThreads), 0, st, tid_a, pos,
-                       flag, cigar_off, cigar, n, tid, flag_mask, diff, slots, bad);
+    const uint64_t wi = (n + kIdxThreads - 1) / kIdxThreads, wf = (n + kFarThreads - 1) / kFarThreads;
+    hipLaunchKernelGGL(k_depth_index<Recs>, dim3((unsigned)(wi < cap * 4 ? wi : cap * 4)), dim3(kIdxThreads), 0, st, recs, n, tid, ix);
+    hipLaunchKernelGGL(k_depth_tiles<Recs>, dim3(ix.ntiles), dim3(kTileThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, bad);
+    hipLaunchKernelGGL(k_depth_fill, dim3(ix.ntiles), dim3(256), 0, st, diff, slots, ix);
+    hipLaunchKernelGGL(k_depth_far<Recs>, dim3((unsigned)(wf < cap ? wf : cap)), dim3(kFarThreads), 0, st, recs, n, tid, flag_mask, diff,
+                       slots, ix, bad);
     return hipGetLastError();
 }
 
-uint64_t depth_scan_tiles(uint64_t slots) { return (slots + kDsTile - 1) / kDsTile; }
+hipError_t launch_depth_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
+                            const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots,
+                            void *ws, uint32_t *bad, int n_cu, hipStream_t st)
+{
+    return depth_add(SoaRecs{tid_a, pos, flag, cigar_off, cigar}, n, tid, flag_mask, diff, slots, ws, bad, n_cu, st);
+}
 
-// ws: [0] ticket, [1] err (uint32 each), then u64 n_runs, then st_cov[tiles], st_cnt[tiles]
-hipError_t launch_depth_scan(const int32_t *diff, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
+hipError_t launch_depth_add_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
+                                uint64_t slots, void *ws, uint32_t *bad, int n_cu, hipStream_t st)
+{
+    return depth_add(RawRecs{raw, rec_off}, n, tid, flag_mask, diff, slots, ws, bad, n_cu, st);
+}
+
+// ws: [0] ticket, [1] err (uint32 each), then u64 n_runs, then status[2 * tiles]
+size_t depth_scan_bytes(uint64_t slots) { return 16 + kStStride * scan_tiles(slots) * sizeof(u64); }
+
+hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
                              uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st)
 {
-    const uint64_t tiles = depth_scan_tiles(slots);
-    hipError_t e = hipMemsetAsync(ws, 0, 16 + 2 * tiles * sizeof(u64), st);
+    const uint64_t tiles = scan_tiles(slots);
+    hipError_t e = hipMemsetAsync(ws, 0, depth_scan_bytes(slots), st);
     if (e != hipSuccess) return e;
     uint32_t *ticket = (uint32_t *)ws;
     u64 *n_runs = (u64 *)ws + 1;
-    u64 *st_cov = (u64 *)ws + 2, *st_cnt = st_cov + tiles;
+    u64 *status = (u64 *)ws + 2;
     DepthOut out{runs, runs_cap, n_runs, win_sum};
-    hipLaunchKernelGGL(k_depth_scan, dim3((unsigned)tiles), dim3(kDsThreads), 0, st, diff, slots, target_len, W, out, st_cov,
-                       st_cnt, ticket, ticket + 1);
+    hipLaunchKernelGGL(k_depth_scan, dim3((unsigned)tiles), dim3(kDsThreads), 0, st, diff, written, slots, target_len, W, out, status,
+                       ticket, ticket + 1);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@
 //   k_raw_index    per block: byte offset of every record -> rec_off[]
 //   k_raw_fields   per record: refID, pos, flag, l_seq, offset of the packed sequence
 //                  (the SoA view k_window_add takes; the sequence stays where it is)
-//   k_depth_scatter_raw   K3 (bam2depth.c:86-110) reading core fields and CIGAR in place
+// K3 (bam2depth.c:86-110) reads core fields and CIGAR in place through RawRecs (bam_depth.hip).
 #include "common.hpp"
 
 namespace hpn {
@@ -140,36 +140,6 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_fields(const uint8_t *__res
     }
 }
 
-// K3 on raw records: the loop of k_depth_scatter (bam_depth.hip), fields and CIGAR read in place.
-__global__ __launch_bounds__(kRawThreads) void k_depth_scatter_raw(const uint8_t *__restrict__ raw,
-                                                                   const uint64_t *__restrict__ rec_off, uint64_t n, int32_t tid,
-                                                                   uint32_t flag_mask, int32_t *__restrict__ diff, uint64_t slots,
-                                                                   uint32_t *__restrict__ bad)
-{
-    for (uint64_t r = (uint64_t)blockIdx.x * kRawThreads + threadIdx.x; r < n; r += (uint64_t)gridDim.x * kRawThreads) {
-        const uint8_t *p = raw + rec_off[r];
-        if ((int32_t)ld32(p + 4) != tid || tid < 0 || (ld16(p + 18) & flag_mask)) continue;  // bam2depth.c:90
-        uint64_t q = ld32(p + 8);  // unsigned int temp_start = c->pos (:93)
-        const uint32_t n_cigar = ld16(p + 16);
-        const uint8_t *cig = p + 36u + p[12];
-        for (uint32_t k = 0; k < n_cigar; ++k) {
-            const uint32_t w = ld32(cig + 4u * k), op = w & 0xfu, len = w >> 4;
-            if (op == 2u || op == 3u) {
-                q += len;
-            } else if (op == 0u) {
-                const uint64_t e = q + len;
-                if (e >= slots) {
-                    atomicOr(bad, 1u);
-                    break;
-                }
-                atomicAdd(&diff[q], 1);
-                atomicAdd(&diff[e], -1);
-                q = e;
-            }
-        }
-    }
-}
-
 hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
                             uint32_t *counts, u64 *bases, int32_t *info, hipStream_t st)
 {
@@ -201,15 +171,6 @@ hipError_t launch_raw_fields(const uint8_t *raw, const uint64_t *rec_off, uint64
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_raw_fields, dim3(rec_grid(n, n_cu)), dim3(kRawThreads), 0, st, raw, rec_off, n, tid, pos, flag, l_qseq,
                        seq_off);
-    return hipGetLastError();
-}
-
-hipError_t launch_depth_scatter_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask,
-                                    int32_t *diff, uint64_t slots, uint32_t *bad, int n_cu, hipStream_t st)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_depth_scatter_raw, dim3(rec_grid(n, n_cu)), dim3(kRawThreads), 0, st, raw, rec_off, n, tid, flag_mask,
-                       diff, slots, bad);
     return hipGetLastError();
 }
 

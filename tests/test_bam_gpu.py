@@ -98,6 +98,66 @@ def test_depth_incremental_batches_and_capacity(ctx):
     assert np.array_equal(runs2, whole_runs) and win2.sum() == whole_win.sum()
 
 
+FAR_CIGARS = ["150M", "50M2047N50M", "50M2048N50M", "30M1999D20M100N40M", "10M20000N10M30000N10M", "5M100000D5M",
+              "1M16383N1M", "40M2I108M", "10S140M", "2049M", "17000M", "1N1M", "40000M"]
+
+
+@pytest.mark.parametrize("n,seed,sort", [(40_000, 31, True), (40_000, 32, False), (300, 33, True)])
+def test_depth_far_breakpoints(ctx, n, seed, sort):
+    """Breakpoints far behind a record's pos (long D / N / M: beyond the reach the owner tile gathers) go through the
+    counted far path; the result is the dense model's whatever the distances."""
+    refs = [("chrA", 1_500_000), ("chrB", 200_000)]
+    soa = make_soa(n, refs, seed, sort=sort, cigars=FAR_CIGARS, max_start_frac=0.9)
+    _depth_all(ctx, soa, 20000)
+    _depth_all(ctx, soa, 313, mask=0x4)
+
+
+def test_depth_tile_edges(ctx):
+    """Records and breakpoints exactly on tile thresholds (16384 k, 16384 k - 2048) and one past / before them."""
+    refs = [("c", 120_000)]
+    T, R = 16384, 2048
+    starts = sorted({max(0, t * T + d) for t in range(0, 7) for d in (-R - 1, -R, -R + 1, -151, -150, -149, -1, 0, 1)} | {0, 1})
+    recs = []
+    for p in starts:
+        for cg in ("150M", "1M", "10M2037N1M", "10M2038N1M", "10M2039N1M", "100M100D100M"):
+            recs.append((p, cg))
+    soa = bamio.BamSoA(refs=refs, tid=np.zeros(len(recs), np.int32), pos=np.array([p for p, _ in recs], np.int32),
+                       flag=np.zeros(len(recs), np.uint32), l_qseq=np.zeros(len(recs), np.int32),
+                       cigar_off=np.concatenate([[0], np.cumsum([len(bamio.parse_cigar(c)) for _, c in recs])]).astype(np.uint32),
+                       cigar=np.concatenate([bamio.parse_cigar(c) for _, c in recs]).astype(np.uint32),
+                       seq_off=np.zeros(len(recs) + 1, np.uint64), seq4=np.zeros(1, np.uint8))
+    _depth_all(ctx, soa, 1000)
+
+
+def test_depth_batches_overlap_and_mix_sorted_with_unsorted(ctx):
+    """hpn_depth_add calls whose position ranges overlap (tiles written before are added to), an unsorted call in
+    between (global atomics on tiles some of which were never written), far breakpoints in every call."""
+    import ctypes as C
+    refs = [("chrA", 900_000)]
+    parts = [make_soa(30_000, refs, 41, sort=True, cigars=FAR_CIGARS, max_start_frac=0.5),
+             make_soa(30_000, refs, 42, sort=False, cigars=FAR_CIGARS, max_start_frac=0.9),
+             make_soa(30_000, refs, 43, sort=True, cigars=FAR_CIGARS, max_start_frac=0.9),
+             make_soa(5, refs, 44, sort=True, cigars=["150M"], max_start_frac=0.9)]
+    L, keep = ctx.L, []
+    assert L.hpn_depth_begin(ctx.h, 0, refs[0][1], 0x704) == 0
+    for part in parts:
+        bb = ctx._batch(part, keep)
+        assert L.hpn_depth_add(ctx.h, C.byref(bb)) == 0
+    runs, win = ctx.depth_finish(refs[0][1], 1000)
+    whole = bamio.BamSoA(refs=refs, tid=np.concatenate([p.tid for p in parts]), pos=np.concatenate([p.pos for p in parts]),
+                         flag=np.concatenate([p.flag for p in parts]), l_qseq=np.concatenate([p.l_qseq for p in parts]),
+                         cigar_off=np.concatenate([[0], np.cumsum(np.concatenate([np.diff(p.cigar_off.astype(np.int64)) for p in parts]))]).astype(np.uint32),
+                         cigar=np.concatenate([p.cigar for p in parts]), seq_off=np.zeros(1, np.uint64), seq4=np.zeros(1, np.uint8))
+    rc, wruns, wbins = orc.depth_target(whole, 0, 1000, 0x704)
+    assert rc == 0 and np.array_equal(runs, wruns) and np.array_equal(win.astype(np.float64), wbins)
+    # a second target on the same context starts from nothing although the array was not cleared
+    refs2 = [("x", 1), ("chrB", 400_000)]
+    soa2 = make_soa(2_000, refs2, 45)
+    runs2, win2 = ctx.depth_target(soa2, 1, refs2[1][1], 1000)
+    rc, wruns2, wbins2 = orc.depth_target(soa2, 1, 1000, 0x704)
+    assert np.array_equal(runs2, wruns2) and np.array_equal(win2.astype(np.float64), wbins2)
+
+
 def test_depth_domain_error(ctx):
     import highperformancengs_amd as hp
     from highperformancengs_amd import _lib
