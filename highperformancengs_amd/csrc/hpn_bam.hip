@@ -18,7 +18,7 @@ size_t depth_scan_bytes(uint64_t slots);
 hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
                              uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st);
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
-                             const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint32_t W, int32_t n_targets,
+                             const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
                              u64 *n_count, uint32_t *bad, int n_cu, hipStream_t st);
 hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
@@ -212,7 +212,7 @@ int hpn_depth_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
     return HPN_OK;
 }
 
-static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b);
+static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b, uint64_t seq_end);
 
 int hpn_window_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
 {
@@ -236,7 +236,7 @@ int hpn_window_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
     b.n = n;
     b.tid = (const int32_t *)c->r_tid.p, b.pos = (const int32_t *)c->r_pos.p, b.flag = (const uint32_t *)c->r_flag.p;
     b.l_qseq = (const int32_t *)c->r_lq.p, b.seq_off = (const uint64_t *)c->r_soff.p, b.seq4 = d_raw;
-    return window_add_common(c, &b);
+    return window_add_common(c, &b, ~0ull);   // the inflated stream is padded (hpn_bgzf_inflate_dev's contract): no limit
 }
 
 // ---- bam_sliding_count -------------------------------------------------------------------
@@ -270,11 +270,12 @@ int hpn_window_begin(hpn_ctx *c, int32_t n_targets, const uint64_t *win_off, uin
     return HPN_OK;
 }
 
-static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b)
+// seq_end: first byte offset of b->seq4 that must not be read; 0 = seq_off[n] (read on the device)
+static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b, uint64_t seq_end)
 {
     uint8_t *m = (uint8_t *)c->w_misc.p;
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamWindow], c->stream));
-    HPN_HIP(c, launch_window_add(b->tid, b->pos, b->flag, b->l_qseq, b->seq_off, b->seq4, b->n, c->win_W, c->win_targets,
+    HPN_HIP(c, launch_window_add(b->tid, b->pos, b->flag, b->l_qseq, b->seq_off, b->seq4, b->n, seq_end, c->win_W, c->win_targets,
                                  (const uint64_t *)c->w_off.p, (uint32_t *)c->w_bins.p, (u64 *)c->w_gc.p,
                                  (uint32_t *)c->w_len.p, (uint32_t *)(m + 64), (u64 *)(m + 8), (uint32_t *)(m + 16),
                                  c->n_cu, c->stream));
@@ -289,7 +290,7 @@ int hpn_window_add_dev(hpn_ctx *c, const hpn_bam_batch *b)
     if (!c->win_open) return fail(c, HPN_E_STATE, "hpn_window_add before hpn_window_begin");
     if (b->n && (!b->tid || !b->pos || !b->flag || !b->l_qseq || !b->seq_off || !b->seq4)) return HPN_E_ARG;
     HPN_HIP(c, hipSetDevice(c->device));
-    return window_add_common(c, b);
+    return window_add_common(c, b, 0);
 }
 
 int hpn_window_add(hpn_ctx *c, const hpn_bam_batch *b)
@@ -313,7 +314,7 @@ int hpn_window_add(hpn_ctx *c, const hpn_bam_batch *b)
     uint8_t *ds = (uint8_t *)c->s_f.p + pad;
     if (s1 > s0) HPN_HIP(c, hipMemcpyAsync(ds, b->seq4 + s0, s1 - s0, hipMemcpyHostToDevice, c->stream));
     d.seq4 = ds - s0;
-    return window_add_common(c, &d);
+    return window_add_common(c, &d, s1 + 16);   // the staging buffer has slack behind the last byte
 }
 
 int hpn_window_finish(hpn_ctx *c, uint32_t *bins, uint64_t *gc, uint32_t *len, uint8_t *touched, uint64_t *n_count)

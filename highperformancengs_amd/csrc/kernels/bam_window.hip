@@ -7,150 +7,231 @@
 // All integer here; the float32 arithmetic of calc_winGC (:126-138) is replayed
 // on the host in reference order (csrc/host/report.cpp).
 //
-// One lane per record.  The packed sequence is read with aligned 16-byte loads
-// and counted with nibble-wise SWAR.  Records of a coordinate-sorted BAM that are
-// near each other fall into the same window, so a workgroup first adds into a
-// small LDS table indexed by (slot - lowest slot of its chunk) and flushes that
-// with one global atomic per touched window; slots outside the table (unsorted
-// input) go to global atomics directly.
+// Waves work on their own: one lane per record for the fields; the packed sequences are read by the wave together
+// (eight lanes per record, 16-byte pieces: gc_of_wave_records) and counted with nibble-wise SWAR; the sums of the
+// window a wave is in stay in registers and go to memory with three atomics when the window changes (records of a
+// coordinate-sorted BAM that are near each other fall into the same window).  No LDS table, no barrier.
 // Bound: HBM read of 16 B + ceil(l_qseq/2) B per record.
 #include "common.hpp"
 
 namespace hpn {
 
 constexpr int kWinThreads = 256;
-constexpr int kWinPer = 4;                        // records per lane per chunk
-constexpr int kWinChunk = kWinThreads * kWinPer;  // 1024 records
-constexpr int kWinTable = 256;                    // LDS window slots per chunk
 
-// number of nibbles of w equal to 2 or 4 (exact per nibble, no carries)
+// number of nibbles of w equal to 2 (C) or 4 (G): bits 8 and 1 clear, exactly one of bits 2 and 4 set
 __device__ __forceinline__ uint32_t gc_nibbles(uint32_t w)
 {
-    const uint32_t a = w ^ 0x22222222u, b = w ^ 0x44444444u;
-    const uint32_t za = ~(((a & 0x77777777u) + 0x77777777u) | a | 0x77777777u);  // 0x8 where nibble == 2
-    const uint32_t zb = ~(((b & 0x77777777u) + 0x77777777u) | b | 0x77777777u);  // 0x8 where nibble == 4
-    return __builtin_popcount(za) + __builtin_popcount(zb);
+    return __builtin_popcount(((w >> 1) ^ (w >> 2)) & ~(w >> 3) & ~w & 0x11111111u);
 }
 
-// GC count of bases [0, l_qseq) of the packed sequence starting at byte s of seq4
-// (base i = high nibble of byte i/2 for even i, bam1_seqi, bam.h:260).
-__device__ __forceinline__ uint32_t gc_of_record(const uint8_t *__restrict__ seq4, uint64_t s, int32_t l_qseq)
+// GC count of the first `nbytes` (1..16) bytes of a 16-byte piece of a packed sequence (base i = high nibble of byte
+// i/2 for even i, bam1_seqi, bam.h:260); clip: the piece ends the sequence of an odd-length read, whose last low
+// nibble is padding, not a base.
+__device__ __forceinline__ uint32_t gc_of_piece(const u32 q, int nbytes, bool clip)
 {
-    if (l_qseq <= 0) return 0;
-    const uint64_t end = s + (uint64_t)((l_qseq + 1) >> 1);
-    const uintptr_t base = (uintptr_t)seq4;
-    const uintptr_t a0 = (base + s) & ~(uintptr_t)15, a1 = base + end;
     uint32_t gc = 0;
-    for (uintptr_t v = a0; v < a1; v += 16) {
-        const u32 q = *reinterpret_cast<const u32 *>(seq4 + (v - base));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t w0 = (int64_t)(v + 4 * j) - (int64_t)(base + s);   // record-relative byte of the word's byte 0
-            const int64_t nb = (int64_t)(end - s);
-            const int lo = (int)min(max(-w0, (int64_t)0), (int64_t)4);
-            const int hi = (int)min(max(nb - w0, (int64_t)0), (int64_t)4);
-            if (hi <= lo) continue;
-            const uint32_t mh = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
-            const uint32_t ml = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
-            uint32_t w = q[j] & mh & ~ml;
-            // odd length: the low nibble of the last byte is padding, not a base
-            if ((l_qseq & 1) && nb - 1 - w0 >= 0 && nb - 1 - w0 < 4) w &= ~(0xfu << (8 * (int)(nb - 1 - w0)));
-            gc += gc_nibbles(w);
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int hi = min(max(nbytes - 4 * j, 0), 4);                       // bytes of word j that count
+        uint32_t m = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+        if (clip && hi > 0 && nbytes - 4 * j <= 4) m &= ~(0xfu << (8 * (hi - 1)));
+        gc += gc_nibbles(q[j] & m);
     }
     return gc;
 }
 
-struct WinLds {
-    uint32_t bins[kWinTable];
-    uint32_t len[kWinTable];
-    uint32_t gc[kWinTable];
-    unsigned long long base;  // lowest slot of the chunk
-};
+// 16 bytes from byte offset a of seq4 (any alignment); nothing at or beyond offset lim is touched (the last pieces of a
+// batch: the caller's buffer may end with its last sequence byte)
+__device__ __forceinline__ u32 load16u(const uint8_t *__restrict__ seq4, uint64_t a, uint64_t lim)
+{
+    u32 v;
+    if (a + 16 <= lim) {
+        __builtin_memcpy(&v, seq4 + a, 16);
+    } else {
+        v = u32{0, 0, 0, 0};
+        for (int k = 0; k < 16 && a + k < lim; ++k) v[k >> 2] |= (uint32_t)seq4[a + k] << (8 * (k & 3));
+    }
+    return v;
+}
+
+// GC counts of 64 records, one per lane (s = byte offset of the packed sequence in seq4, l_qseq <= 0: none), computed by
+// the wave together: in step t the eight lanes of group g read the sequence of record 8 t + g, lane i of the group its
+// bytes [16 i, 16 i + 16) (unaligned 16-byte loads: only the last piece of a record needs a mask), so a wave
+// instruction reads eight neighbouring records = one contiguous span.  One lane per record reads 64 scattered
+// segments per instruction and spent ~10x the instructions on masks (0.26 of the HBM peak).  Eight steps, all their
+// loads in flight together when no record of the wave is longer than 128 bytes (256 bases); longer reads loop.
+__device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict__ seq4, uint64_t s, int32_t l_qseq, uint64_t lim)
+{
+    const int lane = lane_id(), sub = lane & 7, grp = lane >> 3;
+    const int my_nb = l_qseq > 0 ? (l_qseq + 1) >> 1 : 0;
+    uint32_t mine = 0;
+    const u64 has_seq = __ballot(l_qseq > 0);
+    if (!has_seq) return 0;
+    const int lq0 = __shfl(l_qseq, __builtin_ctzll(has_seq), kWave);   // records without a sequence ride along, their sum is dropped
+    if (lq0 <= 256 && __ballot(l_qseq > 0 && l_qseq != lq0) == 0) {
+        // every record of the wave has the same length (the normal case): which bytes of its piece a lane counts
+        // depends on the lane only, so the masks are built once, not per record
+        const int nb = lq0 > 0 ? (lq0 + 1) >> 1 : 0, rem = nb - 16 * sub;
+        uint32_t m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hi = min(max(rem - 4 * j, 0), 4);
+            m[j] = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+            if ((lq0 & 1) && hi > 0 && rem - 4 * j <= 4) m[j] &= ~(0xfu << (8 * (hi - 1)));
+        }
+        u32 q[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint64_t st = __shfl((u64)s, t * 8 + grp, kWave);
+            q[t] = u32{0, 0, 0, 0};
+            if (rem > 0) q[t] = load16u(seq4, st + 16u * sub, lim);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            uint32_t g = gc_nibbles(q[t][0] & m[0]) + gc_nibbles(q[t][1] & m[1]) + gc_nibbles(q[t][2] & m[2]) + gc_nibbles(q[t][3] & m[3]);
+            g += __shfl_xor(g, 1, kWave), g += __shfl_xor(g, 2, kWave), g += __shfl_xor(g, 4, kWave);
+            const uint32_t r = __shfl(g, sub * 8 + t, kWave);   // lane 8 t + g takes group g's sum of step t
+            if (grp == t) mine = r;
+        }
+    } else if (__ballot(my_nb > 128) == 0) {
+        u32 q[8];
+        int rem[8];
+        bool clip[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int src = t * 8 + grp;
+            const uint64_t st = __shfl((u64)s, src, kWave);
+            const int lq = __shfl(l_qseq, src, kWave), nb = lq > 0 ? (lq + 1) >> 1 : 0;
+            rem[t] = nb - 16 * sub;                                         // bytes of the record from this piece on
+            clip[t] = (lq & 1) && rem[t] <= 16;
+            q[t] = u32{0, 0, 0, 0};
+            if (rem[t] > 0) q[t] = load16u(seq4, st + 16u * sub, lim);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            uint32_t g = rem[t] > 0 ? gc_of_piece(q[t], min(rem[t], 16), clip[t]) : 0u;
+            g += __shfl_xor(g, 1, kWave), g += __shfl_xor(g, 2, kWave), g += __shfl_xor(g, 4, kWave);
+            const uint32_t r = __shfl(g, sub * 8 + t, kWave);   // lane 8 t + g takes group g's sum of step t
+            if (grp == t) mine = r;
+        }
+    } else {
+        for (int t = 0; t < 8; ++t) {
+            const int src = t * 8 + grp;
+            const uint64_t st = __shfl((u64)s, src, kWave);
+            const int lq = __shfl(l_qseq, src, kWave), nb = lq > 0 ? (lq + 1) >> 1 : 0;
+            uint32_t g = 0;
+            for (int at = 16 * sub; at < nb; at += 8 * 16)
+                g += gc_of_piece(load16u(seq4, st + at, lim), min(nb - at, 16), (lq & 1) && nb - at <= 16);
+            g += __shfl_xor(g, 1, kWave), g += __shfl_xor(g, 2, kWave), g += __shfl_xor(g, 4, kWave);
+            const uint32_t r = __shfl(g, sub * 8 + t, kWave);
+            if (grp == t) mine = r;
+        }
+    }
+    return l_qseq > 0 ? mine : 0u;
+}
+
+constexpr int kWinSpan = 1024;                    // consecutive records per wave: one run of passes with private sums
+
+// masked wave sums (valid in every lane)
+__device__ __forceinline__ uint32_t wave_sum_if(bool in, uint32_t v) { return wave_sum(in ? v : 0u); }
 
 __global__ __launch_bounds__(kWinThreads) void k_window_add(
     const int32_t *__restrict__ rec_tid, const int32_t *__restrict__ rec_pos, const uint32_t *__restrict__ rec_flag,
     const int32_t *__restrict__ l_qseq, const uint64_t *__restrict__ seq_off, const uint8_t *__restrict__ seq4,
-    uint64_t n, uint32_t W, int32_t n_targets, const uint64_t *__restrict__ win_off, uint32_t *__restrict__ bins,
-    u64 *__restrict__ gc, uint32_t *__restrict__ len, uint32_t *__restrict__ touched, u64 *__restrict__ n_count,
-    uint32_t *__restrict__ bad)
+    uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets, const uint64_t *__restrict__ win_off,
+    uint32_t *__restrict__ bins, u64 *__restrict__ gc, uint32_t *__restrict__ len, uint32_t *__restrict__ touched,
+    u64 *__restrict__ n_count, uint32_t *__restrict__ bad)
 {
-    __shared__ WinLds s;
-    const int tid = threadIdx.x;
-    u64 counted = 0;
-    const uint64_t nchunk = (n + kWinChunk - 1) / kWinChunk;
-    for (uint64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-        for (int i = tid; i < kWinTable; i += kWinThreads) s.bins[i] = 0, s.len[i] = 0, s.gc[i] = 0;
-        if (tid == 0) s.base = ~0ull;
-        __syncthreads();
-        uint64_t slot[kWinPer];
-        uint32_t g[kWinPer], lq[kWinPer];
-        bool ok[kWinPer];
-#pragma unroll
-        for (int k = 0; k < kWinPer; ++k) {
-            const uint64_t r = ch * kWinChunk + (uint64_t)k * kWinThreads + tid;
-            ok[k] = false;
-            slot[k] = 0, g[k] = 0, lq[k] = 0;
-            if (r >= n) continue;
-            const int32_t t = rec_tid[r];
-            if (t < 0 || (rec_flag[r] & 4u)) continue;        // :96-97
-            if (t >= n_targets) { atomicOr(bad, 1u); continue; }
-            // c->pos / window in int, then (unsigned short) (:117)
-            const uint32_t w16 = (uint32_t)(uint16_t)(rec_pos[r] / (int32_t)W);
-            const uint64_t lo = win_off[t], hi = win_off[t + 1];
-            if (lo + w16 >= hi) { atomicOr(bad, 2u); continue; }   // the reference would write out of bounds
-            ok[k] = true;
-            slot[k] = lo + w16;
-            lq[k] = (uint32_t)l_qseq[r];
-            g[k] = (uint32_t)(uint16_t)gc_of_record(seq4, seq_off[r], l_qseq[r]);  // unsigned short current_GC (:118)
-            touched[t] = 1u;                                   // benign same-value race
-            ++counted;
-            atomicMin(&s.base, (unsigned long long)slot[k]);
-        }
-        __syncthreads();
-        const uint64_t base = s.base;
-#pragma unroll
-        for (int k = 0; k < kWinPer; ++k) {
-            if (!ok[k]) continue;
-            const uint64_t rel = slot[k] - base;
-            if (rel < kWinTable) {
-                atomicAdd(&s.bins[rel], 1u);
-                atomicAdd(&s.len[rel], lq[k]);
-                atomicAdd(&s.gc[rel], g[k]);
-            } else {
-                atomicAdd(&bins[slot[k]], 1u);
-                atomicAdd(&len[slot[k]], lq[k]);
-                atomicAdd(&gc[slot[k]], (u64)g[k]);
+    // Waves work on their own: no LDS table, no barrier.  A wave takes spans of 1024 consecutive records, 64 per pass, and
+    // keeps the sums of the window it is in (a coordinate-sorted BAM stays in one window for thousands of records at WGS
+    // depth); they go to memory with three atomics when the window changes.  Passes with more than eight different
+    // windows (unsorted input) hand the rest to per-record atomics.
+    const int lane = lane_id();
+    const uint64_t lim = seq_end ? seq_end : seq_off[n];   // first byte offset of seq4 that must not be read
+    const uint64_t nspan = (n + kWinSpan - 1) / kWinSpan;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (kWinThreads / kWave) + wave_id(), nwaves = (uint64_t)gridDim.x * (kWinThreads / kWave);
+    uint32_t counted = 0;
+    for (uint64_t span = wave0; span < nspan; span += nwaves) {
+        u64 cur = ~0ull;                                   // window slot the sums belong to (same value in every lane)
+        uint32_t a_bins = 0, a_len = 0, cur_tid = 0;
+        u64 a_gc = 0;
+        auto flush = [&]() {
+            if (cur != ~0ull && lane == 0) {
+                atomicAdd(&bins[cur], a_bins);
+                atomicAdd(&len[cur], a_len);
+                atomicAdd(&gc[cur], a_gc);
+                touched[cur_tid] = 1u;
             }
-        }
-        __syncthreads();
-        if (base != ~0ull) {
-            for (int i = tid; i < kWinTable; i += kWinThreads) {
-                if (s.bins[i]) {
-                    atomicAdd(&bins[base + i], s.bins[i]);
-                    atomicAdd(&len[base + i], s.len[i]);
-                    atomicAdd(&gc[base + i], (u64)s.gc[i]);
+        };
+        for (int pass = 0; pass < kWinSpan / kWave; ++pass) {
+            const uint64_t r = span * kWinSpan + (uint64_t)pass * kWave + lane;
+            if (__ballot(r < n) == 0) break;
+            bool ok = false;
+            uint64_t slot = 0, so = 0;
+            uint32_t lq = 0, tt = 0;
+            int32_t lqs = 0;
+            if (r < n) {
+                const int32_t t = rec_tid[r], p = rec_pos[r], l = l_qseq[r];
+                const uint32_t f = rec_flag[r];
+                so = seq_off[r], lqs = l;                      // skipped records are read too: a wave of one length stays one
+                if (t >= 0 && !(f & 4u)) {                     // :96-97
+                    if (t >= n_targets) {
+                        atomicOr(bad, 1u);
+                    } else {
+                        // c->pos / window in int, then (unsigned short) (:117)
+                        const uint32_t w16 = (uint32_t)(uint16_t)(p / (int32_t)W);
+                        const uint64_t lo = win_off[t], hi = win_off[t + 1];
+                        if (lo + w16 >= hi) {
+                            atomicOr(bad, 2u);                 // the reference would write out of bounds
+                        } else {
+                            ok = true, slot = lo + w16, lq = (uint32_t)l, tt = (uint32_t)t;
+                        }
+                    }
                 }
             }
+            // every lane takes part (lanes without a record contribute an empty sequence)
+            const uint32_t g = (uint32_t)(uint16_t)gc_of_wave_records(seq4, so, lqs, lim);   // unsigned short current_GC (:118)
+            u64 rem = __ballot(ok);
+            counted += (uint32_t)__builtin_popcountll(rem);   // n_count (:104); the same in every lane
+            for (int it = 0; rem; ++it) {
+                if (it == 8) {                                 // many windows under one pass: unsorted input
+                    if (ok && ((rem >> lane) & 1)) {
+                        atomicAdd(&bins[slot], 1u);
+                        atomicAdd(&len[slot], lq);
+                        atomicAdd(&gc[slot], (u64)g);
+                        touched[tt] = 1u;                      // benign same-value race
+                    }
+                    break;
+                }
+                const int f = __builtin_ctzll(rem);
+                const u64 s0 = __shfl((u64)slot, f, kWave);
+                const bool in = ok && slot == s0;
+                const u64 m = __ballot(in);
+                if (s0 != cur) {
+                    flush();
+                    cur = s0, a_bins = 0, a_len = 0, a_gc = 0, cur_tid = __shfl(tt, f, kWave);
+                }
+                a_bins += (uint32_t)__builtin_popcountll(m);
+                a_len += wave_sum_if(in, lq);
+                a_gc += wave_sum_if(in, g);
+                rem &= ~m;
+            }
         }
-        __syncthreads();
+        flush();
     }
-    // n_count (:104)
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) counted += __shfl_xor(counted, o, kWave);
-    if (lane_id() == 0 && counted) atomicAdd(n_count, counted);
+    if (lane == 0 && counted) atomicAdd(n_count, (u64)counted);
 }
 
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
-                             const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint32_t W, int32_t n_targets,
+                             const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
                              u64 *n_count, uint32_t *bad, int n_cu, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    uint64_t want = (n + kWinChunk - 1) / kWinChunk;
+    uint64_t want = ((n + kWinSpan - 1) / kWinSpan + kWinThreads / kWave - 1) / (kWinThreads / kWave);
     const uint64_t cap = (uint64_t)n_cu * 8;
     hipLaunchKernelGGL(k_window_add, dim3((unsigned)(want < cap ? want : cap)), dim3(kWinThreads), 0, st, tid_a, pos, flag,
-                       l_qseq, seq_off, seq4, n, W, n_targets, win_off, bins, gc, len, touched, n_count, bad);
+                       l_qseq, seq_off, seq4, n, seq_end, W, n_targets, win_off, bins, gc, len, touched, n_count, bad);
     return hipGetLastError();
 }
 

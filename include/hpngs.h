@@ -337,7 +337,9 @@ int hpn_window_finish(hpn_ctx *ctx, uint32_t *bins, uint64_t *gc, uint32_t *len,
  * the block's end (a file written otherwise), 2 = a block failed to inflate -- in both cases
  * nothing is indexed and the caller decodes the file on the host.  Synchronous (returns the
  * record count and the refID range of the batch).  The two add calls then run the depth /
- * window kernels over the indexed records, like hpn_depth_add_dev / hpn_window_add_dev. */
+ * window kernels over the indexed records, like hpn_depth_add_dev / hpn_window_add_dev.
+ * d_raw must be readable 16 bytes past the end of the inflated stream (the window kernel
+ * reads packed sequences in unaligned 16-byte pieces). */
 typedef struct hpn_raw_info {
     uint64_t n_records;
     int32_t tid_min, tid_max;
