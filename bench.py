@@ -4,13 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of hpn_fastq_tally over the rank's resident batch of synthetic
+The headline: a step = one pass of hpn_fastq_tally over the rank's resident batch of synthetic
 reads (BASELINE.json configs[1]: 1e9 x 150 bp per GPU, generated in HBM by the
 counter-based generator), plus -- for N > 1 -- the one sum all-reduce of the
 count vector, plus the fetch of the counts to the host.  Inputs are resident in
 HBM when the timed region starts (inflate / PCIe are host work).
 Weak scaling: every rank holds its own 1e9-read shard (configs[4]: 8e9 reads on 8 GPUs).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Its `extra` object (bench_extra.py) holds what the headline does not: the exact check of
+the headline launch, the kernels of the other named configurations (K1L, K2, K3 + K4, K5) with their own
+roofline fractions, and end-to-end legs through the CLI binaries with the reference binary timed beside each.
 """
 import argparse
 import ctypes as C
@@ -38,6 +40,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--full-matrix", action="store_true", help="also build Quality[128][512] (kthread -L path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: skip the exact check, the other kernels and the end-to-end legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target wall time of the CPU baseline leg")
     return ap.parse_args()
 
@@ -142,46 +145,24 @@ def main():
     need = n * (L + 8) + (1 << 30)
     if need > free * 0.92:  # smaller HBM than expected: shrink the resident batch, say so
         n = int(free * 0.92 - (1 << 30)) // (L + 8)
-    first = rank * n  # global record index of this shard (counter-based generator)
+    first = shard.weak_shard_first(rank, n)  # global record index of this shard (counter-based generator)
     d_qual = torch.empty(n * L, dtype=torch.uint8, device="cuda")
     d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     ctx.synth_fastq_dev(12345, first, n, L, d_qual, None, d_off)
     ctx.sync()
 
-    # ---- the one collective: native RCCL on the context's stream, else torch.distributed --
-    allreduce = "none"
-    if world > 1:
-        try:
-            uid = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(hp.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            ctx.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-            allreduce = "rccl-native"
-        except Exception as e:  # noqa: BLE001
-            allreduce = "torch.distributed"
-            if rank == 0:
-                print(f"[bench] native RCCL init failed ({e}); using torch.distributed", file=sys.stderr)
-        ok = torch.tensor([1 if allreduce == "rccl-native" else 0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            allreduce = "torch.distributed"
-    flags = _lib.TALLY_QUAL_HIST if a.full_matrix else 0
-    words = _lib.TALLY_WORDS if a.full_matrix else _lib.W_BAD + 1
-    d_acc = ctx.tally_devptr()
+    # ---- the one collective: native RCCL on the context's stream, else torch.distributed (shard.ShardedTally) --
+    job = shard.ShardedTally(ctx, rank, world, device="cuda", full_matrix=a.full_matrix)
+    allreduce = job.setup(hp.comm_unique_id)
+    if allreduce == "torch.distributed" and rank == 0:
+        print(f"[bench] native RCCL init failed on some rank ({getattr(job, 'why', 'another rank')}); using torch.distributed",
+              file=sys.stderr)
     kernel_ms = []
 
     def step():
-        ctx.fastq_tally_dev(d_qual, d_off, n, flags=flags)
-        if allreduce == "rccl-native":
-            ctx.allreduce_u64(d_acc, words)
-        res = ctx.fastq_tally_fetch(qual_hist=a.full_matrix)
+        out = job.step(d_qual, d_off, n)
         kernel_ms.append(ctx.last_kernel_ms(0))
-        if allreduce == "torch.distributed":
-            v = torch.from_numpy(shard.pack_counts(res.seqlen, res.total, res.q20, res.q30)).cuda()
-            shard.allreduce_counts(v)
-            return shard.unpack_counts(v.cpu().numpy())
-        return {"seqlen": res.seqlen.copy(), "total": res.total, "q20": res.q20, "q30": res.q30}
+        return out
 
     def fence():
         ctx.sync()
@@ -198,17 +179,30 @@ def main():
     for _ in range(a.steps):
         out = step()
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = shard.max_over_ranks(time.perf_counter() - t0, "cuda")
 
-    # ---- result sanity: counts are exact and closed-form checkable -----------------------
-    assert out["total"] == world * n * L, (out["total"], world, n, L)
-    assert int(out["seqlen"][L]) == world * n
-    q20, q30 = out["q20"] / out["total"], out["q30"] / out["total"]
-    assert abs(q20 - 0.55) < 1e-3 and abs(q30 - 0.30) < 1e-3, (q20, q30)
+    # ---- result checks (after the timed region) ------------------------------------------------
+    # closed form: every record of every rank counted once, at its length
+    job.check_closed_form(out, n, L)
+    extra = {}
+    if not a.no_extra:
+        # exact: this rank's K1 counts against an independent kernel (K1L) over the same resident bytes, and three
+        # 2e5-read windows against the CPU oracle (bench_extra.exact_check)
+        import bench_extra
+        ctx.fastq_tally_dev(d_qual, d_off, n, flags=0)
+        loc = ctx.fastq_tally_fetch()
+        local = {"seqlen": loc.seqlen.copy(), "total": loc.total, "q20": loc.q20, "q30": loc.q30}
+        extra["exact"] = bench_extra.exact_check(ctx, d_qual, d_off, n, L, 12345, first, local)
+        if world == 1:
+            assert (out["total"], out["q20"], out["q30"]) == (local["total"], local["q20"], local["q30"])
+    del d_qual, d_off
+    torch.cuda.empty_cache()
+    if world == 1 and not a.no_extra:
+        extra["kernel_legs"] = bench_extra.kernel_legs(ctx)
+        try:
+            extra["end_to_end"] = bench_extra.e2e_legs(ctx, usable_cpus())
+        except Exception as e:  # noqa: BLE001  (file-system or toolchain trouble must not take the GPU line down)
+            extra["end_to_end"] = [{"leg": "failed", "why": str(e)[:300]}]
 
     if rank == 0:
         bases = world * n * L * a.steps
@@ -244,6 +238,8 @@ def main():
             except Exception as e:  # noqa: BLE001  (a reported baseline must not take the GPU line down)
                 line["cpu_baseline"] = {"value": None, "unit": "Gbases/s", "cores": usable_cpus(), "kind": "port",
                                         "sample": f"failed: {e}"}
+        if extra:
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,331 @@
+"""bench_extra.py -- the other named configurations, reported beside bench.py's headline in its `extra` object.
+
+  kernel_legs(ctx)      K1L (fastq_count_kthread -L), K2 (fastq_trim, BASELINE configs[2] shape), K3 + K4 (bam2depth on a
+                        chr1-sized target at 30x, configs[3]) and K5 (bam_sliding_count): device-resident synthetic input,
+                        algorithmic bytes of SURVEY.md §8(d), kernel time from the library's HIP events -> fraction of 8 TB/s.
+  exact_check(...)      the headline kernel's counts on the full resident batch against an independent kernel (K1L's
+                        Quality matrix: total / Q20 / Q30 are its row sums) and, after all timing, three windows of the
+                        batch against the CPU oracle (checker use only).
+  e2e_legs(...)         file -> report through the built CLI binaries (host inflate / framing / PCIe / text output included),
+                        the reference binary timed beside each when oracle/_ref holds it.  Never the headline `value`.
+"""
+import ctypes as C
+import filecmp
+import os
+import shutil
+import statistics
+import subprocess
+import tempfile
+import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(ROOT, "highperformancengs_amd", "bin")
+REF = os.path.join(ROOT, "oracle", "_ref")
+PEAK = 8000.0
+
+
+def _leg(name, ms, alg_bytes, **more):
+    gbs = alg_bytes / ms / 1e6
+    return {"kernel": name, "kernel_ms": round(ms, 4), "algorithmic_bytes": int(alg_bytes), "achieved_GBps": round(gbs, 1),
+            "frac": round(gbs / PEAK, 4), **more}
+
+
+def _median_ms(ctx, fn, family, reps):
+    ts = []
+    for r in range(reps + 1):
+        fn()
+        ctx.sync()
+        if r:
+            ts.append(ctx.last_kernel_ms(family))
+    return statistics.median(ts)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# kernel legs
+# --------------------------------------------------------------------------------------------------------------
+def kernel_legs(ctx, reps=5):
+    import torch
+    legs = []
+    # ---- FASTQ: K1L and K2 on 2e8 x 150 bp ------------------------------------------------------------------
+    n, L = 200_000_000, 150
+    dq = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    db = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_fastq_dev(7, 0, n, L, dq, db, do)
+    ctx.sync()
+
+    def k1l():
+        ctx.fastq_tally_dev(dq, do, n, flags=1)
+        ctx.fastq_tally_fetch(qual_hist=True)
+    legs.append(_leg("K1L k_tally_hist: Quality[128][512] (fastq_count_kthread -L)", _median_ms(ctx, k1l, 0, reps),
+                     n * L + (n + 1) * 8, reads=n, read_len=L))
+
+    def k1ln():
+        ctx.fastq_tally_dev(dq, do, n, d_base=db, flags=3)
+        ctx.fastq_tally_fetch(qual_hist=True, nuc_hist=True)
+    legs.append(_leg("K1L k_tally_hist: + Nucleotide[5][512] (hpn_fastq_rqc)", _median_ms(ctx, k1ln, 0, reps),
+                     2 * n * L + (n + 1) * 8, reads=n, read_len=L))
+    S, E = 5, 140
+    oq = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
+    ob = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
+    oo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ms = _median_ms(ctx, lambda: ctx.fastq_trim_dev(db, dq, do, n, S, E, ob, oq, oo), 1, reps)
+    legs.append(_leg("K2 k_trim_scan + k_trim_copy: fastq_trim -s 5 -e 140, one mate", ms,
+                     2 * n * L + 16 * n + 2 * n * (E - S) + 8 * n, reads=n, read_len=L))
+    # trimmed output = strided view of the input (exact, on the device)
+    assert int(oo[-1].item()) == n * (E - S)
+    k = 1_000_003
+    assert torch.equal(oq[k * (E - S):(k + 1) * (E - S)], dq[k * L + S:k * L + E])
+    del dq, db, do, oq, ob, oo
+    torch.cuda.empty_cache()
+
+    # ---- BAM: chr1-sized target at 30x (SURVEY §8d CIGAR / flag mix) ------------------------------------------
+    TL, L = 248_956_422, 150
+    n = 30 * TL // L
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pos = torch.sort(torch.randint(0, TL - 200, (n,), device="cuda", generator=g, dtype=torch.int32)).values
+    tid = torch.zeros(n, dtype=torch.int32, device="cuda")
+    fl = torch.tensor([0, 16] * 9 + [4, 256, 512, 1024], dtype=torch.int32, device="cuda")[
+        torch.randint(0, 22, (n,), device="cuda", generator=g)]
+    pick = torch.randint(0, 20, (n,), device="cuda", generator=g)
+    kind = torch.where(pick < 17, 0, pick - 16)       # 85 % 150M, 5 % 40M2I108M, 5 % 60M5D90M, 5 % 10S140M
+    table = torch.tensor([[150 << 4, 0, 0], [40 << 4, (2 << 4) | 1, 108 << 4], [60 << 4, (5 << 4) | 2, 90 << 4],
+                          [(10 << 4) | 4, 140 << 4, 0]], dtype=torch.int32, device="cuda")
+    ncig = torch.tensor([1, 3, 3, 2], dtype=torch.int32, device="cuda")[kind]
+    words = table[kind]
+    keep = torch.arange(3, device="cuda")[None, :] < ncig[:, None]
+    cigar = words[keep].contiguous()
+    cigar_off = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    cigar_off[1:] = torch.cumsum(ncig, 0)
+    m_per = torch.tensor([150, 148, 150, 140], dtype=torch.int64, device="cuda")[kind]   # M bases per record
+    del pick, kind, words, keep
+
+    class D:
+        pass
+    d = D()
+    d.tid, d.pos, d.flag, d.cigar_off, d.cigar = tid, pos, fl, cigar_off, cigar
+    d.l_qseq = torch.full((n,), L, dtype=torch.int32, device="cuda")
+    d.seq_off = torch.arange(n + 1, device="cuda", dtype=torch.int64) * ((L + 1) // 2)
+    d.seq4 = torch.randint(0, 256, (n * ((L + 1) // 2),), device="cuda", generator=g, dtype=torch.uint8)
+    n_ops, n_m = int(cigar.numel()), int(((cigar & 15) == 0).sum().item())
+    keep_alive, ts3, ts4 = [], [], []
+    for r in range(reps + 1):
+        ctx._ck(ctx.L.hpn_depth_begin(ctx.h, 0, TL, 0x704), "hpn_depth_begin")
+        b = ctx._batch(d, keep_alive)
+        ctx._ck(ctx.L.hpn_depth_add_dev(ctx.h, C.byref(b)), "hpn_depth_add_dev")
+        ctx.sync()
+        t3 = ctx.last_kernel_ms(2)
+        runs, win = ctx.depth_finish(TL, 20000, runs_cap=1 << 27)
+        t4 = ctx.last_kernel_ms(2)
+        if r:
+            ts3.append(t3), ts4.append(t4)
+    slots = TL + 1 + (1 << 21)
+    legs.append(_leg("K3 k_depth_index + k_depth_tiles: CIGAR-M difference array (bam2depth fetch_func)",
+                     statistics.median(ts3), n * 16 + 4 * n_ops + 8 * n_m, records=n, cigar_ops=n_ops, target_len=TL))
+    legs.append(_leg("K4 k_depth_scan: prefix sum + runs + window sums (hash2BedGraph, overlap)", statistics.median(ts4),
+                     slots * 4 + 12 * len(runs) + 8 * len(win), positions=slots, runs=len(runs)))
+    # size-independent properties of the result: coverage mass = M bases of the kept records, runs sorted and disjoint
+    m_bases = int(m_per[(fl & 0x704) == 0].sum().item())
+    assert int(win.sum()) == m_bases, (int(win.sum()), m_bases)
+    assert int(((runs[:, 1] - runs[:, 0]).astype(np.int64) * runs[:, 2]).sum()) == m_bases
+    assert bool((runs[1:, 0] >= runs[:-1, 1]).all()) and bool((runs[:, 2] > 0).all())
+    del runs, win
+    off = np.array([0, TL // 20000 + 1], np.uint64)
+    ts5 = []
+    for r in range(reps + 1):
+        bins, gc, ln, touched, nc = ctx.window_counts(d, off, 20000, dev=True)
+        if r:
+            ts5.append(ctx.last_kernel_ms(3))
+    counted = int(((fl & 4) == 0).sum().item())
+    assert int(bins.sum()) == nc == counted and int(ln.sum()) == counted * L
+    legs.append(_leg("K5 k_window_add: per-window count / GC / length (bam_sliding_count fetch_func + cal_GC)",
+                     statistics.median(ts5), n * (20 + (L + 1) // 2), records=n))
+    del d, tid, pos, fl, cigar, cigar_off, m_per
+    torch.cuda.empty_cache()
+    return legs
+
+
+# --------------------------------------------------------------------------------------------------------------
+# exactness of the headline launch
+# --------------------------------------------------------------------------------------------------------------
+def exact_check(ctx, d_qual, d_off, n, L, seed, first, local_counts):
+    """local_counts: what K1 returned for THIS rank's resident batch (before any all-reduce)."""
+    import torch
+    # (1) an independent kernel over the same resident bytes: K1L builds Quality[128][512]; total / Q20 / Q30 are row sums
+    ctx.fastq_tally_dev(d_qual, d_off, n, flags=1)
+    full = ctx.fastq_tally_fetch(qual_hist=True)
+    qh = np.asarray(full.qual_hist, np.uint64)
+    rows = qh.sum(axis=1)
+    k1l = (int(rows.sum()), int(rows[53:].sum()), int(rows[63:].sum()))
+    k1 = (int(local_counts["total"]), int(local_counts["q20"]), int(local_counts["q30"]))
+    assert k1 == k1l, ("K1 and K1L disagree on the resident batch", k1, k1l)
+    assert (full.total, full.q20, full.q30) == k1l and np.array_equal(np.asarray(full.seqlen), np.asarray(local_counts["seqlen"]))
+    assert int(qh[:, L:].sum()) == 0 and bool((qh[:, :L].sum(axis=0) == n).all())   # every cycle of every read, once
+    # (2) three windows of the batch against the CPU oracle (checker use, after the timed region)
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
+    orc.orc_counts_new.restype = C.c_void_p
+    orc.orc_counts_free.argtypes = [C.c_void_p]
+    u8p, u64p = np.ctypeslib.ndpointer(np.uint8, flags="C"), np.ctypeslib.ndpointer(np.uint64, flags="C")
+    orc.orc_count_soa.argtypes = [u8p, u64p, C.c_uint64, C.c_void_p]
+    orc.orc_counts_flat_quality.argtypes = [C.c_void_p, u64p]
+    orc.orc_synth_soa.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u8p, u8p, u64p]
+    w = min(200_000, n)
+    windows = []
+    for a in sorted({0, (n - w) // 2, n - w}):
+        q = d_qual[a * L:(a + w) * L].cpu().numpy()
+        o = (d_off[a:a + w + 1] - d_off[a]).cpu().numpy().astype(np.uint64)
+        box = orc.orc_counts_new()
+        assert orc.orc_count_soa(q, o, w, box) == 0
+        want = np.zeros(128 * 512, np.uint64)
+        orc.orc_counts_flat_quality(box, want)
+        orc.orc_counts_free(box)
+        want = want.reshape(128, 512)
+        ctx.fastq_tally_dev(d_qual[a * L:], d_off[a:a + w + 1] - d_off[a], w, flags=1)
+        got = ctx.fastq_tally_fetch(qual_hist=True)
+        assert np.array_equal(np.asarray(got.qual_hist, np.uint64), want), f"window at record {a}: Quality matrix differs from the oracle"
+        ctx.fastq_tally_dev(d_qual[a * L:], d_off[a:a + w + 1] - d_off[a], w, flags=0)
+        fast = ctx.fastq_tally_fetch()
+        assert (fast.total, fast.q20, fast.q30) == (int(want.sum()), int(want[53:].sum()), int(want[63:].sum()))
+        # and the resident bytes are the generator's (the oracle restates the same counter-based function)
+        sq, qq, oo = np.zeros(w * L, np.uint8), np.zeros(w * L, np.uint8), np.zeros(w + 1, np.uint64)
+        orc.orc_synth_soa(seed, first + a, w, L, L, sq, qq, oo)
+        assert np.array_equal(qq, q)
+        windows.append(int(a))
+    return {"k1_equals_k1l_on_resident_batch": True, "reads": int(n), "total": k1[0], "q20": k1[1], "q30": k1[2],
+            "oracle_windows": {"records_each": int(w), "starts": windows, "matrix_and_counts_identical": True}}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# end to end through the CLI binaries
+# --------------------------------------------------------------------------------------------------------------
+def _fastq_text(ctx, n, L, seed):
+    """n fixed-length records as FASTQ text (names zero-padded: every record has the same byte length)."""
+    import torch
+    dq = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    db = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_fastq_dev(seed, 0, n, L, dq, db, do)
+    ctx.sync()
+    name_w = 10
+    rec = 1 + 1 + name_w + 1 + L + 1 + 2 + L + 1                      # "@r" name \n seq \n +\n qual \n
+    t = torch.empty((n, rec), dtype=torch.uint8, device="cuda")
+    t[:, 0], t[:, 1] = ord("@"), ord("r")
+    idx = torch.arange(n, device="cuda", dtype=torch.int64)
+    for k in range(name_w):
+        t[:, 2 + k] = (48 + (idx // 10 ** (name_w - 1 - k)) % 10).to(torch.uint8)
+    p = 2 + name_w
+    t[:, p] = 10
+    t[:, p + 1:p + 1 + L] = db.view(n, L)
+    t[:, p + 1 + L] = 10
+    t[:, p + 2 + L], t[:, p + 3 + L] = ord("+"), 10
+    t[:, p + 4 + L:p + 4 + 2 * L] = dq.view(n, L)
+    t[:, p + 4 + 2 * L] = 10
+    return t.cpu().numpy().reshape(-1)
+
+
+def _gz_members(buf, n_members, threads):
+    """Concatenated gzip members (what `cat a.gz b.gz` or bgzip-less pipelines give; gzread reads them as one stream)."""
+    cuts = [len(buf) * i // n_members for i in range(n_members + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda i: _gzip_one(buf[cuts[i]:cuts[i + 1]]), range(n_members)))
+    return b"".join(parts)
+
+
+def _gzip_one(b):
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    return co.compress(b) + co.flush()
+
+
+def _gz_single_member(buf, pieces, threads):
+    """ONE gzip member made in parallel the way pigz does: raw deflate pieces ending on sync-flush points, one trailer."""
+    cuts = [len(buf) * i // pieces for i in range(pieces + 1)]
+
+    def piece(i):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        b = buf[cuts[i]:cuts[i + 1]]
+        return co.compress(b) + co.flush(zlib.Z_FINISH if i == pieces - 1 else zlib.Z_FULL_FLUSH), zlib.crc32(b), len(b)
+    with ThreadPoolExecutor(threads) as ex:
+        out = list(ex.map(piece, range(pieces)))
+    crc = zlib.crc32(buf)
+    return (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\xff" + b"".join(o[0] for o in out) +
+            (crc & 0xffffffff).to_bytes(4, "little") + (len(buf) & 0xffffffff).to_bytes(4, "little"))
+
+
+def _timed(cmd, cwd, env=None):
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **(env or {})})
+    return time.perf_counter() - t0, p
+
+
+def _outputs(d, inputs):
+    return sorted(f for f in os.listdir(d) if f not in inputs and not f.endswith("_hits.png"))
+
+
+def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
+    legs = []
+    td = tempfile.mkdtemp(prefix="hpn_e2e_")
+    try:
+        text = _fastq_text(ctx, reads, L, 31)
+        raw = text.tobytes()
+        del text
+        files = {"plain.fq": raw, "members.fq.gz": _gz_members(raw, 32, cores), "single.fq.gz": _gz_single_member(raw, 64, cores)}
+        for name, blob in files.items():
+            with open(os.path.join(td, name), "wb") as f:
+                f.write(blob)
+        sizes = {k: len(v) for k, v in files.items()}
+        del files, raw
+        bases = reads * L
+
+        def pair(label, tool, args_of, inputs, unit_bases, warm=True):
+            """Time our binary and the reference's on the same input in fresh directories; compare every output byte."""
+            res, outs = {"leg": label}, {}
+            for who, d in (("hpngs", BIN), ("reference", REF)):
+                exe = os.path.join(d, tool)
+                if not os.access(exe, os.X_OK):
+                    res[who] = None
+                    continue
+                wd = tempfile.mkdtemp(prefix=f"{who}_", dir=td)
+                for i in inputs:
+                    os.symlink(os.path.join(td, i), os.path.join(wd, i))
+                if warm and who == "hpngs":                       # first run pays HIP start-up and the page cache
+                    _timed([exe] + args_of(wd), wd)
+                    for f in _outputs(wd, inputs):
+                        os.unlink(os.path.join(wd, f))
+                dt, p = _timed([exe] + args_of(wd), wd)
+                res[who] = {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode}
+                outs[who] = (wd, _outputs(wd, inputs), p.stdout)
+            if len(outs) == 2:
+                a, b = outs["hpngs"], outs["reference"]
+                res["outputs_identical"] = bool(a[1] == b[1] and a[2] == b[2] and all(
+                    filecmp.cmp(os.path.join(a[0], f), os.path.join(b[0], f), shallow=False) for f in a[1]))
+                res["speedup"] = round(res["reference"]["seconds"] / res["hpngs"]["seconds"], 2)
+            for wd, _, _ in outs.values():
+                shutil.rmtree(wd, ignore_errors=True)
+            return res
+
+        for name, what in (("plain.fq", "plain text"), ("members.fq.gz", "gzip, 32 members"), ("single.fq.gz", "gzip, one member")):
+            r = pair(f"fastq_count, {reads:.0e} x {L} bp, {what} ({sizes[name] / 1e6:.0f} MB)", "fastq_count",
+                     lambda wd, n=name: ["-o", "rep.txt", n], [name], bases)
+            legs.append(r)
+        legs.append(pair(f"fastq_count_kthread -L, {reads:.0e} x {L} bp, plain text", "fastq_count_kthread",
+                         lambda wd: ["-L", "-o", "m.tsv", "plain.fq"], ["plain.fq"], bases))
+        legs.append(pair(f"fastq_trim -s 5 -e 140, {reads:.0e} x {L} bp, plain text -> file", "fastq_trim",
+                         lambda wd: ["-i", "plain.fq", "-s", "5", "-e", "140", "-o", "t"], ["plain.fq"], bases))
+        for f in ("plain.fq", "members.fq.gz", "single.fq.gz"):
+            os.unlink(os.path.join(td, f))
+        # ---- BAM --------------------------------------------------------------------------------------------------
+        synth = os.path.join(td, "bam_synth")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "scripts", "bam_synth.cpp"), "-o", synth, "-lz", "-lpthread"])
+        subprocess.check_call([synth, os.path.join(td, "s.bam"), str(bam_reads), "2", "5000000", str(cores)])
+        bsz = os.path.getsize(os.path.join(td, "s.bam"))
+        ins = ["s.bam", "s.bam.bai"]
+        for tool, args in (("bam2depth", ["-o", "d", "s.bam"]), ("bam2wig", ["-o", "w", "s.bam"]), ("bam_sliding_count", ["-o", "s", "s.bam"])):
+            legs.append(pair(f"{tool}, {bam_reads:.0e} x 150 bp over 2 x 5 Mb (30x), BAM {bsz / 1e6:.0f} MB -> reports", tool,
+                             lambda wd, a=args: a, ins, bam_reads * 150))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return legs

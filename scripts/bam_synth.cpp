@@ -4,14 +4,15 @@
 //   /tmp/bam_synth out.bam <reads> <contigs> <contig_len> [threads] [packed]
 // 150 bp reads, starts uniform per contig, CIGAR mix 85 % 150M, 5 % 40M2I108M, 5 % 60M5D90M,
 // 5 % 10S140M; flags 90 % {0,16}, 10 % from {4,256,512,1024}; bases ACGT + 1 % N.
-// Writes out.bam and an EMPTY out.bam.bai (our tools only test that the index exists; the
-// reference tools need a real one -- use tests/bam_synth.py + highperformancengs_amd/bamio.py for those).
+// Writes out.bam and out.bam.bai (bins + 16 kb linear index, as samtools index would: the reference
+// tools load it with bam_index_load and fetch through it).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,7 +49,62 @@ static std::vector<uint8_t> bgzf_block(const uint8_t *src, size_t n)
 
 // records = true: `raw` is a run of whole BAM records and no record may straddle two blocks
 // (what samtools' bam_write1 guarantees through bgzf_flush_try, bam.c:238)
-static void write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads, bool records)
+struct BlockAt {
+    uint64_t file_off;     // where the compressed block starts in the file
+    size_t raw_beg, raw_end;
+};
+
+// .bai under construction: bin -> chunks of virtual offsets, and the 16 kb linear index, per contig
+struct Index {
+    std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;
+    std::vector<std::vector<uint64_t>> lin;
+    static uint32_t reg2bin(uint32_t beg, uint32_t end)
+    {
+        --end;
+        if (beg >> 14 == end >> 14) return 4681 + (beg >> 14);
+        if (beg >> 17 == end >> 17) return 585 + (beg >> 17);
+        if (beg >> 20 == end >> 20) return 73 + (beg >> 20);
+        if (beg >> 23 == end >> 23) return 9 + (beg >> 23);
+        if (beg >> 26 == end >> 26) return 1 + (beg >> 26);
+        return 0;
+    }
+    void add(int tid, uint32_t pos, uint32_t rend, uint64_t vbeg, uint64_t vend)
+    {
+        auto &ch = bins[(size_t)tid][reg2bin(pos, rend)];
+        if (!ch.empty() && ch.back().second == vbeg) ch.back().second = vend;
+        else ch.emplace_back(vbeg, vend);
+        auto &l = lin[(size_t)tid];
+        for (uint32_t w = pos >> 14; w <= (rend - 1) >> 14; ++w) {
+            if (l.size() <= w) l.resize(w + 1, 0);
+            if (l[w] == 0 || vbeg < l[w]) l[w] = vbeg;
+        }
+    }
+    void write(const std::string &path) const
+    {
+        FILE *f = fopen(path.c_str(), "wb");
+        auto w32 = [&](uint32_t x) { fwrite(&x, 4, 1, f); };
+        auto w64 = [&](uint64_t x) { fwrite(&x, 8, 1, f); };
+        fwrite("BAI\1", 1, 4, f);
+        w32((uint32_t)bins.size());
+        for (size_t t = 0; t < bins.size(); ++t) {
+            w32((uint32_t)bins[t].size());
+            for (auto &kv : bins[t]) {
+                w32(kv.first), w32((uint32_t)kv.second.size());
+                for (auto &c : kv.second) w64(c.first), w64(c.second);
+            }
+            w32((uint32_t)lin[t].size());
+            uint64_t last = 0;
+            for (uint64_t v : lin[t]) {   // windows without a record carry the previous offset (bam_index.c fill_missing)
+                if (v == 0) v = last;
+                last = v;
+                w64(v);
+            }
+        }
+        fclose(f);
+    }
+};
+
+static std::vector<BlockAt> write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads, bool records)
 {
     const size_t kIn = 0xff00;
     std::vector<size_t> cut{0};
@@ -73,7 +129,15 @@ static void write_blocks(FILE *f, const std::vector<uint8_t> &raw, int threads, 
                 if (cut[b + 1] > cut[b]) out[b] = bgzf_block(raw.data() + cut[b], cut[b + 1] - cut[b]);
         });
     for (auto &t : th) t.join();
-    for (auto &o : out) fwrite(o.data(), 1, o.size(), f);
+    std::vector<BlockAt> at;
+    uint64_t off = (uint64_t)ftello(f);
+    for (size_t b = 0; b < nb; ++b) {
+        if (out[b].empty()) continue;
+        at.push_back(BlockAt{off, cut[b], cut[b + 1]});
+        fwrite(out[b].data(), 1, out[b].size(), f);
+        off += out[b].size();
+    }
+    return at;
 }
 
 int main(int argc, char **argv)
@@ -117,6 +181,8 @@ int main(int argc, char **argv)
         }
         write_blocks(f, raw, threads, false);
     }
+    Index idx;
+    idx.bins.resize((size_t)contigs), idx.lin.resize((size_t)contigs);
     const uint64_t per = reads / (uint64_t)contigs, kBatch = 1u << 20;
     static const uint32_t cig[4][3] = {{150u << 4, 0, 0}, {40u << 4, (2u << 4) | 1, 108u << 4}, {60u << 4, (5u << 4) | 2, 90u << 4}, {(10u << 4) | 4, 140u << 4, 0}};
     static const int ncig[4] = {1, 3, 3, 2};
@@ -161,11 +227,34 @@ int main(int argc, char **argv)
             for (auto &t : th) t.join();
             raw.clear();
             for (auto &p : part) raw.insert(raw.end(), p.begin(), p.end());
-            write_blocks(f, raw, threads, argc <= 6);  // a 7th argument: pack records across blocks instead
+            const std::vector<BlockAt> at = write_blocks(f, raw, threads, argc <= 6);  // a 7th argument: pack records across blocks instead
+            if (argc <= 6) {                                   // index the batch: every record lies inside one block
+                const uint64_t after = (uint64_t)ftello(f);
+                for (size_t b = 0; b < at.size(); ++b) {
+                    const uint64_t next = b + 1 < at.size() ? at[b + 1].file_off : after;
+                    for (size_t p = at[b].raw_beg; p < at[b].raw_end;) {
+                        uint32_t bs, pos, flag_nc;
+                        memcpy(&bs, raw.data() + p, 4), memcpy(&pos, raw.data() + p + 8, 4), memcpy(&flag_nc, raw.data() + p + 16, 4);
+                        const uint8_t *cg = raw.data() + p + 36 + raw[p + 12];
+                        uint32_t rl = 0;
+                        for (uint32_t q = 0; q < (flag_nc & 0xffffu); ++q) {
+                            uint32_t w;
+                            memcpy(&w, cg + 4 * q, 4);
+                            if ((w & 15) == 0 || (w & 15) == 2 || (w & 15) == 3 || (w & 15) == 7 || (w & 15) == 8) rl += w >> 4;
+                        }
+                        const size_t e = p + 4 + bs;
+                        const uint64_t vbeg = at[b].file_off << 16 | (uint64_t)(p - at[b].raw_beg);
+                        const uint64_t vend = e < at[b].raw_end ? (at[b].file_off << 16 | (uint64_t)(e - at[b].raw_beg)) : next << 16;
+                        idx.add(c, pos, pos + (rl ? rl : 1), vbeg, vend);
+                        p = e;
+                    }
+                }
+            }
         }
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, 28, f);
     fclose(f);
-    fclose(fopen((std::string(argv[1]) + ".bai").c_str(), "wb"));
+    if (argc <= 6) idx.write(std::string(argv[1]) + ".bai");
+    else fclose(fopen((std::string(argv[1]) + ".bai").c_str(), "wb"));   // packed records: our tools only (they need the file to exist)
     return 0;
 }

@@ -81,3 +81,93 @@ def test_summarise_min_rule():
     h[0], h[4], h[6] = 2, 1, 1
     rep = shard.summarise(h, 10, 10, 8)
     assert (rep["reads"], rep["min_len"], rep["max_len"], rep["bases"]) == (4, 4, 6, 10.0)
+
+
+# ---- bench.py's rank arithmetic (shard.ShardedTally) driven on CPU with a stub context -----------------------------
+
+class _StubCtx:
+    """What ShardedTally needs of api.Context, on the CPU: tallies come from the oracle, the 'native' all-reduce is a
+    gloo all-reduce of the context's count vector (where hpn_allreduce_u64 would run RCCL on its stream)."""
+
+    def __init__(self, rank, fail_init):
+        self.rank, self.fail_init, self.inits, self.vec = rank, fail_init, 0, None
+
+    def comm_init(self, rank, world, uid):
+        assert len(uid) == 128 and uid == bytes(range(128))      # rank 0's id reached this rank
+        self.inits += 1
+        if self.fail_init:
+            raise RuntimeError("no RCCL on this rank")
+
+    def fastq_tally_dev(self, d_qual, d_off, n, flags=0):
+        import orc
+        from highperformancengs_amd import shard
+        rc, c = orc.count_soa(d_qual, d_off)
+        s = c.summary()
+        self.vec = torch.from_numpy(shard.pack_counts(c.seqlen, s.sum, s.q20, s.q30,
+                                                      qual_hist=c.quality if flags else None))
+
+    def tally_devptr(self):
+        return self.vec
+
+    def allreduce_u64(self, vec, words):
+        assert len(vec) == words
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+
+    def fastq_tally_fetch(self, qual_hist=False):
+        from highperformancengs_amd import shard
+
+        class R:
+            pass
+        r, u = R(), shard.unpack_counts(self.vec.numpy())
+        r.seqlen, r.total, r.q20, r.q30, r.qual_hist = u["seqlen"], u["total"], u["q20"], u["q30"], u.get("qual_hist")
+        return r
+
+
+def _bench_worker(rank, world, port, n_per_rank, fail_rank, full, q):
+    import orc
+    from highperformancengs_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _StubCtx(rank, fail_init=(rank == fail_rank))
+    job = shard.ShardedTally(ctx, rank, world, device="cpu", full_matrix=full)
+    mode = job.setup(lambda: bytes(range(128)))
+    first = shard.weak_shard_first(rank, n_per_rank)
+    seq, qual, off = orc.synth_soa(99, first, n_per_rank, 60, 60)
+    out = job.step(qual, off, n_per_rank)
+    job.check_closed_form(out, n_per_rank, 60)
+    slowest = shard.max_over_ranks(1.0 + rank, "cpu")
+    q.put((rank, mode, ctx.inits, out["total"], out["q20"], out["q30"], out["seqlen"].copy(),
+           out.get("qual_hist", np.zeros(1)).copy(), slowest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("fail_rank,full,want_mode", [(-1, False, "rccl-native"), (1, False, "torch.distributed"),
+                                                      (0, True, "torch.distributed"), (-1, True, "rccl-native")])
+def test_bench_rank_arithmetic_two_ranks(fail_rank, full, want_mode):
+    """Every rank gets rank 0's unique id, ONE failing hpn_comm_init moves both ranks to the torch.distributed sum (no
+    rank is left alone in a collective), both routes give the whole job's counts on every rank, time = slowest rank."""
+    import orc
+    world, n_per_rank = 2, 700
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bench_worker, args=(r, world, port, n_per_rank, fail_rank, full, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seq, qual, off = orc.synth_soa(99, 0, world * n_per_rank, 60, 60)
+    rc, want = orc.count_soa(qual, off)
+    s = want.summary()
+    for rank, mode, inits, total, q20, q30, seqlen, qh, slowest in got:
+        assert mode == want_mode and inits == 1
+        assert (total, q20, q30) == (s.sum, s.q20, s.q30) and np.array_equal(seqlen, want.seqlen)
+        if full:
+            assert np.array_equal(qh, want.quality)
+        assert slowest == 2.0
