@@ -204,6 +204,14 @@ class Context:
                  "hpn_fastq_text_count")
         return info
 
+    def text_records(self, chunk, last=False):
+        """One chunk of FASTQ text -> hpn_text_info with the records it completes (gzfastq_sample's count_read)."""
+        chunk, n = self._text(chunk)
+        info = _lib.TextInfo()
+        self._ck(self.L.hpn_fastq_text_records(self.h, _ptr(chunk) if n else None, n, int(bool(last)), C.byref(info)),
+                 "hpn_fastq_text_records")
+        return info
+
     def text_trim(self, chunk, S, E, last=False):
         """One chunk of FASTQ text -> (trimmed text bytes, hpn_text_info)."""
         chunk, n = self._text(chunk)

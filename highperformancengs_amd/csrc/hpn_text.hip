@@ -121,6 +121,14 @@ int hpn_fastq_text_count(hpn_ctx *c, const void *text, uint64_t nbytes, int last
                         f.n, f.total, flags);
 }
 
+int hpn_fastq_text_records(hpn_ctx *c, const void *text, uint64_t nbytes, int last, hpn_text_info *info)
+{
+    if (!c || !info) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    Framed f;
+    return text_frame(c, text, nbytes, last, false, 0, 0, info, &f);   // lines + records only: nothing is gathered or tallied
+}
+
 int hpn_fastq_text_trim(hpn_ctx *c, const void *text, uint64_t nbytes, int last, int32_t S, int32_t E, void *out_text,
                         uint64_t out_cap, hpn_text_info *info)
 {

@@ -217,6 +217,11 @@ int hpn_fastq_text_begin(hpn_ctx *ctx);
  * hpn_fastq_tally_dev (collect with hpn_fastq_tally_fetch).  tally_flags: HPN_TALLY_*. */
 int hpn_fastq_text_count(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, uint32_t tally_flags,
                          hpn_text_info *info);
+/* gzfastq_sample.c:214-225 count_read: the same four gzgets per record with nothing but i++ in the
+ * loop (its "total_reads_num").  Frames the chunk like hpn_fastq_text_count and tallies nothing:
+ * info->n_records of every chunk add up to the reference's i (= the ReadCount column of fastq_count
+ * for the same file).  Irregular text is reported the same way; the host framer then counts. */
+int hpn_fastq_text_records(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, hpn_text_info *info);
 /* readNextNode + fprintf("%s\n%s\n+\n%s\n") (fastq_trim.c:67-89,101): writes the
  * trimmed records of this chunk as text into out_text (host or device pointer,
  * capacity out_cap; nbytes + 8192 always suffices). */

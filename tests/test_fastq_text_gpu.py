@@ -242,3 +242,38 @@ def test_state_errors(ctx):
     with pytest.raises(HpnError):
         ctx.text_begin()
         ctx.text_trim(b"@a\nAC\n+\nII\n", 5, 2, last=True)  # E < S
+
+
+# ---- gzfastq_sample.c:214-225 count_read: four gzgets per record and i++ -------------------------
+# The tool itself is unbuildable here (fastq-tools' common.c includes an autoconf-generated version.h), but its
+# count_read is fastq_count's loop without the tally, so its i is the ReadCount column the reference's fastq_count
+# prints for the same file: that column is golden.
+
+@pytest.mark.parametrize("name", FASTQS)
+def test_record_count_equals_the_reference_read_count(ctx, name, manifest):
+    from conftest import expected
+    case = {c["inputs"][0].split("/")[-1]: k for k, c in manifest.items() if k.startswith("count_") and c["tool"] == "fastq_count"
+            and len(c["inputs"]) == 1}.get(name)
+    if case is None:
+        pytest.skip("no single-file fastq_count golden for " + name)
+    row = [l for l in expected(case).decode().split("\n") if l and not l.startswith("#")][0].split("\t")
+    want = int(row[1])
+    text = _text(golden_path("fastq", name))
+    for size in (None, 1000, 97):
+        ctx.text_begin()
+        parts = _chunks(text, size)
+        n, irregular = 0, 0
+        for i, p in enumerate(parts):
+            info = ctx.text_records(p, last=(i == len(parts) - 1))
+            if info.irregular:
+                irregular = info.irregular
+                break
+            n += info.n_records
+        if name in REGULAR:
+            assert irregular == 0
+        if not irregular:
+            assert n == want, (name, size)
+    # nothing was tallied by the framing-only call
+    ctx.text_begin()
+    ctx.text_records(b"@a\nAC\n+\nII\n", last=True)
+    assert ctx.fastq_tally_fetch().total == 0

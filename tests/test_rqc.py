@@ -122,3 +122,54 @@ def test_gpu_domain(ctx):
         ctx.fastq_rqc(a, a, np.array([0, 0, 5], np.uint64))
     rc, want = orc.rqc_soa(a[:300], a[:300], np.array([0, 300], np.uint64))
     _same(ctx.fastq_rqc(a[:300], a[:300], np.array([0, 300], np.uint64)), want)
+
+
+# ---- half of the pin that needs no R: the plugin's Quality[q + 128 pos] and Length[len - 1] (Rgzfastq_uniq.c:42-48,174)
+# are the transposes of what the reference's fastq_count_kthread -L prints for the same reads (fastq_count_kthread.c:52-64),
+# and those bytes are golden (tests/golden/expected/kthread_*).  Nucleotide and the per-read GC stay unpinned.
+
+def _read_fastq(path):
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    seqs, quals = lines[1::4], lines[3::4]
+    seqs, quals = seqs[:len(quals)], quals[:len(seqs)]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    return np.frombuffer(b"".join(seqs), np.uint8), np.frombuffer(b"".join(quals), np.uint8), off
+
+
+def _reference_matrix(case, name, idx):
+    from conftest import expected
+    lines = [l for l in expected(case, f"{name}.{idx}.tsv").decode().split("\n") if l and not l.startswith("#Filename")]
+    lens = [int(x) for x in lines[1].split("\t")[1:]]
+    freq = [int(x) for x in lines[2].split("\t")[1:]]
+    mat = np.array([[int(x) for x in l.split("\t")] for l in lines[3:3 + 128]], np.int64)   # [quality byte][cycle]
+    return lens, freq, mat
+
+
+HALF_PIN = [("kthread_a1", "t.fq", 0), ("kthread_a1", "t.fq.gz", 1), ("kthread_syn", "syn_var_a.fq", 0),
+            ("kthread_syn", "syn_var_b.fq.gz", 1), ("kthread_syn", "syn_100.fq.gz", 2)]
+
+
+def _check_half_pin(r, case, name, idx):
+    lens, freq, mat = _reference_matrix(case, name, idx)
+    max_len = mat.shape[1]
+    assert np.array_equal(r["quality"][:max_len].T.astype(np.int64), mat) and int(r["quality"][max_len:].sum()) == 0
+    want_len = np.zeros(300, np.int64)
+    for l, f in zip(lens, freq):
+        want_len[l - 1] = f
+    assert np.array_equal(r["length"].astype(np.int64), want_len)
+
+
+@pytest.mark.parametrize("case,name,idx", HALF_PIN)
+def test_oracle_quality_and_length_equal_the_reference_kthread_matrix(case, name, idx):
+    rc, r = orc.rqc_soa(*_read_fastq(golden_path("fastq", name)))
+    assert rc == 0
+    _check_half_pin(r, case, name, idx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,name,idx", HALF_PIN)
+def test_gpu_quality_and_length_equal_the_reference_kthread_matrix(ctx, case, name, idx):
+    _check_half_pin(ctx.fastq_rqc(*_read_fastq(golden_path("fastq", name))), case, name, idx)
