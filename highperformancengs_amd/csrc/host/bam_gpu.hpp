@@ -21,21 +21,103 @@
 
 namespace hpn {
 
-class BgzfGpuStream {
+// One batch of whole BGZF blocks as the host sees it: the block table, the block carried over from the previous
+// chunk (pageable copy) and the span of the pinned chunk that follows it.
+struct BgzfParsed {
+    std::vector<hpn_bgzf_block> blocks;
+    std::vector<uint8_t> carry;
+    const uint8_t *body = nullptr;
+    size_t body_len = 0;
+    uint64_t out_bytes = 0;      // inflated size of the batch
+    uint32_t first_off = 0;      // offset of the first record inside block 0
+};
+
+// One context's side of the ingest: device buffers, copies, inflate, record index.  Several of these can take the
+// batches of one file in turn (bam_multi.hpp); a BgzfGpuStream owns one.
+class BgzfDevice {
 public:
-    ~BgzfGpuStream()
+    explicit BgzfDevice(hpn_ctx *ctx = nullptr) : ctx_(ctx) {}
+    BgzfDevice(const BgzfDevice &) = delete;
+    ~BgzfDevice()
     {
-        pump_.reset();
         if (ctx_) {
             hpn_dev_free(ctx_, d_comp_), hpn_dev_free(ctx_, d_blocks_), hpn_dev_free(ctx_, d_out_), hpn_dev_free(ctx_, d_status_);
             hpn_host_free(ctx_, h_blocks_);
         }
     }
+    void bind(hpn_ctx *ctx) { ctx_ = ctx; }
+    hpn_ctx *ctx() const { return ctx_; }
+    const uint8_t *d_raw() const { return (const uint8_t *)d_out_; }
+
+    // Bytes and table to the device, inflate, then (records) index or (text) check every block.
+    // 1 = ok, -1 = not decodable here.  On return the pinned chunk `pb.body` points into is free again.
+    int run(const BgzfParsed &pb, bool text_mode, hpn_raw_info *info)
+    {
+        memset(info, 0, sizeof *info);
+        const size_t nb = pb.blocks.size();
+        if (!nb) return 1;
+        const size_t comp_bytes = pb.carry.size() + pb.body_len;
+        if (!reserve<uint8_t>(d_comp_, cap_comp_, comp_bytes + 64) || !reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) ||
+            !reserve<uint8_t>(d_out_, cap_out_, pb.out_bytes + 64) || !reserve<uint32_t>(d_status_, cap_status_, nb))
+            return -1;
+        if (nb > h_blocks_cap_) {
+            if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
+            h_blocks_cap_ = nb + nb / 2 + 1024;
+            if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
+        }
+        memcpy(h_blocks_, pb.blocks.data(), nb * sizeof(hpn_bgzf_block));
+        if (!pb.carry.empty()) {
+            if (hpn_memcpy_h2d(ctx_, d_comp_, pb.carry.data(), pb.carry.size()) != HPN_OK) return -1;
+            if (hpn_ctx_sync(ctx_) != HPN_OK) return -1;  // pageable source
+        }
+        if (pb.body_len && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + pb.carry.size(), pb.body, pb.body_len) != HPN_OK) return -1;
+        if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
+        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
+                                 (uint32_t *)d_status_) != HPN_OK)
+            return -1;
+        if (text_mode) {  // no records: wait, check every block's status
+            status_.resize(nb);
+            if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
+            for (uint32_t st : status_)
+                if (st) return -1;
+            info->n_records = pb.out_bytes;
+            return 1;
+        }
+        // the sync inside the index call also covers the copies out of the pinned chunk
+        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, pb.first_off,
+                                  (const uint32_t *)d_status_, info) != HPN_OK)
+            return -1;
+        return info->flags ? -1 : 1;
+    }
+
+private:
+    template <typename T>
+    bool reserve(void *&p, size_t &cap, size_t n)
+    {
+        if (n * sizeof(T) <= cap) return true;
+        if (p) hpn_dev_free(ctx_, p);
+        p = nullptr, cap = 0;
+        const size_t want = n * sizeof(T) + n * sizeof(T) / 4 + 4096;
+        if (hpn_dev_malloc(ctx_, want, &p) != HPN_OK) return false;
+        cap = want;
+        return true;
+    }
+    hpn_ctx *ctx_;
+    std::vector<uint32_t> status_;
+    void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr;
+    size_t cap_comp_ = 0, cap_blocks_ = 0, cap_out_ = 0, cap_status_ = 0, h_blocks_cap_ = 0;
+};
+
+class BgzfGpuStream {
+public:
+    ~BgzfGpuStream() { pump_.reset(); }
 
     // Parses the BAM header (host, zlib) and positions the stream at the first record.
-    bool open(hpn_ctx *ctx, const char *path, BamHeader &hdr)
+    // nbuf: pinned chunks of read-ahead (one more than the contexts that take batches)
+    bool open(hpn_ctx *ctx, const char *path, BamHeader &hdr, int nbuf = 3)
     {
         ctx_ = ctx;
+        dev_.bind(ctx);
         FILE *f = fopen(path, "rb");
         if (!f) return false;
         std::vector<uint8_t> text, raw;
@@ -76,7 +158,7 @@ public:
         if (!ok) return false;
         chunk_ = (size_t)88 << 20;  // ~4,500 blocks: one full round of the inflate kernel's 4,608 wave slots
         if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
-        pump_.reset(new TextPump(ctx, path, chunk_, 3, true));
+        pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         if (!pump_->ok()) return false;
         skip_ = start_;
         return true;
@@ -87,6 +169,7 @@ public:
     bool open_text(hpn_ctx *ctx, const char *path)
     {
         ctx_ = ctx;
+        dev_.bind(ctx);
         text_mode_ = true;
         chunk_ = (size_t)88 << 20;
         if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
@@ -95,7 +178,17 @@ public:
     }
     bool at_eof() const { return eof_ && carry_.empty(); }
 
-    const uint8_t *d_raw() const { return (const uint8_t *)d_out_; }
+    // Continue at a BGZF virtual offset (compressed block offset << 16 | offset inside the inflated block), as the
+    // .bai gives it for the first record of a target: the same buffers, a fresh read-ahead.
+    bool seek(uint64_t voffset)
+    {
+        if (!pump_ || !pump_->restart(voffset >> 16)) return false;
+        first_off_ = (uint32_t)(voffset & 0xffff), skip_ = 0, eof_ = false;
+        carry_.clear();
+        return true;
+    }
+
+    const uint8_t *d_raw() const { return dev_.d_raw(); }
 
     // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
     // be empty), 0 = end of file, -1 = not decodable here (the caller switches to the host path).
@@ -116,7 +209,9 @@ public:
                 if (eof_) return carry_.empty() ? 0 : -1;
                 continue;
             }
-            const int r = submit(c, at, info);
+            BgzfParsed pb;
+            int r = parse(c, at, pb);
+            if (r == 1) r = dev_.run(pb, text_mode_, info);
             pump_->recycle(c);
             return r;
         }
@@ -149,27 +244,16 @@ private:
         return 1;
     }
 
-    template <typename T>
-    bool reserve(void *&p, size_t &cap, size_t n)
-    {
-        if (n * sizeof(T) <= cap) return true;
-        if (p) hpn_dev_free(ctx_, p);
-        p = nullptr, cap = 0;
-        const size_t want = n * sizeof(T) + n * sizeof(T) / 4 + 4096;
-        if (hpn_dev_malloc(ctx_, want, &p) != HPN_OK) return false;
-        cap = want;
-        return true;
-    }
-
-    // Blocks of carry_ + chunk[at..): table on the host, bytes and table to the device, inflate, index.
-    int submit(const TextPump::Chunk &c, size_t at, hpn_raw_info *info)
+    // Blocks of carry_ + chunk[at..): the table, on the host (stream state: carry_ moves on to the chunk's partial tail).
+    // 1 = ok (`pb` describes the batch; it may hold no block), -1 = not BGZF / truncated.
+    int parse(const TextPump::Chunk &c, size_t at, BgzfParsed &pb)
     {
         const uint8_t *p = c.p + at;
         const size_t n = c.n - at;
         size_t done = 0;
-        blocks_.clear();
-        uint64_t out = 0, in = 0;
-        size_t carry_used = 0;
+        pb = BgzfParsed();
+        pb.first_off = first_off_;
+        uint64_t in = 0;
         if (!carry_.empty()) {  // complete the block the previous chunk ended in
             while (carry_.size() < 18 && done < n) carry_.push_back(p[done++]);
             if (carry_.size() < 18) return eof_ ? -1 : 1;
@@ -181,63 +265,27 @@ private:
             }
             carry_.insert(carry_.end(), p + done, p + done + more);
             done += more;
-            if (!add_block(carry_.data(), 0, bsize, &out)) return -1;
-            carry_used = in = bsize;
+            if (!add_block(pb, carry_.data(), 0, bsize)) return -1;
+            pb.carry.assign(carry_.begin(), carry_.begin() + bsize);
+            in = bsize;
+            carry_.clear();
         }
-        const size_t body = done;  // chunk bytes [body, stop) go to the device behind the carried block
+        pb.body = p + done;     // chunk bytes [body, body + body_len) go to the device behind the carried block
         size_t q = done;
         while (q + 18 <= n) {
             const uint32_t bsize = (p[q + 16] | (p[q + 17] << 8)) + 1u;
             if (q + bsize > n) break;
-            if (!add_block(p + q, in + (q - body), bsize, &out)) return -1;
+            if (!add_block(pb, p + q, in + (q - done), bsize)) return -1;
             q += bsize;
         }
-        const size_t stop = q;
-        std::vector<uint8_t> tail(p + stop, p + n);  // a partial block: kept for the next chunk
-        const size_t nb = blocks_.size();
-        const size_t comp_bytes = carry_used + (stop - body);
-        if (nb) {
-            if (!reserve<uint8_t>(d_comp_, cap_comp_, comp_bytes + 64) || !reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) ||
-                !reserve<uint8_t>(d_out_, cap_out_, out + 64) || !reserve<uint32_t>(d_status_, cap_status_, nb))
-                return -1;
-            if (nb > h_blocks_cap_) {
-                if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
-                h_blocks_cap_ = nb + nb / 2 + 1024;
-                if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
-            }
-            memcpy(h_blocks_, blocks_.data(), nb * sizeof(hpn_bgzf_block));
-            if (carry_used) {
-                if (hpn_memcpy_h2d(ctx_, d_comp_, carry_.data(), carry_used) != HPN_OK) return -1;
-                if (hpn_ctx_sync(ctx_) != HPN_OK) return -1;  // carry_ is pageable and replaced below
-            }
-            if (stop > body && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + carry_used, p + body, stop - body) != HPN_OK) return -1;
-            if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
-            if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
-                                     (uint32_t *)d_status_) != HPN_OK)
-                return -1;
-            if (text_mode_) {  // no records: wait, check every block's status
-                status_.resize(nb);
-                if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
-                for (uint32_t st : status_)
-                    if (st) return -1;
-                info->n_records = out;
-                carry_.swap(tail);
-                if (eof_ && !carry_.empty()) return -1;
-                return 1;
-            }
-            // the sync inside the index call also covers the copies out of the pinned chunk
-            if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
-                                      (const uint32_t *)d_status_, info) != HPN_OK)
-                return -1;
-            first_off_ = 0;
-            if (info->flags) return -1;
-        }
-        carry_.swap(tail);
+        pb.body_len = q - done;
+        carry_.assign(p + q, p + n);  // a partial block: kept for the next chunk
+        if (!pb.blocks.empty()) first_off_ = 0;
         if (eof_ && !carry_.empty()) return -1;
         return 1;
     }
 
-    bool add_block(const uint8_t *h, uint64_t in_off, uint32_t bsize, uint64_t *out)
+    static bool add_block(BgzfParsed &pb, const uint8_t *h, uint64_t in_off, uint32_t bsize)
     {
         if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') return false;
         const uint32_t xlen = h[10] | (h[11] << 8);
@@ -247,9 +295,9 @@ private:
         b.in_len = bsize - xlen - 20u;
         memcpy(&b.out_len, h + bsize - 4, 4);
         if (b.out_len > 65536u) return false;
-        b.out_off = *out;
-        *out += b.out_len;
-        blocks_.push_back(b);
+        b.out_off = pb.out_bytes;
+        pb.out_bytes += b.out_len;
+        pb.blocks.push_back(b);
         return true;
     }
 
@@ -259,11 +307,10 @@ private:
     uint64_t start_ = 0, skip_ = 0;  // file offset of the block holding the first record
     uint32_t first_off_ = 0;         // ... and the record's offset inside it
     bool eof_ = false, text_mode_ = false;
-    std::vector<uint32_t> status_;
     std::vector<uint8_t> carry_;
-    std::vector<hpn_bgzf_block> blocks_;
-    void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr;
-    size_t cap_comp_ = 0, cap_blocks_ = 0, cap_out_ = 0, cap_status_ = 0, h_blocks_cap_ = 0;
+    BgzfDevice dev_;
+
+    friend class BgzfFanout;
 };
 
 inline bool bam_gpu_enabled()

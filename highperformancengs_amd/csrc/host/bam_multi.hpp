@@ -1,0 +1,265 @@
+// bam_multi.hpp -- bam2depth / bam2wig over several GPUs: the per-target loop of the reference (bam2depth.c:325-339)
+// is independent per target, so targets are handed out largest first to one worker per device (own context, own
+// read-ahead of the compressed file, started at the target's first record as the .bai gives it) and their results
+// are written by the caller in target order.  No collective: a chromosome's 1 GB difference array never leaves its
+// GPU.  HPN_NGPU=n forces n workers (device = worker % devices): the way this path is exercised on a
+// single-GPU box.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "bam_gpu.hpp"
+
+namespace hpn {
+
+// First record of every target from a .bai (SAM spec 5.2; samtools-0.1.19 bam_index.c:348 bam_index_load_core):
+// the smallest chunk start over the target's bins (the metadata pseudo-bin 37450 aside).  ~0 = no record.
+inline bool bai_first_offsets(const char *bam, int32_t n_targets, std::vector<uint64_t> &first)
+{
+    std::string a = std::string(bam) + ".bai", b = bam;
+    FILE *f = fopen(a.c_str(), "rb");
+    if (!f && b.size() > 3 && b.compare(b.size() - 3, 3, "bam") == 0) {
+        b.replace(b.size() - 3, 3, "bai");
+        f = fopen(b.c_str(), "rb");
+    }
+    if (!f) return false;
+    char magic[4];
+    int32_t n_ref = 0;
+    bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "BAI\1", 4) && fread(&n_ref, 4, 1, f) == 1 && n_ref == n_targets;
+    first.assign((size_t)(n_targets > 0 ? n_targets : 0), ~0ull);
+    for (int32_t t = 0; ok && t < n_ref; ++t) {
+        int32_t n_bin = 0;
+        ok = fread(&n_bin, 4, 1, f) == 1 && n_bin >= 0;
+        for (int32_t k = 0; ok && k < n_bin; ++k) {
+            uint32_t bin;
+            int32_t n_chunk = 0;
+            ok = fread(&bin, 4, 1, f) == 1 && fread(&n_chunk, 4, 1, f) == 1 && n_chunk >= 0;
+            for (int32_t c = 0; ok && c < n_chunk; ++c) {
+                uint64_t be[2];
+                ok = fread(be, 8, 2, f) == 2;
+                if (ok && bin != 37450u && be[0] < first[(size_t)t]) first[(size_t)t] = be[0];
+            }
+        }
+        int32_t n_intv = 0;
+        ok = ok && fread(&n_intv, 4, 1, f) == 1 && n_intv >= 0 && fseek(f, (long)n_intv * 8, SEEK_CUR) == 0;
+    }
+    fclose(f);
+    return ok;
+}
+
+inline int multi_gpu_workers()
+{
+    if (const char *e = getenv("HPN_NGPU")) return atoi(e) > 1 ? atoi(e) : 1;
+    int n = 1;
+    if (hpn_device_count(&n) != HPN_OK || n < 1) n = 1;
+    return n;
+}
+
+struct TargetOut {
+    std::vector<hpn_run> runs;
+    uint64_t n_runs = 0;
+    std::vector<uint64_t> win;
+    int state = 0;   // 0 pending, 1 ready, -1 failed (the file goes back to the single-stream route)
+};
+
+// Runs every target of `path` through hpn_depth_begin / add / finish on `workers` contexts and calls
+// emit(j, out) for j = 0, 1, ... in order from the calling thread.  false: not usable for this file (no index
+// offsets, a block not decodable on the GPU, no second context) -- nothing has been emitted for targets >= the
+// returned *emitted, and the caller runs the remaining work on the single-stream route from scratch.
+template <class Emit>
+bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, uint32_t window, bool want_win, int workers,
+                         Emit emit)
+{
+    const int32_t nt = hdr.n_targets();
+    std::vector<uint64_t> first;
+    if (nt < 2 || !bai_first_offsets(path, nt, first)) return false;
+    std::vector<int32_t> order((size_t)nt);
+    for (int32_t j = 0; j < nt; ++j) order[(size_t)j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return hdr.target_len[a] > hdr.target_len[b]; });
+    std::vector<TargetOut> out((size_t)nt);
+    std::mutex m;
+    std::condition_variable cv;
+    size_t next = 0;
+    bool failed = false;
+    int devices = 1;
+    if (hpn_device_count(&devices) != HPN_OK || devices < 1) devices = 1;
+    auto work = [&](int w) {
+        hpn_ctx *ctx = nullptr;
+        bool ok = hpn_ctx_create(w % devices, &ctx) == HPN_OK;
+        BgzfGpuStream gs;
+        BamHeader h2;
+        ok = ok && gs.open(ctx, path, h2) && h2.n_targets() == nt;
+        for (;;) {
+            int32_t j;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!ok) failed = true;
+                if (failed || next >= order.size()) break;
+                j = order[next++];
+            }
+            TargetOut &o = out[(size_t)j];
+            int rc = hpn_depth_begin(ctx, j, hdr.target_len[j], mask);
+            if (rc == HPN_OK && first[(size_t)j] != ~0ull) {
+                ok = gs.seek(first[(size_t)j]);
+                hpn_raw_info info;
+                int r;
+                while (ok && rc == HPN_OK && (r = gs.next(&info)) != 0) {
+                    if (r < 0) {
+                        ok = false;
+                        break;
+                    }
+                    if (!info.n_records) continue;
+                    if (info.tid_min <= j && j <= info.tid_max) rc = hpn_depth_add_raw_dev(ctx, gs.d_raw());
+                    if (info.tid_min > j || info.tid_max > j || info.tid_min < 0) break;   // past the target (or into the unmapped tail)
+                }
+            }
+            if (ok && rc == HPN_OK) {
+                o.win.assign(want_win ? (size_t)hdr.target_len[j] / window + 1 : 0, 0);
+                if (o.runs.empty()) o.runs.resize(1u << 20);
+                rc = hpn_depth_finish(ctx, window, o.runs.data(), o.runs.size(), &o.n_runs, want_win ? o.win.data() : nullptr);
+                if (rc == HPN_E_CAPACITY) {
+                    o.runs.resize(o.n_runs);
+                    rc = hpn_depth_finish(ctx, window, o.runs.data(), o.runs.size(), &o.n_runs, want_win ? o.win.data() : nullptr);
+                }
+            }
+            if (rc != HPN_OK && rc != 1) {
+                fprintf(stderr, "[hpn] target %d on worker %d: %s\n", j, w, ctx ? hpn_ctx_last_error(ctx) : "no context");
+                ok = false;
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                o.state = ok ? 1 : -1;
+                if (!ok) failed = true;
+            }
+            cv.notify_all();
+        }
+        cv.notify_all();
+        // contexts are left to process exit (quick_exit_ok): tearing one down costs as much as making it
+    };
+    std::vector<std::thread> th;
+    for (int w = 0; w < workers; ++w) th.emplace_back(work, w);
+    bool good = true;
+    for (int32_t j = 0; j < nt && good; ++j) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return out[(size_t)j].state != 0 || failed; });
+            good = out[(size_t)j].state == 1;
+        }
+        if (good) {
+            emit(j, out[(size_t)j]);
+            std::vector<hpn_run>().swap(out[(size_t)j].runs);   // a chromosome's runs are ~1 GB: give them back
+        }
+    }
+    for (auto &t : th) t.join();
+    return good;
+}
+
+// One file, batches of whole BGZF blocks handed to `workers` contexts in turn (bam_sliding_count: records are
+// independent): ONE reader walks the block headers (BgzfGpuStream's host side), every worker owns a
+// context, device buffers and the inflate + record index of the batches it is given.
+//   setup(w, ctx) once per worker, batch(w, ctx, d_raw, info) per indexed batch on the worker's thread,
+//   finish(w, ctx) at the end; each returns false to abandon.  false: the file is not usable this way (a block that
+//   does not start at a record, damage, a context that cannot be made) -- the caller starts over on one stream.
+class BgzfFanout {
+public:
+    template <class Setup, class Batch, class Finish>
+    static bool run(const char *path, int workers, Setup setup, Batch batch, Finish finish)
+    {
+        int devices = 1;
+        if (hpn_device_count(&devices) != HPN_OK || devices < 1) devices = 1;
+        struct Box {
+            std::mutex m;
+            std::condition_variable cv;
+            bool has = false, quit = false;
+            TextPump::Chunk c;
+            BgzfParsed pb;
+        };
+        std::vector<std::unique_ptr<Box>> box;
+        for (int w = 0; w < workers; ++w) box.emplace_back(new Box());
+        std::vector<hpn_ctx *> ctxs((size_t)workers, nullptr);
+        for (int w = 0; w < workers; ++w)
+            if (hpn_ctx_create(w % devices, &ctxs[(size_t)w]) != HPN_OK) return false;
+        BgzfGpuStream gs;                       // the reader: header, read-ahead, block tables
+        BamHeader hdr;
+        if (!gs.open(ctxs[0], path, hdr, workers + 2)) return false;
+        std::atomic<bool> failed{false};
+        std::vector<std::thread> th;
+        for (int w = 0; w < workers; ++w)
+            th.emplace_back([&, w] {
+                hpn_ctx *ctx = ctxs[(size_t)w];
+                BgzfDevice dev(ctx);
+                bool ok = setup(w, ctx);
+                Box &b = *box[(size_t)w];
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(b.m);
+                    b.cv.wait(lk, [&] { return b.has || b.quit; });
+                    if (!b.has) break;
+                    lk.unlock();
+                    hpn_raw_info info;
+                    if (ok && !failed) {
+                        ok = dev.run(b.pb, false, &info) == 1;
+                        if (ok && info.n_records) ok = batch(w, ctx, dev.d_raw(), info);
+                    }
+                    gs.pump_->recycle(b.c);
+                    if (!ok) failed = true;
+                    lk.lock();
+                    b.has = false;
+                    lk.unlock();
+                    b.cv.notify_all();
+                }
+                if (ok && !failed) ok = finish(w, ctx);
+                if (!ok) failed = true;
+            });
+        int turn = 0;
+        for (;;) {                              // BgzfGpuStream::next, with the device side handed out
+            TextPump::Chunk c;
+            if (failed || gs.eof_ || !gs.pump_->next(c)) {
+                if (!gs.carry_.empty()) failed = true;   // a partial block at the end: truncated file
+                break;
+            }
+            if (c.eof) gs.eof_ = true;
+            size_t at = 0;
+            if (gs.skip_) {
+                const size_t k = gs.skip_ < c.n ? (size_t)gs.skip_ : c.n;
+                gs.skip_ -= k, at = k;
+            }
+            if (at == c.n) {
+                gs.pump_->recycle(c);
+                continue;
+            }
+            BgzfParsed pb;
+            if (gs.parse(c, at, pb) != 1) {     // not BGZF, or the file ends inside a block
+                gs.pump_->recycle(c);
+                failed = true;
+                break;
+            }
+            if (pb.blocks.empty()) {
+                gs.pump_->recycle(c);
+                continue;
+            }
+            Box &b = *box[(size_t)turn];
+            {
+                std::unique_lock<std::mutex> lk(b.m);
+                b.cv.wait(lk, [&] { return !b.has; });
+                b.c = c, b.pb = std::move(pb), b.has = true;
+            }
+            b.cv.notify_all();
+            turn = (turn + 1) % workers;
+        }
+        for (auto &b : box) {
+            {
+                std::unique_lock<std::mutex> lk(b->m);
+                b->cv.wait(lk, [&] { return !b->has; });
+                b->quit = true;
+            }
+            b->cv.notify_all();
+        }
+        for (auto &t : th) t.join();
+        return !failed;
+    }
+};
+
+}  // namespace hpn

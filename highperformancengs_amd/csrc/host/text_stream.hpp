@@ -73,7 +73,8 @@ public:
     };
 
     // raw: deliver the file's own bytes whatever they are (compressed BGZF for the device inflater)
-    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false) : ctx_(ctx), cap_(chunk)
+    // start: file offset the stream begins at (plain / raw files only)
+    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false, uint64_t start = 0) : ctx_(ctx), cap_(chunk), pos_(start)
     {
         struct stat sb;
         uint8_t magic[2] = {0, 0};
@@ -114,6 +115,18 @@ public:
     }
     bool ok() const { return ok_; }
     size_t chunk_bytes() const { return cap_; }
+
+    // Start over at file offset `pos` with the same pinned buffers (plain / raw files only): what was read ahead is dropped.
+    bool restart(uint64_t pos)
+    {
+        if (fd_ < 0 || !ok_) return false;
+        halt();
+        full_.clear(), free_.clear();
+        for (size_t i = 0; i < buf_.size(); ++i) free_.push_back((int)i);
+        stop_ = false, done_ = false, pos_ = pos;
+        th_ = std::thread([this] { loop(); });
+        return true;
+    }
 
     // Next filled chunk in stream order; false once the eof chunk has been handed out.
     bool next(Chunk &c)
@@ -237,7 +250,7 @@ private:
     hpn_ctx *ctx_;
     size_t cap_;
     int fd_ = -1;
-    uint64_t pos_ = 0;
+    uint64_t pos_ = 0;   // (declared after cap_: the constructor initialises them in this order)
     InStream in_;
     bool ok_ = false, handed_over_ = false;
     std::vector<uint8_t *> buf_;

@@ -156,7 +156,7 @@ int hpn_dev_free(hpn_ctx *c, void *dptr)
 int hpn_host_malloc(hpn_ctx *c, size_t bytes, void **hptr)
 {
     if (!c || !hptr) return HPN_E_ARG;
-    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocPortable);   // pinned for every device: one reader may feed several contexts
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(c, HPN_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));

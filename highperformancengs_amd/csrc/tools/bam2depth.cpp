@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "../host/bam_gpu.hpp"
+#include "../host/bam_multi.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
 
@@ -81,13 +82,20 @@ int main(int argc, char *argv[])
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
 
     char suffix[64];
+    const int workers = multi_gpu_workers();   // > 1: targets are spread over the GPUs (host/bam_multi.hpp)
     for (int i = 0; i < n_in; ++i) {
+      bool try_multi = workers > 1 && bam_gpu_enabled();
       // first with the BGZF inflate and the record walk on the GPU; a file that cannot be decoded
       // there (records straddling blocks, damaged block) is done again with the host reader
       for (int pass = bam_gpu_enabled() ? 0 : 1; pass < 2; ++pass) {
         DepthFeeder bam;
         BamHeader hdr;
-        if (!bam.open(ctx, infiles[i], hdr, pass == 0)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        if (try_multi) {
+            BamReader r;
+            if (!r.open(infiles[i], hdr)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        } else if (!bam.open(ctx, infiles[i], hdr, pass == 0)) {
+            err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        }
         std::string nm = infiles[i];
         snprintf(suffix, sizeof suffix, ".%u.bedGraph", i + 1);
         FILE *bedGraph = fcreat_outfile(basename(&nm[0]), suffix);
@@ -103,6 +111,30 @@ int main(int argc, char *argv[])
         if (!index_exists(infiles[i])) {
             fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
             exit(1);
+        }
+        if (try_multi) {   // one worker per GPU, targets largest first, results written here in target order
+            try_multi = false;
+            const bool done = depth_targets_multi(infiles[i], hdr, BAM_DEF_MASK, window, true, workers, [&](int32_t j, TargetOut &o) {
+                const char *name = hdr.target_name[j].c_str();
+                const uint32_t tlen = hdr.target_len[j];
+                print_bedgraph(bedGraph, name, o.runs.data(), o.n_runs);
+                print_depth_bins(depth, name, tlen, window, o.win.data());
+                if (wig) {
+                    print_wig_bins(WIG, name, tlen, window, o.win.data());
+                    fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
+                }
+                fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
+            });
+            if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, done ? "" : "  (abandoned)");
+            fclose(bedGraph);
+            fclose(depth);
+            if (wig) {
+                fclose(WIG);
+                fclose(chrSize);
+            }
+            if (done) break;
+            --pass;        // the single-stream route starts the file over (its outputs are re-created)
+            continue;
         }
         // two result buffers: target j is formatted and written by a thread of its own while the GPU
         // already ingests target j + 1 (the writers run one after the other, so the files stay in order)

@@ -11,6 +11,7 @@
 #include <getopt.h>
 
 #include "../host/bam_gpu.hpp"
+#include "../host/bam_multi.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
 
@@ -72,11 +73,18 @@ int main(int argc, char *argv[])
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
 
     char suffix[64];
+    const int workers = multi_gpu_workers();   // > 1: targets are spread over the GPUs (host/bam_multi.hpp)
     for (int i = 0; i < n_in; ++i) {
+      bool try_multi = workers > 1 && bam_gpu_enabled();
       for (int pass = bam_gpu_enabled() ? 0 : 1; pass < 2; ++pass) {  // GPU ingest first, host reader if the file needs it
         DepthFeeder bam;
         BamHeader hdr;
-        if (!bam.open(ctx, infiles[i], hdr, pass == 0)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        if (try_multi) {
+            BamReader r;
+            if (!r.open(infiles[i], hdr)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        } else if (!bam.open(ctx, infiles[i], hdr, pass == 0)) {
+            err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        }
         snprintf(suffix, sizeof suffix, ".%u.wig", i + 1);
         FILE *wig = fcreat_outfile(outfile, suffix);
         snprintf(suffix, sizeof suffix, ".%u.chromSize.txt", i + 1);
@@ -88,6 +96,24 @@ int main(int argc, char *argv[])
         std::vector<hpn_run> runs(1u << 20);
         std::vector<double> bins;
         bool redo = false;
+        if (try_multi) {   // one worker per GPU, targets largest first, results written here in target order
+            try_multi = false;
+            const bool done = depth_targets_multi(infiles[i], hdr, BAM_FUNMAP, window, false, workers, [&](int32_t j, TargetOut &o) {
+                const char *name = hdr.target_name[j].c_str();
+                const uint32_t tlen = hdr.target_len[j];
+                bins.assign((size_t)tlen / window + 2, 0.0);
+                wig_bins_from_runs(o.runs.data(), o.n_runs, tlen, window, bins.data());
+                print_wig_bins_d(wig, name, tlen, window, bins.data());
+                fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
+                fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
+            });
+            if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, done ? "" : "  (abandoned)");
+            fclose(wig);
+            fclose(chrSize);
+            if (done) break;
+            --pass;
+            continue;
+        }
         for (int32_t j = 0; j < hdr.n_targets(); ++j) {
             const uint32_t tlen = hdr.target_len[j];
             const char *name = hdr.target_name[j].c_str();

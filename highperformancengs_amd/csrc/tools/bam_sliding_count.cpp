@@ -13,6 +13,7 @@
 #include <cctype>
 
 #include "../host/bam_gpu.hpp"
+#include "../host/bam_multi.hpp"
 #include "../host/bam_reader.hpp"
 #include "../host/report.hpp"
 
@@ -131,7 +132,42 @@ int main(int argc, char *argv[])
         // Whole-file mode: BGZF inflate and record walk on the GPU when the file allows it (every block
         // starts at a record boundary, as samtools writes them); else, and for -r, the host reader.
         bool on_gpu = false;
-        if (whole && bam_gpu_enabled()) {
+        const int workers = multi_gpu_workers();
+        std::vector<uint32_t> m_bins, m_len;          // several GPUs: the workers' per-window vectors, summed here
+        std::vector<uint64_t> m_gc;
+        std::vector<uint8_t> m_touched;
+        uint64_t m_count = 0;
+        bool multi_done = false;
+        if (whole && bam_gpu_enabled() && workers > 1) {
+            // record batches go to the GPUs in turn; bins / GC / length are sums, so each GPU keeps private vectors and the
+            // host adds them (3 x ~155 K entries for hg38 at W = 20000) before the float32 replay of calc_winGC
+            const int32_t nt = hdr.n_targets() > 0 ? hdr.n_targets() : 1;
+            const size_t total = off.back() ? off.back() : 1;
+            m_bins.assign(total, 0), m_len.assign(total, 0), m_gc.assign(total, 0), m_touched.assign((size_t)nt, 0);
+            std::mutex sum_m;
+            multi_done = BgzfFanout::run(
+                infiles[i], workers,
+                [&](int, hpn_ctx *c) { return hpn_window_begin(c, nt, off.data(), (uint32_t)window) == HPN_OK; },
+                [&](int, hpn_ctx *c, const uint8_t *d_raw, const hpn_raw_info &) { return hpn_window_add_raw_dev(c, d_raw) == HPN_OK; },
+                [&](int w, hpn_ctx *c) {
+                    std::vector<uint32_t> b(total), l(total);
+                    std::vector<uint64_t> g(total);
+                    std::vector<uint8_t> t((size_t)nt);
+                    uint64_t n = 0;
+                    const int r = hpn_window_finish(c, b.data(), g.data(), l.data(), t.data(), &n);
+                    if (r != HPN_OK) {
+                        fprintf(stderr, "[hpn] worker %d: %s\n", w, hpn_ctx_last_error(c));
+                        return false;
+                    }
+                    std::lock_guard<std::mutex> lk(sum_m);
+                    for (size_t k = 0; k < total; ++k) m_bins[k] += b[k], m_len[k] += l[k], m_gc[k] += g[k];   // unsigned: wraps like the reference's
+                    for (size_t k = 0; k < (size_t)nt; ++k) m_touched[k] |= t[k];
+                    m_count += n;
+                    return true;
+                });
+            if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, multi_done ? "" : "  (abandoned)");
+        }
+        if (!multi_done && whole && bam_gpu_enabled()) {
             BgzfGpuStream gs;
             BamHeader h2;
             if (gs.open(ctx, infiles[i], h2)) {
@@ -146,9 +182,9 @@ int main(int argc, char *argv[])
                 }
             }
         }
-        if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] %s ingest\n", on_gpu ? "GPU" : "host");
+        if (getenv("HPN_TIMING") && !multi_done) fprintf(stderr, "[hpn] %s ingest\n", on_gpu ? "GPU" : "host");
         BamBatch batch, one;
-        bool more = !on_gpu;
+        bool more = !on_gpu && !multi_done;
         while (more) {
             batch.clear();
             while (batch.n() < (2u << 20)) {
@@ -184,8 +220,12 @@ int main(int argc, char *argv[])
         std::vector<uint64_t> gc(bins.size());
         std::vector<uint8_t> touched((size_t)(hdr.n_targets() > 0 ? hdr.n_targets() : 1));
         uint64_t n_count = 0;
-        if ((rc = hpn_window_finish(ctx, bins.data(), gc.data(), len.data(), touched.data(), &n_count)) != HPN_OK)
+        if (multi_done) {
+            hpn_window_finish(ctx, bins.data(), gc.data(), len.data(), touched.data(), &n_count);   // closes this context's (unused) accumulation
+            bins = m_bins, len = m_len, gc = m_gc, touched = m_touched, n_count = m_count;
+        } else if ((rc = hpn_window_finish(ctx, bins.data(), gc.data(), len.data(), touched.data(), &n_count)) != HPN_OK) {
             die_hpn(ctx, rc, infiles[i]);
+        }
         fprintf(stderr, "Done load bam file %s at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
         if (i == 0) {
             hdr0 = hdr, off0 = off, bins0 = bins, len0 = len, gc0 = gc, touched0 = touched, n_count0 = n_count;

@@ -87,6 +87,54 @@ def test_drop_in_bam_routes(manifest, case, env, tmp_path):
         assert open(tmp_path / f, "rb").read() == expected(case, f), f
 
 
+# Several GPUs: bam2depth / bam2wig hand whole targets, largest first, to one worker per device and write the
+# results in target order; bam_sliding_count hands record batches to the devices in turn and adds their per-window
+# vectors before the float32 replay.  HPN_NGPU forces that many workers on whatever devices exist (worker % devices), so
+# the path runs on a one-GPU box: the bytes must be the reference's, and the route must really have been taken.
+@pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_BAM_CHUNK": "65600"}], ids=["2workers", "3workers-chunk64k"])
+@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("depth_", "wig_", "sliding_"))])
+def test_drop_in_bam_multi_gpu_route(manifest, case, env, tmp_path):
+    c = manifest[case]
+    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, {**env, "HPN_TIMING": "1"})
+    assert p.returncode == c["returncode"], p.stderr.decode()
+    assert p.stdout == expected(case), p.stderr.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    if "-r" not in c["args"]:      # (a region goes through the index on the host reader)
+        assert f"GPU ingest on {env['HPN_NGPU']} workers".encode() in p.stderr and b"abandoned" not in p.stderr, p.stderr.decode()
+
+
+def test_bam_multi_gpu_route_falls_back(tmp_path):
+    """A file the GPU ingest cannot take (records packed across blocks) abandons the several-worker route too and still
+    gives the reference's bytes through the host reader."""
+    import zlib
+    src = golden_path("bam", "rand.bam")
+    raw, o, data = open(src, "rb").read(), 0, b""
+    while o < len(raw):
+        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
+        xlen = int.from_bytes(raw[o + 10:o + 12], "little")
+        data += zlib.decompress(raw[o + 12 + xlen:o + bsize - 8], -15)
+        o += bsize
+    with open(tmp_path / "rand.bam", "wb") as fh:
+        for i in range(0, len(data), 20000):
+            piece = data[i:i + 20000]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = co.compress(piece) + co.flush()
+            fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
+                     (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
+        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    shutil.copy(src + ".bai", tmp_path / "rand.bam.bai")
+    for tool, args, case, outs in (("bam2depth", ["-o", "r", "rand.bam"], "depth_rand", ["rand.bam.1.bedGraph", "r.1.depth"]),
+                                   ("bam_sliding_count", ["rand.bam"], "sliding_rand", ["out.txt"])):
+        p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env={**os.environ, "HPN_TIMING": "1", "HPN_NGPU": "2"})
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"workers  (abandoned)" in p.stderr
+        for f in outs:
+            assert open(tmp_path / f, "rb").read() == expected(case, f), (tool, f)
+
+
 def test_bam_gpu_ingest_is_used_and_falls_back(tmp_path):
     """HPN_TIMING names the ingest: golden BAMs (record-aligned blocks) decode on the GPU; the same
     records packed across block boundaries are detected and decoded by the host reader."""
