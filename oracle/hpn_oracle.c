@@ -497,19 +497,24 @@ int orc_depth_target(const int32_t *rec_tid, const int32_t *rec_pos, const uint3
     if (W == 0) return ORC_E_ARG;
     /* Breakpoints may lie past target_len (reads overhanging the contig end are
      * not clipped); size the difference array to the furthest one. */
-    uint64_t hi = target_len;
+    uint64_t hi = target_len, hi_bp = 0;
     for (uint64_t r = 0; r < n; ++r) {
         if (rec_tid[r] != tid || rec_tid[r] < 0 || (rec_flag[r] & flag_mask)) continue;
         uint64_t p = (uint32_t)rec_pos[r];
         for (uint32_t k = cigar_off[r]; k < cigar_off[r + 1]; ++k) {
             uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
-            if (op == 0 || op == 2 || op == 3) p += len;
+            if (op == 2 || op == 3) p += len;
+            else if (op == 0) {
+                p += len;
+                if (p > hi_bp) hi_bp = p;      /* the breakpoint one past an M block */
+            }
         }
-        if (p > hi) hi = p;
     }
-    /* int2char keeps 28 bits of a position (hashtbl.c:243-249): beyond that the
-     * reference aliases keys; outside the restated domain. */
-    if (hi >= (1ull << 28)) return ORC_E_DOMAIN;
+    /* int2char keeps 28 bits of a position (hashtbl.c:243-249): a BREAKPOINT at 2^28 or beyond
+     * aliases another key in the reference; outside the restated domain.  (A longer contig whose
+     * reads all end below 2^28 is fine: only breakpoints become keys.) */
+    if (hi_bp >= (1ull << 28)) return ORC_E_DOMAIN;
+    if (hi_bp > hi) hi = hi_bp;
     int32_t *diff = (int32_t *)calloc(hi + 2, sizeof(int32_t));
     if (!diff) return ORC_E_NOMEM;
     for (uint64_t r = 0; r < n; ++r) {

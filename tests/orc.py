@@ -239,9 +239,10 @@ def depth_target(soa, tid, W, flag_mask=0x704):
                             tlen, W, flag_mask, C.byref(runs), C.byref(nr), bins)
     if rc != 0:
         return rc, None, None
-    arr = np.zeros((nr.value, 3), np.int32)
-    for i in range(nr.value):
-        arr[i] = (runs[i].start, runs[i].end, runs[i].depth)
+    if nr.value:
+        arr = np.ctypeslib.as_array(C.cast(runs, C.POINTER(C.c_int32)), shape=(nr.value * 3,)).reshape(-1, 3).copy()
+    else:
+        arr = np.zeros((0, 3), np.int32)
     L._libc.free(C.cast(runs, C.c_void_p))
     return rc, arr, bins
 
