@@ -128,6 +128,13 @@ def kernel_legs(ctx, reps=5):
                      statistics.median(ts3), n * 16 + 4 * n_ops + 8 * n_m, records=n, cigar_ops=n_ops, target_len=TL))
     legs.append(_leg("K4 k_depth_scan: prefix sum + runs + window sums (hash2BedGraph, overlap)", statistics.median(ts4),
                      slots * 4 + 12 * len(runs) + 8 * len(win), positions=slots, runs=len(runs)))
+    tsf = []
+    for r in range(reps + 1):
+        text_bytes = ctx.depth_bedgraph_format("chr1")
+        if r:
+            tsf.append(ctx.last_kernel_ms(2))
+    legs.append(_leg("k_bedgraph_text: the runs as bedGraph lines, formatted on the device (hash2BedGraph's fprintf)",
+                     statistics.median(tsf), 12 * len(runs) + text_bytes, runs=len(runs), text_bytes=int(text_bytes)))
     # size-independent properties of the result: coverage mass = M bases of the kept records, runs sorted and disjoint
     m_bases = int(m_per[(fl & 0x704) == 0].sum().item())
     assert int(win.sum()) == m_bases, (int(win.sum()), m_bases)

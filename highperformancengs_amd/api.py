@@ -272,6 +272,22 @@ class Context:
             self._ck(rc, "hpn_depth_finish")
             return runs[:nr.value], win
 
+    def depth_bedgraph_format(self, name):
+        """Format the bedGraph text of the last depth_finish on the device; returns its size (the text stays there)."""
+        nb = C.c_uint64(0)
+        self._ck(self.L.hpn_depth_bedgraph_format(self.h, name.encode(), C.byref(nb)), "hpn_depth_bedgraph_format")
+        return nb.value
+
+    def depth_bedgraph(self, name):
+        """bedGraph text of the runs of the last depth_finish, formatted on the device (read back in two pieces on purpose)."""
+        nb = C.c_uint64(0)
+        self._ck(self.L.hpn_depth_bedgraph_format(self.h, name.encode(), C.byref(nb)), "hpn_depth_bedgraph_format")
+        out = np.zeros(max(nb.value, 1), np.uint8)
+        cut = nb.value // 3
+        self._ck(self.L.hpn_depth_bedgraph_read(self.h, 0, _ptr(out), cut), "hpn_depth_bedgraph_read")
+        self._ck(self.L.hpn_depth_bedgraph_read(self.h, cut, out[cut:].ctypes.data, nb.value - cut), "hpn_depth_bedgraph_read")
+        return out[:nb.value].tobytes()
+
     def window_counts(self, soa, win_off, W, dev=False):
         keep = []
         win_off = np.ascontiguousarray(win_off, np.uint64)

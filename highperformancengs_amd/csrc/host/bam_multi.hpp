@@ -60,6 +60,7 @@ inline int multi_gpu_workers()
 
 struct TargetOut {
     std::vector<hpn_run> runs;
+    std::vector<char> text;      // bedGraph lines formatted on the device (text_name given), instead of runs
     uint64_t n_runs = 0;
     std::vector<uint64_t> win;
     int state = 0;   // 0 pending, 1 ready, -1 failed (the file goes back to the single-stream route)
@@ -69,9 +70,10 @@ struct TargetOut {
 // emit(j, out) for j = 0, 1, ... in order from the calling thread.  false: not usable for this file (no index
 // offsets, a block not decodable on the GPU, no second context) -- nothing has been emitted for targets >= the
 // returned *emitted, and the caller runs the remaining work on the single-stream route from scratch.
+// bedgraph_text: the workers return the bedGraph lines of a target (hpn_depth_bedgraph_format) instead of its runs.
 template <class Emit>
 bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, uint32_t window, bool want_win, int workers,
-                         Emit emit)
+                         Emit emit, bool bedgraph_text = false)
 {
     const int32_t nt = hdr.n_targets();
     std::vector<uint64_t> first;
@@ -116,7 +118,16 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
                     if (info.tid_min > j || info.tid_max > j || info.tid_min < 0) break;   // past the target (or into the unmapped tail)
                 }
             }
-            if (ok && rc == HPN_OK) {
+            if (ok && rc == HPN_OK && bedgraph_text) {
+                o.win.assign(want_win ? (size_t)hdr.target_len[j] / window + 1 : 0, 0);
+                uint64_t nbytes = 0;
+                rc = hpn_depth_finish(ctx, window, nullptr, 0, &o.n_runs, want_win ? o.win.data() : nullptr);
+                if (rc == HPN_OK) rc = hpn_depth_bedgraph_format(ctx, hdr.target_name[j].c_str(), &nbytes);
+                if (rc == HPN_OK) {
+                    o.text.resize(nbytes);
+                    rc = hpn_depth_bedgraph_read(ctx, 0, o.text.data(), nbytes);
+                }
+            } else if (ok && rc == HPN_OK) {
                 o.win.assign(want_win ? (size_t)hdr.target_len[j] / window + 1 : 0, 0);
                 if (o.runs.empty()) o.runs.resize(1u << 20);
                 rc = hpn_depth_finish(ctx, window, o.runs.data(), o.runs.size(), &o.n_runs, want_win ? o.win.data() : nullptr);
@@ -151,6 +162,7 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
         if (good) {
             emit(j, out[(size_t)j]);
             std::vector<hpn_run>().swap(out[(size_t)j].runs);   // a chromosome's runs are ~1 GB: give them back
+            std::vector<char>().swap(out[(size_t)j].text);
         }
     }
     for (auto &t : th) t.join();

@@ -17,6 +17,10 @@ const uint32_t *depth_written(void *ws, uint64_t slots);
 size_t depth_scan_bytes(uint64_t slots);
 hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
                              uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st);
+uint64_t bedgraph_text_bound(uint64_t n_runs, int name_len);
+size_t bedgraph_ws_bytes(uint64_t n_runs);
+hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char *name, int name_len, const uint8_t *d_long_name,
+                                uint8_t *out, void *ws, hipStream_t st);
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
                              const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
@@ -71,6 +75,7 @@ int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_
     c->depth_mask = flag_mask;
     c->depth_slots = slots;
     c->depth_scanned = false;
+    c->depth_text_bytes = 0;
     return HPN_OK;
 }
 
@@ -151,6 +156,10 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
     c->depth_nruns = head.n_runs;
     *n_runs = head.n_runs;
     if (win_sum) HPN_HIP(c, hipMemcpyAsync(win_sum, c->d_win.p, windows * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (!runs && runs_cap == 0) {   // the caller wants the count only (it takes the text: hpn_depth_bedgraph_format)
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+        return HPN_OK;
+    }
     if (head.n_runs > runs_cap || (!runs && head.n_runs)) {
         HPN_HIP(c, hipStreamSynchronize(c->stream));
         return fail(c, HPN_E_CAPACITY, "%llu runs, caller buffer holds %llu", (unsigned long long)head.n_runs,
@@ -162,6 +171,46 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
     return HPN_OK;
 }
 
+
+int hpn_depth_bedgraph_format(hpn_ctx *c, const char *name, uint64_t *n_bytes)
+{
+    if (!c || !name || !n_bytes) return HPN_E_ARG;
+    if (!c->depth_open || !c->depth_scanned) return fail(c, HPN_E_STATE, "hpn_depth_bedgraph_format needs a finished scan (hpn_depth_finish)");
+    HPN_HIP(c, hipSetDevice(c->device));
+    const size_t name_len = strlen(name);
+    if (name_len > 4096) return fail(c, HPN_E_ARG, "target name of %zu characters", name_len);
+    const uint64_t n = c->depth_nruns;
+    c->depth_text_bytes = 0;
+    *n_bytes = 0;
+    if (n == 0) return HPN_OK;
+    int rc;
+    if ((rc = scratch_reserve(c, c->d_text, bedgraph_text_bound(n, (int)name_len))) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->d_ws, bedgraph_ws_bytes(n) + 4096 + 64)) != HPN_OK) return rc;
+    uint8_t *d_name = (uint8_t *)c->d_ws.p + bedgraph_ws_bytes(n) + 32;   // names beyond 64 characters ride behind the workspace
+    if (name_len > 64) HPN_HIP(c, hipMemcpyAsync(d_name, name, name_len, hipMemcpyHostToDevice, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
+    HPN_HIP(c, launch_bedgraph_text((const hpn_run *)c->d_runs.p, n, name, (int)name_len, d_name, (uint8_t *)c->d_text.p, c->d_ws.p, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
+    c->ev_valid[kFamDepth] = true;
+    struct { uint32_t ticket, err; u64 total; } head;
+    HPN_HIP(c, hipMemcpyAsync(&head, c->d_ws.p, sizeof head, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    if (head.err) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
+    c->depth_text_bytes = head.total;
+    *n_bytes = head.total;
+    return HPN_OK;
+}
+
+int hpn_depth_bedgraph_read(hpn_ctx *c, uint64_t offset, void *dst, uint64_t nbytes)
+{
+    if (!c || (nbytes && !dst)) return HPN_E_ARG;
+    if (offset + nbytes > c->depth_text_bytes) return fail(c, HPN_E_ARG, "bytes %llu..%llu of a text of %llu", (unsigned long long)offset,
+                                                        (unsigned long long)(offset + nbytes), (unsigned long long)c->depth_text_bytes);
+    HPN_HIP(c, hipSetDevice(c->device));
+    if (nbytes) HPN_HIP(c, hipMemcpyAsync(dst, (const uint8_t *)c->d_text.p + offset, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    return HPN_OK;
+}
 
 // ---- records in place in inflated BGZF blocks -------------------------------------------------
 

@@ -40,7 +40,7 @@ struct hpn_ctx {
     hpn::u64 *d_sched() const { return d_acc + HPN_TALLY_WORDS; }
     hpn::u64 *h_acc = nullptr;  // pinned mirror
     hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;  // staging of host batches
-    hpn::Scratch d_diff, d_runs, d_win, d_ws, d_tidx;     // bam2depth: difference array, runs, window sums, scan workspace, tile index
+    hpn::Scratch d_diff, d_runs, d_win, d_ws, d_tidx, d_text;     // bam2depth: difference array, runs, window sums, scan workspace, tile index
     hpn::Scratch w_off, w_bins, w_len, w_gc, w_misc;      // bam_sliding_count accumulators
     hipEvent_t ev_beg[hpn::kFamCount] = {};
     hipEvent_t ev_end[hpn::kFamCount] = {};
@@ -53,6 +53,7 @@ struct hpn_ctx {
     bool depth_scanned = false;
     uint64_t depth_nruns = 0;
     uint64_t depth_runs_cap = 0;  // entries the device runs buffer holds
+    uint64_t depth_text_bytes = 0;  // bedGraph text formatted on the device (hpn_depth_bedgraph_format)
     // bam_sliding_count state
     bool win_open = false;
     int32_t win_targets = 0;

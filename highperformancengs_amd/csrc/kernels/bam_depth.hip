@@ -31,6 +31,7 @@
 // Bounds: HBM.  K3 reads 16 B + 4 B x n_cigar per record (x 1.125 for the reach overlap) and writes 4 B per
 // position of the tiles it touches; K4 reads 4 B per written position and writes 12 B per run + 8 B per window.
 #include <stdlib.h>
+#include <string.h>
 
 #include "scan.hpp"
 
@@ -589,6 +590,128 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
 }
 
 // ---------------------------------------------------------------------------
+// bedGraph text on the device: fprintf(bedGraph, "%s\t%d\t%d\t%d\n", chr, start, end, depth) per run
+// (bam2depth.c:217).  hg38 at 30x is ~1e9 such lines = ~25 GB of text: formatted by one host thread that is the
+// longest step of the tool once the scan runs on the GPU.  Here a workgroup takes 512 runs, sizes their lines,
+// finds where its text starts (decoupled look-back over the tiles' byte counts, scan.hpp), builds the text in
+// LDS and copies it out in 16-byte pieces.
+// ---------------------------------------------------------------------------
+constexpr int kFmtThreads = 256, kFmtPer = 2, kFmtTile = kFmtThreads * kFmtPer;
+constexpr int kFmtLds = 40960;                    // bytes of text a tile may stage (512 lines of up to 80 bytes)
+constexpr int kFmtMaxName = kFmtLds / kFmtTile - 34;   // longest target name the staged path takes (46)
+
+__device__ __forceinline__ int dec_digits(uint32_t v)
+{
+    return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) +
+           (v >= 100000000u) + (v >= 1000000000u);
+}
+// decimal digits of v into p[0 .. nd), most significant first
+template <typename P>
+__device__ __forceinline__ void put_dec(P p, uint32_t v, int nd)
+{
+    for (int k = nd - 1; k >= 0; --k) {
+        p[k] = (uint8_t)('0' + v % 10u);
+        v /= 10u;
+    }
+}
+__device__ __forceinline__ int line_len(const hpn_run &r, int name_len)
+{
+    const int neg = (r.start < 0) + (r.end < 0) + (r.depth < 0);   // never, for runs the scan emits; kept printf-exact
+    return name_len + 4 + neg + dec_digits((uint32_t)abs(r.start)) + dec_digits((uint32_t)abs(r.end)) + dec_digits((uint32_t)abs(r.depth));
+}
+template <typename P>
+__device__ __forceinline__ void put_line(P p, const hpn_run &r, const uint8_t *name, int name_len)
+{
+    for (int k = 0; k < name_len; ++k) p[k] = name[k];
+    int at = name_len;
+    const int32_t f[3] = {r.start, r.end, r.depth};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[at++] = '\t';
+        if (f[k] < 0) p[at++] = '-';
+        const uint32_t v = (uint32_t)abs(f[k]);
+        const int nd = dec_digits(v);
+        put_dec(p + at, v, nd);
+        at += nd;
+    }
+    p[at] = '\n';
+}
+
+struct FmtName {
+    uint8_t c[64];
+};
+
+__global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__restrict__ runs, uint64_t n_runs, FmtName name, int name_len,
+                                                               const uint8_t *__restrict__ long_name, uint8_t *__restrict__ out,
+                                                               u64 *__restrict__ status, u64 *__restrict__ total,
+                                                               uint32_t *__restrict__ ticket, uint32_t *__restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[kFmtLds];
+    __shared__ u64 s_w[kFmtThreads / kWave];
+    __shared__ u64 s_x;
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t tile = s_tile, r0 = tile * kFmtTile + (uint64_t)tid * kFmtPer;
+    const uint8_t *nm = name_len <= 64 ? name.c : long_name;
+    hpn_run r[kFmtPer];
+    int len[kFmtPer];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kFmtPer; ++k) {
+        len[k] = 0;
+        if (r0 + k < n_runs) {
+            r[k] = runs[r0 + k];
+            len[k] = line_len(r[k], name_len);
+        }
+        mine += (uint32_t)len[k];
+    }
+    u64 wtot;
+    const u64 wex = wave_excl_scan((u64)mine, wtot);
+    if (lane_id() == kWave - 1) s_w[wave_id()] = wtot;
+    __syncthreads();
+    u64 before = 0, agg = 0;
+#pragma unroll
+    for (int w = 0; w < kFmtThreads / kWave; ++w) {
+        if (w < wave_id()) before += s_w[w];
+        agg += s_w[w];
+    }
+    if (wave_id() == 0) {
+        const u64 ex = scan_lookback(status, tile, agg, err);
+        if (lane_id() == 0) s_x = ex;
+    }
+    __syncthreads();
+    const u64 tile_base = s_x & kScanValueMask;              // byte offset of this tile's text
+    uint32_t at = (uint32_t)(before + wex);                   // ... and of this lane's first line inside it
+    if (name_len <= kFmtMaxName) {                            // staged: build in LDS, copy out in 16-byte pieces
+#pragma unroll
+        for (int k = 0; k < kFmtPer; ++k) {
+            if (len[k]) put_line(s_text + at, r[k], nm, name_len);
+            at += (uint32_t)len[k];
+        }
+        __syncthreads();
+        const uint32_t nbytes = (uint32_t)agg;
+        uint8_t *dst = out + tile_base;
+        for (uint32_t o = (uint32_t)tid * 16u; o < nbytes; o += kFmtThreads * 16u) {
+            if (o + 16u <= nbytes) {
+                const u32 v = *reinterpret_cast<const u32 *>(s_text + o);
+                __builtin_memcpy(dst + o, &v, 16);
+            } else {
+                for (uint32_t b = o; b < nbytes; ++b) dst[b] = s_text[b];
+            }
+        }
+    } else {                                                  // a very long target name: straight to memory
+#pragma unroll
+        for (int k = 0; k < kFmtPer; ++k) {
+            if (len[k]) put_line(out + tile_base + at, r[k], nm, name_len);
+            at += (uint32_t)len[k];
+        }
+    }
+    if (tile == (n_runs - 1) / kFmtTile && tid == kFmtThreads - 1) *total = tile_base + agg;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 uint64_t depth_tiles(uint64_t slots) { return (slots + kTile - 1) / kTile; }
@@ -663,6 +786,25 @@ hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint6
     DepthOut out{runs, runs_cap, n_runs, win_sum};
     hipLaunchKernelGGL(k_depth_scan, dim3((unsigned)tiles), dim3(kDsThreads), 0, st, diff, written, slots, target_len, W, out, status,
                        ticket, ticket + 1);
+    return hipGetLastError();
+}
+
+// bedGraph text of `n_runs` runs into `out` (device; upper bound of the size: bedgraph_text_bound).
+// ws: [0] ticket, [1] err (uint32 each), then u64 total, then status[tiles]
+uint64_t bedgraph_text_bound(uint64_t n_runs, int name_len) { return n_runs * (uint64_t)(name_len + 34 + 3) + 64; }
+size_t bedgraph_ws_bytes(uint64_t n_runs) { return 16 + ((n_runs + kFmtTile - 1) / kFmtTile) * sizeof(u64); }
+
+hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char *name, int name_len, const uint8_t *d_long_name,
+                                uint8_t *out, void *ws, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(ws, 0, bedgraph_ws_bytes(n_runs), st);
+    if (e != hipSuccess || n_runs == 0) return e;
+    FmtName nm;
+    memset(&nm, 0, sizeof nm);
+    if (name_len <= 64) memcpy(nm.c, name, (size_t)name_len);
+    uint32_t *ticket = (uint32_t *)ws;
+    hipLaunchKernelGGL(k_bedgraph_text, dim3((unsigned)((n_runs + kFmtTile - 1) / kFmtTile)), dim3(kFmtThreads), 0, st, runs, n_runs, nm,
+                       name_len, d_long_name, out, (u64 *)ws + 2, (u64 *)ws + 1, ticket, ticket + 1);
     return hipGetLastError();
 }
 

@@ -82,6 +82,8 @@ int main(int argc, char *argv[])
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
 
     char suffix[64];
+    // the bedGraph lines are formatted on the device (hpn_depth_bedgraph_format); HPN_BEDGRAPH_HOST=1: from the runs, on the host
+    const bool dev_text = !(getenv("HPN_BEDGRAPH_HOST") && getenv("HPN_BEDGRAPH_HOST")[0] == '1');
     const int workers = multi_gpu_workers();   // > 1: targets are spread over the GPUs (host/bam_multi.hpp)
     for (int i = 0; i < n_in; ++i) {
       bool try_multi = workers > 1 && bam_gpu_enabled();
@@ -117,14 +119,15 @@ int main(int argc, char *argv[])
             const bool done = depth_targets_multi(infiles[i], hdr, BAM_DEF_MASK, window, true, workers, [&](int32_t j, TargetOut &o) {
                 const char *name = hdr.target_name[j].c_str();
                 const uint32_t tlen = hdr.target_len[j];
-                print_bedgraph(bedGraph, name, o.runs.data(), o.n_runs);
+                if (dev_text) fwrite(o.text.data(), 1, o.text.size(), bedGraph);
+                else print_bedgraph(bedGraph, name, o.runs.data(), o.n_runs);
                 print_depth_bins(depth, name, tlen, window, o.win.data());
                 if (wig) {
                     print_wig_bins(WIG, name, tlen, window, o.win.data());
                     fprintf(chrSize, "%s\t%d\n", name, (int)tlen);
                 }
                 fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
-            });
+            }, dev_text);
             if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, done ? "" : "  (abandoned)");
             fclose(bedGraph);
             fclose(depth);
@@ -139,6 +142,7 @@ int main(int argc, char *argv[])
         // two result buffers: target j is formatted and written by a thread of its own while the GPU
         // already ingests target j + 1 (the writers run one after the other, so the files stay in order)
         std::vector<hpn_run> runs_buf[2] = {std::vector<hpn_run>(1u << 20), std::vector<hpn_run>(1u << 20)};
+        std::vector<char> text_buf[2];
         std::vector<uint64_t> win_buf[2];
         std::thread printer;
         double t_feed = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
@@ -160,17 +164,29 @@ int main(int argc, char *argv[])
             std::vector<uint64_t> &win = win_buf[j & 1];
             win.assign((size_t)tlen / window + 1, 0);
             uint64_t n_runs = 0;
-            rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
-            if (rc == HPN_E_CAPACITY) {
-                runs.resize(n_runs);
+            std::vector<char> &text = text_buf[j & 1];
+            if (dev_text) {
+                uint64_t nbytes = 0;
+                rc = hpn_depth_finish(ctx, window, nullptr, 0, &n_runs, win.data());
+                if (rc == HPN_OK) rc = hpn_depth_bedgraph_format(ctx, name, &nbytes);
+                if (rc == HPN_OK) {
+                    text.resize(nbytes);
+                    rc = hpn_depth_bedgraph_read(ctx, 0, text.data(), nbytes);
+                }
+            } else {
                 rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
+                if (rc == HPN_E_CAPACITY) {
+                    runs.resize(n_runs);
+                    rc = hpn_depth_finish(ctx, window, runs.data(), runs.size(), &n_runs, win.data());
+                }
             }
             if (rc != HPN_OK) die_hpn(ctx, rc, name);
             t_finish += wall_s() - t0;
             t0 = wall_s();
             if (printer.joinable()) printer.join();
-            printer = std::thread([=, &runs, &win] {
-                print_bedgraph(bedGraph, name, runs.data(), n_runs);
+            printer = std::thread([=, &runs, &win, &text] {
+                if (dev_text) fwrite(text.data(), 1, text.size(), bedGraph);
+                else print_bedgraph(bedGraph, name, runs.data(), n_runs);
                 print_depth_bins(depth, name, tlen, window, win.data());
                 if (wig) {
                     print_wig_bins(WIG, name, tlen, window, win.data());

@@ -317,8 +317,16 @@ int hpn_depth_add_dev(hpn_ctx *ctx, const hpn_bam_batch *dev_batch);
 /* runs: caller buffer of runs_cap entries; *n_runs receives the number found
  * (HPN_E_CAPACITY if it exceeds runs_cap; call again with a larger buffer --
  * the scan result stays valid until the next hpn_depth_begin). */
+/* (runs == NULL with runs_cap == 0: the runs stay on the device, *n_runs is still set -- for callers that
+ * take the bedGraph text instead, below.) */
 int hpn_depth_finish(hpn_ctx *ctx, uint32_t W, hpn_run *runs, uint64_t runs_cap, uint64_t *n_runs,
                      uint64_t *win_sum);
+/* hash2BedGraph's fprintf(bedGraph, "%s\t%d\t%d\t%d\n", chr, start, end, depth) (bam2depth.c:217) for every
+ * run of the last hpn_depth_finish, formatted on the device: *n_bytes = size of the text, which stays on
+ * the device until the next hpn_depth_begin / hpn_depth_bedgraph_format; hpn_depth_bedgraph_read copies
+ * text[offset, offset + nbytes) to `dst` (host; pinned memory makes the copy faster). */
+int hpn_depth_bedgraph_format(hpn_ctx *ctx, const char *target_name, uint64_t *n_bytes);
+int hpn_depth_bedgraph_read(hpn_ctx *ctx, uint64_t offset, void *dst, uint64_t nbytes);
 
 /* ---- bam_sliding_count: replaces fetch_func + cal_GC ----------------------------------
  * bam_sliding_count.c:84-124.  Slot of a record = win_off[tid] + (uint16)(pos/W)

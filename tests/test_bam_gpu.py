@@ -25,6 +25,7 @@ def _depth_all(ctx, soa, W, mask=0x704):
     bed, dep = b"", b""
     for tid, (name, tlen) in enumerate(soa.refs):
         runs, win = ctx.depth_target(soa, tid, tlen, W, mask)
+        assert ctx.depth_bedgraph(name) == fmt_bedgraph(name, runs), name   # the same lines, formatted on the device
         rc, wruns, wbins = orc.depth_target(soa, tid, W, mask)
         assert rc == 0
         assert np.array_equal(runs, wruns), (name, len(runs), len(wruns))
@@ -156,6 +157,30 @@ def test_depth_batches_overlap_and_mix_sorted_with_unsorted(ctx):
     runs2, win2 = ctx.depth_target(soa2, 1, refs2[1][1], 1000)
     rc, wruns2, wbins2 = orc.depth_target(soa2, 1, 1000, 0x704)
     assert np.array_equal(runs2, wruns2) and np.array_equal(win2.astype(np.float64), wbins2)
+
+
+def test_bedgraph_text_names_and_numbers(ctx):
+    """Lines of every digit count, names from 1 to 200 characters (beyond 46 the text is not staged in LDS, beyond 64 the
+    name travels through memory), no run at all."""
+    refs = [("c", 268_000_000)]
+    recs = [(0, "1M"), (9, "1M"), (10, "90M"), (99, "901M"), (1000, "9000M"), (99_999, "2M"), (1_000_000, "1M"), (9_999_999, "2M"),
+            (100_000_000, "5M"), (268_000_100, "400M")] + [(5_000_000 + k, "70M") for k in range(3000)] + [(6_000_000 + 3 * k, "2M") for k in range(3000)]
+    soa = bamio.BamSoA(refs=refs, tid=np.zeros(len(recs), np.int32), pos=np.array([p for p, _ in recs], np.int32),
+                       flag=np.zeros(len(recs), np.uint32), l_qseq=np.zeros(len(recs), np.int32),
+                       cigar_off=np.arange(len(recs) + 1, dtype=np.uint32),
+                       cigar=np.array([bamio.parse_cigar(c)[0] for _, c in recs], np.uint32),
+                       seq_off=np.zeros(len(recs) + 1, np.uint64), seq4=np.zeros(1, np.uint8))
+    order = np.argsort(soa.pos, kind="stable")
+    soa.pos, soa.cigar = soa.pos[order], soa.cigar[order]
+    runs, win = ctx.depth_target(soa, 0, refs[0][1], 20000)
+    assert len(runs) > 3000 and runs[:, 2].max() == 70      # several tiles of 512 lines, depths of one and two digits
+    for name in ("c", "chr1", "x" * 46, "y" * 47, "z" * 64, "w" * 65, "HLA-" + "q" * 196):
+        assert ctx.depth_bedgraph(name) == fmt_bedgraph(name, runs), len(name)
+    empty = bamio.BamSoA(refs=refs, tid=np.zeros(0, np.int32), pos=np.zeros(0, np.int32), flag=np.zeros(0, np.uint32),
+                         l_qseq=np.zeros(0, np.int32), cigar_off=np.zeros(1, np.uint32), cigar=np.zeros(1, np.uint32),
+                         seq_off=np.zeros(1, np.uint64), seq4=np.zeros(1, np.uint8))
+    runs, win = ctx.depth_target(empty, 0, 1000, 100)
+    assert len(runs) == 0 and ctx.depth_bedgraph("c") == b""
 
 
 def test_depth_domain_error(ctx):

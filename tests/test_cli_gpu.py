@@ -75,7 +75,8 @@ def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
 # The BAM tools inflate BGZF blocks and walk the records on the GPU when every block starts at a
 # record boundary (as samtools writes them), else on the host: both routes, and compressed
 # chunks that cut blocks every 64 KiB, must give the reference's bytes.
-@pytest.mark.parametrize("env", [{"HPN_BAM_GPU": "0"}, {"HPN_BAM_CHUNK": "65600"}], ids=["host-ingest", "chunk64k"])
+@pytest.mark.parametrize("env", [{"HPN_BAM_GPU": "0"}, {"HPN_BAM_CHUNK": "65600"}, {"HPN_BEDGRAPH_HOST": "1"}],
+                         ids=["host-ingest", "chunk64k", "bedgraph-from-runs"])
 @pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("depth_", "wig_", "sliding_"))])
 def test_drop_in_bam_routes(manifest, case, env, tmp_path):
     c = manifest[case]
