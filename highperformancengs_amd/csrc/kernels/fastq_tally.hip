@@ -40,7 +40,7 @@ namespace hpn {
 constexpr int kHistThreads = 1024;
 constexpr int kHistWaves = kHistThreads / kWave;
 constexpr int kHistRecs = 4096;    // records per chunk: 600 KB at 150 bp between barriers
-constexpr int kSpanRound = 8;      // dword items a lane keeps in flight
+constexpr int kSpanRound = 8;      // dword items a lane keeps in flight (12, 16, 24: no faster)
 constexpr int kLdsCycles = 256;    // cycles held in LDS; later cycles go to global atomics
 constexpr int kRowWords = kLdsCycles;
 
@@ -57,9 +57,15 @@ __device__ __forceinline__ uint32_t nuc_code(uint32_t b)
     return c;
 }
 
+// junk words (one per lane of a wave) directly behind each image, addressed relative to the image's first word
+constexpr uint32_t kJunkQ = HPN_QUAL_ROWS * kRowWords, kJunkN = HPN_NUC_CODES * kRowWords;
+
 struct HistLds {
     uint32_t qh[HPN_QUAL_ROWS * kRowWords];
+    uint32_t qjunk[64];
     uint32_t nh[HPN_NUC_CODES * kRowWords];
+    uint32_t njunk[64];
+    uint8_t nlut[256];       // nuc_code of every byte value: one LDS read per base instead of ten VALU operations
     uint32_t loff[kHistRecs + 1];
     uint32_t lhist[HPN_LEN_BINS + 1];
     u64 red[3][kHistWaves];
@@ -107,77 +113,87 @@ __device__ __forceinline__ uint32_t load_unaligned4(const uint8_t *p)
 }
 
 // Equal-length chunk, 16 <= len0 <= 256: cnt reads of len0 bytes starting at arr + base_off.
-// Work item = (read r, group j) = cycles 4j..4j+3 of read r, one unaligned dword load
-// (256 B per wave-instruction: four times the bytes in flight of byte loads, which ran into
-// the per-CU limit on outstanding requests).  A lane's items are tid + 1024 m; (r, j) advance
-// by a per-chunk constant with carry: one division per chunk.
-template <bool kQual>
-__device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint32_t cnt,
+// Work item = (read r, group j) = cycles 4j..4j+3 of read r, one unaligned dword load (256 B per
+// wave-instruction: four times the bytes in flight of byte loads, which ran into the per-CU limit on
+// outstanding requests).  The workgroup takes floor(1024 / ngr) whole reads per round, so a lane keeps its
+// group j for the whole chunk: its LDS column addresses are computed once, its load address advances by a
+// constant, and the only per-item arithmetic left is one add and one compare (PMC, round 2: the item-index
+// arithmetic of lanes that changed (r, j) every item was 5 of the kernel's 7.4 VALU operations per byte,
+// and VALU issue, not the LDS, was what the kernel waited for).
+template <bool kQual, bool kPartial>   // kPartial: len0 % 4 != 0 (the chunk's reads end in a partial group)
+__device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint64_t arr_end, uint32_t cnt,
                                                uint32_t len0, uint32_t &bad)
 {
     uint32_t *hist = kQual ? s.qh : s.nh;
     const uint8_t *p0 = arr + base_off;
-    const uint32_t ngr = len0 >> 2;               // whole 4-cycle groups per read
-    const uint32_t items = cnt * ngr;
-    const uint32_t dr = kHistThreads / ngr, dj = kHistThreads - dr * ngr;
-    uint32_t w = threadIdx.x;
-    uint32_t r = w / ngr, j = w - r * ngr;        // the one division per chunk
-    uint32_t va[kSpanRound], vb[kSpanRound], ja[kSpanRound], jb[kSpanRound];
-    auto fetch = [&](uint32_t (&v)[kSpanRound], uint32_t (&jj)[kSpanRound]) {
+    // 4-cycle groups per read; the last one holds only len0 % 4 cycles when that is not 0 (its load reaches into the next
+    // read's first bytes, which are masked: a lane per read walking those tail bytes one by one put 4096 x 2 byte loads
+    // and as many 32-way bank conflicts into every chunk -- 22 % of the kernel at 150 bp)
+    const uint32_t ngr = (len0 + 3u) >> 2;
+    const uint32_t rpr = kHistThreads / ngr;              // reads per round (>= 16: ngr <= 64)
+    const uint32_t lr = threadIdx.x / ngr, j = threadIdx.x - lr * ngr;   // the one division per chunk
+    const uint32_t nvalid = min(4u, len0 - 4u * j);       // bytes of this lane's group that belong to the read
+    const bool lane_on = lr < rpr;                        // the last 1024 - rpr * ngr lanes have no item
+    const uint32_t step = rpr * len0;                     // bytes between a lane's items of consecutive rounds
+    uint32_t off = lr * len0 + 4u * j;                    // chunk-relative byte offset of this lane's item
+    uint32_t r = lr;                                      // ... and its read
+    uint32_t col[4];                                      // byte k of every item of this lane goes to word row*256 + col[k]
+    uint32_t rmask[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool mine = (uint32_t)k < nvalid;
+        rmask[k] = mine ? ~0u : 0u;
+        col[k] = mine ? 64u * k + j : (kQual ? kJunkQ : kJunkN) + (threadIdx.x & 63u);
+    }
+    uint32_t va[kSpanRound], vb[kSpanRound];
+    uint32_t na = 0, nb = 0;                              // items of the set that exist (wave-varying only in the last round)
+    auto fetch = [&](uint32_t (&v)[kSpanRound], uint32_t &nv) {
+        nv = 0;
 #pragma unroll
         for (int m = 0; m < kSpanRound; ++m) {
-            // no branch around the load (an idle lane re-reads the chunk's first bytes): the
+            // no branch around the load (a lane without an item re-reads the chunk's first bytes): the
             // compiler then counts the loads in flight instead of draining them all
-            const bool on = w < items;
-            v[m] = load_unaligned4(on ? p0 + (size_t)r * len0 + 4u * j : p0);
-            jj[m] = on ? j : ~0u;
-            w += kHistThreads;
-            r += dr, j += dj;
-            if (j >= ngr) j -= ngr, ++r;
+            const bool on = lane_on && r < cnt;
+            // the partial group of the batch's very last read: the dword is taken `back` bytes earlier, so that it ends
+            // with the batch, and shifted down (no branch: the loads of a set stay together)
+            const uint32_t back = kPartial && base_off + off + 4u > arr_end ? 4u - nvalid : 0u;
+            v[m] = load_unaligned4(p0 + (on ? off - back : 0u)) >> (8u * back);
+            nv += on;
+            off += step, r += rpr;
         }
     };
     // A quality byte >= 128 has no row: bit 7 of every byte is OR-ed into `seen` (checked once
     // per chunk; the batch is then rejected) and the row index is masked to 7 bits so that the
     // LDS address stays in range: no compare, no exec-mask juggling per byte.
     uint32_t seen = 0;
-    auto tally = [&](const uint32_t (&v)[kSpanRound], const uint32_t (&jj)[kSpanRound]) {
+    auto tally = [&](const uint32_t (&v)[kSpanRound], uint32_t nv) {
 #pragma unroll
         for (int m = 0; m < kSpanRound; ++m) {
-            if (jj[m] == ~0u) continue;
+            if ((uint32_t)m >= nv) break;                 // a lane's items of a set are its first nv
             const uint32_t d = v[m];
-            if (kQual) seen |= d;
+            if (kQual) seen |= d;   // (the bytes behind a partial group are the next read's: quality bytes as well)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t byte = (d >> (8 * k)) & (kQual ? 0x7fu : 0xffu);
-                const uint32_t row = kQual ? byte : nuc_code(byte);
-                atomicAdd(&hist[row * kRowWords + 64 * k + jj[m]], 1u);
+                const uint32_t row = kQual ? byte : (uint32_t)s.nlut[byte];
+                // bytes behind a partial group go to this lane's junk word behind the image: no branch per byte
+                atomicAdd(&hist[(kPartial ? row & rmask[k] : row) * kRowWords + col[k]], 1u);
             }
         }
     };
-    if (items) {
-        fetch(va, ja);
-        for (;;) {
-            const bool more_b = w < items;
-            fetch(vb, jb);
-            tally(va, ja);
-            if (!more_b) break;
-            const bool more_a = w < items;
-            fetch(va, ja);
-            tally(vb, jb);
-            if (!more_a) break;
-        }
+    const uint32_t rounds = (cnt + rpr - 1) / rpr;        // uniform: every lane runs the same number of fetches
+    for (uint32_t q = 0; q < rounds; q += 2 * kSpanRound) {
+        if (q == 0) fetch(va, na);
+        const bool more_b = q + kSpanRound < rounds;
+        if (more_b) fetch(vb, nb);
+        tally(va, na);
+        if (!more_b) break;
+        const bool more_a = q + 2 * kSpanRound < rounds;
+        if (more_a) fetch(va, na);
+        tally(vb, nb);
+        if (!more_a) break;
     }
     if (seen & 0x80808080u) bad = 1;
-    // tails: the last len0 % 4 bytes of every read, one lane per read
-    const uint32_t rem = len0 & 3u;
-    if (rem) {
-        HiTot unused;
-#pragma unroll 1
-        for (uint32_t rr = threadIdx.x; rr < cnt; rr += kHistThreads) {
-            const uint8_t *q = p0 + (size_t)rr * len0 + 4u * ngr;
-            for (uint32_t k = 0; k < rem; ++k) bump<kQual>(hist, nullptr, q[k], 4u * ngr + k, bad, unused);
-        }
-    }
 }
 
 // Any chunk: aligned vectors of the byte range, each located by binary search.
@@ -248,11 +264,13 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
     for (int i = tid; i < HPN_QUAL_ROWS * kRowWords; i += kHistThreads) s.qh[i] = 0;
     for (int i = tid; i < HPN_NUC_CODES * kRowWords; i += kHistThreads) s.nh[i] = 0;
     for (int i = tid; i <= HPN_LEN_BINS; i += kHistThreads) s.lhist[i] = 0;
+    if (tid < 256) s.nlut[tid] = (uint8_t)nuc_code((uint32_t)tid);
     __syncthreads();
 
     uint32_t bad = 0;
     u64 *gq = acc + HPN_TALLY_W_QUAL, *gn = acc + HPN_TALLY_W_NUC;
     HiTot hi;
+    const uint64_t arr_end = off[n];          // first byte offset that is not the batch's
     const uint64_t nchunk = (n + kHistRecs - 1) / kHistRecs;
     for (uint64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
         const uint64_t r0 = ch * kHistRecs;
@@ -281,8 +299,8 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
         if (!__syncthreads_or((int)bad)) {
             const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16 && len0 <= (uint32_t)kLdsCycles;
             if (uniform) {
-                if (kQualHist) stream_uniform<true>(s, qual, base_off, cnt, len0, bad);
-                if (kNucHist) stream_uniform<false>(s, base, base_off, cnt, len0, bad);
+                if (kQualHist) (len0 & 3u) ? stream_uniform<true, true>(s, qual, base_off, arr_end, cnt, len0, bad) : stream_uniform<true, false>(s, qual, base_off, arr_end, cnt, len0, bad);
+                if (kNucHist) (len0 & 3u) ? stream_uniform<false, true>(s, base, base_off, arr_end, cnt, len0, bad) : stream_uniform<false, false>(s, base, base_off, arr_end, cnt, len0, bad);
             } else {
                 if (kQualHist) stream_ragged<true>(s, gq, qual, base_off, cnt, bad, hi);
                 if (kNucHist) stream_ragged<false>(s, gn, base, base_off, cnt, bad, hi);
