@@ -317,7 +317,7 @@ __device__ __forceinline__ DepthSum ds_shfl_down(const DepthSum &v, int o)
 }
 __device__ __forceinline__ uint32_t ds_starts(const DepthSum &v, int64_t c_in) { return v.nz - ((int64_t)v.m == -c_in ? v.z : 0u); }
 
-constexpr int kLook = 1;       // tiles per lane per look-back hop (2, 4, 8 were slower: more polling loads, same one hop)
+constexpr int kLbWaves = 1;    // waves of a workgroup that poll side by side, 64 tiles each (2 / 4 / 8 / 16: 0.80 / 0.82 / 0.84 / 0.89 ms)
 constexpr int kStStride = 8;   // u64 words between the status entries of consecutive tiles: two entries per 128-byte line
                                // (0.85 -> 0.80 ms against packed entries: fewer pollers per line)
 
@@ -333,76 +333,48 @@ __device__ __forceinline__ void ds_publish(u64 *status, uint64_t tile, u64 flag,
 }
 __device__ __forceinline__ int32_t sext31(uint32_t x) { return (int32_t)(x << 1) >> 1; }
 
-// All lanes of wave 0.  Returns the composition of tiles 0 .. tile-1 and publishes this tile's inclusive prefix.
-__device__ __forceinline__ DepthSum ds_lookback(u64 *status, uint64_t tile, const DepthSum &aggregate, uint32_t *err)
+// One look-back window, all lanes of one wave: lane L inspects tile newest - L.  Spins until those tiles have
+// published at least their aggregate, then returns (in every lane) the composition, oldest first, of the tiles from
+// the nearest one that holds a full prefix up to `newest`; *has_prefix = such a tile exists in the window.
+// Tiles before 0 count as the empty prefix.
+__device__ __forceinline__ DepthSum ds_window(u64 *status, int64_t newest, bool *has_prefix, uint32_t *err)
 {
-    if (tile == 0) {
-        if (lane_id() == 0) ds_publish(status, 0, kScanPrefix, aggregate);
-        return ds_identity();
-    }
-    if (lane_id() == 0) ds_publish(status, tile, kScanAggregate, aggregate);
-    DepthSum exclusive = ds_identity();           // of the tiles looked at so far (the newest ones)
-    int64_t idx = (int64_t)tile - 1;              // lane L inspects tiles idx - kLook L - j, j = 0 .. kLook-1
-    // One hop is one round trip (~1 us) whatever it inspects, and every resident workgroup waits on the same chain: with
-    // one tile per lane the prefix advanced 64 tiles per round trip = 16 ns per tile, the floor of the whole kernel.
-    // kLook tiles per lane: 256 per hop, as many as there are resident workgroups.
+    const int64_t t = newest - lane_id();
+    u64 h0 = kScanPrefix << 62, h1 = kScanPrefix << 62;
+    uint32_t spins = 0;
     for (;;) {
-        u64 h0[kLook], h1[kLook];
-        uint32_t spins = 0;
-        for (;;) {
-            bool ready = true;
-#pragma unroll
-            for (int j = 0; j < kLook; ++j) {
-                const int64_t t = idx - (int64_t)lane_id() * kLook - j;
-                h0[j] = h1[j] = kScanPrefix << 62;   // tiles before 0: the empty prefix
-                if (t >= 0) {
-                    h0[j] = __hip_atomic_load(&status[kStStride * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    h1[j] = __hip_atomic_load(&status[kStStride * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kLook; ++j) ready = ready && (h0[j] >> 62) != kScanInvalid && (h0[j] >> 62) == (h1[j] >> 62);
-            if (__ballot(!ready) == 0) break;
-            if (++spins > kScanSpinLimit) {
-                if (lane_id() == 0) atomicOr(err, 1u);
-                return exclusive;
-            }
-            __builtin_amdgcn_s_sleep(1);
+        if (t >= 0) {
+            h0 = __hip_atomic_load(&status[kStStride * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h1 = __hip_atomic_load(&status[kStStride * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // this lane's tiles, oldest first, from its nearest full prefix on (a prefix already holds everything older)
-        DepthSum v = ds_identity();
-        bool mine_prefix = false;
-#pragma unroll
-        for (int j = 0; j < kLook; ++j) {
-            if (mine_prefix) continue;
-            const int64_t t = idx - (int64_t)lane_id() * kLook - j;
-            if (t >= 0)
-                v = ds_compose(DepthSum{sext31((uint32_t)(h0[j] >> 31) & 0x7fffffffu), sext31((uint32_t)h0[j] & 0x7fffffffu),
-                                        (uint32_t)(h1[j] >> 31) & 0x7fffffffu, (uint32_t)h1[j] & 0x7fffffffu}, v);
-            mine_prefix = (h0[j] >> 62) == kScanPrefix;
+        const bool ready = (h0 >> 62) != kScanInvalid && (h0 >> 62) == (h1 >> 62);
+        if (__ballot(!ready) == 0) break;
+        if (++spins > kScanSpinLimit) {           // a hand-off that never arrives: report, and end the look-back
+            if (lane_id() == 0) atomicOr(err, 1u);
+            *has_prefix = true;
+            return ds_identity();
         }
-        const u64 has_prefix = __ballot(mine_prefix);
-        const int stop = has_prefix ? __builtin_ctzll(has_prefix) : kWave;   // lane holding the nearest full prefix
-        if (lane_id() > stop) v = ds_identity();
-        // ordered reduction: higher lanes hold older tiles and come first
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const DepthSum older = ds_shfl_down(v, o);
-            if (lane_id() + o < kWave) v = ds_compose(older, v);
-        }
-        const DepthSum win{__shfl(v.s, 0, kWave), __shfl(v.m, 0, kWave), __shfl(v.z, 0, kWave), __shfl(v.nz, 0, kWave)};
-        exclusive = ds_compose(win, exclusive);
-        if (has_prefix) break;
-        idx -= kWave * kLook;
+        __builtin_amdgcn_s_sleep(1);
     }
-    if (lane_id() == 0) ds_publish(status, tile, kScanPrefix, ds_compose(exclusive, aggregate));
-    return exclusive;
+    const u64 pfx = __ballot((h0 >> 62) == kScanPrefix);
+    const int stop = pfx ? __builtin_ctzll(pfx) : kWave;                      // lane of the nearest full prefix
+    DepthSum v = ds_identity();
+    if (lane_id() <= stop && t >= 0)
+        v = DepthSum{sext31((uint32_t)(h0 >> 31) & 0x7fffffffu), sext31((uint32_t)h0 & 0x7fffffffu),
+                     (uint32_t)(h1 >> 31) & 0x7fffffffu, (uint32_t)h1 & 0x7fffffffu};
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {         // ordered reduction: higher lanes hold older tiles and come first
+        const DepthSum older = ds_shfl_down(v, o);
+        if (lane_id() + o < kWave) v = ds_compose(older, v);
+    }
+    *has_prefix = pfx != 0;
+    return DepthSum{__shfl(v.s, 0, kWave), __shfl(v.m, 0, kWave), __shfl(v.z, 0, kWave), __shfl(v.nz, 0, kWave)};
 }
 
-constexpr int kDsThreads = 1024;
-constexpr int kDsPer = 16;                       // positions per lane, four 16-byte loads
+constexpr int kDsThreads = 1024;                 // (768 x 16, two workgroups per CU: 0.93 ms; 512: 1.04)
+constexpr int kDsPer = 16;                       // positions per lane, four 16-byte loads (32: 128 VGPRs + spills, 0.87 ms)
 constexpr int kDsTile = kDsThreads * kDsPer;     // positions per workgroup
-static_assert((kDsTile % kTile == 0 || kTile % kDsTile == 0) && kTile % kDsPer == 0, "a lane's positions lie in one K3 tile");
+static_assert(kTile % kDsPer == 0, "a lane's 16 positions lie in one K3 tile (whatever the scan's own tile)");
 
 struct DepthOut {
     hpn_run *runs;
@@ -417,6 +389,8 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                                                           uint32_t *__restrict__ err)
 {
     __shared__ DepthSum s_w[kDsThreads / kWave];
+    __shared__ DepthSum s_lb[kLbWaves];
+    __shared__ uint32_t s_lbp[kLbWaves];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
@@ -471,23 +445,52 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     if (lane_id() == 0) lanes_before = ds_identity();
     if (lane_id() == kWave - 1) s_w[wave_id()] = inc;
     __syncthreads();
-    // wave 0: the waves' totals -> what lies before each wave inside the tile, the tile's aggregate, the chain
+    // wave 0: the waves' totals -> what lies before each wave inside the tile, and the tile's aggregate, published at once
+    constexpr int kWaves = kDsThreads / kWave;
+    DepthSum excl = ds_identity(), agg = ds_identity();   // (wave 0 only)
     if (wave_id() == 0) {
-        constexpr int kWaves = kDsThreads / kWave;
         DepthSum w = lane_id() < kWaves ? s_w[lane_id()] : ds_identity();
-        const DepthSum own = w;
 #pragma unroll
         for (int o = 1; o < kWaves; o <<= 1) {
             const DepthSum t = ds_shfl_up(w, o);
             if (lane_id() >= o) w = ds_compose(t, w);
         }
-        const DepthSum agg{__shfl(w.s, kWaves - 1, kWave), __shfl(w.m, kWaves - 1, kWave), __shfl(w.z, kWaves - 1, kWave),
-                           __shfl(w.nz, kWaves - 1, kWave)};
-        DepthSum excl = ds_shfl_up(w, 1);              // waves before this lane's wave
+        agg = DepthSum{__shfl(w.s, kWaves - 1, kWave), __shfl(w.m, kWaves - 1, kWave), __shfl(w.z, kWaves - 1, kWave),
+                       __shfl(w.nz, kWaves - 1, kWave)};
+        excl = ds_shfl_up(w, 1);                       // waves before this lane's wave
         if (lane_id() == 0) excl = ds_identity();
-        (void)own;
-        const DepthSum ex = ds_lookback(status, tile, agg, err);
-        if (lane_id() < kWaves) s_w[lane_id()] = ds_compose(ex, excl);   // everything before wave `lane`
+        if (tile > 0 && lane_id() == 0) ds_publish(status, tile, kScanAggregate, agg);
+    }
+    // The chain.  Per-tile stamps (profiles/r02/k3_k4_sweeps.txt): a tile finds a full prefix within one hop (1.03 hops,
+    // 1.26 polls on average) -- it does not wait for its predecessors -- but that one round trip of agent-scope loads
+    // takes 3.3 us under streaming load, and with one 1024-thread workgroup per CU nothing overlaps it.  Wider hops
+    // (more tiles per lane, several polling waves), more workgroups per CU and larger tiles were all measured slower.
+    DepthSum exclusive = ds_identity();               // of tiles 0 .. tile-1; the same in every thread
+    if (tile > 0) {
+        int64_t newest = (int64_t)tile - 1;
+        for (;;) {
+            if (wave_id() < kLbWaves) {
+                bool hp = false;
+                const DepthSum win = ds_window(status, newest - (int64_t)kWave * wave_id(), &hp, err);
+                if (lane_id() == 0) s_lb[wave_id()] = win, s_lbp[wave_id()] = hp ? 1u : 0u;
+            }
+            __syncthreads();
+            bool found = false;
+#pragma unroll
+            for (int v = 0; v < kLbWaves; ++v) {
+                if (!found) {
+                    exclusive = ds_compose(s_lb[v], exclusive);   // older windows come first
+                    found = s_lbp[v] != 0;
+                }
+            }
+            if (found) break;
+            newest -= (int64_t)kWave * kLbWaves;
+            __syncthreads();                          // s_lb is written again
+        }
+    }
+    if (wave_id() == 0) {
+        if (lane_id() == 0) ds_publish(status, tile, kScanPrefix, ds_compose(exclusive, agg));
+        if (lane_id() < kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before wave `lane`
     }
     __syncthreads();
     const DepthSum before = ds_compose(s_w[wave_id()], lanes_before);   // everything before this lane
