@@ -327,11 +327,12 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
         # ---- BAM --------------------------------------------------------------------------------------------------
         synth = os.path.join(td, "bam_synth")
         subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "scripts", "bam_synth.cpp"), "-o", synth, "-lz", "-lpthread"])
-        subprocess.check_call([synth, os.path.join(td, "s.bam"), str(bam_reads), "2", "5000000", str(cores)])
+        contig = bam_reads * 150 // 30 // 2                         # two contigs at 30x
+        subprocess.check_call([synth, os.path.join(td, "s.bam"), str(bam_reads), "2", str(contig), str(cores)])
         bsz = os.path.getsize(os.path.join(td, "s.bam"))
         ins = ["s.bam", "s.bam.bai"]
         for tool, args in (("bam2depth", ["-o", "d", "s.bam"]), ("bam2wig", ["-o", "w", "s.bam"]), ("bam_sliding_count", ["-o", "s", "s.bam"])):
-            legs.append(pair(f"{tool}, {bam_reads:.0e} x 150 bp over 2 x 5 Mb (30x), BAM {bsz / 1e6:.0f} MB -> reports", tool,
+            legs.append(pair(f"{tool}, {bam_reads:.0e} x 150 bp over 2 x {contig / 1e6:.0f} Mb (30x), BAM {bsz / 1e6:.0f} MB -> reports", tool,
                              lambda wd, a=args: a, ins, bam_reads * 150))
     finally:
         shutil.rmtree(td, ignore_errors=True)

@@ -599,9 +599,11 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
 // finds where its text starts (decoupled look-back over the tiles' byte counts, scan.hpp), builds the text in
 // LDS and copies it out in 16-byte pieces.
 // ---------------------------------------------------------------------------
-constexpr int kFmtThreads = 256, kFmtPer = 2, kFmtTile = kFmtThreads * kFmtPer;
-constexpr int kFmtLds = 40960;                    // bytes of text a tile may stage (512 lines of up to 80 bytes)
-constexpr int kFmtMaxName = kFmtLds / kFmtTile - 34;   // longest target name the staged path takes (46)
+constexpr int kFmtThreads = 256, kFmtPer = 2, kFmtSub = kFmtThreads * kFmtPer;   // 512 runs are staged at a time ...
+constexpr int kFmtSubs = 8, kFmtTile = kFmtSub * kFmtSubs;   // ... and a workgroup takes 8 such pieces in a row: one chain entry
+                                                             // per 4096 runs (one per 512 was 131 K entries x ~14 ns = 1.9 of 2.0 ms)
+constexpr int kFmtLds = 40960;                    // bytes of text a piece may stage (512 lines of up to 80 bytes)
+constexpr int kFmtMaxName = kFmtLds / kFmtSub - 34;   // longest target name the staged path takes (46)
 
 __device__ __forceinline__ int dec_digits(uint32_t v)
 {
@@ -650,68 +652,83 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
                                                                uint32_t *__restrict__ ticket, uint32_t *__restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_text[kFmtLds];
-    __shared__ u64 s_w[kFmtThreads / kWave];
+    __shared__ u64 s_w[kFmtSubs][kFmtThreads / kWave];
     __shared__ u64 s_x;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
-    const uint64_t tile = s_tile, r0 = tile * kFmtTile + (uint64_t)tid * kFmtPer;
+    const uint64_t tile = s_tile;
     const uint8_t *nm = name_len <= 64 ? name.c : long_name;
-    hpn_run r[kFmtPer];
-    int len[kFmtPer];
-    uint32_t mine = 0;
+    // sizes of all the tile's lines first (piece by piece: lane l holds lines 2l, 2l+1 of every piece)
+    hpn_run r[kFmtSubs][kFmtPer];
+    uint32_t len[kFmtSubs][kFmtPer], wex[kFmtSubs];
 #pragma unroll
-    for (int k = 0; k < kFmtPer; ++k) {
-        len[k] = 0;
-        if (r0 + k < n_runs) {
-            r[k] = runs[r0 + k];
-            len[k] = line_len(r[k], name_len);
+    for (int sb = 0; sb < kFmtSubs; ++sb) {
+        const uint64_t r0 = tile * kFmtTile + (uint64_t)sb * kFmtSub + (uint64_t)tid * kFmtPer;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < kFmtPer; ++k) {
+            len[sb][k] = 0;
+            if (r0 + k < n_runs) {
+                r[sb][k] = runs[r0 + k];
+                len[sb][k] = (uint32_t)line_len(r[sb][k], name_len);
+            }
+            mine += len[sb][k];
         }
-        mine += (uint32_t)len[k];
+        u64 wtot;
+        wex[sb] = (uint32_t)wave_excl_scan((u64)mine, wtot);
+        if (lane_id() == kWave - 1) s_w[sb][wave_id()] = wtot;
     }
-    u64 wtot;
-    const u64 wex = wave_excl_scan((u64)mine, wtot);
-    if (lane_id() == kWave - 1) s_w[wave_id()] = wtot;
     __syncthreads();
-    u64 before = 0, agg = 0;
+    u64 agg = 0;                                              // bytes of the whole tile
 #pragma unroll
-    for (int w = 0; w < kFmtThreads / kWave; ++w) {
-        if (w < wave_id()) before += s_w[w];
-        agg += s_w[w];
-    }
+    for (int sb = 0; sb < kFmtSubs; ++sb)
+#pragma unroll
+        for (int w = 0; w < kFmtThreads / kWave; ++w) agg += s_w[sb][w];
     if (wave_id() == 0) {
         const u64 ex = scan_lookback(status, tile, agg, err);
         if (lane_id() == 0) s_x = ex;
     }
     __syncthreads();
-    const u64 tile_base = s_x & kScanValueMask;              // byte offset of this tile's text
-    uint32_t at = (uint32_t)(before + wex);                   // ... and of this lane's first line inside it
-    if (name_len <= kFmtMaxName) {                            // staged: build in LDS, copy out in 16-byte pieces
+    u64 piece_base = s_x & kScanValueMask;                    // byte offset of the piece being written
 #pragma unroll
-        for (int k = 0; k < kFmtPer; ++k) {
-            if (len[k]) put_line(s_text + at, r[k], nm, name_len);
-            at += (uint32_t)len[k];
+    for (int sb = 0; sb < kFmtSubs; ++sb) {
+        u64 before = 0, piece = 0;
+#pragma unroll
+        for (int w = 0; w < kFmtThreads / kWave; ++w) {
+            if (w < wave_id()) before += s_w[sb][w];
+            piece += s_w[sb][w];
         }
-        __syncthreads();
-        const uint32_t nbytes = (uint32_t)agg;
-        uint8_t *dst = out + tile_base;
-        for (uint32_t o = (uint32_t)tid * 16u; o < nbytes; o += kFmtThreads * 16u) {
-            if (o + 16u <= nbytes) {
-                const u32 v = *reinterpret_cast<const u32 *>(s_text + o);
-                __builtin_memcpy(dst + o, &v, 16);
-            } else {
-                for (uint32_t b = o; b < nbytes; ++b) dst[b] = s_text[b];
+        uint32_t at = (uint32_t)before + wex[sb];             // this lane's first line inside the piece
+        if (name_len <= kFmtMaxName) {                        // staged: build in LDS, copy out in 16-byte pieces
+#pragma unroll
+            for (int k = 0; k < kFmtPer; ++k) {
+                if (len[sb][k]) put_line(s_text + at, r[sb][k], nm, name_len);
+                at += len[sb][k];
+            }
+            __syncthreads();
+            const uint32_t nbytes = (uint32_t)piece;
+            uint8_t *dst = out + piece_base;
+            for (uint32_t o = (uint32_t)tid * 16u; o < nbytes; o += kFmtThreads * 16u) {
+                if (o + 16u <= nbytes) {
+                    const u32 v = *reinterpret_cast<const u32 *>(s_text + o);
+                    __builtin_memcpy(dst + o, &v, 16);
+                } else {
+                    for (uint32_t b = o; b < nbytes; ++b) dst[b] = s_text[b];
+                }
+            }
+            __syncthreads();                                  // the buffer is rewritten by the next piece
+        } else {                                              // a very long target name: straight to memory
+#pragma unroll
+            for (int k = 0; k < kFmtPer; ++k) {
+                if (len[sb][k]) put_line(out + piece_base + at, r[sb][k], nm, name_len);
+                at += len[sb][k];
             }
         }
-    } else {                                                  // a very long target name: straight to memory
-#pragma unroll
-        for (int k = 0; k < kFmtPer; ++k) {
-            if (len[k]) put_line(out + tile_base + at, r[k], nm, name_len);
-            at += (uint32_t)len[k];
-        }
+        piece_base += piece;
     }
-    if (tile == (n_runs - 1) / kFmtTile && tid == kFmtThreads - 1) *total = tile_base + agg;
+    if (tile == (n_runs - 1) / kFmtTile && tid == kFmtThreads - 1) *total = piece_base;
 }
 
 // ---------------------------------------------------------------------------

@@ -17,7 +17,7 @@
 namespace hpn {
 
 constexpr int kTrimThreads = 256;
-constexpr int kTrimPerThread = 4;
+constexpr int kTrimPerThread = 16;   // 4096 records per tile: every tile costs ~12 ns of chain (ticket + hand-off), 4 per thread made 195 K tiles = 2.4 ms per 2e8 records
 constexpr int kTrimTile = kTrimThreads * kTrimPerThread;
 
 __device__ __forceinline__ uint64_t cut_len(uint64_t len, uint64_t S, uint64_t E)
