@@ -25,15 +25,15 @@ inline int tally_stream(hpn_ctx *ctx, const InStream &fq, hpn_tally *acc, bool *
         void *d_qual = nullptr, *d_off = nullptr;
     } slot[2];
     int rc = HPN_OK;
-    for (Slot &s : slot) {  // pinned host batches + device staging, allocated once
+    for (Slot &s : slot) {  // pinned host batches + device staging, allocated once (a failure frees what exists, below)
         void *q = nullptr, *o = nullptr;
-        if ((rc = hpn_host_malloc(ctx, kBatchBytes + kLineBuf, &q)) != HPN_OK) return rc;
-        if ((rc = hpn_host_malloc(ctx, (kBatchRecs + 1) * sizeof(uint64_t), &o)) != HPN_OK) return rc;
-        s.b.qual = (uint8_t *)q, s.b.off = (uint64_t *)o, s.b.off[0] = 0;
+        if (rc == HPN_OK && (rc = hpn_host_malloc(ctx, kBatchBytes + kLineBuf, &q)) == HPN_OK) s.b.qual = (uint8_t *)q;
+        if (rc == HPN_OK && (rc = hpn_host_malloc(ctx, (kBatchRecs + 1) * sizeof(uint64_t), &o)) == HPN_OK) s.b.off = (uint64_t *)o, s.b.off[0] = 0;
         s.b.cap_bytes = kBatchBytes, s.b.cap_recs = kBatchRecs;
-        if ((rc = hpn_dev_malloc(ctx, kBatchBytes + kLineBuf + 64, &s.d_qual)) != HPN_OK) return rc;
-        if ((rc = hpn_dev_malloc(ctx, (kBatchRecs + 1) * sizeof(uint64_t), &s.d_off)) != HPN_OK) return rc;
+        if (rc == HPN_OK) rc = hpn_dev_malloc(ctx, kBatchBytes + kLineBuf + 64, &s.d_qual);
+        if (rc == HPN_OK) rc = hpn_dev_malloc(ctx, (kBatchRecs + 1) * sizeof(uint64_t), &s.d_off);
     }
+    const bool allocated = rc == HPN_OK;
     const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
     CountFramer framer(fq);
     bool more = true, bad = false;
@@ -55,11 +55,13 @@ inline int tally_stream(hpn_ctx *ctx, const InStream &fq, hpn_tally *acc, bool *
         cur ^= 1;
     }
     if (rc == HPN_OK) rc = hpn_fastq_tally_fetch(ctx, acc);
-    else hpn_ctx_sync(ctx);
+    else if (allocated) hpn_ctx_sync(ctx);
     for (Slot &s : slot) {
-        hpn_host_free(ctx, s.b.qual), hpn_host_free(ctx, s.b.off);
+        if (s.b.qual) hpn_host_free(ctx, s.b.qual);
+        if (s.b.off) hpn_host_free(ctx, s.b.off);
         s.b.qual = nullptr, s.b.off = nullptr;
-        hpn_dev_free(ctx, s.d_qual), hpn_dev_free(ctx, s.d_off);
+        if (s.d_qual) hpn_dev_free(ctx, s.d_qual);
+        if (s.d_off) hpn_dev_free(ctx, s.d_off);
     }
     return rc;
 }

@@ -214,6 +214,9 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
         uint64_t pos = (uint64_t)b.in_pos * 8u - b.bc;
         if (!err && last) pos = (pos + 7u) & ~(uint64_t)7u;          // the trailer is byte-aligned
         if (!err && !last && !arrived) err = 21;                      // cannot happen: the loop only leaves on one of these
+        // a final block inside a stretch that was given an end: the member ends before the next stretch's start, which
+        // therefore is not proven by this one (a second member, or bytes behind the stream): the caller hands the file back
+        if (!err && last && end_bit != ~0ull) err = 22;
         if (lane == 0) {
             GzMeta m;
             m.n_out = op, m.status = err, m.final_block = last ? 1u : 0u, m.reserved = 0;

@@ -264,7 +264,8 @@ int hpn_bgzf_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_bgzf_blo
  * final block (0: none), end_bit = bit position that stretch reached (the member trailer).
  * Synchronous.  CRC-32 is not checked (ISIZE is the caller's to check).  in_len < 2^31.
  * status codes: 1-11 malformed block header or code tables, 12/14 out of symbol scratch (sym_cap), 13/15 invalid
- * code in the data, 17 ran past in_len, 20 the stretch did not end on end_bit at a block boundary. */
+ * code in the data, 17 ran past in_len, 20 the stretch did not end on end_bit at a block boundary, 22 a final block
+ * inside a stretch that was given an end (the member stops before the next stretch: its start is unproven). */
 typedef struct hpn_gz_chunk {
     uint64_t in_off;
     uint64_t end_bit;

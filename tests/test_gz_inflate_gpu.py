@@ -148,3 +148,22 @@ def test_wrong_ends_and_damage_are_reported(ctx):
             want = None
         if info.status == 0:
             assert want is not None and got == want, trial
+
+
+def test_final_block_inside_a_bounded_stretch_is_reported(ctx):
+    """Two deflate streams back to back (what `cat a.gz b.gz` holds between its members' headers): a stretch that was given
+    an end but meets a final block stops before that end, so the next stretch's start is not proven -- status 22, whatever
+    the bytes behind the first stream look like."""
+    rng = np.random.default_rng(22)
+    a, b = _fastq(rng, 1500), _fastq(rng, 1500)
+    ca, sa = _stream([a[:60000], a[60000:]], 6, zlib.Z_SYNC_FLUSH)
+    cb, sb = _stream([b], 6, zlib.Z_SYNC_FLUSH)
+    comp = ca + cb
+    # stretch 1 is told to end where the second stream starts; it ends earlier, at stream a's final block ... exactly there
+    # in bytes, but through a final block, which a stretch with an end must not contain
+    starts = [sa[0], sa[1], len(ca)]
+    info, got, _ = _run(ctx, comp, starts, [a[:60000], a[60000:], b])
+    assert info.status == 22 and info.bad_chunk == 1
+    # the same first stream alone, last stretch open-ended: fine
+    info, got, _ = _run(ctx, ca, sa, [a[:60000], a[60000:]])
+    assert info.status == 0 and got == a
