@@ -60,7 +60,14 @@ __device__ __forceinline__ u32 load16u(const uint8_t *__restrict__ seq4, uint64_
 // instruction reads eight neighbouring records = one contiguous span.  One lane per record reads 64 scattered
 // segments per instruction and spent ~10x the instructions on masks (0.26 of the HBM peak).  Eight steps, all their
 // loads in flight together when no record of the wave is longer than 128 bytes (256 bases); longer reads loop.
-__device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict__ seq4, uint64_t s, int32_t l_qseq, uint64_t lim)
+// what a lane does in the passes of one read length (kept across passes: the division and the masks are made once per length)
+struct GcLayout {
+    int lq = -1, rps = 0, steps = 0, pg = 0, psub = 0;
+    uint32_t m[4] = {0, 0, 0, 0};
+};
+
+__device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict__ seq4, uint64_t s, int32_t l_qseq, uint64_t lim,
+                                                       uint32_t *wave_gc /* 64 LDS words of this wave */, GcLayout &lay)
 {
     const int lane = lane_id(), sub = lane & 7, grp = lane >> 3;
     const int my_nb = l_qseq > 0 ? (l_qseq + 1) >> 1 : 0;
@@ -68,31 +75,52 @@ __device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict
     const u64 has_seq = __ballot(l_qseq > 0);
     if (!has_seq) return 0;
     const int lq0 = __shfl(l_qseq, __builtin_ctzll(has_seq), kWave);   // records without a sequence ride along, their sum is dropped
-    if (lq0 <= 256 && __ballot(l_qseq > 0 && l_qseq != lq0) == 0) {
-        // every record of the wave has the same length (the normal case): which bytes of its piece a lane counts
-        // depends on the lane only, so the masks are built once, not per record
-        const int nb = lq0 > 0 ? (lq0 + 1) >> 1 : 0, rem = nb - 16 * sub;
-        uint32_t m[4];
+    // byte offsets relative to the wave's first sequence: one 32-bit shuffle per step (records without a sequence read
+    // the first one's; 64 neighbouring records 4 GiB apart do not happen -- if they do, the generic paths take the wave)
+    const uint64_t s0 = __shfl((u64)s, __builtin_ctzll(has_seq), kWave);
+    const bool rel_ok = l_qseq <= 0 || (s >= s0 && s - s0 < (1ull << 32));
+    const uint32_t srel = l_qseq > 0 ? (uint32_t)(s - s0) : 0u;
+    if (lq0 <= 256 && __ballot((l_qseq > 0 && l_qseq != lq0) || !rel_ok) == 0) {
+        // every record of the wave has the same length (the normal case): P = pieces per record lanes serve one record, so
+        // floor(64 / P) records are read per step (12 at 150 bases: 60 of 64 lanes busy, 6 steps; eight lanes per record
+        // kept 5 of 8 busy over 8 steps), and which bytes of its piece a lane counts depends on the lane only: the masks are
+        // built once.  A record's pieces are summed with one LDS add per lane into the wave's own 64 words.
+        if (lq0 != lay.lq) {               // a new read length: lane -> (record of the step, piece) and the byte masks
+            const int nb = (lq0 + 1) >> 1, P = (nb + 15) >> 4;                // 1..8, the same in every lane
+            lay.lq = lq0, lay.rps = kWave / P, lay.steps = (kWave + lay.rps - 1) / lay.rps;
+            lay.pg = lane / P, lay.psub = lane - lay.pg * P;
+            const int rem = nb - 16 * lay.psub;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int hi = min(max(rem - 4 * j, 0), 4);
-            m[j] = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
-            if ((lq0 & 1) && hi > 0 && rem - 4 * j <= 4) m[j] &= ~(0xfu << (8 * (hi - 1)));
+            for (int j = 0; j < 4; ++j) {
+                const int hi = min(max(rem - 4 * j, 0), 4);
+                lay.m[j] = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+                if ((lq0 & 1) && hi > 0 && rem - 4 * j <= 4) lay.m[j] &= ~(0xfu << (8 * (hi - 1)));
+            }
         }
+        const int rps = lay.rps, steps = lay.steps, pg = lay.pg, psub = lay.psub;
+        const bool used = pg < rps;
+        const uint32_t *m = lay.m;
+        uint32_t *acc = wave_gc + lane;
+        __hip_atomic_store(acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         u32 q[8];
+        int rec[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const uint64_t st = __shfl((u64)s, t * 8 + grp, kWave);
+            rec[t] = t * rps + pg;
+            const bool on = t < steps && used && rec[t] < kWave;
+            const uint32_t st = __shfl(srel, on ? rec[t] : 0, kWave);
             q[t] = u32{0, 0, 0, 0};
-            if (rem > 0) q[t] = load16u(seq4, st + 16u * sub, lim);
+            if (on) q[t] = load16u(seq4, s0 + st + 16u * (uint32_t)psub, lim);
+            else rec[t] = -1;
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            uint32_t g = gc_nibbles(q[t][0] & m[0]) + gc_nibbles(q[t][1] & m[1]) + gc_nibbles(q[t][2] & m[2]) + gc_nibbles(q[t][3] & m[3]);
-            g += __shfl_xor(g, 1, kWave), g += __shfl_xor(g, 2, kWave), g += __shfl_xor(g, 4, kWave);
-            const uint32_t r = __shfl(g, sub * 8 + t, kWave);   // lane 8 t + g takes group g's sum of step t
-            if (grp == t) mine = r;
+            if (t >= steps) break;
+            const uint32_t g = gc_nibbles(q[t][0] & m[0]) + gc_nibbles(q[t][1] & m[1]) + gc_nibbles(q[t][2] & m[2]) + gc_nibbles(q[t][3] & m[3]);
+            if (rec[t] >= 0) __hip_atomic_fetch_add(wave_gc + rec[t], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                // the wave's own LDS operations: in order
+        mine = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (__ballot(my_nb > 128) == 0) {
         u32 q[8];
         int rem[8];
@@ -146,11 +174,13 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
     // keeps the sums of the window it is in (a coordinate-sorted BAM stays in one window for thousands of records at WGS
     // depth); they go to memory with three atomics when the window changes.  Passes with more than eight different
     // windows (unsorted input) hand the rest to per-record atomics.
+    __shared__ uint32_t s_gc[kWinThreads / kWave][kWave];   // per wave: the GC sums of the 64 records of a pass
     const int lane = lane_id();
     const uint64_t lim = seq_end ? seq_end : seq_off[n];   // first byte offset of seq4 that must not be read
     const uint64_t nspan = (n + kWinSpan - 1) / kWinSpan;
     const uint64_t wave0 = (uint64_t)blockIdx.x * (kWinThreads / kWave) + wave_id(), nwaves = (uint64_t)gridDim.x * (kWinThreads / kWave);
     uint32_t counted = 0;
+    GcLayout lay;
     for (uint64_t span = wave0; span < nspan; span += nwaves) {
         u64 cur = ~0ull;                                   // window slot the sums belong to (same value in every lane)
         uint32_t a_bins = 0, a_len = 0, cur_tid = 0;
@@ -190,7 +220,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                 }
             }
             // every lane takes part (lanes without a record contribute an empty sequence)
-            const uint32_t g = (uint32_t)(uint16_t)gc_of_wave_records(seq4, so, lqs, lim);   // unsigned short current_GC (:118)
+            const uint32_t g = (uint32_t)(uint16_t)gc_of_wave_records(seq4, so, lqs, lim, s_gc[wave_id()], lay);   // unsigned short current_GC (:118)
             u64 rem = __ballot(ok);
             counted += (uint32_t)__builtin_popcountll(rem);   // n_count (:104); the same in every lane
             for (int it = 0; rem; ++it) {
