@@ -69,6 +69,26 @@ def kernel_legs(ctx, reps=5):
         ctx.fastq_tally_fetch(qual_hist=True, nuc_hist=True)
     legs.append(_leg("K1L k_tally_hist: + Nucleotide[5][512] (hpn_fastq_rqc)", _median_ms(ctx, k1ln, 0, reps),
                      2 * n * L + (n + 1) * 8, reads=n, read_len=L))
+    # K1 on reads of mixed lengths (trimmed data): the offset pass cannot take its one-add-per-1024-equal-lengths shortcut
+    g0 = torch.Generator(device="cuda").manual_seed(11)
+    rl = torch.randint(100, 152, (n,), device="cuda", generator=g0, dtype=torch.int64)
+    ro = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(rl, 0, out=ro[1:])
+    tot = int(ro[-1].item())
+    assert tot <= n * L                               # lengths <= 151 on average 125.5: the bytes of dq[:tot] serve
+
+    def k1r():
+        ctx.fastq_tally_dev(dq, ro, n, flags=0)
+        return ctx.fastq_tally_fetch()
+    ms = _median_ms(ctx, k1r, 0, reps)
+    fast = k1r()
+    ctx.fastq_tally_dev(dq, ro, n, flags=1)
+    full = ctx.fastq_tally_fetch(qual_hist=True)      # exact: the independent kernel over the same ragged batch
+    rows = np.asarray(full.qual_hist, np.uint64).sum(axis=1)
+    assert (fast.total, fast.q20, fast.q30) == (tot, int(rows[53:].sum()), int(rows[63:].sum())) and int(rows.sum()) == tot
+    assert np.array_equal(np.asarray(fast.seqlen), np.asarray(full.seqlen)) and int(fast.seqlen[100:152].sum()) == n
+    legs.insert(0, _leg("K1 k_tally_scan on ragged reads (lengths 100..151)", ms, tot + (n + 1) * 8, reads=n, bases=tot))
+    del rl, ro
     S, E = 5, 140
     oq = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
     ob = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
