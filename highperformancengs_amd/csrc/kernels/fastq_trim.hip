@@ -106,11 +106,36 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__res
         const uint64_t e = Er < len ? Er : len;
         const uint32_t cnt = e > b ? (uint32_t)(e - b) : 0u;
         const uint64_t src = a + b;
-        // Four records per wave-instruction: the 16 lanes of quarter g serve record
+        const int sub = lane & 15, g = lane >> 4;
+        const uint32_t c0 = __shfl(cnt, 0, kWave);
+        const uint64_t s0 = __shfl(src, 0, kWave), d0 = __shfl(d, 0, kWave);
+        if (c0 >= 16 && c0 <= 1024 && __ballot(cnt != c0 || ((src - s0) >> 32) || ((d - d0) >> 32)) == 0) {
+            // every record of the wave keeps the same number of bytes (fixed-length reads, always): P = ceil(cnt / 16) lanes
+            // serve one record and floor(64 / P) records go per wave-instruction -- 7 at 135 bytes, 63 of 64 lanes busy,
+            // 10 steps per 64 records where 16 lanes per record took 16 steps with 9 of 16 busy.  The last piece of a record
+            // overlaps the one before it (same bytes written twice) instead of a byte tail.
+            const int P = (int)((c0 + 15u) >> 4), rps = kWave / P, steps = (kWave + rps - 1) / rps;
+            const int pg = lane / P, ps = lane - pg * P;
+            const uint32_t o = min(16u * (uint32_t)ps, c0 - 16u);
+            const uint32_t srel = (uint32_t)(src - s0), drel = (uint32_t)(d - d0);   // 64 neighbouring records: within 4 GiB (checked)
+            for (int t = 0; t < steps; ++t) {
+                const int rec = t * rps + pg;
+                const bool on = pg < rps && rec < kWave;
+                const uint32_t sj = __shfl(srel, on ? rec : 0, kWave), dj = __shfl(drel, on ? rec : 0, kWave);
+                if (on) {
+                    u32 s4, q4;
+                    __builtin_memcpy(&s4, seq + s0 + sj + o, 16);
+                    __builtin_memcpy(&q4, qual + s0 + sj + o, 16);
+                    __builtin_memcpy(out_seq + d0 + dj + o, &s4, 16);
+                    __builtin_memcpy(out_qual + d0 + dj + o, &q4, 16);
+                }
+            }
+            continue;
+        }
+        // Mixed lengths.  Four records per wave-instruction: the 16 lanes of quarter g serve record
         // 4*it + g, 16 bytes per lane through unaligned dwordx4 accesses.  A span that is
         // not a multiple of 16 ends with one overlapping 16-byte piece (same bytes written
         // twice); spans shorter than 16 are copied bytewise by the quarter's first lanes.
-        const int sub = lane & 15, g = lane >> 4;
 #pragma unroll 2
         for (int it = 0; it < kWave / 4; ++it) {
             const int j = 4 * it + g;
