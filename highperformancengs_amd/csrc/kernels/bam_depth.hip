@@ -494,8 +494,11 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     }
     __syncthreads();
     const DepthSum before = ds_compose(s_w[wave_id()], lanes_before);   // everything before this lane
-    const int64_t cov_in = before.s;             // coverage just before this lane's first position
-    u64 idx = ds_starts(before, 0);              // runs started before it (the target starts at coverage 0)
+    // 32-bit from here on: coverage stays below 2^30 (else `over` reports the target as out of domain) and a target has
+    // fewer than 2^28 runs -- the 64-bit forms of these sixteen steps were a third of the kernel's VALU instructions
+    const int32_t cov_in = before.s;             // coverage just before this lane's first position
+    uint32_t idx = ds_starts(before, 0);         // runs started before it (the target starts at coverage 0)
+    const uint32_t cap32 = out.runs_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)out.runs_cap;
 
     // ---- change points -> runs ------------------------------------------------------------
     // A run [s, e) of depth c: at s coverage becomes c > 0; at e it changes again.  With idx = number
@@ -505,33 +508,34 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     // pieces ({start, -, depth} here, `end` by the lane that sees the next change point).
     {
         typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
-        int64_t c = cov_in;
+        int32_t c = cov_in;
         bool pending = false;  // a run started in this lane and not yet closed
         int32_t rs = 0, rd = 0;
         uint32_t over = 0;
+        const int32_t pb = (int32_t)p0;
 #pragma unroll
         for (int k = 0; k < kDsPer; ++k) {
-            const int64_t prev = c;
+            const int32_t prev = c;
             c += d[k];
-            over |= (uint32_t)(c >> 30);         // coverage >= 2^30 (or negative): outside the chain's 31-bit fields
+            over |= (uint32_t)c;                 // bit 30 or 31 set: coverage >= 2^30 (or negative): outside the chain's 31-bit fields
             if (d[k] != 0) {
-                const int32_t p = (int32_t)(p0 + k);
-                if (prev > 0 && idx - 1 < out.runs_cap) {
-                    if (pending) *reinterpret_cast<i32x3 *>(&out.runs[idx - 1]) = i32x3{rs, p, rd};
-                    else out.runs[idx - 1].end = p;
+                const int32_t p = pb + k;
+                if (prev > 0 && idx - 1u < cap32) {
+                    if (pending) *reinterpret_cast<i32x3 *>(&out.runs[idx - 1u]) = i32x3{rs, p, rd};
+                    else out.runs[idx - 1u].end = p;
                 }
                 pending = false;
                 if (c > 0) {
-                    rs = p, rd = (int32_t)c, pending = true;
+                    rs = p, rd = c, pending = true;
                     ++idx;
                 }
             }
         }
-        if (pending && idx - 1 < out.runs_cap) {
-            out.runs[idx - 1].start = rs;
-            out.runs[idx - 1].depth = rd;
+        if (pending && idx - 1u < cap32) {
+            out.runs[idx - 1u].start = rs;
+            out.runs[idx - 1u].depth = rd;
         }
-        if (over) atomicOr(err, 2u);
+        if (over >> 30) atomicOr(err, 2u);
     }
     // ---- window sums (overlap(), bam2depth.c:132-176): sum of coverage per window, clipped at
     // target_len.  A wave covers 1024 consecutive positions: when those touch at most two windows
@@ -546,14 +550,18 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
             const uint32_t nb = (w0 + 1) * W;                                // first position of window w0+1
             if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
                 u64 sa = 0, sb = 0;
-                int64_t c = cov_in;
+                {
+                    int32_t c = cov_in;
+                    uint32_t a32 = 0, b32 = 0;           // sixteen coverages below 2^30 may pass 2^32: carried into 64 bits twice
 #pragma unroll
-                for (int k = 0; k < kDsPer; ++k) {
-                    const uint32_t p = q0 + k;
-                    c += d[k];
-                    const u64 cc = p < target_len ? (u64)c : 0;
-                    if (p < nb) sa += cc;
-                    else sb += cc;
+                    for (int k = 0; k < kDsPer; ++k) {
+                        const uint32_t p = q0 + k;
+                        c += d[k];
+                        const uint32_t cc = p < target_len ? (uint32_t)c : 0u;
+                        if (p < nb) a32 += cc;
+                        else b32 += cc;
+                        if (k == kDsPer / 4 - 1 || k == kDsPer / 2 - 1 || k == 3 * kDsPer / 4 - 1 || k == kDsPer - 1) sa += a32, sb += b32, a32 = 0, b32 = 0;
+                    }
                 }
                 // coverage below 2^21 everywhere under the wave (always, outside pile-ups): the 1024-position sums fit 32 bits
                 if (__ballot((sa | sb) >> 25) == 0) {
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                 u64 s = 0;
                 uint32_t w = q0 / W;
                 uint32_t nbl = (w + 1) * W;
-                int64_t c = cov_in;
+                int32_t c = cov_in;
 #pragma unroll
                 for (int k = 0; k < kDsPer; ++k) {
                     const uint32_t p = q0 + k;
@@ -583,13 +591,13 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                         s = 0, ++w, nbl += W;
                     }
                     c += d[k];
-                    s += (u64)c;
+                    s += (u64)(uint32_t)c;
                 }
                 if (s) atomicAdd(&out.win_sum[w], s);
             }
         }
     }
-    if (tile == (slots - 1) / kDsTile && tid == kDsThreads - 1) *out.n_runs = idx;
+    if (tile == (slots - 1) / kDsTile && tid == kDsThreads - 1) *out.n_runs = idx;   // (< 2^28: one run needs a position)
 }
 
 // ---------------------------------------------------------------------------
