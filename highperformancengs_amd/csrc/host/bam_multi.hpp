@@ -50,6 +50,50 @@ inline bool bai_first_offsets(const char *bam, int32_t n_targets, std::vector<ui
     return ok;
 }
 
+// Where bam_fetch(tid, beg, ...) starts reading: the 16 kb linear index entry of `beg` (every record that overlaps that
+// window starts at or behind it; samtools-0.1.19 bam_index.c:608-640), else the target's first record.  false: the target
+// has no record (or there is no usable index).
+inline bool bai_region_start(const char *bam, int32_t n_targets, int32_t tid, uint32_t beg, uint64_t *voffset)
+{
+    std::string a = std::string(bam) + ".bai", b = bam;
+    FILE *f = fopen(a.c_str(), "rb");
+    if (!f && b.size() > 3 && b.compare(b.size() - 3, 3, "bam") == 0) {
+        b.replace(b.size() - 3, 3, "bai");
+        f = fopen(b.c_str(), "rb");
+    }
+    if (!f) return false;
+    char magic[4];
+    int32_t n_ref = 0;
+    bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "BAI\1", 4) && fread(&n_ref, 4, 1, f) == 1 && n_ref == n_targets && tid < n_ref;
+    uint64_t first = ~0ull, lin = 0;
+    for (int32_t t = 0; ok && t <= tid; ++t) {
+        int32_t n_bin = 0;
+        ok = fread(&n_bin, 4, 1, f) == 1 && n_bin >= 0;
+        for (int32_t k = 0; ok && k < n_bin; ++k) {
+            uint32_t bin;
+            int32_t n_chunk = 0;
+            ok = fread(&bin, 4, 1, f) == 1 && fread(&n_chunk, 4, 1, f) == 1 && n_chunk >= 0;
+            for (int32_t c = 0; ok && c < n_chunk; ++c) {
+                uint64_t be[2];
+                ok = fread(be, 8, 2, f) == 2;
+                if (ok && t == tid && bin != 37450u && be[0] < first) first = be[0];
+            }
+        }
+        int32_t n_intv = 0;
+        ok = ok && fread(&n_intv, 4, 1, f) == 1 && n_intv >= 0;
+        if (ok && t == tid) {
+            const int64_t w = (int64_t)(beg >> 14);
+            if (w < n_intv && fseek(f, (long)w * 8, SEEK_CUR) == 0 && fread(&lin, 8, 1, f) != 1) lin = 0;
+        } else if (ok) {
+            ok = fseek(f, (long)n_intv * 8, SEEK_CUR) == 0;
+        }
+    }
+    fclose(f);
+    if (!ok || first == ~0ull) return false;
+    *voffset = lin > first ? lin : first;
+    return true;
+}
+
 inline int multi_gpu_workers()
 {
     if (const char *e = getenv("HPN_NGPU")) return atoi(e) > 1 ? atoi(e) : 1;

@@ -33,10 +33,12 @@ class BgzfReader {
 public:
     // threads: inflate workers (0 = the usable CPUs minus three -- file reader, decoder, GPU runtime --
     // overridable with HPN_BGZF_THREADS)
-    bool open(const char *path, int threads = 0)
+    // start: file offset of the BGZF block to begin with (a virtual offset >> 16)
+    bool open(const char *path, int threads = 0, uint64_t start = 0)
     {
         fp_ = fopen(path, "rb");
         if (!fp_) return false;
+        if (start && fseeko(fp_, (off_t)start, SEEK_SET) != 0) return false;
         if (threads <= 0) {
             const char *e = getenv("HPN_BGZF_THREADS");
             long n = e ? atol(e) : usable_cpus() - 3;
@@ -262,6 +264,21 @@ struct BamBatch {
 
 class BamReader {
 public:
+    // Records from a BGZF virtual offset on (block offset << 16 | offset inside the inflated block), as a .bai gives it:
+    // what bam_fetch's iterator does with the index (bam_index.c:682) -- no header is read here.
+    bool open_at(const char *path, uint64_t voffset)
+    {
+        if (!z_.open(path, 0, voffset >> 16)) return false;
+        size_t skip = (size_t)(voffset & 0xffff);
+        while (skip) {
+            uint8_t tmp[4096];
+            const size_t k = z_.read(tmp, skip < sizeof tmp ? skip : sizeof tmp);
+            if (!k) return false;
+            skip -= k;
+        }
+        return true;
+    }
+
     // samopen(fn, "rb") + bam_header_read (bam.c:81)
     bool open(const char *path, BamHeader &h)
     {

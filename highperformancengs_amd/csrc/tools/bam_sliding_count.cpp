@@ -185,6 +185,18 @@ int main(int argc, char *argv[])
         if (getenv("HPN_TIMING") && !multi_done) fprintf(stderr, "[hpn] %s ingest\n", on_gpu ? "GPU" : "host");
         BamBatch batch, one;
         bool more = !on_gpu && !multi_done;
+        // -r: bam_fetch reads from where the index says the region's first record can be, up to the first record that
+        // starts at or behind the region's end (a coordinate-sorted file; reading every record from the top of the file,
+        // as round 1 did, is O(file) for a region the reference answers in milliseconds)
+        BamReader at;
+        BamReader *rd = &bam;
+        if (!whole) {
+            uint64_t vo = 0;
+            if (!bai_region_start(infiles[i], hdr.n_targets(), ref, (uint32_t)beg, &vo)) more = false;   // the target holds no record
+            else if (!at.open_at(infiles[i], vo)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+            else rd = &at;
+            if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] region: reading from virtual offset %llu\n", (unsigned long long)vo);
+        }
         while (more) {
             batch.clear();
             while (batch.n() < (2u << 20)) {
@@ -192,8 +204,12 @@ int main(int argc, char *argv[])
                     if (!(more = bam.next(batch, true))) break;
                 } else {  // bam_fetch(ref, beg, end): records of `ref` overlapping [beg, end) (bam_index.c:571,682)
                     one.clear();
-                    if (!(more = bam.next(one, true))) break;
-                    if (one.tid[0] != ref) continue;
+                    if (!(more = rd->next(one, true))) break;
+                    if (one.tid[0] != ref || (uint32_t)one.pos[0] >= (uint32_t)end) {   // past the region: nothing further overlaps it
+                        if (one.tid[0] > ref || one.tid[0] < 0 || (one.tid[0] == ref && (uint32_t)one.pos[0] >= (uint32_t)end)) more = false;
+                        if (!more) break;
+                        continue;
+                    }
                     uint32_t rend = (uint32_t)one.pos[0] + 1;
                     if (!one.cigar.empty()) {
                         rend = (uint32_t)one.pos[0];

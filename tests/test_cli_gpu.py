@@ -136,6 +136,32 @@ def test_bam_multi_gpu_route_falls_back(tmp_path):
             assert open(tmp_path / f, "rb").read() == expected(case, f), (tool, f)
 
 
+def test_region_reads_from_the_index_offset(tmp_path):
+    """bam_sliding_count -r: the records come from where the .bai's linear index puts the region's start (not from the top
+    of the file) and reading stops behind the region's end; the report is the reference's (golden sliding_region*)."""
+    src = golden_path("bam", "rand.bam")
+    for args, case in ((["-w", "1000", "-r", "chr2:1,001-20000", "-o", "reg", "rand.bam"], "sliding_region"),
+                       (["-w", "5000", "-r", "chr1", "-o", "reg", "rand.bam"], "sliding_region_chr"),
+                       (["-w", "1000", "-r", "chr2:49,000-60,000", "-o", "reg", "rand.bam"], None),
+                       (["-w", "1000", "-r", "chrE", "-o", "reg", "rand.bam"], None)):          # a target without records
+        p, files = _run("bam_sliding_count", args, [src], tmp_path, {"HPN_TIMING": "1"})
+        assert p.returncode == 0, p.stderr.decode()
+        line = [l for l in p.stderr.split(b"\n") if l.startswith(b"[hpn] region: reading from virtual offset")]
+        assert len(line) == 1
+        off = int(line[0].split()[-1])
+        if b"chr2" in " ".join(args).encode():
+            assert off >> 16 > 0            # chr2's records lie blocks behind the header
+        if case:
+            assert p.stdout == expected(case) and open(tmp_path / "reg.txt", "rb").read() == expected(case, "reg.txt")
+        else:   # no golden: the whole-file oracle restricted to the region
+            soa = bamio.read_bam_records(src)
+            ref, beg, end = (1, 48999, 60000) if "chr2:49,000-60,000" in args else (2, 0, 1 << 29)
+            assert open(tmp_path / "reg.txt", "rb").read() == orc.window_report(orc.region_subset(soa, ref, beg, end), 1000)
+        for f in files:
+            os.unlink(tmp_path / f)
+        os.unlink(tmp_path / "rand.bam"), os.unlink(tmp_path / "rand.bam.bai")
+
+
 def test_bam_gpu_ingest_is_used_and_falls_back(tmp_path):
     """HPN_TIMING names the ingest: golden BAMs (record-aligned blocks) decode on the GPU; the same
     records packed across block boundaries are detected and decoded by the host reader."""
