@@ -5,6 +5,8 @@
 // GPU.  HPN_NGPU=n forces n workers (device = worker % devices): the way this path is exercised on a
 // single-GPU box.
 #pragma once
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -102,6 +104,21 @@ inline int multi_gpu_workers()
     return n;
 }
 
+// ... and for one file handed out in batches: no more workers than the file has batches' worth of bytes (a context costs
+// ~0.1 s to make; a 600 MB BAM is seven batches of 88 MB)
+inline int multi_gpu_workers_for(const char *path)
+{
+    int n = multi_gpu_workers();
+    if (n > 1 && !getenv("HPN_NGPU")) {
+        struct stat sb;
+        if (stat(path, &sb) == 0) {
+            const long batches = (long)(sb.st_size / ((off_t)88 << 20)) + 1;
+            if (batches < n) n = (int)batches;
+        }
+    }
+    return n;
+}
+
 struct TargetOut {
     std::vector<hpn_run> runs;
     std::vector<char> text;      // bedGraph lines formatted on the device (text_name given), instead of runs
@@ -122,6 +139,10 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
     const int32_t nt = hdr.n_targets();
     std::vector<uint64_t> first;
     if (nt < 2 || !bai_first_offsets(path, nt, first)) return false;
+    int with_records = 0;
+    for (uint64_t f : first) with_records += f != ~0ull;
+    if (workers > with_records) workers = with_records;      // a context per target that holds records at most
+    if (workers < 2) return false;
     std::vector<int32_t> order((size_t)nt);
     for (int32_t j = 0; j < nt; ++j) order[(size_t)j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return hdr.target_len[a] > hdr.target_len[b]; });

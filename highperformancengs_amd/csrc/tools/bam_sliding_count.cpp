@@ -132,7 +132,7 @@ int main(int argc, char *argv[])
         // Whole-file mode: BGZF inflate and record walk on the GPU when the file allows it (every block
         // starts at a record boundary, as samtools writes them); else, and for -r, the host reader.
         bool on_gpu = false;
-        const int workers = multi_gpu_workers();
+        const int workers = multi_gpu_workers_for(infiles[i]);
         std::vector<uint32_t> m_bins, m_len;          // several GPUs: the workers' per-window vectors, summed here
         std::vector<uint64_t> m_gc;
         std::vector<uint8_t> m_touched;
