@@ -39,8 +39,10 @@ namespace hpn {
 
 constexpr int kHistThreads = 1024;
 constexpr int kHistWaves = kHistThreads / kWave;
-constexpr int kHistRecs = 4096;    // records per chunk: 600 KB at 150 bp between barriers
-constexpr int kSpanRound = 8;      // dword items a lane keeps in flight (12, 16, 24: no faster)
+constexpr int kHistRecs = 4096;    // records per chunk: 600 KB at 150 bp between barriers (2048 / 1024: +6 % / +12 %)
+// dword items a lane keeps in flight: 4 / 8 / 16 -> 9.05 / 8.22 / 7.79 ms per 2e8 x 150 bp (128 VGPRs at 16; 20 spills; the kernel that
+// builds both matrices spills at 16)
+constexpr int kSpanOne = 16, kSpanBoth = 12;   // (both matrices: 8 / 10 / 12 / 14 -> 17.8 / 19.1 / 17.4 / 18.7 ms)
 constexpr int kLdsCycles = 256;    // cycles held in LDS; later cycles go to global atomics
 constexpr int kRowWords = kLdsCycles;
 
@@ -120,7 +122,7 @@ __device__ __forceinline__ uint32_t load_unaligned4(const uint8_t *p)
 // constant, and the only per-item arithmetic left is one add and one compare (PMC, round 2: the item-index
 // arithmetic of lanes that changed (r, j) every item was 5 of the kernel's 7.4 VALU operations per byte,
 // and VALU issue, not the LDS, was what the kernel waited for).
-template <bool kQual, bool kPartial>   // kPartial: len0 % 4 != 0 (the chunk's reads end in a partial group)
+template <bool kQual, bool kPartial, int kSpanRound>   // kPartial: len0 % 4 != 0 (the chunk's reads end in a partial group); kSpanRound: dword items a lane keeps in flight
 __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint64_t arr_end, uint32_t cnt,
                                                uint32_t len0, uint32_t &bad)
 {
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
                                                             u64 *__restrict__ acc)
 {
     __shared__ HistLds s;
+    constexpr int kSp = (kQualHist && kNucHist) ? kSpanBoth : kSpanOne;
     const int tid = threadIdx.x;
     for (int i = tid; i < HPN_QUAL_ROWS * kRowWords; i += kHistThreads) s.qh[i] = 0;
     for (int i = tid; i < HPN_NUC_CODES * kRowWords; i += kHistThreads) s.nh[i] = 0;
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
         if (!__syncthreads_or((int)bad)) {
             const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16 && len0 <= (uint32_t)kLdsCycles;
             if (uniform) {
-                if (kQualHist) (len0 & 3u) ? stream_uniform<true, true>(s, qual, base_off, arr_end, cnt, len0, bad) : stream_uniform<true, false>(s, qual, base_off, arr_end, cnt, len0, bad);
-                if (kNucHist) (len0 & 3u) ? stream_uniform<false, true>(s, base, base_off, arr_end, cnt, len0, bad) : stream_uniform<false, false>(s, base, base_off, arr_end, cnt, len0, bad);
+                if (kQualHist) (len0 & 3u) ? stream_uniform<true, true, kSp>(s, qual, base_off, arr_end, cnt, len0, bad) : stream_uniform<true, false, kSp>(s, qual, base_off, arr_end, cnt, len0, bad);
+                if (kNucHist) (len0 & 3u) ? stream_uniform<false, true, kSp>(s, base, base_off, arr_end, cnt, len0, bad) : stream_uniform<false, false, kSp>(s, base, base_off, arr_end, cnt, len0, bad);
             } else {
                 if (kQualHist) stream_ragged<true>(s, gq, qual, base_off, cnt, bad, hi);
                 if (kNucHist) stream_ragged<false>(s, gn, base, base_off, cnt, bad, hi);
