@@ -140,12 +140,13 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
     }
 }
 
-// first record of the wanted target with pos >= thr (thr in positions), from the index
-__device__ __forceinline__ uint32_t first_at(const uint32_t *table, uint32_t k, u64 thr, const uint32_t *head)
+// first record of the wanted target with pos >= thr (thr in positions): the head's values, or the table entry `tab`
+// (loaded by the caller beside the head, whether it is needed or not: one round trip instead of two dependent ones)
+__device__ __forceinline__ uint32_t first_at(uint32_t tab, u64 thr, uint32_t r0, uint32_t r1, uint32_t pmin, uint32_t pmax)
 {
-    if (head[kHdR0] == head[kHdR1] || thr <= head[kHdPmin]) return head[kHdR0];
-    if (thr > head[kHdPmax]) return head[kHdR1];
-    return table[k];
+    if (r0 == r1 || thr <= pmin) return r0;
+    if (thr > pmax) return r1;
+    return tab;
 }
 
 template <typename Recs>
@@ -154,14 +155,17 @@ __global__ __launch_bounds__(kTileThreads) void k_depth_tiles(Recs recs, int32_t
 {
     __shared__ int32_t s_d[kTile];
     const uint32_t t = blockIdx.x;
-    if (ix.head[kHdFlags] & kUnsorted) return;   // k_depth_far does the whole batch
+    // head and table entries in ONE round trip (the table words are garbage outside the batch's position range and then unused)
+    const uint32_t h_flags = ix.head[kHdFlags], h_r0 = ix.head[kHdR0], h_r1 = ix.head[kHdR1], h_pmin = ix.head[kHdPmin], h_pmax = ix.head[kHdPmax];
+    const uint32_t t_lo = ix.first_lo[t], t_hi = ix.first_hi[t], t_hi1 = ix.first_hi[t + 1], was_written = ix.written[t];
+    if (h_flags & kUnsorted) return;             // k_depth_far does the whole batch
     const u64 lo = (u64)t * kTile, hi = lo + kTile;
-    const uint32_t r_first = first_at(ix.first_lo, t, lo > kReach ? lo - kReach : 0, ix.head);
-    const uint32_t r_home = first_at(ix.first_hi, t, lo, ix.head);
-    const uint32_t r_end = t + 1 == ix.ntiles ? ix.head[kHdR1] : first_at(ix.first_hi, t + 1, hi, ix.head);
+    const uint32_t r_first = first_at(t_lo, lo > kReach ? lo - kReach : 0, h_r0, h_r1, h_pmin, h_pmax);
+    const uint32_t r_home = first_at(t_hi, lo, h_r0, h_r1, h_pmin, h_pmax);
+    const uint32_t r_end = t + 1 == ix.ntiles ? h_r1 : first_at(t_hi1, hi, h_r0, h_r1, h_pmin, h_pmax);
     if (r_first >= r_end) return;                // nothing can land here: the tile is not touched
     const int tid = threadIdx.x;
-    const bool add = ix.written[t] != 0;         // read by every wave before the first barrier; set again after the flush
+    const bool add = was_written != 0;           // read by every wave before the first barrier; set again after the flush
     {
         u32 *z = reinterpret_cast<u32 *>(s_d);
 #pragma unroll
