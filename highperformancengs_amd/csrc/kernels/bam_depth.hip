@@ -387,117 +387,32 @@ struct DepthOut {
     u64 *win_sum;         // [target_len / W + 1]
 };
 
-__global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__restrict__ diff, const uint32_t *__restrict__ written,
-                                                          uint64_t slots, uint32_t target_len, uint32_t W, DepthOut out,
-                                                          u64 *__restrict__ status, uint32_t *__restrict__ ticket,
-                                                          uint32_t *__restrict__ err)
+// what this lane's 16 positions tell their successors
+__device__ __forceinline__ DepthSum scan_lane_sum(const int32_t (&d)[kDsPer])
 {
-    __shared__ DepthSum s_w[kDsThreads / kWave];
-    __shared__ DepthSum s_lb[kLbWaves];
-    __shared__ uint32_t s_lbp[kLbWaves];
-    __shared__ uint32_t s_tile;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint64_t tile = s_tile;
-    const uint64_t p0 = tile * kDsTile + (uint64_t)tid * kDsPer;  // this lane's first position
+    int32_t pre = 0, m = INT32_MAX;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < kDsPer; ++k) {
+        pre += d[k];
+        m = pre < m ? pre : m;
+        nz += d[k] != 0;
+    }
+    uint32_t z = 0;
+    pre = 0;
+#pragma unroll
+    for (int k = 0; k < kDsPer; ++k) {
+        pre += d[k];
+        z += (d[k] != 0 && pre == m);
+    }
+    return DepthSum{pre, m, z, nz};
+}
 
-    int32_t d[kDsPer];
-    const bool have = p0 < slots && written[p0 / kTile] != 0;
-    if (!have) {                                 // never touched by K3: zeros, nothing to load
-#pragma unroll
-        for (int k = 0; k < kDsPer; ++k) d[k] = 0;
-    } else if (p0 + kDsPer <= slots) {
-        const u32 *v = reinterpret_cast<const u32 *>(diff + p0);
-#pragma unroll
-        for (int k = 0; k < kDsPer / 4; ++k) {
-            const u32 q = v[k];
-            d[4 * k] = (int32_t)q[0], d[4 * k + 1] = (int32_t)q[1], d[4 * k + 2] = (int32_t)q[2], d[4 * k + 3] = (int32_t)q[3];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kDsPer; ++k) d[k] = p0 + k < slots ? diff[p0 + k] : 0;
-    }
-
-    // ---- this lane's stretch, then lanes -> waves -> tile -> chain ----------------------
-    DepthSum mine;
-    {
-        int32_t pre = 0, m = INT32_MAX;
-        uint32_t nz = 0;
-#pragma unroll
-        for (int k = 0; k < kDsPer; ++k) {
-            pre += d[k];
-            m = pre < m ? pre : m;
-            nz += d[k] != 0;
-        }
-        uint32_t z = 0;
-        pre = 0;
-#pragma unroll
-        for (int k = 0; k < kDsPer; ++k) {
-            pre += d[k];
-            z += (d[k] != 0 && pre == m);
-        }
-        mine = DepthSum{pre, m, z, nz};
-    }
-    DepthSum inc = mine;                          // inclusive scan across the wave
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const DepthSum t = ds_shfl_up(inc, o);
-        if (lane_id() >= o) inc = ds_compose(t, inc);
-    }
-    DepthSum lanes_before = ds_shfl_up(inc, 1);
-    if (lane_id() == 0) lanes_before = ds_identity();
-    if (lane_id() == kWave - 1) s_w[wave_id()] = inc;
-    __syncthreads();
-    // wave 0: the waves' totals -> what lies before each wave inside the tile, and the tile's aggregate, published at once
-    constexpr int kWaves = kDsThreads / kWave;
-    DepthSum excl = ds_identity(), agg = ds_identity();   // (wave 0 only)
-    if (wave_id() == 0) {
-        DepthSum w = lane_id() < kWaves ? s_w[lane_id()] : ds_identity();
-#pragma unroll
-        for (int o = 1; o < kWaves; o <<= 1) {
-            const DepthSum t = ds_shfl_up(w, o);
-            if (lane_id() >= o) w = ds_compose(t, w);
-        }
-        agg = DepthSum{__shfl(w.s, kWaves - 1, kWave), __shfl(w.m, kWaves - 1, kWave), __shfl(w.z, kWaves - 1, kWave),
-                       __shfl(w.nz, kWaves - 1, kWave)};
-        excl = ds_shfl_up(w, 1);                       // waves before this lane's wave
-        if (lane_id() == 0) excl = ds_identity();
-        if (tile > 0 && lane_id() == 0) ds_publish(status, tile, kScanAggregate, agg);
-    }
-    // The chain.  Per-tile stamps (profiles/r02/k3_k4_sweeps.txt): a tile finds a full prefix within one hop (1.03 hops,
-    // 1.26 polls on average) -- it does not wait for its predecessors -- but that one round trip of agent-scope loads
-    // takes 3.3 us under streaming load, and with one 1024-thread workgroup per CU nothing overlaps it.  Wider hops
-    // (more tiles per lane, several polling waves), more workgroups per CU and larger tiles were all measured slower.
-    DepthSum exclusive = ds_identity();               // of tiles 0 .. tile-1; the same in every thread
-    if (tile > 0) {
-        int64_t newest = (int64_t)tile - 1;
-        for (;;) {
-            if (wave_id() < kLbWaves) {
-                bool hp = false;
-                const DepthSum win = ds_window(status, newest - (int64_t)kWave * wave_id(), &hp, err);
-                if (lane_id() == 0) s_lb[wave_id()] = win, s_lbp[wave_id()] = hp ? 1u : 0u;
-            }
-            __syncthreads();
-            bool found = false;
-#pragma unroll
-            for (int v = 0; v < kLbWaves; ++v) {
-                if (!found) {
-                    exclusive = ds_compose(s_lb[v], exclusive);   // older windows come first
-                    found = s_lbp[v] != 0;
-                }
-            }
-            if (found) break;
-            newest -= (int64_t)kWave * kLbWaves;
-            __syncthreads();                          // s_lb is written again
-        }
-    }
-    if (wave_id() == 0) {
-        if (lane_id() == 0) ds_publish(status, tile, kScanPrefix, ds_compose(exclusive, agg));
-        if (lane_id() < kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before wave `lane`
-    }
-    __syncthreads();
-    const DepthSum before = ds_compose(s_w[wave_id()], lanes_before);   // everything before this lane
+// Runs and window sums of one lane's 16 positions (first one p0), given everything before them.  Returns the number of
+// runs started up to and including these positions.
+__device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const DepthSum &before, uint64_t p0, uint64_t sub_first,
+                                              uint32_t target_len, uint32_t W, const DepthOut &out, uint32_t *__restrict__ err)
+{
     // 32-bit from here on: coverage stays below 2^30 (else `over` reports the target as out of domain) and a target has
     // fewer than 2^28 runs -- the 64-bit forms of these sixteen steps were a third of the kernel's VALU instructions
     const int32_t cov_in = before.s;             // coverage just before this lane's first position
@@ -547,7 +462,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     // atomics; per-lane atomics on one address cost ~4 ms per chr1-sized pass.
     if (W) {
         const uint32_t q0 = (uint32_t)p0;                                   // positions are < 2^28
-        const uint32_t wave_lo = (uint32_t)(tile * kDsTile) + (uint32_t)wave_id() * (kWave * kDsPer);
+        const uint32_t wave_lo = (uint32_t)sub_first + (uint32_t)wave_id() * (kWave * kDsPer);
         const uint32_t wave_hi = (uint32_t)min((uint64_t)wave_lo + kWave * kDsPer, (uint64_t)target_len);
         if (wave_lo < wave_hi) {
             const uint32_t w0 = wave_lo / W;                                 // one 32-bit division per lane
@@ -601,7 +516,123 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
             }
         }
     }
-    if (tile == (slots - 1) / kDsTile && tid == kDsThreads - 1) *out.n_runs = idx;   // (< 2^28: one run needs a position)
+    return idx;
+}
+
+// kDsSub sub-tiles of 16384 positions per workgroup, ONE ticket, ONE chain entry, one drain of the stores: the loads of all
+// sub-tiles are in flight together, and what a tile pays once whatever its size -- the ticket's round trip, the look-back's
+// (3.3 us under load), the wait for its stores before the workgroup may leave (4.3 us) -- is paid per 65536 positions.
+// (32 positions per lane in ONE scan step spilled; two steps of 16 with their own registers do not.)
+constexpr int kDsSub = 4;                        // 1 / 2 / 3 / 4 sub-tiles: 0.81 / 0.74 / 0.68 / 0.67 ms (4 x 16 waves = the 64 lanes of wave 0's scan)
+constexpr int kDsGroup = kDsSub * kDsTile;       // positions per workgroup = per chain entry
+static_assert(kDsSub * (kDsThreads / kWave) <= kWave, "wave 0 scans one (sub-tile, wave) total per lane");
+
+__global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__restrict__ diff, const uint32_t *__restrict__ written,
+                                                          uint64_t slots, uint32_t target_len, uint32_t W, DepthOut out,
+                                                          u64 *__restrict__ status, uint32_t *__restrict__ ticket,
+                                                          uint32_t *__restrict__ err)
+{
+    constexpr int kWaves = kDsThreads / kWave;
+    __shared__ DepthSum s_w[kDsSub * kWaves];    // [sub][wave]: in stream order
+    __shared__ DepthSum s_lb[kLbWaves];
+    __shared__ uint32_t s_lbp[kLbWaves];
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t tile = s_tile;                // the group's index = its chain entry
+
+    int32_t d[kDsSub][kDsPer];
+    uint64_t p0[kDsSub];
+#pragma unroll
+    for (int sb = 0; sb < kDsSub; ++sb) {
+        p0[sb] = tile * kDsGroup + (uint64_t)sb * kDsTile + (uint64_t)tid * kDsPer;  // this lane's first position in the sub-tile
+        const bool have = p0[sb] < slots && written[p0[sb] / kTile] != 0;
+        if (!have) {                             // never touched by K3: zeros, nothing to load
+#pragma unroll
+            for (int k = 0; k < kDsPer; ++k) d[sb][k] = 0;
+        } else if (p0[sb] + kDsPer <= slots) {
+            const u32 *v = reinterpret_cast<const u32 *>(diff + p0[sb]);
+#pragma unroll
+            for (int k = 0; k < kDsPer / 4; ++k) {
+                const u32 q = v[k];
+                d[sb][4 * k] = (int32_t)q[0], d[sb][4 * k + 1] = (int32_t)q[1], d[sb][4 * k + 2] = (int32_t)q[2], d[sb][4 * k + 3] = (int32_t)q[3];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kDsPer; ++k) d[sb][k] = p0[sb] + k < slots ? diff[p0[sb] + k] : 0;
+        }
+    }
+    // ---- this lane's stretches, then lanes -> waves -> group -> chain ----------------------
+    DepthSum lanes_before[kDsSub];
+#pragma unroll
+    for (int sb = 0; sb < kDsSub; ++sb) {
+        DepthSum inc = scan_lane_sum(d[sb]);      // inclusive scan across the wave
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const DepthSum t = ds_shfl_up(inc, o);
+            if (lane_id() >= o) inc = ds_compose(t, inc);
+        }
+        lanes_before[sb] = ds_shfl_up(inc, 1);
+        if (lane_id() == 0) lanes_before[sb] = ds_identity();
+        if (lane_id() == kWave - 1) s_w[sb * kWaves + wave_id()] = inc;
+    }
+    __syncthreads();
+    // wave 0: the (sub-tile, wave) totals in stream order -> what lies before each of them inside the group, and the group's
+    // aggregate, published at once
+    DepthSum excl = ds_identity(), agg = ds_identity();   // (wave 0 only)
+    if (wave_id() == 0) {
+        DepthSum w = lane_id() < kDsSub * kWaves ? s_w[lane_id()] : ds_identity();
+#pragma unroll
+        for (int o = 1; o < kDsSub * kWaves; o <<= 1) {
+            const DepthSum t = ds_shfl_up(w, o);
+            if (lane_id() >= o) w = ds_compose(t, w);
+        }
+        agg = DepthSum{__shfl(w.s, kDsSub * kWaves - 1, kWave), __shfl(w.m, kDsSub * kWaves - 1, kWave),
+                       __shfl(w.z, kDsSub * kWaves - 1, kWave), __shfl(w.nz, kDsSub * kWaves - 1, kWave)};
+        excl = ds_shfl_up(w, 1);                       // what comes before this lane's (sub-tile, wave)
+        if (lane_id() == 0) excl = ds_identity();
+        if (tile > 0 && lane_id() == 0) ds_publish(status, tile, kScanAggregate, agg);
+    }
+    // The chain.  Per-tile stamps (profiles/r02/k3_k4_sweeps.txt): a tile finds a full prefix within one hop (1.03 hops,
+    // 1.26 polls on average) -- it does not wait for its predecessors -- but that one round trip of agent-scope loads
+    // takes 3.3 us under streaming load, and with one 1024-thread workgroup per CU nothing overlaps it.  Wider hops
+    // (more tiles per lane, several polling waves), more workgroups per CU and larger tiles were all measured slower.
+    DepthSum exclusive = ds_identity();               // of tiles 0 .. tile-1; the same in every thread
+    if (tile > 0) {
+        int64_t newest = (int64_t)tile - 1;
+        for (;;) {
+            if (wave_id() < kLbWaves) {
+                bool hp = false;
+                const DepthSum win = ds_window(status, newest - (int64_t)kWave * wave_id(), &hp, err);
+                if (lane_id() == 0) s_lb[wave_id()] = win, s_lbp[wave_id()] = hp ? 1u : 0u;
+            }
+            __syncthreads();
+            bool found = false;
+#pragma unroll
+            for (int v = 0; v < kLbWaves; ++v) {
+                if (!found) {
+                    exclusive = ds_compose(s_lb[v], exclusive);   // older windows come first
+                    found = s_lbp[v] != 0;
+                }
+            }
+            if (found) break;
+            newest -= (int64_t)kWave * kLbWaves;
+            __syncthreads();                          // s_lb is written again
+        }
+    }
+    if (wave_id() == 0) {
+        if (lane_id() == 0) ds_publish(status, tile, kScanPrefix, ds_compose(exclusive, agg));
+        if (lane_id() < kDsSub * kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before (sub-tile, wave) `lane`
+    }
+    __syncthreads();
+    uint32_t idx = 0;
+#pragma unroll
+    for (int sb = 0; sb < kDsSub; ++sb) {
+        const DepthSum before = ds_compose(s_w[sb * kWaves + wave_id()], lanes_before[sb]);   // everything before this lane's positions
+        idx = scan_emit(d[sb], before, p0[sb], tile * kDsGroup + (uint64_t)sb * kDsTile, target_len, W, out, err);
+    }
+    if (tile == (slots - 1) / kDsGroup && tid == kDsThreads - 1) *out.n_runs = idx;   // (< 2^28: one run needs a position)
 }
 
 // ---------------------------------------------------------------------------
@@ -747,7 +778,7 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
 // launchers
 // ---------------------------------------------------------------------------
 uint64_t depth_tiles(uint64_t slots) { return (slots + kTile - 1) / kTile; }
-static uint64_t scan_tiles(uint64_t slots) { return (slots + kDsTile - 1) / kDsTile; }
+static uint64_t scan_tiles(uint64_t slots) { return (slots + kDsGroup - 1) / kDsGroup; }
 
 // bytes of the per-target index: head | first_hi | first_lo | written | need
 size_t depth_index_bytes(uint64_t slots)
