@@ -410,28 +410,69 @@ __device__ __forceinline__ DepthSum scan_lane_sum(const int32_t (&d)[kDsPer])
 
 // Runs and window sums of one lane's 16 positions (first one p0), given everything before them.  Returns the number of
 // runs started up to and including these positions.
+// Runs are staged in LDS and written out by scan_flush() as whole 16-byte pieces in lane order.  The image holds the
+// sub-tile's stretch of runs[] dword for dword, from the 16-byte piece that holds the `end` of run base-1 (base = runs
+// started before the sub-tile: that run may be open on entry and closed here): word j of the image is dword origin + j of
+// runs[].  Runs beyond the image (a sub-tile of dense change points) go to memory directly.
+constexpr uint32_t kStageRuns = 10240;            // 120 KB of LDS; a sub-tile at 30x holds ~4400 runs
+constexpr uint32_t kStageWords = 3 * (kStageRuns + 1) + 8;
+__device__ __forceinline__ int32_t stage_origin(uint32_t base) { return ((int32_t)(3u * base) - 2) & ~3; }   // (-4 for base 0: never touched)
+
+// n / W for n < 2^32 with M = 0xffffffff / W: the estimate is short by at most one
+__device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t W, uint32_t M)
+{
+    const uint32_t q = __umulhi(n, M);
+    return q + (n - q * W >= W ? 1u : 0u);
+}
+
+// Runs and window sums of one lane's 16 positions (first one p0), given everything before them.  Returns the number of
+// runs started up to and including these positions.
 __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const DepthSum &before, uint64_t p0, uint64_t sub_first,
-                                              uint32_t target_len, uint32_t W, const DepthOut &out, uint32_t *__restrict__ err)
+                                              uint32_t target_len, uint32_t W, uint32_t Wm, const DepthOut &out, uint32_t *__restrict__ err,
+                                              uint32_t *__restrict__ stage, uint32_t base)
 {
     // 32-bit from here on: coverage stays below 2^30 (else `over` reports the target as out of domain) and a target has
     // fewer than 2^28 runs -- the 64-bit forms of these sixteen steps were a third of the kernel's VALU instructions
     const int32_t cov_in = before.s;             // coverage just before this lane's first position
     uint32_t idx = ds_starts(before, 0);         // runs started before it (the target starts at coverage 0)
-    const uint32_t cap32 = out.runs_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)out.runs_cap;
+    const int32_t origin = stage_origin(base);
+    const int32_t pb = (int32_t)p0;
+    uint32_t over = 0, tot = 0;                  // tot: sum of the 16 coverages (exact in 32 bits while they stay below 2^27)
+    bool tot_ok = false;
 
     // ---- change points -> runs ------------------------------------------------------------
     // A run [s, e) of depth c: at s coverage becomes c > 0; at e it changes again.  With idx = number
     // of runs started before position p: a start at p is run idx, a run ending at p is run idx-1.
-    // At 30x nearly every run starts and ends inside one lane's 16 positions: such a run is
-    // written as ONE 12-byte store; only runs that cross into another lane are written in two
-    // pieces ({start, -, depth} here, `end` by the lane that sees the next change point).
-    {
+    if (__ballot(idx + kDsPer - base > kStageRuns) == 0) {
+        // every piece lies inside the image: no branches, three predicated LDS stores per position
+        uint32_t *q = stage + ((int32_t)(3u * idx) - 2 - origin);   // `end` of run idx-1; run idx starts two words on
+        uint32_t *const q0 = q;
+        int32_t c = cov_in;
+#pragma unroll
+        for (int k = 0; k < kDsPer; ++k) {
+            const bool was = c > 0;
+            c += d[k];
+            over |= (uint32_t)c;
+            tot += (uint32_t)c;
+            const bool chg = d[k] != 0;
+            if (chg && was) q[0] = (uint32_t)(pb + k);
+            if (chg && c > 0) {
+                q[2] = (uint32_t)(pb + k);
+                q[4] = (uint32_t)c;
+                q += 3;
+            }
+        }
+        idx += (uint32_t)(q - q0) / 3u;
+        tot_ok = true;
+    } else {
+        // At 30x nearly every run starts and ends inside one lane's 16 positions: such a run is
+        // written as ONE 12-byte store; only runs that cross into another lane are written in two
+        // pieces ({start, -, depth} here, `end` by the lane that sees the next change point).
         typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+        const uint32_t cap32 = out.runs_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)out.runs_cap;
         int32_t c = cov_in;
         bool pending = false;  // a run started in this lane and not yet closed
         int32_t rs = 0, rd = 0;
-        uint32_t over = 0;
-        const int32_t pb = (int32_t)p0;
 #pragma unroll
         for (int k = 0; k < kDsPer; ++k) {
             const int32_t prev = c;
@@ -439,9 +480,16 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
             over |= (uint32_t)c;                 // bit 30 or 31 set: coverage >= 2^30 (or negative): outside the chain's 31-bit fields
             if (d[k] != 0) {
                 const int32_t p = pb + k;
-                if (prev > 0 && idx - 1u < cap32) {
-                    if (pending) *reinterpret_cast<i32x3 *>(&out.runs[idx - 1u]) = i32x3{rs, p, rd};
-                    else out.runs[idx - 1u].end = p;
+                if (prev > 0) {
+                    const uint32_t r = idx - 1u;               // >= base - 1
+                    if (r + 1u - base <= kStageRuns) {
+                        uint32_t *q = stage + ((int32_t)(3u * r) - origin);
+                        if (pending) q[0] = (uint32_t)rs, q[2] = (uint32_t)rd;
+                        q[1] = (uint32_t)p;
+                    } else if (r < cap32) {
+                        if (pending) *reinterpret_cast<i32x3 *>(&out.runs[r]) = i32x3{rs, p, rd};
+                        else out.runs[r].end = p;
+                    }
                 }
                 pending = false;
                 if (c > 0) {
@@ -450,12 +498,23 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
                 }
             }
         }
-        if (pending && idx - 1u < cap32) {
-            out.runs[idx - 1u].start = rs;
-            out.runs[idx - 1u].depth = rd;
+        if (pending) {
+            const uint32_t r = idx - 1u;
+            if (r + 1u - base <= kStageRuns) {
+                uint32_t *q = stage + ((int32_t)(3u * r) - origin);
+                q[0] = (uint32_t)rs, q[2] = (uint32_t)rd;
+            } else if (r < cap32) {
+                out.runs[r].start = rs;
+                out.runs[r].depth = rd;
+            }
         }
-        if (over >> 30) atomicOr(err, 2u);
     }
+#ifndef DIAG_NOCHAIN
+    if (over >> 30) atomicOr(err, 2u);
+#endif
+#ifdef DIAG_NOWIN
+    W = 0;
+#endif
     // ---- window sums (overlap(), bam2depth.c:132-176): sum of coverage per window, clipped at
     // target_len.  A wave covers 1024 consecutive positions: when those touch at most two windows
     // (W >= 1024, the tool's default is 20000) it reduces both partial sums and issues at most two
@@ -465,9 +524,14 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
         const uint32_t wave_lo = (uint32_t)sub_first + (uint32_t)wave_id() * (kWave * kDsPer);
         const uint32_t wave_hi = (uint32_t)min((uint64_t)wave_lo + kWave * kDsPer, (uint64_t)target_len);
         if (wave_lo < wave_hi) {
-            const uint32_t w0 = wave_lo / W;                                 // one 32-bit division per lane
+            const uint32_t w0 = div_by(wave_lo, W, Wm);
             const uint32_t nb = (w0 + 1) * W;                                // first position of window w0+1
-            if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
+            if (tot_ok && wave_lo + kWave * kDsPer <= min(nb, target_len) && __ballot(over >> 27) == 0) {
+                // the usual wave: inside one window, the sums already taken above
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+                if (lane_id() == 0 && tot) atomicAdd(&out.win_sum[w0], (u64)tot);
+            } else if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
                 u64 sa = 0, sb = 0;
                 {
                     int32_t c = cov_in;
@@ -498,7 +562,7 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
                 }
             } else {  // many small windows under one wave: per-lane segments
                 u64 s = 0;
-                uint32_t w = q0 / W;
+                uint32_t w = div_by(q0, W, Wm);
                 uint32_t nbl = (w + 1) * W;
                 int32_t c = cov_in;
 #pragma unroll
@@ -519,6 +583,35 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
     return idx;
 }
 
+// The staged runs [base, next) of a sub-tile -> memory, 16 bytes per lane, consecutive lanes consecutive pieces.  Left alone:
+// the `end` of a run still open where the sub-tile ends (cov_end > 0; whoever sees the next change point writes it), and of
+// run base-1 all but its `end`, and that only when the sub-tile closed it (closes_prev).
+__device__ __forceinline__ void scan_flush(const uint32_t *__restrict__ stage, uint32_t base, uint32_t next, bool closes_prev,
+                                           int32_t cov_end, const DepthOut &out)
+{
+    uint32_t n = next - base;
+    n = n < kStageRuns ? n : kStageRuns;
+    const int32_t origin = stage_origin(base);
+    const int32_t g_lo = (int32_t)(3u * base);                           // in dwords of runs[]; < 2^30
+    const uint64_t lim = 3ull * out.runs_cap;
+    int32_t g_hi = g_lo + (int32_t)(3u * n);
+    if ((uint64_t)g_hi > lim) g_hi = (int32_t)lim;
+    const int32_t prev_end = closes_prev && (uint64_t)g_lo <= lim ? g_lo - 2 : -8;
+    if (g_hi <= g_lo && prev_end < 0) return;
+    const int32_t skip = (cov_end > 0 && next - base - 1u < kStageRuns) ? (int32_t)(3u * (next - 1u)) + 1 : -8;
+    uint32_t *__restrict__ dst = reinterpret_cast<uint32_t *>(out.runs);
+    for (int32_t g = origin + 4 * (int32_t)threadIdx.x; g < g_hi; g += 4 * kDsThreads) {
+        const u32 v = *reinterpret_cast<const u32 *>(stage + (g - origin));
+        if (g >= g_lo && g + 4 <= g_hi && (uint32_t)(skip - g) >= 4u) {
+            *reinterpret_cast<u32 *>(dst + g) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((g + e >= g_lo && g + e < g_hi) || g + e == prev_end) && g + e != skip) dst[g + e] = v[e];
+        }
+    }
+}
+
 // kDsSub sub-tiles of 16384 positions per workgroup, ONE ticket, ONE chain entry, one drain of the stores: the loads of all
 // sub-tiles are in flight together, and what a tile pays once whatever its size -- the ticket's round trip, the look-back's
 // (3.3 us under load), the wait for its stores before the workgroup may leave (4.3 us) -- is paid per 65536 positions.
@@ -533,7 +626,8 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
                                                           uint32_t *__restrict__ err)
 {
     constexpr int kWaves = kDsThreads / kWave;
-    __shared__ DepthSum s_w[kDsSub * kWaves];    // [sub][wave]: in stream order
+    __shared__ DepthSum s_w[kDsSub * kWaves + 1]; // [sub][wave]: in stream order; the last one: the whole group
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageWords];
     __shared__ DepthSum s_lb[kLbWaves];
     __shared__ uint32_t s_lbp[kLbWaves];
     __shared__ uint32_t s_tile;
@@ -541,6 +635,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint64_t tile = s_tile;                // the group's index = its chain entry
+    const uint32_t Wm = W ? 0xffffffffu / W : 0u; // div_by()
 
     int32_t d[kDsSub][kDsPer];
     uint64_t p0[kDsSub];
@@ -599,7 +694,11 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     // takes 3.3 us under streaming load, and with one 1024-thread workgroup per CU nothing overlaps it.  Wider hops
     // (more tiles per lane, several polling waves), more workgroups per CU and larger tiles were all measured slower.
     DepthSum exclusive = ds_identity();               // of tiles 0 .. tile-1; the same in every thread
+#ifdef DIAG_NOCHAIN
+    if (false) {
+#else
     if (tile > 0) {
+#endif
         int64_t newest = (int64_t)tile - 1;
         for (;;) {
             if (wave_id() < kLbWaves) {
@@ -622,7 +721,11 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
         }
     }
     if (wave_id() == 0) {
-        if (lane_id() == 0) ds_publish(status, tile, kScanPrefix, ds_compose(exclusive, agg));
+        if (lane_id() == 0) {
+            const DepthSum all = ds_compose(exclusive, agg);
+            ds_publish(status, tile, kScanPrefix, all);
+            s_w[kDsSub * kWaves] = all;
+        }
         if (lane_id() < kDsSub * kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before (sub-tile, wave) `lane`
     }
     __syncthreads();
@@ -630,7 +733,15 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
 #pragma unroll
     for (int sb = 0; sb < kDsSub; ++sb) {
         const DepthSum before = ds_compose(s_w[sb * kWaves + wave_id()], lanes_before[sb]);   // everything before this lane's positions
-        idx = scan_emit(d[sb], before, p0[sb], tile * kDsGroup + (uint64_t)sb * kDsTile, target_len, W, out, err);
+        const DepthSum upto0 = s_w[sb * kWaves];                             // everything before the sub-tile
+        const DepthSum upto = s_w[(sb + 1) * kWaves];                        // everything up to its end
+        const uint32_t base = ds_starts(upto0, 0);                           // runs started before the sub-tile
+        idx = scan_emit(d[sb], before, p0[sb], tile * kDsGroup + (uint64_t)sb * kDsTile, target_len, W, Wm, out, err, s_stage, base);
+        __syncthreads();
+#ifndef DIAG_NOFLUSH
+        scan_flush(s_stage, base, ds_starts(upto, 0), upto0.s > 0 && upto.nz != upto0.nz, upto.s, out);
+#endif
+        if (sb + 1 < kDsSub) __syncthreads();     // the image is written again
     }
     if (tile == (slots - 1) / kDsGroup && tid == kDsThreads - 1) *out.n_runs = idx;   // (< 2^28: one run needs a position)
 }

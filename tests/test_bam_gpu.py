@@ -130,6 +130,40 @@ def test_depth_tile_edges(ctx):
     _depth_all(ctx, soa, 1000)
 
 
+@pytest.mark.parametrize("W", [1, 7, 1000, 1024, 20000, 70000])
+def test_depth_dense_change_points(ctx, W):
+    """A change point at (nearly) every position over several sub-tiles of the scan: more runs per 16384 positions than the
+    scan stages in LDS (10240), so both its staged and its direct stores run, side by side in one sub-tile; stretches
+    without coverage, one run open across a whole sub-tile and more, runs that begin and end on sub-tile and group edges."""
+    refs = [("d", 400_000)]
+    rng = np.random.default_rng(77)
+    pos, cg = [], []
+    for p in range(1000, 40_000):                       # one or two 31-base reads per position: coverage changes at EVERY position
+        for _ in range(1 + p % 2):
+            pos.append(p), cg.append("31M")
+    for p in range(40_000, 90_000):                     # a read of random length at every position: ~3 of 4 positions change
+        pos.append(p), cg.append("%dM" % rng.integers(1, 40))
+    pos.append(95_000), cg.append("60000M")             # one run open across sub-tiles 6 .. 9
+    for p in range(100_000, 131_072, 3):                # on top of it: every third position
+        pos.append(p), cg.append("2M")
+    for e in (16384, 65536, 131072, 196608):            # runs that end / begin exactly on the edges
+        for dlt in (-2, -1, 0, 1):
+            pos.append(e + dlt + 200_000 - e % 7), cg.append("1M")
+        pos.append(e + 150_000 - 100), cg.append("100M")
+        pos.append(e + 150_000), cg.append("100M")
+    order = np.argsort(np.array(pos), kind="stable")
+    pos, cg = np.array(pos, np.int32)[order], [cg[i] for i in order]
+    soa = bamio.BamSoA(refs=refs, tid=np.zeros(len(pos), np.int32), pos=pos, flag=np.zeros(len(pos), np.uint32),
+                       l_qseq=np.zeros(len(pos), np.int32), cigar_off=np.arange(len(pos) + 1, dtype=np.uint32),
+                       cigar=np.array([bamio.parse_cigar(c)[0] for c in cg], np.uint32),
+                       seq_off=np.zeros(len(pos) + 1, np.uint64), seq4=np.zeros(1, np.uint8))
+    runs, win = ctx.depth_target(soa, 0, refs[0][1], W)
+    rc, wruns, wbins = orc.depth_target(soa, 0, W, 0x704)
+    assert rc == 0 and len(wruns) > 80_000 and (np.diff(wruns[100:30_000, 0]) == 1).all()
+    assert np.array_equal(runs, wruns)
+    assert np.array_equal(win.astype(np.float64), wbins)
+
+
 def test_depth_batches_overlap_and_mix_sorted_with_unsorted(ctx):
     """hpn_depth_add calls whose position ranges overlap (tiles written before are added to), an unsorted call in
     between (global atomics on tiles some of which were never written), far breakpoints in every call."""
