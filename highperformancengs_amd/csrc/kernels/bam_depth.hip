@@ -319,7 +319,41 @@ __device__ __forceinline__ DepthSum ds_shfl_down(const DepthSum &v, int o)
 {
     return DepthSum{__shfl_down(v.s, o, kWave), __shfl_down(v.m, o, kWave), __shfl_down(v.z, o, kWave), __shfl_down(v.nz, o, kWave)};
 }
+// Scans across a wave with DPP moves (full-rate VALU; __shfl_up is an LDS round trip per field and step): shifts by
+// 1, 2, 4, 8 inside rows of 16 lanes, then lane 15 of a row into the next row (rows 1, 3), then lane 31 into rows 2, 3.
+// Lanes without a source keep `old` = the identity.
+template <int kCtrl, int kRows>
+__device__ __forceinline__ DepthSum ds_dpp(const DepthSum &v)
+{
+    return DepthSum{__builtin_amdgcn_update_dpp(0, v.s, kCtrl, kRows, 0xf, false), __builtin_amdgcn_update_dpp(kMInf, v.m, kCtrl, kRows, 0xf, false),
+                    (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, kCtrl, kRows, 0xf, false),
+                    (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.nz, kCtrl, kRows, 0xf, false)};
+}
+__device__ __forceinline__ DepthSum ds_wave_inclusive(DepthSum v);
+__device__ __forceinline__ uint32_t wave_total(uint32_t x)        // sum over the wave, valid in lane 63 and returned from there
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, kWave - 1);
+}
+
 __device__ __forceinline__ uint32_t ds_starts(const DepthSum &v, int64_t c_in) { return v.nz - ((int64_t)v.m == -c_in ? v.z : 0u); }
+
+__device__ __forceinline__ DepthSum ds_wave_inclusive(DepthSum v)
+{
+    v = ds_compose(ds_dpp<0x111, 0xf>(v), v);
+    v = ds_compose(ds_dpp<0x112, 0xf>(v), v);
+    v = ds_compose(ds_dpp<0x114, 0xf>(v), v);
+    v = ds_compose(ds_dpp<0x118, 0xf>(v), v);
+    v = ds_compose(ds_dpp<0x142, 0xa>(v), v);
+    v = ds_compose(ds_dpp<0x143, 0xc>(v), v);
+    return v;
+}
+__device__ __forceinline__ DepthSum ds_lane_before(const DepthSum &inc) { return ds_dpp<0x138, 0xf>(inc); }   // wave_shr:1; lane 0: the identity
 
 constexpr int kLbWaves = 1;    // waves of a workgroup that poll side by side, 64 tiles each (2 / 4 / 8 / 16: 0.80 / 0.82 / 0.84 / 0.89 ms)
 constexpr int kStStride = 8;   // u64 words between the status entries of consecutive tiles: two entries per 128-byte line
@@ -375,7 +409,8 @@ __device__ __forceinline__ DepthSum ds_window(u64 *status, int64_t newest, bool 
     return DepthSum{__shfl(v.s, 0, kWave), __shfl(v.m, 0, kWave), __shfl(v.z, 0, kWave), __shfl(v.nz, 0, kWave)};
 }
 
-constexpr int kDsThreads = 1024;                 // (768 x 16, two workgroups per CU: 0.93 ms; 512: 1.04)
+constexpr int kDsThreads = 512;                  // two workgroups per CU (61 KB of LDS and 8 waves of <= 128 VGPRs each): one's loads, look-back
+                                                 // and store drain overlap the other's arithmetic.  1024 / 768 / 512 / 256: 0.52 / 0.57 / 0.48 / 0.51 ms
 constexpr int kDsPer = 16;                       // positions per lane, four 16-byte loads (32: 128 VGPRs + spills, 0.87 ms)
 constexpr int kDsTile = kDsThreads * kDsPer;     // positions per workgroup
 static_assert(kTile % kDsPer == 0, "a lane's 16 positions lie in one K3 tile (whatever the scan's own tile)");
@@ -414,7 +449,7 @@ __device__ __forceinline__ DepthSum scan_lane_sum(const int32_t (&d)[kDsPer])
 // sub-tile's stretch of runs[] dword for dword, from the 16-byte piece that holds the `end` of run base-1 (base = runs
 // started before the sub-tile: that run may be open on entry and closed here): word j of the image is dword origin + j of
 // runs[].  Runs beyond the image (a sub-tile of dense change points) go to memory directly.
-constexpr uint32_t kStageRuns = 10240;            // 120 KB of LDS; a sub-tile at 30x holds ~4400 runs
+constexpr uint32_t kStageRuns = 5100;             // 61 KB of LDS; a sub-tile of 8192 positions at 30x holds ~2200 runs
 constexpr uint32_t kStageWords = 3 * (kStageRuns + 1) + 8;
 __device__ __forceinline__ int32_t stage_origin(uint32_t base) { return ((int32_t)(3u * base) - 2) & ~3; }   // (-4 for base 0: never touched)
 
@@ -528,8 +563,7 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
             const uint32_t nb = (w0 + 1) * W;                                // first position of window w0+1
             if (tot_ok && wave_lo + kWave * kDsPer <= min(nb, target_len) && __ballot(over >> 27) == 0) {
                 // the usual wave: inside one window, the sums already taken above
-#pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+                tot = wave_total(tot);
                 if (lane_id() == 0 && tot) atomicAdd(&out.win_sum[w0], (u64)tot);
             } else if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
                 u64 sa = 0, sb = 0;
@@ -612,11 +646,11 @@ __device__ __forceinline__ void scan_flush(const uint32_t *__restrict__ stage, u
     }
 }
 
-// kDsSub sub-tiles of 16384 positions per workgroup, ONE ticket, ONE chain entry, one drain of the stores: the loads of all
+// kDsSub sub-tiles of 8192 positions per workgroup, ONE ticket, ONE chain entry, one drain of the stores: the loads of all
 // sub-tiles are in flight together, and what a tile pays once whatever its size -- the ticket's round trip, the look-back's
-// (3.3 us under load), the wait for its stores before the workgroup may leave (4.3 us) -- is paid per 65536 positions.
-// (32 positions per lane in ONE scan step spilled; two steps of 16 with their own registers do not.)
-constexpr int kDsSub = 4;                        // 1 / 2 / 3 / 4 sub-tiles: 0.81 / 0.74 / 0.68 / 0.67 ms (4 x 16 waves = the 64 lanes of wave 0's scan)
+// (3.3 us under load), the wait for its stores before the workgroup may leave (4.3 us) -- is paid per 32768 positions.
+// (32 positions per lane in ONE scan step spilled; steps of 16 with their own registers do not.)
+constexpr int kDsSub = 4;                        // with 1024 threads, 1 / 2 / 3 / 4 sub-tiles: 0.81 / 0.74 / 0.68 / 0.67 ms; 64 registers of differences
 constexpr int kDsGroup = kDsSub * kDsTile;       // positions per workgroup = per chain entry
 static_assert(kDsSub * (kDsThreads / kWave) <= kWave, "wave 0 scans one (sub-tile, wave) total per lane");
 
@@ -662,14 +696,8 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     DepthSum lanes_before[kDsSub];
 #pragma unroll
     for (int sb = 0; sb < kDsSub; ++sb) {
-        DepthSum inc = scan_lane_sum(d[sb]);      // inclusive scan across the wave
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const DepthSum t = ds_shfl_up(inc, o);
-            if (lane_id() >= o) inc = ds_compose(t, inc);
-        }
-        lanes_before[sb] = ds_shfl_up(inc, 1);
-        if (lane_id() == 0) lanes_before[sb] = ds_identity();
+        const DepthSum inc = ds_wave_inclusive(scan_lane_sum(d[sb]));
+        lanes_before[sb] = ds_lane_before(inc);
         if (lane_id() == kWave - 1) s_w[sb * kWaves + wave_id()] = inc;
     }
     __syncthreads();
@@ -677,16 +705,10 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     // aggregate, published at once
     DepthSum excl = ds_identity(), agg = ds_identity();   // (wave 0 only)
     if (wave_id() == 0) {
-        DepthSum w = lane_id() < kDsSub * kWaves ? s_w[lane_id()] : ds_identity();
-#pragma unroll
-        for (int o = 1; o < kDsSub * kWaves; o <<= 1) {
-            const DepthSum t = ds_shfl_up(w, o);
-            if (lane_id() >= o) w = ds_compose(t, w);
-        }
+        const DepthSum w = ds_wave_inclusive(lane_id() < kDsSub * kWaves ? s_w[lane_id()] : ds_identity());
         agg = DepthSum{__shfl(w.s, kDsSub * kWaves - 1, kWave), __shfl(w.m, kDsSub * kWaves - 1, kWave),
                        __shfl(w.z, kDsSub * kWaves - 1, kWave), __shfl(w.nz, kDsSub * kWaves - 1, kWave)};
-        excl = ds_shfl_up(w, 1);                       // what comes before this lane's (sub-tile, wave)
-        if (lane_id() == 0) excl = ds_identity();
+        excl = ds_lane_before(w);                      // what comes before this lane's (sub-tile, wave)
         if (tile > 0 && lane_id() == 0) ds_publish(status, tile, kScanAggregate, agg);
     }
     // The chain.  Per-tile stamps (profiles/r02/k3_k4_sweeps.txt): a tile finds a full prefix within one hop (1.03 hops,
