@@ -6,33 +6,36 @@
 // The default report needs neither: that is K1, fastq_scan.hip.
 //
 // One 1024-thread workgroup per CU owns a histogram image in LDS: 32-bit counters,
-// 128 symbol rows x cycles 0..255, 256 dwords per row, cycles stored transposed in
-// groups of four:  word(row, cycle) = row*256 + (cycle & 3)*64 + (cycle >> 2).
+// 128 symbol rows x cycles 0..255, 256 dwords per row.  With group g = cycle >> 2:
+//     word(row, cycle) = row*256 + (cycle & 3)*64 + (g & 1)*32 + (g >> 1)        (lds_word())
 // Cycles 256..511 (reads longer than 256 bases) go to the global matrix directly.
 // The image is flushed once, at the end of the kernel (a 32-bit counter cannot wrap
 // within one launch); sum / Q20 / Q30 are row sums taken during that flush.
 //
-//   chunk of equal-length reads, 16 <= len <= 256 (the normal case):
-//     work item = (read r, group j) = cycles 4j..4j+3 OF THE READ, one unaligned dword
-//     load.  Byte k of the item goes to word row*256 + k*64 + j, so the 32 lanes of a
-//     half-wave (consecutive j) hit 32 different banks for every k, whatever the symbols
-//     are: conflict-free ds_add_u32 (16 lane-ops/clk/CU measured, against ~10.5 for
-//     16-bytes-per-lane vectors and ~12.6 for random words, scripts/lds_atomic_ubench.hip),
+//   records of one length, 16 <= len <= 256 (the normal case; up to 4 x 4096 records per workgroup turn):
+//     work item = (read r, group j) = cycles 8j..8j+7 OF THE READ, one unaligned 8-byte buffer load
+//     (descriptor of the chunk + lane offset + m * step in an SGPR: no address arithmetic per load).
+//     Byte 4e + k of the item goes to word row*256 + k*64 + 32e + j, so in each of the eight adds
+//     the lanes of a read hit different banks whatever the symbols are, and the reads under one wave
+//     stay within the four lanes per bank that an LDS atomic handles at no extra cost
+//     (scripts/micro/lds_atomic.hip: 4.3 clocks per wave ds_add_u32 = 16 lanes per clock per CU,
+//     free up to 4 lanes per bank, +2 clocks per extra lane on one ADDRESS).
 //     2 VALU + 1 LDS per byte, no per-byte compare: bit 7 of every byte is OR-ed into one
-//     flag and the row index is masked.  A lane's items are tid + 1024 m; (r, j) advance by
-//     a per-chunk constant with carry (one division per chunk).  Eight dwords per lane are
-//     in flight, one round ahead of the round being tallied, behind counted vmcnt waits.
-//     The len%4 tail bytes of each read are walked by one lane per read.
-//   anything else (ragged lengths, very short or very long reads):
+//     flag and the row index is masked.  A lane keeps its group j for the whole chunk; two sets of
+//     eight items: one in flight while the other is tallied.
+//   anything else (ragged lengths, very short or very long reads), 4096 records at a time:
 //     aligned 16-byte vectors of the chunk's byte range, binary search over the LDS
 //     boundaries per vector, per-byte walk.
 //
-// PMC history (profiles/r01b), 2e8 x 150 bp: 22.5 ms aligned 16-B vectors + binary search;
-// 14.9 -> lanes diverged on cycle parity / read boundaries (2x LDS and VALU instruction
-// counts); 12.1 read-aligned 16-B vectors, LDS at the random-scatter conflict rate (70 % of
-// LDS cycles were conflict cycles); 11.1 byte loads, conflict-free but too few bytes in
-// flight per request slot and 6 SALU + 11 VALU per byte; 10.1 predicate-free body;
-// 8.8 ms this form.  No MFMA: there is no contraction here.
+// History, 2e8 x 150 bp: 22.5 ms aligned 16-B vectors + binary search; 14.9 lanes diverged on cycle
+// parity / read boundaries; 12.1 read-aligned 16-B vectors (LDS at the random-scatter conflict
+// rate); 11.1 byte loads; 10.1 predicate-free body; 8.8 dword items (round 1).  Round 2: 8.2 the
+// len % 4 tail as a masked partial group; 7.5 static lane -> group mapping, 16 dwords in flight;
+// 6.3 buffer loads with SGPR offsets (a wave64 VALU instruction holds its SIMD for 4 clocks: the
+// address arithmetic of flat loads was a quarter of the kernel's issue slots); 6.06 8-byte items
+// and one-length turns of 16384 records.  Timing-only builds of this form: without the LDS
+// atomics 6.2 ms, without the loads 4.9 ms, without both 3.0 ms: what bounds it is the memory
+// side at ~5 TB/s (K1 streams 6.9), not the atomics.  No MFMA: there is no contraction here.
 #include "tally_util.hpp"
 
 namespace hpn {
@@ -40,9 +43,22 @@ namespace hpn {
 constexpr int kHistThreads = 1024;
 constexpr int kHistWaves = kHistThreads / kWave;
 constexpr int kHistRecs = 4096;    // records per chunk: 600 KB at 150 bp between barriers (2048 / 1024: +6 % / +12 %)
-// dword items a lane keeps in flight: 4 / 8 / 16 -> 9.05 / 8.22 / 7.79 ms per 2e8 x 150 bp (128 VGPRs at 16; 20 spills; the kernel that
-// builds both matrices spills at 16)
-constexpr int kSpanOne = 16, kSpanBoth = 12;   // (both matrices: 8 / 10 / 12 / 14 -> 17.8 / 19.1 / 17.4 / 18.7 ms)
+// Items per set and sets in the ring (A/B builds: -DHPN_SPAN1=.. -DHPN_SETS=..).  With buffer loads, dword items: 4 / 6 / 8 / 10 /
+// 12 / 16 per set -> 7.6 / 6.5 / 6.4 / 6.7 / 7.3 / 7.0 ms; 2 / 3 / 4 sets of 8 -> 6.3 / 6.7 / 6.9: more loads in flight per
+// wave do not help.  Chunks per one-length turn 1 / 2 / 4 / 8 / 16 -> 6.29 / 6.09 / 6.06 / 6.16 / 6.38.
+#ifndef HPN_HIST_BIG
+#define HPN_HIST_BIG 4
+#endif
+#ifndef HPN_SETS
+#define HPN_SETS 2
+#endif
+#ifndef HPN_SPAN1
+#define HPN_SPAN1 8
+#endif
+#ifndef HPN_SPAN2
+#define HPN_SPAN2 8
+#endif
+constexpr int kSpanOne = HPN_SPAN1, kSpanBoth = HPN_SPAN2;
 constexpr int kLdsCycles = 256;    // cycles held in LDS; later cycles go to global atomics
 constexpr int kRowWords = kLdsCycles;
 
@@ -73,14 +89,12 @@ struct HistLds {
     u64 red[3][kHistWaves];
 };
 
-// Index of (row, cycle) inside the LDS image.  Cycles are stored TRANSPOSED in groups of four:
-//     word(row, cycle) = row * 256 + (cycle & 3) * 64 + (cycle >> 2)
-// A lane that holds the four bytes of cycles 4j..4j+3 of a read adds byte k at word
-// row*256 + k*64 + j: the 32 lanes of a half-wave (consecutive j) hit 32 different banks for
-// every k, whatever the symbols are.
+// Index of (row, cycle) inside the LDS image: see the head of the file.  A lane that holds the eight bytes of
+// cycles 8j..8j+7 of a read adds byte 4e + k at word row*256 + k*64 + 32e + j.
 __device__ __forceinline__ uint32_t lds_word(uint32_t row, uint32_t pos)
 {
-    return row * kRowWords + ((pos & 3u) << 6) + (pos >> 2);
+    const uint32_t g = pos >> 2;
+    return row * kRowWords + ((pos & 3u) << 6) + ((g & 1u) << 5) + (g >> 1);
 }
 
 struct HiTot {  // quality bytes tallied at cycles >= 256 (they bypass the LDS image and its row sums)
@@ -122,80 +136,131 @@ __device__ __forceinline__ uint32_t load_unaligned4(const uint8_t *p)
 // constant, and the only per-item arithmetic left is one add and one compare (PMC, round 2: the item-index
 // arithmetic of lanes that changed (r, j) every item was 5 of the kernel's 7.4 VALU operations per byte,
 // and VALU issue, not the LDS, was what the kernel waited for).
-template <bool kQual, bool kPartial, int kSpanRound>   // kPartial: len0 % 4 != 0 (the chunk's reads end in a partial group); kSpanRound: dword items a lane keeps in flight
+// kPartial: len0 % 8 != 0 (the chunk's reads end in a partial group); kSpanRound: 8-byte items per set
+template <bool kQual, bool kPartial, int kSpanRound>
 __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint64_t arr_end, uint32_t cnt,
                                                uint32_t len0, uint32_t &bad)
 {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x2 item_t;
     uint32_t *hist = kQual ? s.qh : s.nh;
     const uint8_t *p0 = arr + base_off;
-    // 4-cycle groups per read; the last one holds only len0 % 4 cycles when that is not 0 (its load reaches into the next
-    // read's first bytes, which are masked: a lane per read walking those tail bytes one by one put 4096 x 2 byte loads
-    // and as many 32-way bank conflicts into every chunk -- 22 % of the kernel at 150 bp)
-    const uint32_t ngr = (len0 + 3u) >> 2;
-    const uint32_t rpr = kHistThreads / ngr;              // reads per round (>= 16: ngr <= 64)
+    // Work item = (read r, 8-cycle group j) = cycles 8j..8j+7 of the read = two 4-cycle groups 2j, 2j+1 = ONE unaligned
+    // 8-byte load.  (The CU holds a bounded number of vector-memory INSTRUCTIONS in flight, not of bytes: with dword items
+    // the kernel ran at the same 4.8 TB/s with and without its LDS atomics, whatever the number of loads a wave kept
+    // outstanding.)  The last group holds only len0 % 8 cycles when that is not 0: its load reaches into the next read's
+    // first bytes, which are masked.
+    const uint32_t ngr = (len0 + 7u) >> 3;
+    // reads per round (>= 32: ngr <= 32).  (Items that start off a dword boundary -- any length that is not a multiple of
+    // 4 -- were also tried as three ALIGNED dwords per lane shifted with v_alignbyte: the same 6.1-6.2 ms at 150 and 151 bp.)
+    const uint32_t rpr = kHistThreads / ngr;
     const uint32_t lr = threadIdx.x / ngr, j = threadIdx.x - lr * ngr;   // the one division per chunk
-    const uint32_t nvalid = min(4u, len0 - 4u * j);       // bytes of this lane's group that belong to the read
+    const uint32_t nvalid = min(8u, len0 - 8u * j);       // bytes of this lane's group that belong to the read
     const bool lane_on = lr < rpr;                        // the last 1024 - rpr * ngr lanes have no item
-    const uint32_t step = rpr * len0;                     // bytes between a lane's items of consecutive rounds
-    uint32_t off = lr * len0 + 4u * j;                    // chunk-relative byte offset of this lane's item
-    uint32_t r = lr;                                      // ... and its read
-    uint32_t col[4];                                      // byte k of every item of this lane goes to word row*256 + col[k]
-    uint32_t rmask[4];
+    // byte b = 4e + k of every item of this lane goes to word row*256 + k*64 + 32e + j (col_of()): the lanes of a read hit
+    // ngr different banks in every one of the eight adds, and the three or four reads under a wave stay within the four
+    // lanes per bank that cost nothing (scripts/micro/lds_atomic.hip)
+    uint32_t col[8], bmask[8];                            // bmask: the byte's 7 (8) bits, or 0 for a byte behind the read
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool mine = (uint32_t)k < nvalid;
-        rmask[k] = mine ? ~0u : 0u;
-        col[k] = mine ? 64u * k + j : (kQual ? kJunkQ : kJunkN) + (threadIdx.x & 63u);
+    for (int b8 = 0; b8 < 8; ++b8) {
+        const bool mine = !kPartial || (uint32_t)b8 < nvalid;
+        bmask[b8] = mine ? (kQual ? 0x7fu : 0xffu) : 0u;
+        col[b8] = mine ? 64u * (b8 & 3) + 32u * (b8 >> 2) + j : (kQual ? kJunkQ : kJunkN) + (threadIdx.x & 63u);
     }
-    uint32_t va[kSpanRound], vb[kSpanRound];
-    uint32_t na = 0, nb = 0;                              // items of the set that exist (wave-varying only in the last round)
-    auto fetch = [&](uint32_t (&v)[kSpanRound], uint32_t &nv) {
-        nv = 0;
+    // The loads go through a buffer descriptor of the chunk: address = descriptor base + lane offset (VGPR) + m * step
+    // (SGPR), so a set of kSpanRound loads costs ONE vector add (the 64-bit address arithmetic, the per-item compare and
+    // select of flat loads were 1.3 of the kernel's 5.5 VALU operations per byte, and with four cycles per wave64
+    // instruction VALU issue was what the kernel waited for).  Lanes without items carry an offset beyond the
+    // descriptor: the hardware drops their loads.
+    const uint32_t rounds = (cnt + rpr - 1) / rpr;        // uniform
+    uint32_t left = 0;                                    // items this lane still has to fetch
+    if (lane_on && lr < cnt) left = rounds - (lr + (rounds - 1u) * rpr >= cnt ? 1u : 0u);
+    const uint64_t chunk_bytes = (uint64_t)cnt * len0, avail = arr_end - base_off;
+    // The partial group of the batch's very last read cannot be loaded whole (it would reach past the batch): that
+    // one item is left out of the sets and tallied byte by byte after the loop.
+    bool last_mine = false;
+    const uint64_t p0u = (uint64_t)(uintptr_t)p0;         // (the same in every lane: into SGPRs)
+    const uint32_t last_off = (cnt - 1u) * len0 + 8u * j;
+    if (kPartial && left && j == ngr - 1u && lr + (rounds - 1u) * rpr == cnt - 1u && (uint64_t)last_off + 8u > avail) last_mine = true, --left;
+    const uint32_t nrec = (uint32_t)min(avail, chunk_bytes + 7u);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(p0u >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)p0u)),
+        0, (int)__builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+    const uint32_t step = __builtin_amdgcn_readfirstlane(rpr * len0);   // bytes between a lane's items of consecutive rounds
+    constexpr uint32_t kNowhere = 0x7ff00000u;            // an offset no descriptor of a chunk reaches
+    uint32_t voff = left ? lr * len0 + 8u * j : kNowhere; // chunk-relative byte offset of this lane's next item
+    constexpr int kSets = HPN_SETS;
+    item_t v[kSets][kSpanRound];
+    uint32_t nv[kSets] = {};                              // items of the set that exist (below kSpanRound only in a lane's last set)
+    auto fetch = [&](item_t (&vs)[kSpanRound], uint32_t &n) {
+        n = min(left, (uint32_t)kSpanRound);
+        left -= n;
+        // items beyond a lane's last one lie beyond the descriptor's end (the range check covers voffset + soffset, and a
+        // load that straddles the end is dropped whole: scripts/micro/buffer_range.hip): no memory is touched for them
 #pragma unroll
-        for (int m = 0; m < kSpanRound; ++m) {
-            // no branch around the load (a lane without an item re-reads the chunk's first bytes): the
-            // compiler then counts the loads in flight instead of draining them all
-            const bool on = lane_on && r < cnt;
-            // the partial group of the batch's very last read: the dword is taken `back` bytes earlier, so that it ends
-            // with the batch, and shifted down (no branch: the loads of a set stay together)
-            const uint32_t back = kPartial && base_off + off + 4u > arr_end ? 4u - nvalid : 0u;
-            v[m] = load_unaligned4(p0 + (on ? off - back : 0u)) >> (8u * back);
-            nv += on;
-            off += step, r += rpr;
-        }
+#ifdef DIAG_NOLOAD
+        for (int m = 0; m < kSpanRound; ++m) vs[m][0] = (voff + m * 0x01030507u) & 0x3f3f3f3fu, vs[m][1] = (voff + m * 0x03050701u) & 0x3f3f3f3fu;
+#else
+        for (int m = 0; m < kSpanRound; ++m) vs[m] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, n ? voff : kNowhere, m * step, 0);
+#endif
+        voff += kSpanRound * step;
     };
     // A quality byte >= 128 has no row: bit 7 of every byte is OR-ed into `seen` (checked once
     // per chunk; the batch is then rejected) and the row index is masked to 7 bits so that the
     // LDS address stays in range: no compare, no exec-mask juggling per byte.
-    uint32_t seen = 0;
-    auto tally = [&](const uint32_t (&v)[kSpanRound], uint32_t nv) {
+    uint32_t seen = 0, sink = 0;
+    auto tally_item = [&](const item_t d) {
+        if (kQual) seen |= d[0] | d[1];   // (the bytes behind a partial group are the next read's: quality bytes as well)
 #pragma unroll
-        for (int m = 0; m < kSpanRound; ++m) {
-            if ((uint32_t)m >= nv) break;                 // a lane's items of a set are its first nv
-            const uint32_t d = v[m];
-            if (kQual) seen |= d;   // (the bytes behind a partial group are the next read's: quality bytes as well)
+        for (int b8 = 0; b8 < 8; ++b8) {
+            // bytes behind a partial group go to this lane's junk word behind the image (row 0): no branch per byte
+            const uint32_t byte = (d[b8 >> 2] >> (8 * (b8 & 3))) & bmask[b8];
+            const uint32_t row = kQual ? byte : (uint32_t)s.nlut[byte];
+#ifdef DIAG_NOATOM
+            sink += row * kRowWords + col[b8];
+#else
+            atomicAdd(&hist[row * kRowWords + col[b8]], 1u);
+#endif
+        }
+    };
+    auto tally = [&](const item_t (&vs)[kSpanRound], uint32_t n) {
+        if (__ballot(n != (uint32_t)kSpanRound && n != 0u) == 0) {
+            if (n) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t byte = (d >> (8 * k)) & (kQual ? 0x7fu : 0xffu);
-                const uint32_t row = kQual ? byte : (uint32_t)s.nlut[byte];
-                // bytes behind a partial group go to this lane's junk word behind the image: no branch per byte
-                atomicAdd(&hist[(kPartial ? row & rmask[k] : row) * kRowWords + col[k]], 1u);
+                for (int m = 0; m < kSpanRound; ++m) tally_item(vs[m]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kSpanRound; ++m) {
+                if ((uint32_t)m >= n) break;             // a lane's items of a set are its first n
+                tally_item(vs[m]);
             }
         }
     };
-    const uint32_t rounds = (cnt + rpr - 1) / rpr;        // uniform: every lane runs the same number of fetches
-    for (uint32_t q = 0; q < rounds; q += 2 * kSpanRound) {
-        if (q == 0) fetch(va, na);
-        const bool more_b = q + kSpanRound < rounds;
-        if (more_b) fetch(vb, nb);
-        tally(va, na);
-        if (!more_b) break;
-        const bool more_a = q + 2 * kSpanRound < rounds;
-        if (more_a) fetch(va, na);
-        tally(vb, nb);
-        if (!more_a) break;
+    // a ring of kSets sets: kSets - 1 of them in flight while one is tallied
+    const uint32_t nsets = (rounds + kSpanRound - 1) / kSpanRound;       // uniform
+    uint32_t fetched = 0;
+#pragma unroll
+    for (int t = 0; t < kSets - 1; ++t)
+        if (fetched < nsets) fetch(v[t], nv[t]), ++fetched;
+    for (uint32_t i = 0; i < nsets; i += kSets) {
+#pragma unroll
+        for (int t = 0; t < kSets; ++t) {
+            if (i + t >= nsets) break;
+            if (fetched < nsets) fetch(v[(t + kSets - 1) % kSets], nv[(t + kSets - 1) % kSets]), ++fetched;
+            tally(v[t], nv[t]);
+        }
+    }
+    if (kPartial && last_mine) {                          // at most one lane of the batch's last chunk
+        for (uint32_t b8 = 0; b8 < nvalid; ++b8) {
+            const uint32_t byte = p0[last_off + b8];
+            if (kQual) seen |= byte;
+            const uint32_t row = kQual ? (byte & 0x7fu) : (uint32_t)s.nlut[byte];
+            atomicAdd(&hist[row * kRowWords + 64u * (b8 & 3u) + 32u * (b8 >> 2) + j], 1u);
+        }
     }
     if (seen & 0x80808080u) bad = 1;
+    if (sink == 0x12345u) bad = 1;
 }
 
 // Any chunk: aligned vectors of the byte range, each located by binary search.
@@ -246,8 +311,8 @@ __device__ __forceinline__ void hist_flush(const uint32_t *lds, int rows, u64 *_
     for (int w = threadIdx.x; w < rows * kRowWords; w += kHistThreads) {
         const uint32_t v = lds[w];
         if (v) {
-            const int r = w / kRowWords, c = w - r * kRowWords;  // c = (cycle & 3) * 64 + (cycle >> 2)
-            atomicAdd(&gacc[r * HPN_LEN_BINS + 4 * (c & 63) + (c >> 6)], (u64)v);
+            const int r = w / kRowWords, c = w - r * kRowWords;  // c = (cycle & 3) * 64 + (group & 1) * 32 + (group >> 1), group = cycle >> 2
+            atomicAdd(&gacc[r * HPN_LEN_BINS + 4 * (2 * (c & 31) + ((c >> 5) & 1)) + (c >> 6)], (u64)v);
             tot += v;
             if (r >= 53) t20 += v;
             if (r >= 63) t30 += v;
@@ -259,7 +324,7 @@ template <bool kQualHist, bool kNucHist>
 __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__restrict__ qual,
                                                             const uint8_t *__restrict__ base,
                                                             const uint64_t *__restrict__ off, uint64_t n,
-                                                            u64 *__restrict__ acc)
+                                                            u64 *__restrict__ acc, uint32_t big)
 {
     __shared__ HistLds s;
     constexpr int kSp = (kQualHist && kNucHist) ? kSpanBoth : kSpanOne;
@@ -274,42 +339,62 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
     u64 *gq = acc + HPN_TALLY_W_QUAL, *gn = acc + HPN_TALLY_W_NUC;
     HiTot hi;
     const uint64_t arr_end = off[n];          // first byte offset that is not the batch's
-    const uint64_t nchunk = (n + kHistRecs - 1) / kHistRecs;
-    for (uint64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-        const uint64_t r0 = ch * kHistRecs;
-        const uint32_t cnt = (uint32_t)min((uint64_t)kHistRecs, n - r0);
-        const uint64_t base_off = off[r0];
-        // chunk-relative boundaries; a chunk spans < 4096*512 bytes inside the domain
-        for (uint32_t i = tid; i <= cnt; i += kHistThreads) {
-            const uint64_t d = off[r0 + i] - base_off;
-            s.loff[i] = d > 0x7fffffffull ? 0x7fffffffu : (uint32_t)d;
+    // A workgroup takes `big` chunks of kHistRecs records at a time.  When they all have one length (the normal case: checked
+    // from the offsets in registers, no LDS) they are streamed as ONE chunk: the offsets' round trip, the barriers and the
+    // fill and drain of the load pipeline are paid once per big * 4096 records.  Otherwise chunk by chunk, boundaries in LDS.
+    const uint64_t span = (uint64_t)big * kHistRecs;
+    const uint64_t nspan = (n + span - 1) / span;
+    for (uint64_t sp = blockIdx.x; sp < nspan; sp += gridDim.x) {
+        const uint64_t q0 = sp * span;
+        const uint32_t qcnt = (uint32_t)min(span, n - q0);
+        const uint64_t q_off = off[q0];
+        const uint64_t qlen0 = off[q0 + 1] - q_off;
+        bool one_len = qlen0 >= 16 && qlen0 <= (uint64_t)kLdsCycles;
+        if (one_len) {
+            for (uint32_t i = tid; i < qcnt; i += kHistThreads) one_len = one_len && off[q0 + i + 1] - off[q0 + i] == qlen0;
         }
-        __syncthreads();
-        const uint32_t len0 = s.loff[1];
-        bool all_same = true;
-        for (uint32_t i = tid; i < (uint32_t)kHistRecs; i += kHistThreads) {  // same trip count in every lane (ballots inside)
-            const bool valid = i < cnt;
-            uint32_t len = 0;
-            if (valid) {
-                len = s.loff[i + 1] - s.loff[i];
-                if (len >= HPN_LEN_BINS) len = HPN_LEN_BINS, bad = 1;
-                all_same = all_same && len == len0;
+        if (__syncthreads_and((int)one_len)) {
+            const uint32_t len0 = (uint32_t)qlen0;
+            if (tid == 0) atomicAdd(&s.lhist[len0], qcnt);
+            if (kQualHist) (len0 & 7u) ? stream_uniform<true, true, kSp>(s, qual, q_off, arr_end, qcnt, len0, bad) : stream_uniform<true, false, kSp>(s, qual, q_off, arr_end, qcnt, len0, bad);
+            if (kNucHist) (len0 & 7u) ? stream_uniform<false, true, kSp>(s, base, q_off, arr_end, qcnt, len0, bad) : stream_uniform<false, false, kSp>(s, base, q_off, arr_end, qcnt, len0, bad);
+            continue;
+        }
+        for (uint64_t r0 = q0; r0 < q0 + qcnt; r0 += kHistRecs) {
+            const uint32_t cnt = (uint32_t)min((uint64_t)kHistRecs, q0 + qcnt - r0);
+            const uint64_t base_off = off[r0];
+            // chunk-relative boundaries; a chunk spans < 4096*512 bytes inside the domain
+            for (uint32_t i = tid; i <= cnt; i += kHistThreads) {
+                const uint64_t d = off[r0 + i] - base_off;
+                s.loff[i] = d > 0x7fffffffull ? 0x7fffffffu : (uint32_t)d;
             }
-            hist_len(s.lhist, valid, len);
-        }
-        // an over-long record poisons position tracking: stop tallying bytes, the batch
-        // is rejected as a whole (HPN_E_DOMAIN) once `bad` is seen
-        if (!__syncthreads_or((int)bad)) {
-            const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16 && len0 <= (uint32_t)kLdsCycles;
-            if (uniform) {
-                if (kQualHist) (len0 & 3u) ? stream_uniform<true, true, kSp>(s, qual, base_off, arr_end, cnt, len0, bad) : stream_uniform<true, false, kSp>(s, qual, base_off, arr_end, cnt, len0, bad);
-                if (kNucHist) (len0 & 3u) ? stream_uniform<false, true, kSp>(s, base, base_off, arr_end, cnt, len0, bad) : stream_uniform<false, false, kSp>(s, base, base_off, arr_end, cnt, len0, bad);
-            } else {
-                if (kQualHist) stream_ragged<true>(s, gq, qual, base_off, cnt, bad, hi);
-                if (kNucHist) stream_ragged<false>(s, gn, base, base_off, cnt, bad, hi);
+            __syncthreads();
+            const uint32_t len0 = s.loff[1];
+            bool all_same = true;
+            for (uint32_t i = tid; i < (uint32_t)kHistRecs; i += kHistThreads) {  // same trip count in every lane (ballots inside)
+                const bool valid = i < cnt;
+                uint32_t len = 0;
+                if (valid) {
+                    len = s.loff[i + 1] - s.loff[i];
+                    if (len >= HPN_LEN_BINS) len = HPN_LEN_BINS, bad = 1;
+                    all_same = all_same && len == len0;
+                }
+                hist_len(s.lhist, valid, len);
             }
+            // an over-long record poisons position tracking: stop tallying bytes, the batch
+            // is rejected as a whole (HPN_E_DOMAIN) once `bad` is seen
+            if (!__syncthreads_or((int)bad)) {
+                const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16 && len0 <= (uint32_t)kLdsCycles;
+                if (uniform) {
+                    if (kQualHist) (len0 & 7u) ? stream_uniform<true, true, kSp>(s, qual, base_off, arr_end, cnt, len0, bad) : stream_uniform<true, false, kSp>(s, qual, base_off, arr_end, cnt, len0, bad);
+                    if (kNucHist) (len0 & 7u) ? stream_uniform<false, true, kSp>(s, base, base_off, arr_end, cnt, len0, bad) : stream_uniform<false, false, kSp>(s, base, base_off, arr_end, cnt, len0, bad);
+                } else {
+                    if (kQualHist) stream_ragged<true>(s, gq, qual, base_off, cnt, bad, hi);
+                    if (kNucHist) stream_ragged<false>(s, gn, base, base_off, cnt, bad, hi);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     __syncthreads();
     u64 tot = hi.tot, t20 = hi.c20, t30 = hi.c30, ntot = 0, n20 = 0, n30 = 0;
@@ -352,12 +437,16 @@ hipError_t launch_tally_hist(const uint8_t *d_qual, const uint8_t *d_base, const
     const uint64_t nchunk = (n + kHistRecs - 1) / kHistRecs;
     if (nchunk == 0) return hipSuccess;
     const unsigned grid = (unsigned)(nchunk < (uint64_t)n_cu ? nchunk : (uint64_t)n_cu);  // LDS: one image per CU
+    // chunks per workgroup turn: up to kHistBig, fewer when the batch would otherwise leave workgroups without a turn or
+    // make the last round of turns a large part of the whole
+    uint32_t big = HPN_HIST_BIG;
+    while (big > 1 && nchunk < (uint64_t)8 * big * grid) big >>= 1;
     if (qual_hist && nuc_hist)
-        hipLaunchKernelGGL((k_tally_hist<true, true>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc);
+        hipLaunchKernelGGL((k_tally_hist<true, true>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc, big);
     else if (qual_hist)
-        hipLaunchKernelGGL((k_tally_hist<true, false>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc);
+        hipLaunchKernelGGL((k_tally_hist<true, false>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc, big);
     else
-        hipLaunchKernelGGL((k_tally_hist<false, true>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc);
+        hipLaunchKernelGGL((k_tally_hist<false, true>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc, big);
     return hipGetLastError();
 }
 
