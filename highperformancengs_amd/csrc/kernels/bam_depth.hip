@@ -330,17 +330,6 @@ __device__ __forceinline__ DepthSum ds_dpp(const DepthSum &v)
                     (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.nz, kCtrl, kRows, 0xf, false)};
 }
 __device__ __forceinline__ DepthSum ds_wave_inclusive(DepthSum v);
-__device__ __forceinline__ uint32_t wave_total(uint32_t x)        // sum over the wave, valid in lane 63 and returned from there
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
-    return (uint32_t)__builtin_amdgcn_readlane((int)x, kWave - 1);
-}
-
 __device__ __forceinline__ uint32_t ds_starts(const DepthSum &v, int64_t c_in) { return v.nz - ((int64_t)v.m == -c_in ? v.z : 0u); }
 
 __device__ __forceinline__ DepthSum ds_wave_inclusive(DepthSum v)
@@ -453,13 +442,6 @@ constexpr uint32_t kStageRuns = 5100;             // 61 KB of LDS; a sub-tile of
 constexpr uint32_t kStageWords = 3 * (kStageRuns + 1) + 8;
 __device__ __forceinline__ int32_t stage_origin(uint32_t base) { return ((int32_t)(3u * base) - 2) & ~3; }   // (-4 for base 0: never touched)
 
-// n / W for n < 2^32 with M = 0xffffffff / W: the estimate is short by at most one
-__device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t W, uint32_t M)
-{
-    const uint32_t q = __umulhi(n, M);
-    return q + (n - q * W >= W ? 1u : 0u);
-}
-
 // Runs and window sums of one lane's 16 positions (first one p0), given everything before them.  Returns the number of
 // runs started up to and including these positions.
 __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const DepthSum &before, uint64_t p0, uint64_t sub_first,
@@ -563,7 +545,7 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
             const uint32_t nb = (w0 + 1) * W;                                // first position of window w0+1
             if (tot_ok && wave_lo + kWave * kDsPer <= min(nb, target_len) && __ballot(over >> 27) == 0) {
                 // the usual wave: inside one window, the sums already taken above
-                tot = wave_total(tot);
+                tot = wave_sum(tot);
                 if (lane_id() == 0 && tot) atomicAdd(&out.win_sum[w0], (u64)tot);
             } else if (wave_hi - 1 - w0 * W < 2 * (uint64_t)W) {
                 u64 sa = 0, sb = 0;

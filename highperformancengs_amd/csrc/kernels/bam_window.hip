@@ -23,6 +23,15 @@ __device__ __forceinline__ uint32_t gc_nibbles(uint32_t w)
 {
     return __builtin_popcount(((w >> 1) ^ (w >> 2)) & ~(w >> 3) & ~w & 0x11111111u);
 }
+// The same with the verdict of each nibble at its bit 2 and the nibbles to count chosen by `keep` (a subset of 0x44444444:
+// masking the verdicts instead of the input costs nothing), added to acc.  Seven instructions per word: shift; shift-or
+// (bits 0 and 3 meet at bit 2); shift; xor (bits 1 and 2 meet at bit 2); and-not; and; count-and-add.
+__device__ __forceinline__ uint32_t gc_nibbles_at2(uint32_t w, uint32_t keep, uint32_t acc)
+{
+    const uint32_t other = (w << 2) | (w >> 1);            // bit 2 of a nibble: its bit 0 | its bit 3
+    const uint32_t one = (w << 1) ^ w;                     // bit 2 of a nibble: its bit 1 ^ its bit 2
+    return acc + (uint32_t)__builtin_popcount(one & ~other & keep);
+}
 
 // GC count of the first `nbytes` (1..16) bytes of a 16-byte piece of a packed sequence (base i = high nibble of byte
 // i/2 for even i, bam1_seqi, bam.h:260); clip: the piece ends the sequence of an odd-length read, whose last low
@@ -95,6 +104,7 @@ __device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict
                 const int hi = min(max(rem - 4 * j, 0), 4);
                 lay.m[j] = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
                 if ((lq0 & 1) && hi > 0 && rem - 4 * j <= 4) lay.m[j] &= ~(0xfu << (8 * (hi - 1)));
+                lay.m[j] &= 0x44444444u;                   // the nibbles of word j that are bases of the read, as gc_nibbles_at2 wants them
             }
         }
         const int rps = lay.rps, steps = lay.steps, pg = lay.pg, psub = lay.psub;
@@ -102,21 +112,37 @@ __device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict
         const uint32_t *m = lay.m;
         uint32_t *acc = wave_gc + lane;
         __hip_atomic_store(acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // The pieces come through a buffer descriptor that starts at the wave's first sequence and ends where seq4 may no
+        // longer be read: address = descriptor + 32-bit lane offset (no 64-bit arithmetic, no compare against the end per
+        // load -- the hardware drops what lies beyond).  A piece that STRADDLES the end would be dropped whole
+        // (scripts/micro/buffer_range.hip): the batch's last piece, taken byte by byte below.
+        const uint64_t room = lim > s0 ? lim - s0 : 0;
+        const uint32_t nrec = room > 0xffffffffull ? 0xffffffffu : (uint32_t)room;
+        const uint64_t b0 = (uint64_t)(uintptr_t)seq4 + s0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b0)),
+            0, (int)__builtin_amdgcn_readfirstlane(nrec), 0x00020000);
         u32 q[8];
         int rec[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             rec[t] = t * rps + pg;
             const bool on = t < steps && used && rec[t] < kWave;
-            const uint32_t st = __shfl(srel, on ? rec[t] : 0, kWave);
-            q[t] = u32{0, 0, 0, 0};
-            if (on) q[t] = load16u(seq4, s0 + st + 16u * (uint32_t)psub, lim);
-            else rec[t] = -1;
+            const uint32_t at = __shfl(srel, on ? rec[t] : 0, kWave) + 16u * (uint32_t)psub;
+#ifdef DIAG_NOSEQ
+            q[t] = u32{at, at * 3u, at * 5u, at * 7u};
+#else
+            q[t] = __builtin_bit_cast(u32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? at : 0xfffffff0u, 0, 0));
+#endif
+            if (__ballot(on && at < nrec && at + 16u > nrec)) {
+                if (on && at < nrec && at + 16u > nrec) q[t] = load16u(seq4, s0 + at, lim);
+            }
+            if (!on) rec[t] = -1;
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (t >= steps) break;
-            const uint32_t g = gc_nibbles(q[t][0] & m[0]) + gc_nibbles(q[t][1] & m[1]) + gc_nibbles(q[t][2] & m[2]) + gc_nibbles(q[t][3] & m[3]);
+            const uint32_t g = gc_nibbles_at2(q[t][0], m[0], gc_nibbles_at2(q[t][1], m[1], gc_nibbles_at2(q[t][2], m[2], gc_nibbles_at2(q[t][3], m[3], 0u))));
             if (rec[t] >= 0) __hip_atomic_fetch_add(wave_gc + rec[t], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                // the wave's own LDS operations: in order
@@ -181,6 +207,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
     const uint64_t wave0 = (uint64_t)blockIdx.x * (kWinThreads / kWave) + wave_id(), nwaves = (uint64_t)gridDim.x * (kWinThreads / kWave);
     uint32_t counted = 0;
     GcLayout lay;
+    const uint32_t Wm = 0xffffffffu / W;                    // div_by()
     for (uint64_t span = wave0; span < nspan; span += nwaves) {
         u64 cur = ~0ull;                                   // window slot the sums belong to (same value in every lane)
         uint32_t a_bins = 0, a_len = 0, cur_tid = 0;
@@ -193,23 +220,39 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                 touched[cur_tid] = 1u;
             }
         };
+        // the fields of a pass are loaded one pass ahead, beside the sequence loads of the pass before: one exposed round
+        // trip per pass instead of two (fields, then the sequences they point to)
+        struct Fields {
+            int32_t t = -1, p = 0, l = 0;
+            uint32_t f = 0;
+            uint64_t so = 0;
+        };
+        auto fields_of = [&](uint64_t r) {
+            Fields x;
+            if (r < n) x.t = rec_tid[r], x.p = rec_pos[r], x.l = l_qseq[r], x.f = rec_flag[r], x.so = seq_off[r];
+            return x;
+        };
+        Fields nxt = fields_of(span * kWinSpan + lane);
         for (int pass = 0; pass < kWinSpan / kWave; ++pass) {
             const uint64_t r = span * kWinSpan + (uint64_t)pass * kWave + lane;
             if (__ballot(r < n) == 0) break;
+            const Fields cf = nxt;
+            if (pass + 1 < kWinSpan / kWave) nxt = fields_of(r + kWave);
             bool ok = false;
             uint64_t slot = 0, so = 0;
             uint32_t lq = 0, tt = 0;
             int32_t lqs = 0;
             if (r < n) {
-                const int32_t t = rec_tid[r], p = rec_pos[r], l = l_qseq[r];
-                const uint32_t f = rec_flag[r];
-                so = seq_off[r], lqs = l;                      // skipped records are read too: a wave of one length stays one
+                const int32_t t = cf.t, p = cf.p, l = cf.l;
+                const uint32_t f = cf.f;
+                so = cf.so, lqs = l;                           // skipped records are read too: a wave of one length stays one
                 if (t >= 0 && !(f & 4u)) {                     // :96-97
                     if (t >= n_targets) {
                         atomicOr(bad, 1u);
                     } else {
                         // c->pos / window in int, then (unsigned short) (:117)
-                        const uint32_t w16 = (uint32_t)(uint16_t)(p / (int32_t)W);
+                        // (one multiplication when the position is not negative -- always, for a mapped record)
+                        const uint32_t w16 = (uint32_t)(uint16_t)(p >= 0 ? (int32_t)div_by((uint32_t)p, W, Wm) : p / (int32_t)W);
                         const uint64_t lo = win_off[t], hi = win_off[t + 1];
                         if (lo + w16 >= hi) {
                             atomicOr(bad, 2u);                 // the reference would write out of bounds
@@ -220,7 +263,11 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                 }
             }
             // every lane takes part (lanes without a record contribute an empty sequence)
+#ifdef DIAG_NOGC
+            const uint32_t g = (uint32_t)so & 63u;
+#else
             const uint32_t g = (uint32_t)(uint16_t)gc_of_wave_records(seq4, so, lqs, lim, s_gc[wave_id()], lay);   // unsigned short current_GC (:118)
+#endif
             u64 rem = __ballot(ok);
             counted += (uint32_t)__builtin_popcountll(rem);   // n_count (:104); the same in every lane
             for (int it = 0; rem; ++it) {

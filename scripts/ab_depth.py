@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-session A/B of the bam2depth kernels (K3 = hpn_depth_add_dev, K4 = hpn_depth_finish) on the chr1-at-30x shape.
 Run once per variant library:  HPN_LIB=.scratch/ab/<name>/libhpngs.so python scripts/ab_depth.py [reps]
-Prints one line: variant, K3 ms, K4 ms (medians).  No result checks: diagnostic builds leave work out."""
+Prints one line: variant, K3 ms, K4 ms, K5 ms (medians).  No result checks: diagnostic builds leave work out."""
 import ctypes as C
 import os
 import statistics
@@ -57,5 +57,11 @@ if True:
         t4 = ctx.last_kernel_ms(2)
         if r:
             ts3.append(t3), ts4.append(t4)
-    print("%-28s K3 %.3f ms   K4 %.3f ms   (runs %d)" % (os.environ.get("HPN_LIB", "default"), statistics.median(ts3),
-                                                        statistics.median(ts4), len(runs)), flush=True)
+    off = np.array([0, TL // 20000 + 1], np.uint64)
+    ts5 = []
+    for r in range(reps + 1):
+        bins, gc, ln, touched, nc = ctx.window_counts(d, off, 20000, dev=True)
+        if r:
+            ts5.append(ctx.last_kernel_ms(3))
+    print("%-28s K3 %.3f ms   K4 %.3f ms   K5 %.3f ms   (runs %d, gc %d)" % (os.environ.get("HPN_LIB", "default"), statistics.median(ts3),
+                                                        statistics.median(ts4), statistics.median(ts5), len(runs), int(gc.sum())), flush=True)
