@@ -85,9 +85,9 @@ __device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict
     if (!has_seq) return 0;
     const int lq0 = __shfl(l_qseq, __builtin_ctzll(has_seq), kWave);   // records without a sequence ride along, their sum is dropped
     // byte offsets relative to the wave's first sequence: one 32-bit shuffle per step (records without a sequence read
-    // the first one's; 64 neighbouring records 4 GiB apart do not happen -- if they do, the generic paths take the wave)
+    // the first one's; 64 neighbouring records 2 GiB apart do not happen -- if they do, the generic paths take the wave)
     const uint64_t s0 = __shfl((u64)s, __builtin_ctzll(has_seq), kWave);
-    const bool rel_ok = l_qseq <= 0 || (s >= s0 && s - s0 < (1ull << 32));
+    const bool rel_ok = l_qseq <= 0 || (s >= s0 && s - s0 < (1ull << 31) - (1ull << 16));
     const uint32_t srel = l_qseq > 0 ? (uint32_t)(s - s0) : 0u;
     if (lq0 <= 256 && __ballot((l_qseq > 0 && l_qseq != lq0) || !rel_ok) == 0) {
         // every record of the wave has the same length (the normal case): P = pieces per record lanes serve one record, so
@@ -117,7 +117,7 @@ __device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict
         // load -- the hardware drops what lies beyond).  A piece that STRADDLES the end would be dropped whole
         // (scripts/micro/buffer_range.hip): the batch's last piece, taken byte by byte below.
         const uint64_t room = lim > s0 ? lim - s0 : 0;
-        const uint32_t nrec = room > 0xffffffffull ? 0xffffffffu : (uint32_t)room;
+        const uint32_t nrec = room > 0x7fffffffull ? 0x7fffffffu : (uint32_t)room;   // (a wave's records lie within 2^31 - 2^16 bytes: rel_ok)
         const uint64_t b0 = (uint64_t)(uintptr_t)seq4 + s0;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b0)),
@@ -132,7 +132,7 @@ __device__ __forceinline__ uint32_t gc_of_wave_records(const uint8_t *__restrict
 #ifdef DIAG_NOSEQ
             q[t] = u32{at, at * 3u, at * 5u, at * 7u};
 #else
-            q[t] = __builtin_bit_cast(u32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? at : 0xfffffff0u, 0, 0));
+            q[t] = __builtin_bit_cast(u32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, on ? at : 0x80000000u, 0, 0));   // an offset beyond any descriptor: no load
 #endif
             if (__ballot(on && at < nrec && at + 16u > nrec)) {
                 if (on && at < nrec && at + 16u > nrec) q[t] = load16u(seq4, s0 + at, lim);
