@@ -768,40 +768,70 @@ __device__ __forceinline__ int dec_digits(uint32_t v)
     return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) +
            (v >= 100000000u) + (v >= 1000000000u);
 }
-// decimal digits of v into p[0 .. nd), most significant first
+// Decimal digits without a division per digit (v % 10, v / 10 is a quarter-rate 32-bit multiply-high and a multiply-low
+// per digit; the formatting, not the memory traffic, is 0.8 of the kernel's 1.1-1.3 ms: ~400 vector instructions per line).  The number is cut into
+// v = hi * 10^8 + mid * 10^4 + lo with one multiply-high, and every 4-digit group becomes four ASCII bytes with 24-bit
+// multiplies (full rate): x / 100 = x * 5243 >> 19 for x < 43699, y / 10 = y * 103 >> 10 for y < 179.
+__device__ __forceinline__ uint32_t ascii4(uint32_t x)   // x < 10000 -> "dddd", thousands in byte 0
+{
+    const uint32_t h = __umul24(x, 5243u) >> 19, l = x - __umul24(h, 100u);
+    const uint32_t ht = __umul24(h, 103u) >> 10, ho = h - __umul24(ht, 10u);
+    const uint32_t lt = __umul24(l, 103u) >> 10, lo = l - __umul24(lt, 10u);
+    return (ht | ho << 8 | lt << 16 | lo << 24) + 0x30303030u;
+}
+// decimal digits of v into p[0 .. nd), most significant first (nd = dec_digits(v))
 template <typename P>
 __device__ __forceinline__ void put_dec(P p, uint32_t v, int nd)
 {
-    for (int k = nd - 1; k >= 0; --k) {
-        p[k] = (uint8_t)('0' + v % 10u);
-        v /= 10u;
+    const uint32_t hi = v / 100000000u;                                   // 0 .. 42
+    const uint32_t r = v - (__umul24(hi, 390625u) << 8);                  // 10^8 = 390625 * 256
+    // r / 10000 for r < 10^8: (r >> 4) / 625 with a 24-bit multiply-high (13743896 = ceil(2^33 / 625); exact below 2^23)
+    const uint32_t mid = (uint32_t)(((u64)((r >> 4) & 0x7fffffu) * 13743896ull) >> 33);   // v_mul_hi_u32_u24
+    const uint32_t lo = r - __umul24(mid, 10000u);
+    // the ten characters "hhmmmmllll", the last nd of them to p[0 .. nd): character j goes to (p - skip)[j] for j >= skip
+    const uint32_t s0 = ascii4(hi), s1 = ascii4(mid), s2 = ascii4(lo);     // of s0, the last two characters
+    const uint32_t skip = 10u - (uint32_t)nd;                              // 0 .. 9 leading zeros to drop
+    P q = p - skip;
+#pragma unroll
+    for (uint32_t j = 0; j < 10; ++j) {
+        if (j >= skip) q[j] = (uint8_t)((j < 2 ? s0 : j < 6 ? s1 : s2) >> (8 * ((j + 2) & 3)));
     }
 }
-__device__ __forceinline__ int line_len(const hpn_run &r, int name_len)
+// (runs travel as three scalars: an array of hpn_run structs indexed in unrolled loops was kept in scratch memory)
+// length of the line in bits 0..15, the digit counts of its three numbers in bits 16..19, 20..23, 24..27 (counted once)
+__device__ __forceinline__ uint32_t line_info(int32_t start, int32_t end, int32_t depth, int name_len)
 {
-    const int neg = (r.start < 0) + (r.end < 0) + (r.depth < 0);   // never, for runs the scan emits; kept printf-exact
-    return name_len + 4 + neg + dec_digits((uint32_t)abs(r.start)) + dec_digits((uint32_t)abs(r.end)) + dec_digits((uint32_t)abs(r.depth));
+    const int neg = (start < 0) + (end < 0) + (depth < 0);   // never, for runs the scan emits; kept printf-exact
+    const int n1 = dec_digits((uint32_t)abs(start)), n2 = dec_digits((uint32_t)abs(end)), n3 = dec_digits((uint32_t)abs(depth));
+    return (uint32_t)(name_len + 4 + neg + n1 + n2 + n3) | (uint32_t)n1 << 16 | (uint32_t)n2 << 20 | (uint32_t)n3 << 24;
 }
 template <typename P>
-__device__ __forceinline__ void put_line(P p, const hpn_run &r, const uint8_t *name, int name_len)
+__device__ __forceinline__ int put_field(P p, int at, int32_t f, int nd)
 {
-    for (int k = 0; k < name_len; ++k) p[k] = name[k];
-    int at = name_len;
-    const int32_t f[3] = {r.start, r.end, r.depth};
+    p[at++] = '\t';
+    if (f < 0) p[at++] = '-';
+    put_dec(p + at, (uint32_t)abs(f), nd);
+    return at + nd;
+}
+// The target's name: its first eight characters from two SGPRs (chr1 .. chr22, chrX, chrM: the whole name), the rest from
+// `name` (LDS in the staged path).  Read from the kernel argument character by character, the name was a memory round
+// trip per character and line -- most of the kernel's time.
+template <typename P>
+__device__ __forceinline__ void put_line(P p, int32_t start, int32_t end, int32_t depth, uint32_t info, uint32_t n0, uint32_t n1, const uint8_t *name,
+                                         int name_len)
+{
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        p[at++] = '\t';
-        if (f[k] < 0) p[at++] = '-';
-        const uint32_t v = (uint32_t)abs(f[k]);
-        const int nd = dec_digits(v);
-        put_dec(p + at, v, nd);
-        at += nd;
-    }
+    for (int k = 0; k < 8; ++k)
+        if (k < name_len) p[k] = (uint8_t)((k < 4 ? n0 : n1) >> (8 * (k & 3)));   // (name_len is uniform: a scalar branch)
+    for (int k = 8; k < name_len; ++k) p[k] = name[k];
+    int at = put_field(p, name_len, start, (int)(info >> 16) & 15);
+    at = put_field(p, at, end, (int)(info >> 20) & 15);
+    at = put_field(p, at, depth, (int)(info >> 24) & 15);
     p[at] = '\n';
 }
 
 struct FmtName {
-    uint8_t c[64];
+    uint32_t w[16];       // 64 characters
 };
 
 __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__restrict__ runs, uint64_t n_runs, FmtName name, int name_len,
@@ -813,13 +843,17 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
     __shared__ u64 s_w[kFmtSubs][kFmtThreads / kWave];
     __shared__ u64 s_x;
     __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_name[16];
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    if (tid < 16) s_name[tid] = name.w[tid];
     __syncthreads();
     const uint64_t tile = s_tile;
-    const uint8_t *nm = name_len <= 64 ? name.c : long_name;
+    const uint32_t n0 = name.w[0], n1 = name.w[1];
+    const uint8_t *nm = name_len <= 64 ? reinterpret_cast<const uint8_t *>(s_name) : long_name;
     // sizes of all the tile's lines first (piece by piece: lane l holds lines 2l, 2l+1 of every piece)
-    hpn_run r[kFmtSubs][kFmtPer];
+    typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+    int32_t rs[kFmtSubs][kFmtPer], re[kFmtSubs][kFmtPer], rd[kFmtSubs][kFmtPer];
     uint32_t len[kFmtSubs][kFmtPer], wex[kFmtSubs];
 #pragma unroll
     for (int sb = 0; sb < kFmtSubs; ++sb) {
@@ -827,12 +861,13 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
         uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < kFmtPer; ++k) {
-            len[sb][k] = 0;
+            len[sb][k] = 0, rs[sb][k] = 0, re[sb][k] = 0, rd[sb][k] = 0;
             if (r0 + k < n_runs) {
-                r[sb][k] = runs[r0 + k];
-                len[sb][k] = (uint32_t)line_len(r[sb][k], name_len);
+                const i32x3 v = *reinterpret_cast<const i32x3 *>(&runs[r0 + k]);
+                rs[sb][k] = v[0], re[sb][k] = v[1], rd[sb][k] = v[2];
+                len[sb][k] = line_info(v[0], v[1], v[2], name_len);
             }
-            mine += len[sb][k];
+            mine += (len[sb][k] & 0xffffu);
         }
         u64 wtot;
         wex[sb] = (uint32_t)wave_excl_scan((u64)mine, wtot);
@@ -862,8 +897,8 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
         if (name_len <= kFmtMaxName) {                        // staged: build in LDS, copy out in 16-byte pieces
 #pragma unroll
             for (int k = 0; k < kFmtPer; ++k) {
-                if (len[sb][k]) put_line(s_text + at, r[sb][k], nm, name_len);
-                at += len[sb][k];
+                if (len[sb][k]) put_line(s_text + at, rs[sb][k], re[sb][k], rd[sb][k], len[sb][k], n0, n1, nm, name_len);
+                at += (len[sb][k] & 0xffffu);
             }
             __syncthreads();
             const uint32_t nbytes = (uint32_t)piece;
@@ -880,8 +915,8 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
         } else {                                              // a very long target name: straight to memory
 #pragma unroll
             for (int k = 0; k < kFmtPer; ++k) {
-                if (len[sb][k]) put_line(out + piece_base + at, r[sb][k], nm, name_len);
-                at += len[sb][k];
+                if (len[sb][k]) put_line(out + piece_base + at, rs[sb][k], re[sb][k], rd[sb][k], len[sb][k], n0, n1, nm, name_len);
+                at += (len[sb][k] & 0xffffu);
             }
         }
         piece_base += piece;
@@ -979,7 +1014,7 @@ hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char
     if (e != hipSuccess || n_runs == 0) return e;
     FmtName nm;
     memset(&nm, 0, sizeof nm);
-    if (name_len <= 64) memcpy(nm.c, name, (size_t)name_len);
+    memcpy(nm.w, name, (size_t)(name_len < 64 ? name_len : 64));   // (a longer name: its head here, all of it in d_long_name)
     uint32_t *ticket = (uint32_t *)ws;
     hipLaunchKernelGGL(k_bedgraph_text, dim3((unsigned)((n_runs + kFmtTile - 1) / kFmtTile)), dim3(kFmtThreads), 0, st, runs, n_runs, nm,
                        name_len, d_long_name, out, (u64 *)ws + 2, (u64 *)ws + 1, ticket, ticket + 1);

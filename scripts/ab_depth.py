@@ -57,11 +57,16 @@ if True:
         t4 = ctx.last_kernel_ms(2)
         if r:
             ts3.append(t3), ts4.append(t4)
+    tsf = []
+    for r in range(reps + 1):
+        text_bytes = ctx.depth_bedgraph_format("chr1")
+        if r:
+            tsf.append(ctx.last_kernel_ms(2))
     off = np.array([0, TL // 20000 + 1], np.uint64)
     ts5 = []
     for r in range(reps + 1):
         bins, gc, ln, touched, nc = ctx.window_counts(d, off, 20000, dev=True)
         if r:
             ts5.append(ctx.last_kernel_ms(3))
-    print("%-28s K3 %.3f ms   K4 %.3f ms   K5 %.3f ms   (runs %d, gc %d)" % (os.environ.get("HPN_LIB", "default"), statistics.median(ts3),
-                                                        statistics.median(ts4), statistics.median(ts5), len(runs), int(gc.sum())), flush=True)
+    print("%-28s K3 %.3f ms   K4 %.3f ms   text %.3f ms   K5 %.3f ms   (runs %d, gc %d)" % (os.environ.get("HPN_LIB", "default"), statistics.median(ts3),
+                                                        statistics.median(ts4), statistics.median(tsf), statistics.median(ts5), len(runs), int(gc.sum())), flush=True)
