@@ -36,6 +36,8 @@
 // and one-length turns of 16384 records.  Timing-only builds of this form: without the LDS
 // atomics 6.2 ms, without the loads 4.9 ms, without both 3.0 ms: what bounds it is the memory
 // side at ~5 TB/s (K1 streams 6.9), not the atomics.  No MFMA: there is no contraction here.
+#include <stdlib.h>
+
 #include "tally_util.hpp"
 
 namespace hpn {
@@ -441,6 +443,10 @@ hipError_t launch_tally_hist(const uint8_t *d_qual, const uint8_t *d_base, const
     // make the last round of turns a large part of the whole
     uint32_t big = HPN_HIST_BIG;
     while (big > 1 && nchunk < (uint64_t)8 * big * grid) big >>= 1;
+    if (const char *e = getenv("HPN_K1L_BIG")) {   // tests: turns of several chunks on batches that would not get them
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) big = (uint32_t)v;
+    }
     if (qual_hist && nuc_hist)
         hipLaunchKernelGGL((k_tally_hist<true, true>), dim3(grid), dim3(kHistThreads), 0, st, d_qual, d_base, d_off, n, d_acc, big);
     else if (qual_hist)

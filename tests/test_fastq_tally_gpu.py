@@ -72,6 +72,23 @@ def test_synthetic_batches(ctx, n, lo, hi):
     _check(ctx, qual, off, seq)
 
 
+@pytest.mark.parametrize("big", ["2", "4", "7"])
+def test_turns_of_several_chunks(ctx, big, monkeypatch):
+    """K1L takes `big` chunks of 4096 records per workgroup turn when the batch is large; a turn whose records all have one
+    length is streamed as one chunk, any other turn chunk by chunk.  Forced here on small batches: one-length turns, a turn
+    with a single odd record in its last chunk, a ragged turn between one-length turns, a batch that ends inside a turn with
+    a partial last group (length 150 = 18 x 8 + 6: the batch's last item cannot be loaded whole), lengths off every alignment."""
+    monkeypatch.setenv("HPN_K1L_BIG", big)
+    for L, n_tail in ((150, 4096 * 3 + 17), (151, 5000), (64, 4096), (255, 777)):
+        parts = [orc.synth_soa(11 + L, 0, 4096 * 8, L, L), orc.synth_soa(12 + L, 0, 1, L + 1, L + 1), orc.synth_soa(13 + L, 0, 4096 * 5 - 1, L, L),
+                 orc.synth_soa(14 + L, 0, 3000, 20, 300), orc.synth_soa(15 + L, 0, n_tail, L, L)]
+        seq = np.concatenate([p[0] for p in parts])
+        qual = np.concatenate([p[1] for p in parts])
+        lens = np.concatenate([np.diff(p[2].astype(np.int64)) for p in parts])
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        _check(ctx, qual, off, seq)
+
+
 def test_empty_batch(ctx):
     got = ctx.fastq_tally(np.zeros(0, np.uint8), np.zeros(1, np.uint64), qual_hist=True)
     assert got.total == 0 and got.seqlen.sum() == 0 and got.qual_hist.sum() == 0
