@@ -80,6 +80,7 @@ SYMBOLS = [
     ("hpn_ctx_last_error", C.c_char_p, [_vp]),
     ("hpn_ctx_last_kernel_ms", _int, [_vp, _int, C.POINTER(C.c_float)]),
     ("hpn_dev_malloc", _int, [_vp, _sz, C.POINTER(_vp)]),
+    ("hpn_dev_mem_info", _int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("hpn_dev_free", _int, [_vp, _vp]),
     ("hpn_host_malloc", _int, [_vp, _sz, C.POINTER(_vp)]),
     ("hpn_host_free", _int, [_vp, _vp]),

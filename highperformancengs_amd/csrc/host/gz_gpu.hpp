@@ -88,6 +88,15 @@ public:
         if (stretch_bytes < 4096) stretch_bytes = 4096;
         stretch_ = stretch_bytes;
         sym_cap_ = cap_for(ratio_ * 1.4);
+        {   // what a device call holds, at its largest (symbol scratch grown once, compressed bytes, text): within half of the
+            // memory that is free now -- other processes may share the device
+            uint64_t free_b = 0, total_b = 0;
+            if (hpn_dev_mem_info(ctx_, &free_b, &total_b) == HPN_OK && free_b) {
+                const double per_stretch = 2.0 * cap_for(ratio_ * 3.0) + (double)stretch_ * (1.0 + ratio_ * 1.25 * 1.125);
+                const uint64_t fit = (uint64_t)((double)(free_b / 2) / per_stretch);
+                if (fit < max_stretches_) max_stretches_ = fit < 64 ? 64u : (uint32_t)fit;
+            }
+        }
         first_bit_ = (uint64_t)(body - data_) * 8;
         next_start_ = first_bit_;
         // the compressed bytes reach the device through pinned chunks read in parallel (the page cache is not pinned)

@@ -146,6 +146,16 @@ int hpn_dev_malloc(hpn_ctx *c, size_t bytes, void **dptr)
     return HPN_OK;
 }
 
+int hpn_dev_mem_info(hpn_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    if (!c || !free_bytes || !total_bytes) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HPN_HIP(c, hipMemGetInfo(&f, &t));
+    *free_bytes = f, *total_bytes = t;
+    return HPN_OK;
+}
+
 int hpn_dev_free(hpn_ctx *c, void *dptr)
 {
     if (!c) return HPN_E_ARG;

@@ -73,6 +73,7 @@ int hpn_host_malloc(hpn_ctx *ctx, size_t bytes, void **hptr); /* pinned */
 int hpn_host_free(hpn_ctx *ctx, void *hptr);
 int hpn_memcpy_h2d(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream */
 int hpn_memcpy_d2h(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream */
+int hpn_dev_mem_info(hpn_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes); /* of the context's device, now */
 
 /* ---- fastq_count: replaces count_read's scan loop ------------------------------
  * fastq_count.c:112-119 / fastq_count_kthread.c:126-135 (+ AssignQuality :29-35).
