@@ -27,7 +27,9 @@
 //                   breakpoints: the per-record atomic scatter of round 1.
 // K4.  ONE pass over diff: prefix sum = coverage (never materialised), change points -> runs (start, end,
 // depth) of depth > 0 written in order, per-window sums of coverage.  ONE decoupled look-back chain
-// carries (coverage, runs started): see DepthSum.
+// carries (coverage, runs started): see DepthSum.  A 512-thread workgroup takes four sub-tiles of 8192 positions
+// behind one chain entry; a sub-tile's runs are staged in LDS as they lie in memory and flushed as whole 16-byte
+// pieces; wave scans are DPP moves.
 // Bounds: HBM.  K3 reads 16 B + 4 B x n_cigar per record (x 1.125 for the reach overlap) and writes 4 B per
 // position of the tiles it touches; K4 reads 4 B per written position and writes 12 B per run + 8 B per window.
 #include <stdlib.h>
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     }
     // The chain.  Per-tile stamps (profiles/r02/k3_k4_sweeps.txt): a tile finds a full prefix within one hop (1.03 hops,
     // 1.26 polls on average) -- it does not wait for its predecessors -- but that one round trip of agent-scope loads
-    // takes 3.3 us under streaming load, and with one 1024-thread workgroup per CU nothing overlaps it.  Wider hops
+    // takes 3.3 us under streaming load (two 512-thread workgroups per CU overlap each other's).  Wider hops
     // (more tiles per lane, several polling waves), more workgroups per CU and larger tiles were all measured slower.
     DepthSum exclusive = ds_identity();               // of tiles 0 .. tile-1; the same in every thread
 #ifdef DIAG_NOCHAIN
