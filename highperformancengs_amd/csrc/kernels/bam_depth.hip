@@ -109,35 +109,50 @@ struct TileIndex {
     uint32_t ntiles;
 };
 
+#ifndef HPN_IDX_UNROLL
+#define HPN_IDX_UNROLL 2
+#endif
 constexpr int kIdxThreads = 256;
+
+constexpr int kIdxUnroll = HPN_IDX_UNROLL;   // records per thread whose keys are loaded side by side (one at a time: a dependent round trip each)
 
 template <typename Recs>
 __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t n, int32_t want, TileIndex ix)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * kIdxThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kIdxThreads) {
-        int32_t t, tp = 0, tn = 0;
-        uint32_t p, pp = 0, pn = 0;
-        recs.key(i, t, p);
-        if (i) {
-            recs.key(i - 1, tp, pp);
-            // sort order of a BAM: refID as unsigned (unmapped, -1, last), then pos
-            const u64 ka = ((u64)(uint32_t)tp << 32) | pp, kb = ((u64)(uint32_t)t << 32) | p;
-            if (ka > kb) atomicOr(&ix.head[kHdFlags], kUnsorted);
+    const uint64_t stride = (uint64_t)gridDim.x * kIdxThreads;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * kIdxThreads + threadIdx.x; i0 < n; i0 += stride * kIdxUnroll) {
+        int32_t t[kIdxUnroll], tp[kIdxUnroll], tn[kIdxUnroll];
+        uint32_t p[kIdxUnroll], pp[kIdxUnroll], pn[kIdxUnroll];
+#pragma unroll
+        for (int u = 0; u < kIdxUnroll; ++u) {
+            const uint64_t i = i0 + u * stride;
+            t[u] = tp[u] = tn[u] = 0, p[u] = pp[u] = pn[u] = 0;
+            if (i < n) {
+                recs.key(i, t[u], p[u]);
+                if (i) recs.key(i - 1, tp[u], pp[u]);
+                if (i + 1 < n) recs.key(i + 1, tn[u], pn[u]);
+            }
         }
-        if (t != want) continue;
-        const bool first = i == 0 || tp != want;
-        bool last = i + 1 == n;
-        if (!last) {
-            recs.key(i + 1, tn, pn);
-            last = tn != want;
-        }
-        if (first) ix.head[kHdR0] = (uint32_t)i, ix.head[kHdPmin] = p;
-        if (last) ix.head[kHdR1] = (uint32_t)i + 1u, ix.head[kHdPmax] = p;
-        if (!first && pp < p) {
-            // thresholds in (pp, p]: this is the first record at or beyond them
-            for (u64 k = (u64)pp / kTile + 1; k <= (u64)p / kTile && k <= ix.ntiles; ++k) ix.first_hi[k] = (uint32_t)i;
-            for (u64 k = ((u64)pp + kReach) / kTile + 1; k <= ((u64)p + kReach) / kTile && k <= ix.ntiles; ++k)
-                ix.first_lo[k] = (uint32_t)i;
+#pragma unroll
+        for (int u = 0; u < kIdxUnroll; ++u) {
+            const uint64_t i = i0 + u * stride;
+            if (i >= n) break;
+            if (i) {
+                // sort order of a BAM: refID as unsigned (unmapped, -1, last), then pos
+                const u64 ka = ((u64)(uint32_t)tp[u] << 32) | pp[u], kb = ((u64)(uint32_t)t[u] << 32) | p[u];
+                if (ka > kb) atomicOr(&ix.head[kHdFlags], kUnsorted);
+            }
+            if (t[u] != want) continue;
+            const bool first = i == 0 || tp[u] != want;
+            const bool last = i + 1 == n || tn[u] != want;
+            if (first) ix.head[kHdR0] = (uint32_t)i, ix.head[kHdPmin] = p[u];
+            if (last) ix.head[kHdR1] = (uint32_t)i + 1u, ix.head[kHdPmax] = p[u];
+            if (!first && pp[u] < p[u]) {
+                // thresholds in (pp, p]: this is the first record at or beyond them
+                for (u64 k = (u64)pp[u] / kTile + 1; k <= (u64)p[u] / kTile && k <= ix.ntiles; ++k) ix.first_hi[k] = (uint32_t)i;
+                for (u64 k = ((u64)pp[u] + kReach) / kTile + 1; k <= ((u64)p[u] + kReach) / kTile && k <= ix.ntiles; ++k)
+                    ix.first_lo[k] = (uint32_t)i;
+            }
         }
     }
 }
