@@ -7,7 +7,7 @@
 //
 // One 1024-thread workgroup per CU owns a histogram image in LDS: 32-bit counters,
 // 128 symbol rows x cycles 0..255, 256 dwords per row.  With group g = cycle >> 2:
-//     word(row, cycle) = row*256 + (cycle & 3)*64 + (g & 1)*32 + (g >> 1)        (lds_word())
+//     word(row, cycle) = row*256 + k*64 + (g & 1)*32 + ((g >> 1) + 8k) % 32,  k = cycle & 3        (lds_word())
 // Cycles 256..511 (reads longer than 256 bases) go to the global matrix directly.
 // The image is flushed once, at the end of the kernel (a 32-bit counter cannot wrap
 // within one launch); sum / Q20 / Q30 are row sums taken during that flush.
@@ -95,8 +95,8 @@ struct HistLds {
 // cycles 8j..8j+7 of a read adds byte 4e + k at word row*256 + k*64 + 32e + j.
 __device__ __forceinline__ uint32_t lds_word(uint32_t row, uint32_t pos)
 {
-    const uint32_t g = pos >> 2;
-    return row * kRowWords + ((pos & 3u) << 6) + ((g & 1u) << 5) + (g >> 1);
+    const uint32_t g = pos >> 2, k = pos & 3u;
+    return row * kRowWords + (k << 6) + ((g & 1u) << 5) + (((g >> 1) + 8u * k) & 31u);
 }
 
 struct HiTot {  // quality bytes tallied at cycles >= 256 (they bypass the LDS image and its row sums)
@@ -138,8 +138,9 @@ __device__ __forceinline__ uint32_t load_unaligned4(const uint8_t *p)
 // constant, and the only per-item arithmetic left is one add and one compare (PMC, round 2: the item-index
 // arithmetic of lanes that changed (r, j) every item was 5 of the kernel's 7.4 VALU operations per byte,
 // and VALU issue, not the LDS, was what the kernel waited for).
-// kPartial: len0 % 8 != 0 (the chunk's reads end in a partial group); kSpanRound: 8-byte items per set
-template <bool kQual, bool kPartial, int kSpanRound>
+// kPartial: len0 % 8 != 0 (the chunk's reads end in a partial group); kRot: short reads (fewer than 16 groups): the order in
+// which a lane takes the four bytes of a dword is rotated by its read (see below); kSpanRound: 8-byte items per set
+template <bool kQual, bool kPartial, bool kRot, int kSpanRound>
 __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint64_t arr_end, uint32_t cnt,
                                                uint32_t len0, uint32_t &bad)
 {
@@ -162,12 +163,19 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
     // byte b = 4e + k of every item of this lane goes to word row*256 + k*64 + 32e + j (col_of()): the lanes of a read hit
     // ngr different banks in every one of the eight adds, and the three or four reads under a wave stay within the four
     // lanes per bank that cost nothing (scripts/micro/lds_atomic.hip)
-    uint32_t col[8], bmask[8];                            // bmask: the byte's 7 (8) bits, or 0 for a byte behind the read
+    // With fewer than 16 groups per read more than four reads lie under a wave, and their lanes of one group would meet on one
+    // bank in every add (5 lanes per bank at 100 bp).  The column of byte k is shifted by 8k banks, and a lane takes the bytes
+    // of a dword in the order k = (t + rot) % 4, t = 0..3, with rot = its read's number % 4: the reads of a wave then work on
+    // four different windows of banks at a time.  (One more VALU instruction per byte: the shift is no longer a constant.)
+    const uint32_t rot = kRot ? (lr & 3u) : 0u;
+    uint32_t col[8], bmask[8], shift[8];                  // slot b8 = 4e + t; bmask: the byte's 7 (8) bits, or 0 for a byte behind the read
 #pragma unroll
     for (int b8 = 0; b8 < 8; ++b8) {
-        const bool mine = !kPartial || (uint32_t)b8 < nvalid;
+        const uint32_t e = b8 >> 2, k = ((uint32_t)(b8 & 3) + rot) & 3u;
+        const bool mine = !kPartial || 4u * e + k < nvalid;
+        shift[b8] = 8u * k;
         bmask[b8] = mine ? (kQual ? 0x7fu : 0xffu) : 0u;
-        col[b8] = mine ? 64u * (b8 & 3) + 32u * (b8 >> 2) + j : (kQual ? kJunkQ : kJunkN) + (threadIdx.x & 63u);
+        col[b8] = mine ? 64u * k + 32u * e + ((j + 8u * k) & 31u) : (kQual ? kJunkQ : kJunkN) + (threadIdx.x & 63u);
     }
     // The loads go through a buffer descriptor of the chunk: address = descriptor base + lane offset (VGPR) + m * step
     // (SGPR), so a set of kSpanRound loads costs ONE vector add (the 64-bit address arithmetic, the per-item compare and
@@ -216,7 +224,7 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
 #pragma unroll
         for (int b8 = 0; b8 < 8; ++b8) {
             // bytes behind a partial group go to this lane's junk word behind the image (row 0): no branch per byte
-            const uint32_t byte = (d[b8 >> 2] >> (8 * (b8 & 3))) & bmask[b8];
+            const uint32_t byte = (kRot ? d[b8 >> 2] >> shift[b8] : d[b8 >> 2] >> (8 * (b8 & 3))) & bmask[b8];
             const uint32_t row = kQual ? byte : (uint32_t)s.nlut[byte];
 #ifdef DIAG_NOATOM
             sink += row * kRowWords + col[b8];
@@ -258,11 +266,24 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
             const uint32_t byte = p0[last_off + b8];
             if (kQual) seen |= byte;
             const uint32_t row = kQual ? (byte & 0x7fu) : (uint32_t)s.nlut[byte];
-            atomicAdd(&hist[row * kRowWords + 64u * (b8 & 3u) + 32u * (b8 >> 2) + j], 1u);
+            atomicAdd(&hist[row * kRowWords + 64u * (b8 & 3u) + 32u * (b8 >> 2) + ((j + 8u * (b8 & 3u)) & 31u)], 1u);
         }
     }
     if (seen & 0x80808080u) bad = 1;
     if (sink == 0x12345u) bad = 1;
+}
+
+template <bool kQual, int kSp>
+__device__ __forceinline__ void tally_uniform(HistLds &s, const uint8_t *arr, uint64_t base_off, uint64_t arr_end, uint32_t cnt, uint32_t len0,
+                                              uint32_t &bad)
+{
+    if (len0 <= 120u) {   // fewer than 16 groups of 8 cycles
+        (len0 & 7u) ? stream_uniform<kQual, true, true, kSp>(s, arr, base_off, arr_end, cnt, len0, bad)
+                    : stream_uniform<kQual, false, true, kSp>(s, arr, base_off, arr_end, cnt, len0, bad);
+    } else {
+        (len0 & 7u) ? stream_uniform<kQual, true, false, kSp>(s, arr, base_off, arr_end, cnt, len0, bad)
+                    : stream_uniform<kQual, false, false, kSp>(s, arr, base_off, arr_end, cnt, len0, bad);
+    }
 }
 
 // Any chunk: aligned vectors of the byte range, each located by binary search.
@@ -314,7 +335,8 @@ __device__ __forceinline__ void hist_flush(const uint32_t *lds, int rows, u64 *_
         const uint32_t v = lds[w];
         if (v) {
             const int r = w / kRowWords, c = w - r * kRowWords;  // c = (cycle & 3) * 64 + (group & 1) * 32 + (group >> 1), group = cycle >> 2
-            atomicAdd(&gacc[r * HPN_LEN_BINS + 4 * (2 * (c & 31) + ((c >> 5) & 1)) + (c >> 6)], (u64)v);
+            const int k = c >> 6, jj = ((c & 31) - 8 * k) & 31;   // c = k*64 + (group & 1)*32 + ((group >> 1) + 8k) % 32, cycle = 4*group + k
+            atomicAdd(&gacc[r * HPN_LEN_BINS + 4 * (2 * jj + ((c >> 5) & 1)) + k], (u64)v);
             tot += v;
             if (r >= 53) t20 += v;
             if (r >= 63) t30 += v;
@@ -358,8 +380,8 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
         if (__syncthreads_and((int)one_len)) {
             const uint32_t len0 = (uint32_t)qlen0;
             if (tid == 0) atomicAdd(&s.lhist[len0], qcnt);
-            if (kQualHist) (len0 & 7u) ? stream_uniform<true, true, kSp>(s, qual, q_off, arr_end, qcnt, len0, bad) : stream_uniform<true, false, kSp>(s, qual, q_off, arr_end, qcnt, len0, bad);
-            if (kNucHist) (len0 & 7u) ? stream_uniform<false, true, kSp>(s, base, q_off, arr_end, qcnt, len0, bad) : stream_uniform<false, false, kSp>(s, base, q_off, arr_end, qcnt, len0, bad);
+            if (kQualHist) tally_uniform<true, kSp>(s, qual, q_off, arr_end, qcnt, len0, bad);
+            if (kNucHist) tally_uniform<false, kSp>(s, base, q_off, arr_end, qcnt, len0, bad);
             continue;
         }
         for (uint64_t r0 = q0; r0 < q0 + qcnt; r0 += kHistRecs) {
@@ -388,8 +410,8 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
             if (!__syncthreads_or((int)bad)) {
                 const bool uniform = __syncthreads_and((int)all_same) && len0 >= 16 && len0 <= (uint32_t)kLdsCycles;
                 if (uniform) {
-                    if (kQualHist) (len0 & 7u) ? stream_uniform<true, true, kSp>(s, qual, base_off, arr_end, cnt, len0, bad) : stream_uniform<true, false, kSp>(s, qual, base_off, arr_end, cnt, len0, bad);
-                    if (kNucHist) (len0 & 7u) ? stream_uniform<false, true, kSp>(s, base, base_off, arr_end, cnt, len0, bad) : stream_uniform<false, false, kSp>(s, base, base_off, arr_end, cnt, len0, bad);
+                    if (kQualHist) tally_uniform<true, kSp>(s, qual, base_off, arr_end, cnt, len0, bad);
+                    if (kNucHist) tally_uniform<false, kSp>(s, base, base_off, arr_end, cnt, len0, bad);
                 } else {
                     if (kQualHist) stream_ragged<true>(s, gq, qual, base_off, cnt, bad, hi);
                     if (kNucHist) stream_ragged<false>(s, gn, base, base_off, cnt, bad, hi);
