@@ -15,11 +15,13 @@
 //   records of one length, 16 <= len <= 256 (the normal case; up to 4 x 4096 records per workgroup turn):
 //     work item = (read r, group j) = cycles 8j..8j+7 OF THE READ, one unaligned 8-byte buffer load
 //     (descriptor of the chunk + lane offset + m * step in an SGPR: no address arithmetic per load).
-//     Byte 4e + k of the item goes to word row*256 + k*64 + 32e + j, so in each of the eight adds
-//     the lanes of a read hit different banks whatever the symbols are, and the reads under one wave
-//     stay within the four lanes per bank that an LDS atomic handles at no extra cost
+//     Byte 4e + k of the item goes to word row*256 + k*64 + 32e + (j + 8k) % 32, so in each of the
+//     eight adds the lanes of a read hit different banks whatever the symbols are, and the reads under
+//     one wave stay within the four lanes per bank that an LDS atomic handles at no extra cost
 //     (scripts/micro/lds_atomic.hip: 4.3 clocks per wave ds_add_u32 = 16 lanes per clock per CU,
-//     free up to 4 lanes per bank, +2 clocks per extra lane on one ADDRESS).
+//     free up to 4 lanes per bank, +2 clocks per extra lane on one ADDRESS).  Reads shorter than 121
+//     bases (more than four under a wave) take the bytes of a dword in an order rotated by the read's
+//     number: with the 8k shift the wave's reads then work on four different windows of banks.
 //     2 VALU + 1 LDS per byte, no per-byte compare: bit 7 of every byte is OR-ed into one
 //     flag and the row index is masked.  A lane keeps its group j for the whole chunk; two sets of
 //     eight items: one in flight while the other is tallied.
