@@ -800,13 +800,22 @@ __device__ __forceinline__ uint32_t ascii4(uint32_t x)   // x < 10000 -> "dddd",
 template <typename P>
 __device__ __forceinline__ void put_dec(P p, uint32_t v, int nd)
 {
+    if (__ballot(v >= 10000u) == 0) {                                     // (depths: one group of four digits for the whole wave)
+        const uint32_t s2 = ascii4(v), skip = 4u - (uint32_t)nd;
+        P q = p - skip;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            if (j >= skip) q[j] = (uint8_t)(s2 >> (8 * j));
+        return;
+    }
     const uint32_t hi = v / 100000000u;                                   // 0 .. 42
     const uint32_t r = v - (__umul24(hi, 390625u) << 8);                  // 10^8 = 390625 * 256
     // r / 10000 for r < 10^8: (r >> 4) / 625 with a 24-bit multiply-high (13743896 = ceil(2^33 / 625); exact below 2^23)
     const uint32_t mid = (uint32_t)(((u64)((r >> 4) & 0x7fffffu) * 13743896ull) >> 33);   // v_mul_hi_u32_u24
     const uint32_t lo = r - __umul24(mid, 10000u);
     // the ten characters "hhmmmmllll", the last nd of them to p[0 .. nd): character j goes to (p - skip)[j] for j >= skip
-    const uint32_t s0 = ascii4(hi), s1 = ascii4(mid), s2 = ascii4(lo);     // of s0, the last two characters
+    const uint32_t ht = __umul24(hi, 103u) >> 10;                           // hi < 43: two digits
+    const uint32_t s0 = ((ht | (hi - __umul24(ht, 10u)) << 8) << 16) + 0x30300000u, s1 = ascii4(mid), s2 = ascii4(lo);   // of s0, the last two characters
     const uint32_t skip = 10u - (uint32_t)nd;                              // 0 .. 9 leading zeros to drop
     P q = p - skip;
 #pragma unroll
