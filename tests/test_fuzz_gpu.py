@@ -1,5 +1,7 @@
 """GPU: randomized shapes against the oracle -- ragged lengths, odd batch windows, mixed CIGARs.
-Deterministic seeds; every comparison is bit-exact."""
+Deterministic seeds; every comparison is bit-exact.  HPN_FUZZ_X=k runs k times as many seeds (a one-off campaign)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,7 @@ import orc
 from bam_synth import make_soa
 
 pytestmark = pytest.mark.gpu
+_X = max(1, int(os.environ.get("HPN_FUZZ_X", "1")))
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +40,7 @@ def _ragged(rng, n, mode):
     return base, qual, off
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _X))
 def test_tally_fuzz(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(1, 30000))
@@ -60,7 +63,7 @@ def test_tally_fuzz(ctx, seed):
     assert int(full.nuc_hist[1].sum() + full.nuc_hist[3].sum()) == int(np.isin(seg, np.frombuffer(b"CcGg", np.uint8)).sum())
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * _X))
 def test_trim_fuzz(ctx, seed):
     rng = np.random.default_rng(2000 + seed)
     n = int(rng.integers(1, 20000))
@@ -72,7 +75,7 @@ def test_trim_fuzz(ctx, seed):
     assert np.array_equal(goff, woff) and np.array_equal(gseq, wseq) and np.array_equal(gqual, wqual)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * _X))
 def test_depth_window_fuzz(ctx, seed):
     rng = np.random.default_rng(3000 + seed)
     refs = [("a", int(rng.integers(1000, 3_000_000))), ("b", int(rng.integers(300, 200_000))), ("c", 17)]
