@@ -257,6 +257,18 @@ def test_window_synthetic(ctx, n, seed, W, sort):
     _window_check(ctx, soa, W)
 
 
+@pytest.mark.parametrize("cigar", ["150M", "151M", "36M", "75M", "250M", "300M", "16M", "1M", "31M", "33M"])
+@pytest.mark.parametrize("sort", [True, False])
+def test_window_reads_of_one_length(ctx, cigar, sort):
+    """Every read of the batch has the same length: the kernel's lanes then share the records of a step by pieces (P lanes
+    per record) and the next pass's pieces are loaded into LDS while this one is counted -- GC sums against the oracle for
+    piece counts 1 .. 8 and beyond (300 bases: the generic path), odd lengths (padding nibble), whole spans of 1024 records
+    and a ragged last one."""
+    refs = [("chrA", 2_000_000), ("chrB", 700_000)]
+    soa = make_soa(20_011, refs, 17, sort=sort, cigars=[cigar])
+    _window_check(ctx, soa, 1000)
+
+
 def test_window_index_wraps_like_unsigned_short(ctx):
     # target_len / W + 1 > 65536: (unsigned short)(pos / W) wraps (bam_sliding_count.c:117)
     refs = [("long", 10_000_000)]
