@@ -169,6 +169,16 @@ def kernel_legs(ctx, reps=5):
             ts5.append(ctx.last_kernel_ms(3))
     counted = int(((fl & 4) == 0).sum().item())
     assert int(bins.sum()) == nc == counted and int(ln.sum()) == counted * L
+    # GC of the counted records, nibble by nibble (codes 2 = C and 4 = G), by torch on the same resident bytes
+    want_gc, nb = 0, (L + 1) // 2
+    for a in range(0, n, 10_000_000):
+        b = min(n, a + 10_000_000)
+        blk = d.seq4[a * nb:b * nb].view(b - a, nb)
+        hi, lo = blk >> 4, blk & 15
+        per = ((hi == 2) | (hi == 4)).sum(1) + ((lo == 2) | (lo == 4)).sum(1)
+        want_gc += int(per[(fl[a:b] & 4) == 0].sum().item())
+        del blk, hi, lo, per
+    assert int(gc.sum()) == want_gc, (int(gc.sum()), want_gc)
     legs.append(_leg("K5 k_window_add: per-window count / GC / length (bam_sliding_count fetch_func + cal_GC)",
                      statistics.median(ts5), n * (20 + (L + 1) // 2), records=n))
     del d, tid, pos, fl, cigar, cigar_off, m_per
