@@ -236,6 +236,17 @@ class Context:
                  "hpn_gz_inflate_dev")
         return info
 
+    def gz_members(self):
+        """hpn_gz_members: [(text_end, isize)] of the members that ended inside the last hpn_gz_inflate_dev call."""
+        n = C.c_uint32(0)
+        rc = self.L.hpn_gz_members(self.h, None, 0, C.byref(n))
+        if n.value == 0:
+            self._ck(rc, "hpn_gz_members")
+            return []
+        buf = np.zeros(n.value, np.dtype([("text_end", "<u8"), ("isize", "<u4"), ("reserved", "<u4")]))
+        self._ck(self.L.hpn_gz_members(self.h, buf.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "hpn_gz_members")
+        return [(int(r["text_end"]), int(r["isize"])) for r in buf]
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

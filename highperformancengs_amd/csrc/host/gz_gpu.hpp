@@ -108,6 +108,7 @@ public:
     const uint8_t *d_text() const { return (const uint8_t *)d_text_; }
     const char *why() const { return why_; }  // what made open() / next() give up
     double ratio() const { return ratio_; }     // text bytes per compressed byte over the member's first megabytes
+    uint64_t members() const { return n_members_; }   // gzip members met so far
     uint64_t file_bytes() const { return size_; }
     double seconds_find() const { return t_find_; }
     double seconds_upload() const { return t_upload_; }
@@ -225,16 +226,32 @@ public:
             return give_up(why_buf_) - 1;
         }
         ++batch_;
+        {   // members that ended inside this batch (cat a.gz b.gz): every one's ISIZE against the bytes it produced
+            uint32_t nm = 0;
+            int rc = hpn_gz_members(ctx_, nullptr, 0, &nm);
+            if (rc == HPN_E_CAPACITY) {
+                members_.resize(nm);
+                rc = hpn_gz_members(ctx_, members_.data(), nm, &nm);
+            }
+            if (rc != HPN_OK) return give_up("member list") - 1;
+            for (uint32_t k = 0; k < nm; ++k) {
+                const uint64_t end = total_ + members_[k].text_end;
+                if (members_[k].isize != (uint32_t)(end - member_start_)) return give_up("ISIZE mismatch in a member") - 1;
+                member_start_ = end;
+                ++n_members_;
+            }
+        }
         total_ += info.n_bytes;
         *n_bytes = info.n_bytes;
         if (last_batch) {
-            // the member must end the file: final block in the last stretch, 8-byte trailer, nothing behind, ISIZE right
+            // the last member must end the file: final block in the last stretch, 8-byte trailer, nothing behind, ISIZE right
             if (info.final_chunk != n) return give_up("the member ends before the file does") - 1;
             const uint64_t trailer = ((starts_[n - 1] & ~(uint64_t)7) + info.end_bit) >> 3;
             if (trailer + 8 != size_) return give_up("bytes behind the member") - 1;
             uint32_t isize;
             memcpy(&isize, data_ + trailer + 4, 4);
-            if (isize != (uint32_t)total_) return give_up("ISIZE mismatch") - 1;
+            if (isize != (uint32_t)(total_ - member_start_)) return give_up("ISIZE mismatch") - 1;
+            ++n_members_;
             done_ = true;
         } else {
             if (info.final_chunk) return give_up("the member ends inside the file") - 1;  // more members or garbage follow
@@ -304,6 +321,8 @@ private:
     int threads_ = 1;
     uint32_t max_stretches_ = 0, sym_cap_ = 0, batch_ = 0;
     uint64_t first_bit_ = 0, next_start_ = 0, total_ = 0;
+    uint64_t member_start_ = 0, n_members_ = 0;   // text offset where the current member began; members finished
+    std::vector<hpn_gz_member> members_;
     bool done_ = false, grown_ = false;
     double ratio_ = 4.0;
     const char *why_ = "";

@@ -159,7 +159,7 @@ inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
 
 // A single-member .fastq.gz: block starts found on the host, the stretches inflated on the device (host/gz_gpu.hpp),
 // the text framed and tallied where it lands.  *unusable as above.
-inline bool is_plain_gzip_file(const char *path)  // gzip, not BGZF, one member as far as a look at the first 64 MiB tells
+inline bool is_plain_gzip_file(const char *path)  // gzip, not BGZF
 {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return false;
@@ -168,7 +168,10 @@ inline bool is_plain_gzip_file(const char *path)  // gzip, not BGZF, one member 
     const bool gz = pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 &&
                     !((h[3] & 4) && h[12] == 'B' && h[13] == 'C') && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
     const bool force = getenv("HPN_GZ_GPU_FORCE") != nullptr;  // tests: small files too
-    const bool ok = gz && (force || sb.st_size >= (8 << 20)) && !gzip_has_second_member(fd, force);
+    // several members (cat a.gz b.gz) are decoded in one go (kernels/gz_inflate.hip); HPN_GZ_MEMBERS=0: such files go to the
+    // host's member-parallel reader as before
+    const bool members_too = !(getenv("HPN_GZ_MEMBERS") && getenv("HPN_GZ_MEMBERS")[0] == '0');
+    const bool ok = gz && (force || sb.st_size >= (8 << 20)) && (members_too || !gzip_has_second_member(fd, force));
     close(fd);
     return ok;
 }

@@ -1,5 +1,6 @@
 // hpn_ctx.hpp -- the per-GPU context behind the C ABI (include/hpngs.h).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -68,7 +69,8 @@ struct hpn_ctx {
     uint32_t t_carry = 0, t_tail = 0;  // carry bytes and where they start in slot[t_cur ^ 1]
     // records indexed in place in inflated BGZF blocks (hpn_bam_raw_*)
     hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info;
-    hpn::Scratch g_sym, g_meta, g_windows, g_summary;  // single-member gzip: symbols, per-stretch results, histories
+    hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds;  // gzip: symbols, per-stretch results, histories, member ends
+    std::vector<hpn_gz_member> gz_members;              // members that ended inside the last hpn_gz_inflate_dev call
     uint64_t r_n = 0;
     bool r_fields = false;  // the SoA view of the current index has been gathered
     // RCCL

@@ -4,11 +4,14 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "hpn_ctx.hpp"
 
 namespace hpn {
 hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, uint32_t n_chunks, uint16_t *d_sym, uint32_t sym_cap,
-                                 void *d_meta, int n_cu, hipStream_t st);
+                                 void *d_meta, void *d_bounds, uint32_t bounds_cap, int n_cu, hipStream_t st);
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
                              uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st);
 hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
@@ -40,17 +43,35 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     if ((rc = scratch_reserve(c, c->g_meta, (size_t)n_chunks * 32)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->g_windows, ((size_t)n_chunks + 1) * 32768)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->g_summary, 64)) != HPN_OK) return rc;
+    constexpr uint32_t kBounds = 65536;   // members that may end inside one call (beyond: status 23, the caller takes another route)
+    if ((rc = scratch_reserve(c, c->g_bounds, 16 + (size_t)kBounds * 16)) != HPN_OK) return rc;
+    c->gz_members.clear();
     uint16_t *sym = (uint16_t *)c->g_sym.p;
     const double t1 = now();
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamInflate], c->stream));
-    HPN_HIP(c, launch_gz_sym_inflate(d_comp, d_chunks, n_chunks, sym, sym_cap, c->g_meta.p, c->n_cu, c->stream));
+    HPN_HIP(c, launch_gz_sym_inflate(d_comp, d_chunks, n_chunks, sym, sym_cap, c->g_meta.p, c->g_bounds.p, kBounds, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamInflate], c->stream));
     c->ev_valid[kFamInflate] = true;
     HPN_HIP(c, launch_gz_windows(sym, sym_cap, c->g_meta.p, n_chunks, d_window_in, (uint8_t *)c->g_windows.p, d_window_out,
                                  (u64 *)c->g_summary.p, c->n_cu, c->stream));
     u64 summary[4] = {0, 0, 0, 0};
+    uint32_t n_bounds = 0;
     HPN_HIP(c, hipMemcpyAsync(summary, c->g_summary.p, sizeof summary, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(&n_bounds, c->g_bounds.p, 4, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_bounds && !summary[1]) {   // members that ended inside stretches: where in this call's text, and their ISIZE
+        if (n_bounds > kBounds) n_bounds = kBounds;
+        struct Meta { uint32_t n_out, status, final_block, reserved; uint64_t end_bit, text_off; };
+        struct Bound { uint32_t chunk, n_out, isize, reserved; };
+        std::vector<Meta> metas(n_chunks);
+        std::vector<Bound> bounds(n_bounds);
+        HPN_HIP(c, hipMemcpyAsync(metas.data(), c->g_meta.p, (size_t)n_chunks * 32, hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipMemcpyAsync(bounds.data(), (const uint8_t *)c->g_bounds.p + 16, (size_t)n_bounds * 16, hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+        for (const Bound &b : bounds)
+            if (b.chunk < n_chunks) c->gz_members.push_back(hpn_gz_member{metas[b.chunk].text_off + b.n_out, b.isize, 0u});
+        std::sort(c->gz_members.begin(), c->gz_members.end(), [](const hpn_gz_member &a, const hpn_gz_member &b) { return a.text_end < b.text_end; });
+    }
     const double t2 = now();
     info->n_bytes = summary[0];
     info->status = (uint32_t)summary[1], info->bad_chunk = (uint32_t)summary[2], info->final_chunk = (uint32_t)summary[3];
@@ -71,6 +92,15 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
         fprintf(stderr, "[hpn_gz] %u stretches: scratch %.3f s, inflate + histories %.3f s (inflate kernel %.1f ms), translate %.3f s, %.1f MB of text\n",
                 n_chunks, t1 - t0, t2 - t1, ms, now() - t2, info->n_bytes / 1e6);
     }
+    return HPN_OK;
+}
+
+int hpn_gz_members(hpn_ctx *c, hpn_gz_member *out, uint32_t cap, uint32_t *n)
+{
+    if (!c || !n || (cap && !out)) return HPN_E_ARG;
+    *n = (uint32_t)c->gz_members.size();
+    if (*n > cap) return HPN_E_CAPACITY;
+    if (*n) memcpy(out, c->gz_members.data(), (size_t)*n * sizeof(hpn_gz_member));
     return HPN_OK;
 }
 

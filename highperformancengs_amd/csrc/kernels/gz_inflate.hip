@@ -29,6 +29,10 @@ struct GzChunk {  // = hpn_gz_chunk
     uint32_t in_len;   // bytes that may be read from in_off on
     uint32_t start_bit;
 };
+struct GzBound {   // a member that ended inside a stretch, and went on with the next member
+    uint32_t chunk, n_out;   // symbols of the stretch that belong to members up to and including this one
+    uint32_t isize, reserved; // ISIZE of its trailer
+};
 struct GzMeta {
     uint32_t n_out, status, final_block, reserved;
     uint64_t end_bit;   // bit position reached (byte-aligned after a final block), from in_off * 8
@@ -39,7 +43,8 @@ constexpr uint32_t kGzHist = 32768;
 
 __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
                                                           uint32_t n_chunks, uint16_t *__restrict__ symbuf, uint32_t sym_cap,
-                                                          GzMeta *__restrict__ meta)
+                                                          GzMeta *__restrict__ meta, GzBound *__restrict__ bounds, uint32_t bounds_cap,
+                                                          uint32_t *__restrict__ n_bounds)
 {
     __shared__ InfLds s;
     const int lane = lane_id();
@@ -210,6 +215,60 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
                     break;
                 }
             }
+            // ---- the member's final block is done: does another member follow (cat a.gz b.gz, pigz -i ...)? ----
+            // 8 bytes of trailer (CRC-32, ISIZE), then a gzip header (RFC 1952) and the next member's first block: the
+            // stretch goes on with it -- matches never reach back over a member's start, so nothing else changes.  No header
+            // there (the end of the file, bytes that are not gzip): the stretch ends at this final block as before.
+            if (last && !err) {
+                drop(b, b.bc & 7u);
+                const uint32_t at = b.in_pos - (b.bc >> 3);               // byte of the trailer, from in_off
+                if (at + 8u + 10u + 1u <= in_len && bounds) {
+                    const Bits keep = b;                                    // (the ring holds what lies 512 bytes back: see below)
+                    auto byte = [&]() {
+                        refill(s, b, in, in_len);
+                        return take(b, 8);
+                    };
+                    uint32_t isize = 0, hdr_ok = 1;
+                    for (int k = 0; k < 4; ++k) (void)byte();
+                    for (int k = 0; k < 4; ++k) isize |= byte() << (8 * k);
+                    hdr_ok = byte() == 0x1fu;
+                    hdr_ok = (byte() == 0x8bu) && hdr_ok;
+                    hdr_ok = (byte() == 8u) && hdr_ok;
+                    const uint32_t flg = byte();
+                    hdr_ok = hdr_ok && !(flg & 0xe0u);
+                    if (hdr_ok) {
+                        for (int k = 0; k < 6; ++k) (void)byte();          // MTIME, XFL, OS
+                        uint32_t left = in_len - (b.in_pos - (b.bc >> 3));  // every loop below is bounded by the input
+                        if (flg & 4u) {                                     // FEXTRA
+                            uint32_t xlen = byte();
+                            xlen |= byte() << 8;
+                            for (uint32_t k = 0; k < xlen && left > 0; ++k, --left) (void)byte();
+                        }
+                        if (flg & 8u)                                       // FNAME
+                            while (left > 0 && byte() != 0) --left;
+                        if (flg & 16u)                                      // FCOMMENT
+                            while (left > 0 && byte() != 0) --left;
+                        if (flg & 2u) (void)byte(), (void)byte();           // FHCRC
+                        hdr_ok = b.in_pos - (b.bc >> 3) + 1u <= in_len;
+                    }
+                    if (hdr_ok) {
+                        uint32_t slot = 0;
+                        if (lane == 0) slot = atomicAdd(n_bounds, 1u);
+                        slot = uni(__shfl(slot, 0, kWave));
+                        if (slot >= bounds_cap) {
+                            err = 23;                                       // more members than the caller made room for
+                        } else {
+                            if (lane == 0) bounds[slot] = GzBound{ci, op, isize, 0u};
+                            last = false;                                   // the next member's first block
+                        }
+                    } else {
+                        // not a member: un-read the trailer.  The bytes are still in the ring unless the header parse ran far
+                        // (a long FNAME): then the stretch is reported as ending in something this decoder cannot place.
+                        if (b.in_pos - keep.in_pos > kRing / 4) err = 24;
+                        else b = keep;
+                    }
+                }
+            }
         }
         uint64_t pos = (uint64_t)b.in_pos * 8u - b.bc;
         if (!err && last) pos = (pos + 7u) & ~(uint64_t)7u;          // the trailer is byte-aligned
@@ -308,13 +367,19 @@ __global__ __launch_bounds__(kGzTrThreads) void k_gz_translate(const uint16_t *_
         }
 }
 
+// d_bounds: [0] = count (uint32, cleared here), entries from byte 16 on; nullptr: a final block ends its stretch (one member)
 hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, uint32_t n_chunks, uint16_t *d_sym, uint32_t sym_cap,
-                                 void *d_meta, int n_cu, hipStream_t st)
+                                 void *d_meta, void *d_bounds, uint32_t bounds_cap, int n_cu, hipStream_t st)
 {
     if (n_chunks == 0) return hipSuccess;
+    if (d_bounds) {
+        hipError_t e = hipMemsetAsync(d_bounds, 0, 16, st);
+        if (e != hipSuccess) return e;
+    }
     const uint32_t cap = (uint32_t)n_cu * 18u;
     hipLaunchKernelGGL(k_gz_sym_inflate, dim3(n_chunks < cap ? n_chunks : cap), dim3(kWave), 0, st, d_comp, (const GzChunk *)d_chunks,
-                       n_chunks, d_sym, sym_cap, (GzMeta *)d_meta);
+                       n_chunks, d_sym, sym_cap, (GzMeta *)d_meta, d_bounds ? (GzBound *)((uint8_t *)d_bounds + 16) : nullptr, bounds_cap,
+                       (uint32_t *)d_bounds);
     return hipGetLastError();
 }
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,

@@ -266,7 +266,14 @@ int hpn_bgzf_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_bgzf_blo
  * Synchronous.  CRC-32 is not checked (ISIZE is the caller's to check).  in_len < 2^31.
  * status codes: 1-11 malformed block header or code tables, 12/14 out of symbol scratch (sym_cap), 13/15 invalid
  * code in the data, 17 ran past in_len, 20 the stretch did not end on end_bit at a block boundary, 22 a final block
- * inside a stretch that was given an end (the member stops before the next stretch: its start is unproven). */
+ * inside a stretch that was given an end and nothing that starts another member behind it (the next stretch's start is
+ * unproven), 23 more members ended inside the call than it has room for (65536), 24 a header too long to back out of.
+ *
+ * Several members (cat a.gz b.gz): a stretch that meets a final block looks behind the 8-byte trailer for the next
+ * member's header (RFC 1952) and goes on with its first block.  hpn_gz_members() lists the members that ended inside the
+ * last call -- text_end = bytes of the call's text up to the member's end, isize = the ISIZE field of its trailer -- in
+ * text order, so that the caller can check every member's size; the last member of the file ends the last stretch
+ * (hpn_gz_info.final_chunk, .end_bit) as a single member does. */
 typedef struct hpn_gz_chunk {
     uint64_t in_off;
     uint64_t end_bit;
@@ -278,9 +285,14 @@ typedef struct hpn_gz_info {
     uint64_t end_bit;
     uint32_t status, bad_chunk, final_chunk, reserved;
 } hpn_gz_info;
+typedef struct hpn_gz_member {
+    uint64_t text_end;
+    uint32_t isize, reserved;
+} hpn_gz_member;
 int hpn_gz_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks,
                        uint32_t sym_cap, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap,
                        uint8_t *d_window_out, hpn_gz_info *info);
+int hpn_gz_members(hpn_ctx *ctx, hpn_gz_member *out, uint32_t cap, uint32_t *n); /* HPN_E_CAPACITY: *n tells how many */
 
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),

@@ -246,9 +246,9 @@ def test_bgzipped_fastq_is_inflated_on_the_gpu(tmp_path):
 
 
 def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
-    """A plain .fastq.gz (one member): the host finds deflate block starts, the GPU inflates the stretches with the
-    history unknown, resolves it and frames the text; the report equals zlib's route for several stretch sizes and
-    batch splits.  Files the route must hand back: two members, trailing bytes, damage, non-FASTQ text."""
+    """A plain .fastq.gz (one member, or several: cat a.gz b.gz): the host finds deflate block starts, the GPU inflates the
+    stretches with the history unknown, resolves it and frames the text; the report equals zlib's route for several stretch
+    sizes and batch splits.  Files the route must hand back: trailing bytes, damage, non-FASTQ text."""
     import gzip
     import zlib
     rng = np.random.default_rng(8)
@@ -258,6 +258,7 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
     text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, seq[i].tobytes(), qual[i].tobytes()) for i in range(n))   # 6.4 MB
     files = {"one.fq.gz": gzip.compress(text, 6), "lvl1.fq.gz": gzip.compress(text, 1),
              "two.fq.gz": gzip.compress(text[:len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 6),
+             "many.fq.gz": b"".join(gzip.compress(text[a:a + 200_001], 1 + a % 9) for a in range(0, len(text), 200_001)),
              "tail.fq.gz": gzip.compress(text, 6) + b"trailing bytes\n",
              "ragged.fq.gz": gzip.compress(text + b"@x\nACGT\n+\nII\n" + text[:3000], 6)}
     bad = bytearray(files["one.fq.gz"])
@@ -275,9 +276,9 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
             if name != "bad.fq.gz":   # (what survives a damaged stream depends on the reader)
                 assert p.stdout == ref.stdout, (name, env)
             used = b"[hpn] gzip on the GPU" in p.stderr
-            assert used == (name in ("one.fq.gz", "lvl1.fq.gz")), (name, env, p.stderr)
+            assert used == (name in ("one.fq.gz", "lvl1.fq.gz", "two.fq.gz", "many.fq.gz")), (name, env, p.stderr)
     # fastq_trim to a file takes the same route; whatever it has to hand back (here also: a read shorter than -s) starts over
-    for name in ("one.fq.gz", "two.fq.gz", "ragged.fq.gz", "tail.fq.gz"):
+    for name in ("one.fq.gz", "two.fq.gz", "many.fq.gz", "ragged.fq.gz", "tail.fq.gz"):
         outs = []
         for k, env in enumerate(({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "90000", "HPN_GZ_BATCH": "11"},
                                  {"HPN_GZ_GPU": "0"}, {"HPN_NO_MGZ": "1", "HPN_TEXT": "0"})):
@@ -286,7 +287,7 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
             assert p.returncode == 0, p.stderr.decode()
             outs.append((open(tmp_path / f"t{k}.trim.fastq", "rb").read(), [l for l in p.stderr.split(b"\n") if l.startswith(b"Total_reads")]))
             if k < 2:
-                assert (b"[hpn] gzip on the GPU" in p.stderr) == (name == "one.fq.gz"), (name, p.stderr)
+                assert (b"[hpn] gzip on the GPU" in p.stderr) == (name in ("one.fq.gz", "two.fq.gz", "many.fq.gz")), (name, p.stderr)
         assert outs[0] == outs[1] == outs[2] == outs[3], name
     want = orc.fastq_count_report([str(tmp_path / "one.fq.gz")], names=["one.fq.gz"], header=True, length_detail=True)
     assert ref is not None and subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "one.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,

@@ -167,3 +167,54 @@ def test_final_block_inside_a_bounded_stretch_is_reported(ctx):
     # the same first stream alone, last stretch open-ended: fine
     info, got, _ = _run(ctx, ca, sa, [a[:60000], a[60000:]])
     assert info.status == 0 and got == a
+
+
+def _gz_header(name=None, extra=None, comment=None, hcrc=False):
+    flg = (4 if extra is not None else 0) | (8 if name is not None else 0) | (16 if comment is not None else 0) | (2 if hcrc else 0)
+    h = bytes([0x1f, 0x8b, 8, flg, 1, 2, 3, 4, 0, 3])
+    if extra is not None:
+        h += len(extra).to_bytes(2, "little") + extra
+    if name is not None:
+        h += name + b"\0"
+    if comment is not None:
+        h += comment + b"\0"
+    if hcrc:
+        h += b"\x12\x34"
+    return h
+
+
+def test_several_members_are_decoded_in_one_go(ctx):
+    """cat a.gz b.gz c.gz d.gz: a stretch that meets a member's final block skips the trailer, reads the next member's
+    header (plain, with FNAME, with FEXTRA + FCOMMENT + FHCRC) and goes on; hpn_gz_members lists where the members ended
+    in the text and their ISIZE.  Stretch starts: the first block of the file and two sync-flush points, one of them in the
+    third member -- so one stretch holds two member ends, another none."""
+    rng = np.random.default_rng(77)
+    texts = [_fastq(rng, 900), _fastq(rng, 5), _fastq(rng, 2500), _fastq(rng, 700)]
+    heads = [_gz_header(), _gz_header(name=b"reads_2.fq"), _gz_header(extra=b"abcdefgh", comment=b"a comment", hcrc=True), _gz_header(name=b"x" * 70)]
+    comp, starts, marks = b"", [], []
+    for k, (t, h) in enumerate(zip(texts, heads)):
+        pieces = [t] if k != 2 else [t[:100000], t[100000:180000], t[180000:]]
+        body, st = _stream(pieces, 6, zlib.Z_SYNC_FLUSH)
+        at = len(comp) + len(h)
+        if k == 0:
+            starts.append(at)
+        if k == 2:
+            starts += [at + st[1], at + st[2]]
+        comp += h + body + zlib.crc32(t).to_bytes(4, "little") + (len(t) & 0xffffffff).to_bytes(4, "little")
+        marks.append(len(t))
+    whole = b"".join(texts)
+    cut1 = len(texts[0]) + len(texts[1]) + 100000
+    cut2 = cut1 + 80000
+    pieces = [whole[:cut1], whole[cut1:cut2], whole[cut2:]]
+    info, got, _ = _run(ctx, comp, starts, pieces)
+    assert info.status == 0 and got == whole and info.final_chunk == 3
+    ends = np.cumsum(marks)[:-1].tolist()
+    assert ctx.gz_members() == [(e, m & 0xffffffff) for e, m in zip(ends, marks[:-1])]
+    # the trailer of the last member is where the last stretch stopped
+    assert (starts[-1] * 8 + info.end_bit) // 8 + 8 == len(comp)
+    # bytes that are not a gzip header behind a member inside a bounded stretch: status 22 as before
+    bad = bytearray(comp)
+    second = len(heads[0]) + len(_stream([texts[0]])[0]) + 8
+    bad[second] = 0x1e
+    info, got, _ = _run(ctx, bytes(bad), starts, pieces)
+    assert info.status == 22 and info.bad_chunk == 0
