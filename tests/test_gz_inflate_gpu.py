@@ -218,3 +218,15 @@ def test_several_members_are_decoded_in_one_go(ctx):
     bad[second] = 0x1e
     info, got, _ = _run(ctx, bytes(bad), starts, pieces)
     assert info.status == 22 and info.bad_chunk == 0
+
+
+def test_more_members_than_a_call_lists(ctx):
+    """65536 member ends fit the list of one call; one more is status 23 (the tools then take the host's reader)."""
+    import gzip
+    one = b"@r\nACGT\n+\nIIII\n"
+    for n, want_status in ((65536 + 1, 0), (65536 + 2, 23)):       # n members = n - 1 member ends inside the stretch
+        blob = gzip.compress(one, 1) * n
+        info, got, _ = _run(ctx, blob, [10], [one * n])
+        assert info.status == want_status, (n, info.status)
+        if want_status == 0:
+            assert got == one * n and len(ctx.gz_members()) == n - 1
