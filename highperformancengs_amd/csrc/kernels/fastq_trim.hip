@@ -18,7 +18,11 @@ namespace hpn {
 
 constexpr int kTrimThreads = 256;
 constexpr int kTrimPerThread = 16;   // 4096 records per tile: every tile costs ~12 ns of chain (ticket + hand-off), 4 per thread made 195 K tiles = 2.4 ms per 2e8 records
-constexpr int kTrimTile = kTrimThreads * kTrimPerThread;
+#ifndef HPN_TRIM_SCAN_THREADS
+#define HPN_TRIM_SCAN_THREADS 256
+#endif
+constexpr int kTrimScanThreads = HPN_TRIM_SCAN_THREADS;   // the scan's workgroup (256 / 512 / 1024: see profiles/r02/k3_k4_sweeps.txt)
+constexpr int kTrimTile = kTrimScanThreads * kTrimPerThread;
 
 __device__ __forceinline__ uint64_t cut_len(uint64_t len, uint64_t S, uint64_t E)
 {
@@ -26,7 +30,7 @@ __device__ __forceinline__ uint64_t cut_len(uint64_t len, uint64_t S, uint64_t E
     return e > b ? e - b : 0;
 }
 
-__global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__restrict__ off, uint64_t n,
+__global__ __launch_bounds__(kTrimScanThreads) void k_trim_scan(const uint64_t *__restrict__ off, uint64_t n,
                                                            uint64_t S, uint64_t E,
                                                            const uint32_t *__restrict__ pbeg,
                                                            const uint32_t *__restrict__ pend,
@@ -35,17 +39,25 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__re
                                                            uint32_t *__restrict__ ticket,
                                                            uint32_t *__restrict__ err)
 {
-    __shared__ u64 s_wave[kTrimThreads / kWave];
+    __shared__ u64 s_wave[kTrimScanThreads / kWave];
     __shared__ u64 s_excl;
     __shared__ uint32_t s_tile;
+    // A thread scans 16 CONSECUTIVE records, but a wave's loads and stores should cover whole lines: the tile's offsets
+    // come in (and its results go out) with consecutive lanes on consecutive 8 bytes, through this buffer; slot i of the
+    // tile lies at i + i / 16, so that the lanes' 128-byte-strided accesses to it spread over the banks.
+    __shared__ u64 s_io[kTrimTile + 1 + (kTrimTile + 1) / kTrimPerThread + 1];
+    auto slot = [](uint32_t i) { return i + i / kTrimPerThread; };
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // tiles in start order: look-back never waits on a tile not yet running
     __syncthreads();
     const uint64_t tile = s_tile;
-    const uint64_t base = tile * kTrimTile + (uint64_t)tid * kTrimPerThread;
+    const uint64_t tile0 = tile * kTrimTile;
+    for (uint32_t i = (uint32_t)tid; i <= (uint32_t)kTrimTile; i += kTrimScanThreads) s_io[slot(i)] = tile0 + i <= n ? off[tile0 + i] : 0;
+    __syncthreads();
+    const uint64_t base = tile0 + (uint64_t)tid * kTrimPerThread;
     uint64_t o[kTrimPerThread + 1];
 #pragma unroll
-    for (int k = 0; k <= kTrimPerThread; ++k) o[k] = base + k <= n ? off[base + k] : 0;
+    for (int k = 0; k <= kTrimPerThread; ++k) o[k] = s_io[slot((uint32_t)tid * kTrimPerThread + k)];
     uint64_t nl[kTrimPerThread];
     u64 mine = 0;
 #pragma unroll
@@ -57,10 +69,10 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__re
     u64 wtotal;
     const u64 wexcl = wave_excl_scan(mine, wtotal);
     if (lane_id() == kWave - 1) s_wave[wave_id()] = wtotal;
-    __syncthreads();
+    __syncthreads();                                  // (also: every thread has read its offsets out of s_io)
     u64 before = 0, aggregate = 0;
 #pragma unroll
-    for (int w = 0; w < kTrimThreads / kWave; ++w) {
+    for (int w = 0; w < kTrimScanThreads / kWave; ++w) {
         if (w < wave_id()) before += s_wave[w];
         aggregate += s_wave[w];
     }
@@ -72,11 +84,17 @@ __global__ __launch_bounds__(kTrimThreads) void k_trim_scan(const uint64_t *__re
     u64 run = s_excl + before + wexcl;
 #pragma unroll
     for (int k = 0; k < kTrimPerThread; ++k) {
-        if (base + k < n) out_off[base + k] = run;
+        s_io[slot((uint32_t)tid * kTrimPerThread + k)] = run;
         run += nl[k];
-        if (base + k + 1 == n) out_off[n] = run;
     }
-    if (n == 0 && tile == 0 && tid == 0) out_off[0] = 0;
+    if (tid == kTrimScanThreads - 1) s_io[slot(kTrimTile)] = run;   // the tile's end = the next tile's first value (or out_off[n])
+    __syncthreads();
+    // records tile0 .. min(tile0 + kTrimTile, n) - 1, and out_off[n] by the tile that holds record n - 1
+    for (uint32_t i = (uint32_t)tid; i <= (uint32_t)kTrimTile; i += kTrimScanThreads) {
+        const uint64_t r = tile0 + i;
+        if (r < n && i < (uint32_t)kTrimTile) out_off[r] = s_io[slot(i)];
+        else if (r == n && (i > 0 || n == 0)) out_off[n] = s_io[slot(i)];
+    }
 }
 
 __global__ __launch_bounds__(kTrimThreads) void k_trim_copy(const uint8_t *__restrict__ seq,
@@ -167,7 +185,7 @@ hipError_t launch_trim(const uint8_t *d_seq, const uint8_t *d_qual, const uint64
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trim_scan, dim3((unsigned)ntile), dim3(kTrimThreads), 0, st, d_off, n, S, E, d_beg, d_end, d_out_off, d_status,
+    hipLaunchKernelGGL(k_trim_scan, dim3((unsigned)ntile), dim3(kTrimScanThreads), 0, st, d_off, n, S, E, d_beg, d_end, d_out_off, d_status,
                        d_ticket_err, d_ticket_err + 1);
     if (n) {
         uint64_t want = (n + kTrimThreads - 1) / kTrimThreads;
