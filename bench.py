@@ -198,6 +198,7 @@ def main():
     del d_qual, d_off
     torch.cuda.empty_cache()
     if world == 1 and not a.no_extra:
+        extra["plain_traffic"] = bench_extra.plain_traffic()
         extra["kernel_legs"] = bench_extra.kernel_legs(ctx)
         try:
             extra["end_to_end"] = bench_extra.e2e_legs(ctx, usable_cpus())

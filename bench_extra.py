@@ -47,6 +47,30 @@ def _median_ms(ctx, fn, family, reps):
 # --------------------------------------------------------------------------------------------------------------
 # kernel legs
 # --------------------------------------------------------------------------------------------------------------
+def plain_traffic():
+    """What the part gives to plain traffic on this box (torch, 8 GiB): a device-to-device copy (read + write counted) and a
+    fill.  Kernels that write about as much as they read (K2, K3, K4) are priced against 8 TB/s like the others; this is the
+    rate a copy reaches beside them."""
+    import torch
+    x = torch.empty(8 << 30, dtype=torch.uint8, device="cuda")
+    y = torch.empty_like(x)
+    x.fill_(3), y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {}
+    for name, fn, nbytes in (("copy_read_plus_write", lambda: y.copy_(x), 2 * x.numel()), ("fill_write", lambda: y.fill_(7), x.numel())):
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        out[name + "_GBps"] = round(nbytes / ms / 1e6, 1)
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
 def kernel_legs(ctx, reps=5):
     import torch
     legs = []
