@@ -179,7 +179,7 @@ def _gz_header(name=None, extra=None, comment=None, hcrc=False):
     if comment is not None:
         h += comment + b"\0"
     if hcrc:
-        h += b"\x12\x34"
+        h += (zlib.crc32(h) & 0xffff).to_bytes(2, "little")
     return h
 
 
@@ -230,3 +230,43 @@ def test_more_members_than_a_call_lists(ctx):
         assert info.status == want_status, (n, info.status)
         if want_status == 0:
             assert got == one * n and len(ctx.gz_members()) == n - 1
+
+
+def test_damaged_files_of_several_members_never_pass_silently(ctx):
+    """Bit flips anywhere in a four-member file (data, trailers, headers with names and extra fields): the call either reports
+    a status, or its text is what zlib makes of the same bytes member by member (a flip inside a CRC field, a name or MTIME
+    changes nothing zlib or this decoder looks at)."""
+    import gzip
+    rng = np.random.default_rng(99)
+    texts = [_fastq(rng, 400), _fastq(rng, 3), _fastq(rng, 800), _fastq(rng, 150)]
+    heads = [_gz_header(), _gz_header(name=b"b.fq"), _gz_header(extra=b"xyz", comment=b"c"), _gz_header(hcrc=True)]
+    blob = b""
+    for t, h in zip(texts, heads):
+        blob += h + _stream([t])[0] + zlib.crc32(t).to_bytes(4, "little") + (len(t) & 0xffffffff).to_bytes(4, "little")
+    whole = b"".join(texts)
+
+    def zlib_members(raw):
+        out, at = b"", 0
+        try:
+            while at < len(raw):
+                d = zlib.decompressobj(31)
+                out += d.decompress(raw[at:])
+                if not d.eof:
+                    return None
+                at = len(raw) - len(d.unused_data)
+            return out
+        except zlib.error:
+            return None
+
+    assert zlib_members(blob) == whole
+    first = len(heads[0])
+    for trial in range(40):
+        raw = bytearray(blob)
+        pos = int(rng.integers(first, len(raw)))
+        raw[pos] ^= 1 << int(rng.integers(0, 8))
+        info, got, _ = _run(ctx, bytes(raw), [first], [whole + bytes(4096)])
+        if info.status == 0:
+            want = zlib_members(bytes(raw))
+            # zlib also checks CRC-32 and ISIZE (the caller's job here): a flip there makes zlib fail where this call does not
+            if want is not None:
+                assert got == want, (trial, pos)
