@@ -138,7 +138,7 @@ public:
                 const uint64_t k = take.fetch_add(1);
                 if (k > slices || (k == slices && last_batch)) return;
                 const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
-                found[(size_t)k] = gz_find_block_start(data_, size_, lo, hi < size_ * 8 ? hi : size_ * 8, gz_find_scratch(), kGzFindScratch);
+                found[(size_t)k] = find_start(lo, hi < size_ * 8 ? hi : size_ * 8);
             }
         };
         std::vector<std::thread> pool;
@@ -157,7 +157,7 @@ public:
             while (end_bit == kGzNone && k < slices + 1 && (base_byte + (k + 1) * stretch_) < size_) {  // (a slice without a dynamic block)
                 ++k;
                 const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
-                end_bit = gz_find_block_start(data_, size_, lo, hi < size_ * 8 ? hi : size_ * 8, gz_find_scratch(), kGzFindScratch);
+                end_bit = find_start(lo, hi < size_ * 8 ? hi : size_ * 8);
             }
             if (end_bit == kGzNone) {
                 if ((base_byte + (k + 1) * stretch_) < size_) return give_up("no block start where one is expected") - 1;
@@ -261,6 +261,12 @@ public:
     }
 
 private:
+    // a block that is not its member's last, or -- files of many one-block members -- a member's first block
+    uint64_t find_start(uint64_t lo, uint64_t hi) const
+    {
+        const uint64_t b = gz_find_block_start(data_, size_, lo, hi, gz_find_scratch(), kGzFindScratch);
+        return b != kGzNone ? b : gz_find_member_start(data_, size_, lo, hi, gz_find_scratch(), kGzFindScratch);
+    }
     uint32_t cap_for(double ratio) const  // symbols per stretch: its compressed bytes + a block or two, expanded
     {
         const double c = ((double)stretch_ + 131072.0) * ratio + 65536.0;

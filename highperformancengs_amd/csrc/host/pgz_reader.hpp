@@ -142,6 +142,33 @@ inline uint64_t gz_find_block_start(const uint8_t *data, uint64_t size, uint64_t
     return kGzNone;
 }
 
+// First bit position in [lo, hi) that is the first block of a gzip MEMBER: a header (1f 8b 08, reserved flag bits clear,
+// optional fields in range) whose first block decodes to text.  For files of many small members -- every block of such a
+// file is a final block, which gz_find_block_start does not propose -- on the device route, whose decoder continues from one
+// member into the next (kernels/gz_inflate.hip).  Like every proposed start it is proven only by the stretch before it
+// arriving there.
+inline uint64_t gz_find_member_start(const uint8_t *data, uint64_t size, uint64_t lo, uint64_t hi, uint16_t *scratch, size_t cap)
+{
+    const uint8_t *lim = data + size;
+    if (size < 18) return kGzNone;
+    FastInflateT<uint16_t> fi;
+    for (uint64_t byte = lo >> 3; byte * 8 < hi && byte + 18 <= size; ++byte) {
+        const uint8_t *h = (const uint8_t *)memchr(data + byte, 0x1f, (size_t)((hi + 7) / 8 - byte < size - byte ? (hi + 7) / 8 - byte : size - byte));
+        if (!h) break;
+        byte = (uint64_t)(h - data);
+        const uint8_t *body = gzip_header_end(h, lim);
+        if (!body) continue;
+        const uint64_t p = (uint64_t)(body - data) * 8;
+        if (p < lo || p >= hi || ((body[0] >> 1) & 3) == 3) continue;
+        fi.begin(body, lim, 0, true);
+        uint16_t *out = scratch;
+        const int r = fi.run(out, scratch + cap, scratch - kGzFindHist);
+        if ((r != FastInflateT<uint16_t>::kBlockEnd && r != FastInflateT<uint16_t>::kDone) || out == scratch || !gz_texty(scratch, (size_t)(out - scratch))) continue;
+        return p;
+    }
+    return kGzNone;
+}
+
 class PgzReader {
 public:
     // threads <= 0: HPN_GZ_THREADS, else min(16, usable CPUs).  chunk_bytes 0: HPN_PGZ_CHUNK, else 2 MiB.
