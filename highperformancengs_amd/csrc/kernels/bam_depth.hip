@@ -59,7 +59,8 @@ struct SoaRecs {
         cig = cigar + c0, n = c1 - c0;
         return t == want && !(f & mask);                          // bam2depth.c:90
     }
-    static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k) { return cig[k]; }
+    // (the pointer went through a select with nullptr and lost its address space: say it again, a flat load waits on the LDS counter too)
+    static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k) { return ((const __attribute__((address_space(1))) uint32_t *)cig)[k]; }
 };
 
 __device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
@@ -89,7 +90,9 @@ struct RawRecs {
     }
     static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k)
     {
-        return ld32u(reinterpret_cast<const uint8_t *>(cig) + 4u * k);
+        uint32_t v;
+        __builtin_memcpy(&v, (const __attribute__((address_space(1))) uint8_t *)cig + 4u * k, 4);
+        return v;
     }
 };
 
