@@ -827,26 +827,26 @@ __device__ __forceinline__ void put_dec(P p, uint32_t v, int nd)
     }
 }
 // (runs travel as three scalars: an array of hpn_run structs indexed in unrolled loops was kept in scratch memory)
-// Digit count from a table indexed by the bit length b of v: tab[b] = {10^d, d} with d = digits of 2^(b-1); the count is
+// Digit count from a table indexed by the bit length b of v: tab[b] = d << 32 | 10^d with d = digits of 2^(b-1); the count is
 // d, or d + 1 from 10^d on.  Two LDS reads and four instructions instead of nine compares and adds.
-__device__ __forceinline__ int dec_digits_tab(uint32_t v, const uint2 *tab)
+__device__ __forceinline__ int dec_digits_tab(uint32_t v, const u64 *tab)
 {
-    const uint2 e = tab[32 - __builtin_clz(v | 1u)];
-    return (int)e.y + (v >= e.x);
+    const u64 e = ((const __attribute__((address_space(3))) u64 *)tab)[32 - __builtin_clz(v | 1u)];   // (LDS: a ds_read, not a flat load)
+    return (int)(e >> 32) + (v >= (uint32_t)e);
 }
-__device__ __forceinline__ void dec_digits_fill(uint2 *tab, int tid)   // threads 0 .. 32 of the workgroup, before a barrier
+__device__ __forceinline__ void dec_digits_fill(u64 *tab, int tid)   // threads 0 .. 32 of the workgroup, before a barrier
 {
     if (tid <= 32) {
         const u64 lo = tid ? 1ull << (tid - 1) : 0;            // smallest value of bit length tid (0: v == 0 is looked up as 1)
         uint32_t d = 1;
         u64 p10 = 10;
         while (p10 <= lo) p10 *= 10, ++d;
-        tab[tid] = uint2{p10 > 0xffffffffull ? 0xffffffffu : (uint32_t)p10, d};
+        tab[tid] = (u64)d << 32 | (p10 > 0xffffffffull ? 0xffffffffull : p10);
     }
 }
 
 // length of the line in bits 0..15, the digit counts of its three numbers in bits 16..19, 20..23, 24..27 (counted once)
-__device__ __forceinline__ uint32_t line_info(int32_t start, int32_t end, int32_t depth, int name_len, const uint2 *tab)
+__device__ __forceinline__ uint32_t line_info(int32_t start, int32_t end, int32_t depth, int name_len, const u64 *tab)
 {
     const int neg = (start < 0) + (end < 0) + (depth < 0);   // never, for runs the scan emits; kept printf-exact
     const int n1 = dec_digits_tab((uint32_t)abs(start), tab), n2 = dec_digits_tab((uint32_t)abs(end), tab), n3 = dec_digits_tab((uint32_t)abs(depth), tab);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
     __shared__ u64 s_x;
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_name[16];
-    __shared__ uint2 s_dig[33];
+    __shared__ u64 s_dig[33];
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     if (tid < 16) s_name[tid] = name.w[tid];
