@@ -36,6 +36,11 @@ class TextInfo(C.Structure):
                 ("irregular", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class TextPiece(C.Structure):
+    _fields_ = [("n_lines", C.c_uint64), ("irregular", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+TEXT_PIECE_TAIL = 4096
 TEXT_NUL, TEXT_LONG_LINE, TEXT_RAGGED, TEXT_PARTIAL, TEXT_LEN, TEXT_DENSE, TEXT_STALE = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -102,6 +107,9 @@ SYMBOLS = [
     ("hpn_fastq_text_count", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_records", _int, [_vp, _vp, _u64, _int, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_trim", _int, [_vp, _vp, _u64, _int, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
+    ("hpn_fastq_text_piece_lines", _int, [_vp, _vp, _u64, _u32, _u64, _int, C.POINTER(TextPiece)]),
+    ("hpn_fastq_text_piece_count", _int, [_vp, _u64, _u32, C.POINTER(TextInfo)]),
+    ("hpn_fastq_text_piece_trim", _int, [_vp, _u64, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("hpn_gz_inflate_dev", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
     ("hpn_gz_members", _int, [_vp, _vp, _u32, C.POINTER(_u32)]),
@@ -122,6 +130,9 @@ SYMBOLS = [
     ("hpn_comm_init", _int, [_vp, _int, _int, _vp]),
     ("hpn_comm_destroy", _int, [_vp]),
     ("hpn_allreduce_u64", _int, [_vp, _vp, _sz]),
+    ("hpn_comm_init_all", _int, [C.POINTER(_vp), _int]),
+    ("hpn_allreduce_u64_all", _int, [C.POINTER(_vp), C.POINTER(_vp), _int, _sz]),
+    ("hpn_comm_library", C.c_char_p, []),
     ("hpn_synth_fastq_dev", _int, [_vp, _u64, _u64, _u64, _u32, _vp, _vp, _vp]),
 ]
 

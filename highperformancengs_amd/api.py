@@ -221,6 +221,26 @@ class Context:
                                             C.byref(info)), "hpn_fastq_text_trim")
         return out[:0 if info.irregular else int(info.n_bytes)].tobytes(), info
 
+    # ---- one stream framed by several contexts: pieces ---------------------------------
+    def text_piece_lines(self, text, head, own_bytes, last=False):
+        """First half of a piece (hpn_fastq_text_piece_lines): text = head byte + piece + tail; returns hpn_text_piece."""
+        text, n = self._text(text)
+        out = _lib.TextPiece()
+        self._ck(self.L.hpn_fastq_text_piece_lines(self.h, _ptr(text) if n else None, n, head, own_bytes, int(bool(last)), C.byref(out)),
+                 "hpn_fastq_text_piece_lines")
+        return out
+
+    def text_piece_count(self, lines_before, flags=0):
+        info = _lib.TextInfo()
+        self._ck(self.L.hpn_fastq_text_piece_count(self.h, lines_before, flags, C.byref(info)), "hpn_fastq_text_piece_count")
+        return info
+
+    def text_piece_trim(self, lines_before, S, E, cap):
+        info = _lib.TextInfo()
+        out = np.zeros(cap, np.uint8)
+        self._ck(self.L.hpn_fastq_text_piece_trim(self.h, lines_before, S, E, _ptr(out), out.size, C.byref(info)), "hpn_fastq_text_piece_trim")
+        return out[:0 if info.irregular else int(info.n_bytes)].tobytes(), info
+
     # ---- BGZF inflate on the device ----------------------------------------------
     def bgzf_inflate_dev(self, d_comp, d_blocks, n_blocks, d_out, d_status):
         self._ck(self.L.hpn_bgzf_inflate_dev(self.h, _ptr(d_comp), _ptr(d_blocks), n_blocks, _ptr(d_out), _ptr(d_status)),

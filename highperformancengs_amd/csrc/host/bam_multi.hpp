@@ -53,9 +53,10 @@ inline bool bai_first_offsets(const char *bam, int32_t n_targets, std::vector<ui
 }
 
 // Where bam_fetch(tid, beg, ...) starts reading: the 16 kb linear index entry of `beg` (every record that overlaps that
-// window starts at or behind it; samtools-0.1.19 bam_index.c:608-640), else the target's first record.  false: the target
-// has no record (or there is no usable index).
-inline bool bai_region_start(const char *bam, int32_t n_targets, int32_t tid, uint32_t beg, uint64_t *voffset)
+// window starts at or behind it; samtools-0.1.19 bam_index.c:608-640), else the target's first record.
+// 1: *voffset set; 0: the index is sound and the target holds no record; -1: no usable index (missing, bad magic, other
+// target count, truncated) -- the caller then reads the file from its first record.
+inline int bai_region_start(const char *bam, int32_t n_targets, int32_t tid, uint32_t beg, uint64_t *voffset)
 {
     std::string a = std::string(bam) + ".bai", b = bam;
     FILE *f = fopen(a.c_str(), "rb");
@@ -63,7 +64,7 @@ inline bool bai_region_start(const char *bam, int32_t n_targets, int32_t tid, ui
         b.replace(b.size() - 3, 3, "bai");
         f = fopen(b.c_str(), "rb");
     }
-    if (!f) return false;
+    if (!f) return -1;
     char magic[4];
     int32_t n_ref = 0;
     bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "BAI\1", 4) && fread(&n_ref, 4, 1, f) == 1 && n_ref == n_targets && tid < n_ref;
@@ -91,9 +92,10 @@ inline bool bai_region_start(const char *bam, int32_t n_targets, int32_t tid, ui
         }
     }
     fclose(f);
-    if (!ok || first == ~0ull) return false;
+    if (!ok) return -1;
+    if (first == ~0ull) return 0;
     *voffset = lin > first ? lin : first;
-    return true;
+    return 1;
 }
 
 inline int multi_gpu_workers()
@@ -117,6 +119,18 @@ inline int multi_gpu_workers_for(const char *path)
         }
     }
     return n;
+}
+
+// Worker contexts live for the whole process and are reused across input files: a depth context keeps several GB of
+// scratch for a chr1-sized target, and bam2depth / bam2wig / bam_sliding_count come here once per file.
+inline hpn_ctx *pooled_worker_ctx(int worker, int device)
+{
+    static std::mutex m;
+    static std::vector<hpn_ctx *> pool;
+    std::lock_guard<std::mutex> lk(m);
+    if ((size_t)worker >= pool.size()) pool.resize((size_t)worker + 1, nullptr);
+    if (!pool[(size_t)worker] && hpn_ctx_create(device, &pool[(size_t)worker]) != HPN_OK) pool[(size_t)worker] = nullptr;
+    return pool[(size_t)worker];
 }
 
 struct TargetOut {
@@ -153,19 +167,39 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
     bool failed = false;
     int devices = 1;
     if (hpn_device_count(&devices) != HPN_OK || devices < 1) devices = 1;
+    // Finished targets wait in host memory until every earlier one is written (a chr1 at 30x is ~2.6 GB of bedGraph
+    // text): a worker takes a target only while the estimated bytes of everything claimed and not yet emitted stay
+    // within a budget -- except the lowest unclaimed target, which is always allowed (it is what the writer waits for).
+    const uint64_t budget = getenv("HPN_DEPTH_LOOKAHEAD") ? strtoull(getenv("HPN_DEPTH_LOOKAHEAD"), nullptr, 10) : (uint64_t)12 << 30;
+    auto estimate = [&](int32_t j) { return (uint64_t)hdr.target_len[j] * 12u; };
+    std::vector<char> claimed((size_t)nt, 0);
+    uint64_t outstanding = 0;
     auto work = [&](int w) {
-        hpn_ctx *ctx = nullptr;
-        bool ok = hpn_ctx_create(w % devices, &ctx) == HPN_OK;
+        hpn_ctx *ctx = pooled_worker_ctx(w, w % devices);
+        bool ok = ctx != nullptr;
         BgzfGpuStream gs;
         BamHeader h2;
         ok = ok && gs.open(ctx, path, h2) && h2.n_targets() == nt;
         for (;;) {
-            int32_t j;
+            int32_t j = -1;
             {
-                std::lock_guard<std::mutex> lk(m);
+                std::unique_lock<std::mutex> lk(m);
                 if (!ok) failed = true;
-                if (failed || next >= order.size()) break;
-                j = order[next++];
+                for (;;) {
+                    if (failed || next >= order.size()) break;
+                    int32_t lowest = -1;
+                    for (int32_t t = 0; t < nt && lowest < 0; ++t)
+                        if (!claimed[(size_t)t]) lowest = t;
+                    for (int32_t t : order)   // largest first
+                        if (!claimed[(size_t)t] && (t == lowest || outstanding + estimate(t) <= budget)) {
+                            j = t;
+                            break;
+                        }
+                    if (j >= 0) break;
+                    cv.wait(lk);
+                }
+                if (j < 0) break;
+                claimed[(size_t)j] = 1, ++next, outstanding += estimate(j);
             }
             TargetOut &o = out[(size_t)j];
             int rc = hpn_depth_begin(ctx, j, hdr.target_len[j], mask);
@@ -213,7 +247,7 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
             cv.notify_all();
         }
         cv.notify_all();
-        // contexts are left to process exit (quick_exit_ok): tearing one down costs as much as making it
+        // the pooled context stays for the next file (and is left to process exit: tearing one down costs as much as making it)
     };
     std::vector<std::thread> th;
     for (int w = 0; w < workers; ++w) th.emplace_back(work, w);
@@ -228,8 +262,18 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
             emit(j, out[(size_t)j]);
             std::vector<hpn_run>().swap(out[(size_t)j].runs);   // a chromosome's runs are ~1 GB: give them back
             std::vector<char>().swap(out[(size_t)j].text);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                outstanding -= estimate(j);
+            }
+            cv.notify_all();
         }
     }
+    if (!good) {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+    }
+    cv.notify_all();
     for (auto &t : th) t.join();
     return good;
 }
@@ -258,7 +302,7 @@ public:
         for (int w = 0; w < workers; ++w) box.emplace_back(new Box());
         std::vector<hpn_ctx *> ctxs((size_t)workers, nullptr);
         for (int w = 0; w < workers; ++w)
-            if (hpn_ctx_create(w % devices, &ctxs[(size_t)w]) != HPN_OK) return false;
+            if (!(ctxs[(size_t)w] = pooled_worker_ctx(w, w % devices))) return false;
         BgzfGpuStream gs;                       // the reader: header, read-ahead, block tables
         BamHeader hdr;
         if (!gs.open(ctxs[0], path, hdr, workers + 2)) return false;

@@ -9,6 +9,7 @@
 #include "../host/bam_gpu.hpp"
 #include "../host/gz_gpu.hpp"
 #include "../host/text_stream.hpp"
+#include "../host/text_shard.hpp"
 #include "hpngs.h"
 
 namespace hpn {
@@ -231,7 +232,8 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
 }
 
 // One input file of fastq_count / fastq_count_kthread (count_read, fastq_count.c:106-133).
-inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_long)
+// group: the lanes to shard a text input over (host/text_shard.hpp), nullptr = this context alone.
+inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_long, LaneGroup *group = nullptr)
 {
     const bool is_stdin = strncmp(path, "-", 1) == 0 || !strcmp(path, "");
     if (text_path_enabled() && !is_stdin && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(path)) {
@@ -243,6 +245,11 @@ inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_
         bool unusable = false;
         const int rc = tally_gz_on_gpu(ctx, path, acc, &unusable);
         if (!unusable) return rc;
+    }
+    if (text_path_enabled() && !is_stdin && group && group->lanes() > 1) {  // record blocks of this one input over several GPUs
+        bool irregular = false;
+        const int rc = tally_text_sharded(*group, path, acc, &irregular);
+        if (!irregular) return rc;
     }
     if (text_path_enabled() && !is_stdin) {  // an irregular stream is framed again from its first byte
         bool irregular = false;

@@ -42,8 +42,8 @@ inline size_t text_chunk_bytes()
 // hundred MB/s per file, so every file gets its worker, as in the reference.  Plain files
 // stream at tens of GB/s per worker: a few lanes saturate PCIe, and each further GPU context
 // only adds start-up (15-30 ms of hardware-queue creation each, serialised by the driver) --
-// one lane per 4 GiB of input, four at most.
-inline int text_workers(char **files, int n, int requested)
+// one lane per 4 GiB of input, four per device (= per PCIe link) at most.
+inline int text_workers(char **files, int n, int requested, int ndev = 1)
 {
     if (!text_path_enabled() || getenv("HPN_ALL_WORKERS")) return requested;
     uint64_t plain = 0;
@@ -59,7 +59,7 @@ inline int text_workers(char **files, int n, int requested)
         plain += (uint64_t)sb.st_size;
     }
     int lanes = (int)(plain >> 32) + 1;
-    if (lanes > 4) lanes = 4;
+    if (lanes > 4 * (ndev < 1 ? 1 : ndev)) lanes = 4 * (ndev < 1 ? 1 : ndev);
     return lanes < requested ? lanes : requested;
 }
 
@@ -74,7 +74,9 @@ public:
 
     // raw: deliver the file's own bytes whatever they are (compressed BGZF for the device inflater)
     // start: file offset the stream begins at (plain / raw files only)
-    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false, uint64_t start = 0) : ctx_(ctx), cap_(chunk), pos_(start)
+    // pad: writable bytes in front of and behind every chunk (text_shard.hpp puts a piece's head byte and tail there)
+    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false, uint64_t start = 0, size_t pad = 0)
+        : ctx_(ctx), cap_(chunk), pad_(pad), pos_(start)
     {
         struct stat sb;
         uint8_t magic[2] = {0, 0};
@@ -99,7 +101,7 @@ public:
         }
         for (int i = 0; i < nbuf; ++i) {
             void *p = nullptr;
-            if (hpn_host_malloc(ctx_, cap_ + 64, &p) != HPN_OK) break;
+            if (hpn_host_malloc(ctx_, cap_ + 2 * pad_ + 64, &p) != HPN_OK) break;
             buf_.push_back((uint8_t *)p);
             free_.push_back(i);
         }
@@ -115,6 +117,7 @@ public:
     }
     bool ok() const { return ok_; }
     size_t chunk_bytes() const { return cap_; }
+    bool plain_file() const { return fd_ >= 0; }
 
     // Start over at file offset `pos` with the same pinned buffers (plain / raw files only): what was read ahead is dropped.
     bool restart(uint64_t pos)
@@ -232,7 +235,7 @@ private:
             }
             Chunk c;
             c.idx = idx;
-            c.p = buf_[(size_t)idx];
+            c.p = buf_[(size_t)idx] + pad_;
             c.n = fill(c.p);
             c.eof = c.n < cap_;
             {
@@ -248,9 +251,9 @@ private:
     }
 
     hpn_ctx *ctx_;
-    size_t cap_;
+    size_t cap_, pad_;
     int fd_ = -1;
-    uint64_t pos_ = 0;   // (declared after cap_: the constructor initialises them in this order)
+    uint64_t pos_ = 0;   // (declared after cap_, pad_: the constructor initialises them in this order)
     InStream in_;
     bool ok_ = false, handed_over_ = false;
     std::vector<uint8_t *> buf_;

@@ -204,8 +204,9 @@ int hpn_depth_bedgraph_format(hpn_ctx *c, const char *name, uint64_t *n_bytes)
 int hpn_depth_bedgraph_read(hpn_ctx *c, uint64_t offset, void *dst, uint64_t nbytes)
 {
     if (!c || (nbytes && !dst)) return HPN_E_ARG;
-    if (offset + nbytes > c->depth_text_bytes) return fail(c, HPN_E_ARG, "bytes %llu..%llu of a text of %llu", (unsigned long long)offset,
-                                                        (unsigned long long)(offset + nbytes), (unsigned long long)c->depth_text_bytes);
+    if (offset > c->depth_text_bytes || nbytes > c->depth_text_bytes - offset)   // (offset + nbytes may wrap)
+        return fail(c, HPN_E_ARG, "%llu bytes at %llu of a text of %llu", (unsigned long long)nbytes, (unsigned long long)offset,
+                    (unsigned long long)c->depth_text_bytes);
     HPN_HIP(c, hipSetDevice(c->device));
     if (nbytes) HPN_HIP(c, hipMemcpyAsync(dst, (const uint8_t *)c->d_text.p + offset, nbytes, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
@@ -250,9 +251,9 @@ int hpn_depth_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
 {
     if (!c || (c->r_n && !d_raw)) return HPN_E_ARG;
     if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_add before hpn_depth_begin");
+    if (c->r_n > 0xfffffff0ull) return fail(c, HPN_E_ARG, "more than 2^32 records in one batch");
     HPN_HIP(c, hipSetDevice(c->device));
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
-    if (c->r_n > 0xfffffff0ull) return fail(c, HPN_E_ARG, "more than 2^32 records in one batch");
     HPN_HIP(c, launch_depth_add_raw(d_raw, (const uint64_t *)c->r_off.p, c->r_n, c->depth_tid, c->depth_mask, (int32_t *)c->d_diff.p,
                                     c->depth_slots, c->d_tidx.p, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));

@@ -28,10 +28,14 @@ struct Rccl {
     void *h = nullptr;
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
+    char path[512] = {0};   // where the library really came from (dladdr of one of its symbols)
 };
 
 void rccl_load(Rccl &r);
@@ -46,18 +50,26 @@ Rccl &rccl()
 
 void rccl_load(Rccl &r)
 {
+    // A process that already holds an RCCL (PyTorch loads its own torch/lib/librccl.so) must not get a second
+    // one beside it: RTLD_NOLOAD first asks for the copy that is mapped under either soname, and only a process
+    // without any loads the system library.  HPN_RCCL_LIB names a file outright.
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *nm : names) {
-        r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (r.h) break;
-    }
+    if (const char *e = getenv("HPN_RCCL_LIB")) r.h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    for (int i = 0; !r.h && i < 2; ++i) r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!r.h && dlsym(RTLD_DEFAULT, "ncclAllReduce")) r.h = dlopen(nullptr, RTLD_NOW);   // linked into the process under another name
+    for (int i = 0; !r.h && i < 3; ++i) r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!r.h) return;
     r.GetUniqueId = (int (*)(ncclUniqueId *))dlsym(r.h, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(r.h, "ncclCommInitRank");
+    r.CommInitAll = (int (*)(ncclComm_t *, int, const int *))dlsym(r.h, "ncclCommInitAll");
+    r.GroupStart = (int (*)())dlsym(r.h, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.h, "ncclGroupEnd");
     r.CommDestroy = (int (*)(ncclComm_t))dlsym(r.h, "ncclCommDestroy");
     r.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))dlsym(r.h, "ncclAllReduce");
     r.GetErrorString = (const char *(*)(int))dlsym(r.h, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
+    Dl_info di;
+    if (r.AllReduce && dladdr((void *)r.AllReduce, &di) && di.dli_fname) snprintf(r.path, sizeof r.path, "%s", di.dli_fname);
 }
 
 }  // namespace
@@ -111,6 +123,53 @@ int hpn_allreduce_u64(hpn_ctx *c, uint64_t *d_vec, size_t n)
     // One call, no chunking: 515 .. 68k words is latency-bound on any xGMI ring.
     int e = rccl().AllReduce(d_vec, d_vec, n, ncclUint64, ncclSum, (ncclComm_t)c->comm, c->stream);
     if (e != ncclSuccess) return fail(c, HPN_E_RCCL, "ncclAllReduce: %s", rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
+    return HPN_OK;
+}
+
+const char *hpn_comm_library(void) { return rccl().path; }
+
+int hpn_comm_init_all(hpn_ctx **ctxs, int n)
+{
+    if (!ctxs || n < 1 || n > 64) return HPN_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return HPN_E_ARG;
+        if (ctxs[i]->comm) return fail(ctxs[i], HPN_E_STATE, "communicator already initialised");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j]->device == ctxs[i]->device)
+                return fail(ctxs[0], HPN_E_ARG, "contexts %d and %d share device %d: one RCCL rank per device", j, i, ctxs[i]->device);
+    }
+    Rccl &r = rccl();
+    if (!r.ok || !r.CommInitAll || !r.GroupStart || !r.GroupEnd) return fail(ctxs[0], HPN_E_RCCL, "RCCL not loadable: %s", dlerror());
+    ncclComm_t comms[64];
+    int devs[64];
+    for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device, comms[i] = nullptr;
+    const int e = r.CommInitAll(comms, n, devs);
+    if (e != ncclSuccess) return fail(ctxs[0], HPN_E_RCCL, "ncclCommInitAll: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
+    for (int i = 0; i < n; ++i) ctxs[i]->comm = comms[i];
+    return HPN_OK;
+}
+
+int hpn_allreduce_u64_all(hpn_ctx **ctxs, uint64_t **d_vecs, int n, size_t n_words)
+{
+    if (!ctxs || !d_vecs || n < 1 || n > 64) return HPN_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !d_vecs[i]) return HPN_E_ARG;
+        if (!ctxs[i]->comm) return fail(ctxs[i], HPN_E_STATE, "hpn_comm_init_all has not been called");
+    }
+    Rccl &r = rccl();
+    // one group: a single thread drives all ranks, so the n calls must be fused or the first would wait for peers forever
+    int e = r.GroupStart();
+    for (int i = 0; e == ncclSuccess && i < n; ++i) {
+        HPN_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+        e = r.AllReduce(d_vecs[i], d_vecs[i], n_words, ncclUint64, ncclSum, (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream);
+    }
+    const int e2 = r.GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return fail(ctxs[0], HPN_E_RCCL, "grouped ncclAllReduce: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
+    for (int i = 0; i < n; ++i) {
+        HPN_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+        HPN_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+    }
     return HPN_OK;
 }
 

@@ -67,6 +67,9 @@ struct hpn_ctx {
     bool t_open = false;
     int t_cur = 0;
     uint32_t t_carry = 0, t_tail = 0;  // carry bytes and where they start in slot[t_cur ^ 1]
+    // a piece between hpn_fastq_text_piece_lines and _count / _trim
+    int p_state = 0, p_last = 0;
+    uint32_t p_begin = 0, p_end = 0, p_limit = 0, p_head = 0, p_nl_cap = 0;
     // records indexed in place in inflated BGZF blocks (hpn_bam_raw_*)
     hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info;
     hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds;  // gzip: symbols, per-stretch results, histories, member ends

@@ -68,9 +68,11 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
         HPN_HIP(c, hipMemcpyAsync(metas.data(), c->g_meta.p, (size_t)n_chunks * 32, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipMemcpyAsync(bounds.data(), (const uint8_t *)c->g_bounds.p + 16, (size_t)n_bounds * 16, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipStreamSynchronize(c->stream));
+        // stream order = (stretch, symbols the stretch had written at the member's end); an EMPTY member (ISIZE 0,
+        // `cat a.gz empty.gz b.gz`) ends at the same text offset as its predecessor, so text_end alone does not order them
+        std::stable_sort(bounds.begin(), bounds.end(), [](const Bound &a, const Bound &b) { return a.chunk != b.chunk ? a.chunk < b.chunk : a.n_out < b.n_out; });
         for (const Bound &b : bounds)
             if (b.chunk < n_chunks) c->gz_members.push_back(hpn_gz_member{metas[b.chunk].text_off + b.n_out, b.isize, 0u});
-        std::sort(c->gz_members.begin(), c->gz_members.end(), [](const hpn_gz_member &a, const hpn_gz_member &b) { return a.text_end < b.text_end; });
     }
     const double t2 = now();
     info->n_bytes = summary[0];

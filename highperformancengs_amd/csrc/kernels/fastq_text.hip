@@ -34,7 +34,7 @@ constexpr int kRecPerThread = 4;
 constexpr uint32_t kRecTile = kTxtThreads * kRecPerThread;      // records per workgroup
 
 // device state block (uint32 words), zeroed before every chunk
-enum { kTsLines = 0, kTsRecs, kTsFlags, kTsUnterminated, kTsConsumed, kTsTotalLo, kTsTotalHi, kTsErr, kTsTicket1, kTsTicket2, kTsWords = 16 };
+enum { kTsLines = 0, kTsRecs, kTsFlags, kTsUnterminated, kTsConsumed, kTsTotalLo, kTsTotalHi, kTsErr, kTsTicket1, kTsTicket2, kTsOwnLines, kTsWords = 16 };
 
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t x)  // 0x80 in exactly the bytes of x that are 0
 {
@@ -59,10 +59,13 @@ __device__ __forceinline__ uint32_t wave_excl_scan32(uint32_t v, uint32_t &total
 
 // text = slot[begin, end).  With `last`, a final line that lacks its '\n' is closed by a
 // virtual one at position `end` (state word kTsUnterminated tells the record kernel).
+// own_end (pieces of one stream framed by several contexts, hpn_fastq_text_piece_*): the '\n' at
+// positions < own_end are also counted into kTsOwnLines -- what this piece adds to the stream's
+// line count, and how many record starts it can own; 0: not a piece.
 __global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__restrict__ slot, uint32_t begin,
-                                                            uint32_t end, int last, uint32_t *__restrict__ nl,
-                                                            uint32_t nl_cap, u64 *__restrict__ status,
-                                                            uint32_t *__restrict__ st)
+                                                            uint32_t end, int last, uint32_t own_end,
+                                                            uint32_t *__restrict__ nl, uint32_t nl_cap,
+                                                            u64 *__restrict__ status, uint32_t *__restrict__ st)
 {
     __shared__ uint32_t s_w[kTxtRows][kTxtThreads / kWave];
     __shared__ u64 s_excl;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__res
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t a0 = begin & ~15u;
-    uint32_t mask[kTxtRows], cnt[kTxtRows], nul = 0;
+    uint32_t mask[kTxtRows], cnt[kTxtRows], nul = 0, own = 0;
 #pragma unroll
     for (int k = 0; k < kTxtRows; ++k) {
         const uint32_t p = a0 + tile * kTxtTile + (uint32_t)(k * kTxtThreads + tid) * 16u;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__res
             const uint32_t valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
             m &= valid;
             nul |= z & valid;
+            if (own_end > p) own += (uint32_t)__builtin_popcount(own_end - p >= 16u ? m : m & ((1u << (own_end - p)) - 1u));
             if (last && end > begin && end - 1u >= p && end - 1u - p < 16u) {  // this word holds the last byte of the stream
                 if (!((m >> (end - 1u - p)) & 1u)) {
                     m |= 1u << hi;  // virtual '\n' at position end
@@ -139,6 +143,11 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__res
     }
     if (nul) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_NUL);
     if (dense) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_DENSE);
+    if (own_end) {   // (wave-uniform branch; one atomic per wave that saw any)
+        uint32_t wt;
+        (void)wave_excl_scan32(own, wt);
+        if (wt && lane_id() == 0) atomicAdd(&st[kTsOwnLines], wt);
+    }
     if (tile == gridDim.x - 1 && tid == 0) {
         const u64 n = tile_base + aggregate;
         st[kTsLines] = n > nl_cap ? nl_cap : (uint32_t)n;
@@ -152,11 +161,24 @@ __device__ __forceinline__ uint32_t trim_cut(uint32_t l, uint32_t S, uint32_t E,
     return e > b ? e - b : 0u;
 }
 
+// How a chunk's lines group into records.  Chunk mode (first = -1, limit = 0): the text starts at a
+// record, record r = lines 4r .. 4r+3, the lines of an unfinished last record are carried over.  Piece
+// mode (limit != 0; hpn_fastq_text_piece_*): the text is a piece of a stream cut anywhere, handed over
+// with the byte before the piece and a tail behind it; the stream has `L` lines before the text, so a
+// record starts behind local line end i iff (L + i + 1) % 4 == 0 -- `first` is the smallest such i
+// (-1: at `begin` itself, the stream's first byte) -- and the piece owns the records that START before
+// `limit`; their lines reach into the tail.
+struct TextFrame {
+    int32_t first;    // local index of the line end in front of record 0; -1 = record 0 starts at begin
+    uint32_t limit;   // piece mode: records starting at or beyond this position belong to the next piece; 0 = chunk mode
+};
+
 // Launched with an upper bound of tiles (the line count lives on the device).
 template <bool kTrim>
 __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__restrict__ nl, uint32_t begin,
                                                               uint32_t end, int last, uint32_t S, uint32_t E,
-                                                              uint32_t carry_cap, uint64_t *__restrict__ off,
+                                                              uint32_t carry_cap, TextFrame fr,
+                                                              uint64_t *__restrict__ off,
                                                               u64 *__restrict__ status, uint32_t *__restrict__ st)
 {
     __shared__ u64 s_wave[kTxtThreads / kWave];
@@ -164,24 +186,44 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     const uint32_t n_lines = st[kTsLines];
-    const uint32_t n = n_lines >> 2;
     const uint32_t unterminated = st[kTsUnterminated];
+    const bool piece = fr.limit != 0;
+    const uint32_t *__restrict__ nlp = nl + (fr.first + 1);   // record r's four line ends: nlp[4r .. 4r+3]; the one in front: nlp[4r-1]
+    uint32_t n;
+    bool incomplete = false;
+    if (piece) {
+        const uint32_t m = st[kTsOwnLines];   // line ends at positions < limit - 1: those a record of this piece can start behind
+        if (fr.first < 0) n = begin < fr.limit ? 1u + m / 4u : 0u;
+        else n = m > (uint32_t)fr.first ? (m - (uint32_t)fr.first + 3u) / 4u : 0u;
+        // the last record's fourth line end is local line fr.first + 4n: it has to exist in the text handed over
+        if (n && (uint32_t)(fr.first + 1) + 4u * n > n_lines) incomplete = true;
+    } else {
+        n = n_lines >> 2;
+    }
+    const uint32_t lines_used = (uint32_t)(fr.first + 1) + 4u * n;   // local lines up to the last record's end
     if (blockIdx.x == 0 && tid == 0) {
-        st[kTsRecs] = n;
-        uint32_t consumed = n ? nl[4u * n - 1u] + 1u : begin;
-        if (consumed > end) consumed = end;  // the virtual newline
-        st[kTsConsumed] = consumed;
-        const uint32_t left = end - consumed;
         uint32_t f = 0;
-        if (last && left) f |= HPN_TEXT_PARTIAL;
-        if (!last && left > carry_cap) f |= HPN_TEXT_LONG_LINE;
+        if (piece) {
+            if (incomplete) f |= last ? HPN_TEXT_PARTIAL : HPN_TEXT_LONG_LINE;   // (a tail of 4 KiB holds every regular record)
+            st[kTsRecs] = incomplete ? 0u : n;
+            st[kTsConsumed] = end;
+        } else {
+            st[kTsRecs] = n;
+            uint32_t consumed = n ? nl[4u * n - 1u] + 1u : begin;
+            if (consumed > end) consumed = end;  // the virtual newline
+            st[kTsConsumed] = consumed;
+            const uint32_t left = end - consumed;
+            if (last && left) f |= HPN_TEXT_PARTIAL;
+            if (!last && left > carry_cap) f |= HPN_TEXT_LONG_LINE;
+        }
         if (kTrim && unterminated) f |= HPN_TEXT_PARTIAL;
         if (f) atomicOr(&st[kTsFlags], f);
-        if (n == 0) {
+        if (n == 0 || incomplete) {
             off[0] = 0;
             st[kTsTotalLo] = st[kTsTotalHi] = 0;
         }
     }
+    if (incomplete) return;
     // The grid is an upper bound; only the workgroups that have records take a ticket (the
     // same-address atomic is the serial part of the kernel), in start order.
     if ((u64)blockIdx.x * kRecTile >= n) return;
@@ -190,14 +232,16 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__
     const uint32_t tile = s_tile;
     const uint32_t base = tile * kRecTile + (uint32_t)tid * kRecPerThread;
     uint32_t val[kRecPerThread], flags = 0;
-    uint32_t prev = base && base < n ? nl[4u * base - 1u] : begin - 1u;
+    uint32_t prev = begin - 1u;
+    if (base < n && (base || fr.first >= 0)) prev = nlp[4 * (int)base - 1];
     u64 mine = 0;
 #pragma unroll
     for (int k = 0; k < kRecPerThread; ++k) {
         const uint32_t r = base + k;
         val[k] = 0;
         if (r < n) {
-            const u32 e = *(const u32 *)(nl + 4u * r);  // the record's four line ends
+            u32 e;  // the record's four line ends (16-byte aligned in chunk mode only)
+            __builtin_memcpy(&e, nlp + 4u * r, 16);
             const uint32_t L1 = e[0] - prev, L2 = e[1] - e[0], L3 = e[2] - e[1];  // lengths with the '\n'
             uint32_t L4 = e[3] - e[2];
             if (L1 > 1023u || L2 > 1023u || L3 > 1023u || L4 > 1023u) flags |= HPN_TEXT_LONG_LINE;  // gzgets would split it
@@ -208,7 +252,7 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_records(const uint32_t *__
                 uint32_t b;
                 val[k] = L1 + 2u * trim_cut(len, S, E, b) + 4u;
             } else {
-                if (unterminated && r == n - 1u && (n_lines & 3u) == 0u) L4 -= 1u;  // no '\n' in the buffer after the last gzgets
+                if (unterminated && r == n - 1u && lines_used == n_lines) L4 -= 1u;  // no '\n' in the buffer after the last gzgets
                 if (L4 < len) flags |= HPN_TEXT_RAGGED;  // the reference would tally stale buffer bytes
                 if (len >= HPN_LEN_BINS) flags |= HPN_TEXT_LEN;
                 val[k] = len;
@@ -277,7 +321,8 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_gather(const uint8_t *__re
         uint32_t qs = 0, ss = 0, cnt = 0;
         uint64_t d = 0;
         if (r < n) {
-            const u32 e = *(const u32 *)(nl + 4u * r);
+            u32 e;
+            __builtin_memcpy(&e, nl + 4u * r, 16);
             ss = e[0] + 1u, qs = e[2] + 1u, cnt = e[1] - e[0] - 1u;
             d = off[r];
         }
@@ -292,8 +337,9 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_gather(const uint8_t *__re
     }
 }
 
+// nl = the first record's four line ends (k_text_records' nlp); at_begin: record 0 starts at `begin`, else behind nl[-1]
 __global__ __launch_bounds__(kTxtThreads) void k_text_trim(const uint8_t *__restrict__ slot,
-                                                           const uint32_t *__restrict__ nl, uint32_t begin,
+                                                           const uint32_t *__restrict__ nl, uint32_t begin, int at_begin,
                                                            const uint64_t *__restrict__ off, uint32_t n, uint32_t S,
                                                            uint32_t E, uint8_t *__restrict__ out)
 {
@@ -305,8 +351,9 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_trim(const uint8_t *__rest
         uint32_t p0 = 0, L1 = 0, ss = 0, qs = 0, cut = 0;
         uint64_t d = 0;
         if (r < n) {
-            const u32 e = *(const u32 *)(nl + 4u * r);
-            p0 = r ? nl[4u * r - 1u] + 1u : begin;
+            u32 e;
+            __builtin_memcpy(&e, nl + 4u * r, 16);
+            p0 = r || !at_begin ? nl[4 * (int)r - 1] + 1u : begin;
             L1 = e[0] + 1u - p0;  // name line with its '\n'
             uint32_t b;
             cut = trim_cut(e[1] - e[0] - 1u, S, E, b);
@@ -340,24 +387,48 @@ uint64_t text_tiles1(uint32_t begin, uint32_t end)
 }
 uint64_t text_tiles2(uint32_t nl_cap) { return (uint64_t)(nl_cap / 4u) / kRecTile + 1; }
 
+hipError_t launch_text_lines(const uint8_t *d_slot, uint32_t begin, uint32_t end, int last, uint32_t own_end, uint32_t *d_nl,
+                             uint32_t nl_cap, u64 *d_status, uint32_t *d_state, hipStream_t st);
+hipError_t launch_text_records(const uint32_t *d_nl, uint32_t begin, uint32_t end, int last, bool trim, uint32_t S, uint32_t E,
+                               uint32_t carry_cap, int32_t first, uint32_t limit, uint32_t nl_cap, uint64_t *d_off,
+                               u64 *d_status, uint32_t *d_state, hipStream_t st);
+
 // frame: newline index + record validation / scan.  d_status holds text_tiles1 + text_tiles2 words.
 hipError_t launch_text_frame(const uint8_t *d_slot, uint32_t begin, uint32_t end, int last, bool trim, uint32_t S,
                              uint32_t E, uint32_t carry_cap, uint32_t *d_nl, uint32_t nl_cap, uint64_t *d_off,
                              u64 *d_status, uint32_t *d_state, hipStream_t st)
+{
+    hipError_t e = launch_text_lines(d_slot, begin, end, last, 0u, d_nl, nl_cap, d_status, d_state, st);
+    if (e != hipSuccess) return e;
+    return launch_text_records(d_nl, begin, end, last, trim, S, E, carry_cap, -1, 0u, nl_cap, d_off, d_status, d_state, st);
+}
+
+// The two halves on their own (pieces: the line count of a piece is published before its records can be framed).
+hipError_t launch_text_lines(const uint8_t *d_slot, uint32_t begin, uint32_t end, int last, uint32_t own_end, uint32_t *d_nl,
+                             uint32_t nl_cap, u64 *d_status, uint32_t *d_state, hipStream_t st)
 {
     const uint64_t t1 = text_tiles1(begin, end), t2 = text_tiles2(nl_cap);
     hipError_t e = hipMemsetAsync(d_status, 0, (t1 + t2) * sizeof(u64), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_state, 0, kTsWords * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_text_lines, dim3((unsigned)t1), dim3(kTxtThreads), 0, st, d_slot, begin, end, last, d_nl, nl_cap,
-                       d_status, d_state);
+    hipLaunchKernelGGL(k_text_lines, dim3((unsigned)t1), dim3(kTxtThreads), 0, st, d_slot, begin, end, last, own_end, d_nl,
+                       nl_cap, d_status, d_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_records(const uint32_t *d_nl, uint32_t begin, uint32_t end, int last, bool trim, uint32_t S, uint32_t E,
+                               uint32_t carry_cap, int32_t first, uint32_t limit, uint32_t nl_cap, uint64_t *d_off,
+                               u64 *d_status, uint32_t *d_state, hipStream_t st)
+{
+    const uint64_t t1 = text_tiles1(begin, end), t2 = text_tiles2(nl_cap);
+    const TextFrame fr{first, limit};
     if (trim)
         hipLaunchKernelGGL(k_text_records<true>, dim3((unsigned)t2), dim3(kTxtThreads), 0, st, d_nl, begin, end, last, S, E,
-                           carry_cap, d_off, d_status + t1, d_state);
+                           carry_cap, fr, d_off, d_status + t1, d_state);
     else
         hipLaunchKernelGGL(k_text_records<false>, dim3((unsigned)t2), dim3(kTxtThreads), 0, st, d_nl, begin, end, last, S,
-                           E, carry_cap, d_off, d_status + t1, d_state);
+                           E, carry_cap, fr, d_off, d_status + t1, d_state);
     return hipGetLastError();
 }
 
@@ -377,12 +448,12 @@ hipError_t launch_text_gather(const uint8_t *d_slot, const uint32_t *d_nl, const
     return hipGetLastError();
 }
 
-hipError_t launch_text_trim(const uint8_t *d_slot, const uint32_t *d_nl, uint32_t begin, const uint64_t *d_off, uint32_t n,
-                            uint32_t S, uint32_t E, uint8_t *d_out, int n_cu, hipStream_t st)
+hipError_t launch_text_trim(const uint8_t *d_slot, const uint32_t *d_nl, uint32_t begin, int at_begin, const uint64_t *d_off,
+                            uint32_t n, uint32_t S, uint32_t E, uint8_t *d_out, int n_cu, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_text_trim, dim3(copy_grid(n, n_cu)), dim3(kTxtThreads), 0, st, d_slot, d_nl, begin, d_off, n, S, E,
-                       d_out);
+    hipLaunchKernelGGL(k_text_trim, dim3(copy_grid(n, n_cu)), dim3(kTxtThreads), 0, st, d_slot, d_nl, begin, at_begin, d_off, n,
+                       S, E, d_out);
     return hipGetLastError();
 }
 

@@ -192,7 +192,9 @@ int main(int argc, char *argv[])
         BamReader *rd = &bam;
         if (!whole) {
             uint64_t vo = 0;
-            if (!bai_region_start(infiles[i], hdr.n_targets(), ref, (uint32_t)beg, &vo)) more = false;   // the target holds no record
+            const int have = bai_region_start(infiles[i], hdr.n_targets(), ref, (uint32_t)beg, &vo);
+            if (have == 0) more = false;   // the target holds no record
+            else if (have < 0) rd = &bam;  // index present (checked above) but not usable: every record from the top, filtered below
             else if (!at.open_at(infiles[i], vo)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
             else rd = &at;
             if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] region: reading from virtual offset %llu\n", (unsigned long long)vo);

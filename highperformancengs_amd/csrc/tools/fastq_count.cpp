@@ -43,13 +43,13 @@ static void usage(const char *prog)
     exit(1);
 }
 
-static void count_file(hpn_ctx *ctx, const char *infile, FILE *out)
+static void count_file(hpn_ctx *ctx, WorkerLanes &lanes, const char *infile, FILE *out)
 {
     int rc;
     hpn_tally acc;
     memset(&acc, 0, sizeof acc);
     bool too_long = false;
-    rc = tally_file(ctx, infile, &acc, &too_long);  // count_read's loop (:112-119), tally on the GPU
+    rc = tally_file(ctx, infile, &acc, &too_long, lanes.for_file(infile));  // count_read's loop (:112-119), tally on the GPU(s)
     if (too_long) {
         fprintf(stderr, "%s: read longer than 511 bases (outside fastq_count's SeqLen[512])\n", infile);
         exit(2);
@@ -65,14 +65,18 @@ static void count_file(hpn_ctx *ctx, const char *infile, FILE *out)
 
 // One worker = one host thread + one GPU context, like one kt_for worker of the reference;
 // it takes the next unprocessed file (fastq_count.c:213-230 runs them in waves of T).
-static void worker(int slot, FILE *out)
+// With fewer files in flight than devices, a worker spreads each of its inputs over its share of the
+// devices by record block (host/text_shard.hpp; the reference stops at one file per thread).
+static void worker(int slot, int workers, FILE *out)
 {
     hpn_ctx *ctx = nullptr;
     const double t0 = wall_s();
-    const int rc = hpn_ctx_create(g_dev0 + slot % g_ndev, &ctx);
+    const int rel = WorkerLanes::device_of(g_ndev, workers, slot);
+    const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
     if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] worker %d: context %.3f s\n", slot, wall_s() - t0);
-    for (int i; (i = g_next.fetch_add(1)) < g.numInfiles;) count_file(ctx, g.infiles[i], out);
+    WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers));
+    for (int i; (i = g_next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, g.infiles[i], out);
 }
 
 int main(int argc, char *argv[])
@@ -102,10 +106,10 @@ int main(int argc, char *argv[])
     FILE *out = fopen_output_stream(g.outfile);
     if (g.header) print_count_header(out);
     {
-        const int workers = text_workers(g.infiles, g.numInfiles, g.thread);
+        const int workers = text_workers(g.infiles, g.numInfiles, g.thread, g_ndev);
         text_workers_in_flight() = workers;
         std::vector<std::thread> th;
-        for (int j = 0; j < workers && j < g.numInfiles; ++j) th.emplace_back(worker, j, out);
+        for (int j = 0; j < workers && j < g.numInfiles; ++j) th.emplace_back(worker, j, workers < g.numInfiles ? workers : g.numInfiles, out);
         for (auto &t : th) t.join();
     }
     fprintf(stderr, "Finished at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);

@@ -49,11 +49,11 @@ static void usage(const char *prog)
     exit(1);
 }
 
-static void count_file(hpn_ctx *ctx, FileAcc &fa, const char *infile)
+static void count_file(hpn_ctx *ctx, WorkerLanes &lanes, FileAcc &fa, const char *infile)
 {
     int rc;
     bool too_long = false;
-    rc = tally_file(ctx, infile, &fa.t, &too_long);  // count_read's loop (:126-135), tally on the GPU
+    rc = tally_file(ctx, infile, &fa.t, &too_long, lanes.for_file(infile));  // count_read's loop (:126-135), tally on the GPU(s)
     if (too_long) {
         fprintf(stderr, "%s: read longer than 511 bases (outside SeqLen[512])\n", infile);
         exit(2);
@@ -106,14 +106,19 @@ int main(int argc, char *argv[])
         }
         std::atomic<long> next{0};
         std::vector<std::thread> th;
-        const int workers = text_workers(g.infiles, g.numInfiles, g.thread < 1 ? 1 : g.thread);
+        const int workers = text_workers(g.infiles, g.numInfiles, g.thread < 1 ? 1 : g.thread, g_ndev);
         text_workers_in_flight() = workers;
         for (int t = 0; t < workers; ++t)
             th.emplace_back([&, t] {  // one kt_for worker (klib/kthread.c:34-60) = one thread + one GPU context
+                // ... and, with fewer files in flight than devices, its share of the devices to spread each input over
+                // by record block (host/text_shard.hpp); the lanes' count vectors are summed where reduceStats sums files
                 hpn_ctx *ctx = nullptr;
-                const int rc = hpn_ctx_create(g_dev0 + t % g_ndev, &ctx);
+                const int nw = workers < g.numInfiles ? workers : g.numInfiles;
+                const int rel = WorkerLanes::device_of(g_ndev, nw, t);
+                const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
                 if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
-                for (long i; (i = next.fetch_add(1)) < g.numInfiles;) count_file(ctx, acc[(size_t)i], g.infiles[i]);
+                WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, nw));
+                for (long i; (i = next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, acc[(size_t)i], g.infiles[i]);
             });
         for (auto &t : th) t.join();
 

@@ -56,7 +56,10 @@ int main(int argc, char *argv[])
         return 2;
     }
     hpn_ctx *ctx = nullptr;
-    int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
+    int dev0 = 0, ndev = 1;
+    if (const char *d = getenv("HPN_DEVICE")) dev0 = atoi(d);
+    else if (hpn_device_count(&ndev) != HPN_OK || ndev < 1) ndev = 1;
+    int rc = hpn_ctx_create(dev0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
 
     FILE *out = fcreat_outfile(outfile, ".trim.fastq");
@@ -160,6 +163,19 @@ int main(int argc, char *argv[])
         }
         if (usable) done = true;
         else start_over();
+    }
+    // Plain text over several GPUs: record blocks of the one input go to one context per device, every lane cuts its
+    // pieces, the output slabs are written in piece order (host/text_shard.hpp; no collective).  Irregular text: the
+    // output is emptied and the input goes through the one-context path below from its first byte.
+    if (!done && !exact && to_file && from_file) {
+        WorkerLanes lanes(ctx, dev0, 0, ndev, WorkerLanes::cap(ndev, 1));
+        if (LaneGroup *group = lanes.for_file(infile)) {
+            bool irregular = false;
+            rc = trim_text_sharded(*group, infile, start, end, out, &reads, &irregular);
+            if (rc != HPN_OK) die_hpn(ctx, rc, "fastq_trim");
+            if (irregular) start_over();
+            else done = true;
+        }
     }
     if (done) {
     } else if (!exact) {

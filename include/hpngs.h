@@ -229,6 +229,38 @@ int hpn_fastq_text_records(hpn_ctx *ctx, const void *text, uint64_t nbytes, int 
 int hpn_fastq_text_trim(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, int32_t S, int32_t E,
                         void *out_text, uint64_t out_cap, hpn_text_info *info);
 
+/* ---- ONE text stream framed by several contexts (one per GPU): pieces ----------------------------
+ * Record-block sharding of a single FASTQ input (the reference's parallelism stops at
+ * whole files, fastq_count.c:213-230, klib/kthread.c:34-60).  The stream's bytes T[0, N) are cut at
+ * arbitrary positions 0 = b_0 < b_1 < ... into pieces [b_j, b_j+1).  A piece OWNS the records whose
+ * first byte lies in it.  Which lines start a record depends on how many lines the stream has before
+ * the piece, so a piece is framed in two steps, each on the context that holds it:
+ *
+ *   hpn_fastq_text_piece_lines   text = T[b_j - head, b_j+1 + tail): `head` = 1 byte in front of the
+ *       piece (0 for the stream's first piece), own_bytes = b_j+1 - b_j, and a tail of the following
+ *       bytes -- 4096 hold the rest of any regular record that starts in the piece (fewer only where the
+ *       stream ends); last != 0: the piece ends the stream (no tail).  Copies, indexes the lines and
+ *       returns out->n_lines = number of '\n' in T[b_j - head, b_j+1 - 1): the n_lines of pieces
+ *       0 .. j-1 add up to the lines in front of piece j's text -- the only thing pieces tell each other.
+ *   hpn_fastq_text_piece_count / _trim   lines_before = that sum.  Frames the records the piece owns
+ *       and tallies / trims them exactly like hpn_fastq_text_count / _trim do for a chunk.
+ *
+ * Irregular text (same conditions; a record that does not end inside the tail counts as a long line)
+ * is reported in ->irregular by either call and nothing is added: the caller frames the WHOLE stream
+ * another way.  No bytes are carried between pieces, so different contexts may work on different
+ * pieces at the same time; one context handles one piece at a time. */
+typedef struct hpn_text_piece {
+    uint64_t n_lines;
+    uint32_t irregular; /* HPN_TEXT_* reasons visible without record framing (NUL, DENSE) */
+    uint32_t reserved;
+} hpn_text_piece;
+#define HPN_TEXT_PIECE_TAIL 4096u
+int hpn_fastq_text_piece_lines(hpn_ctx *ctx, const void *text, uint64_t nbytes, uint32_t head, uint64_t own_bytes,
+                               int last, hpn_text_piece *out);
+int hpn_fastq_text_piece_count(hpn_ctx *ctx, uint64_t lines_before, uint32_t tally_flags, hpn_text_info *info);
+int hpn_fastq_text_piece_trim(hpn_ctx *ctx, uint64_t lines_before, int32_t S, int32_t E, void *out_text,
+                              uint64_t out_cap, hpn_text_info *info);
+
 /* ---- BGZF: inflate on the device ------------------------------------------------------------
  * A BAM / bgzip file is a chain of independent gzip members of at most 64 KiB (SAM spec 4.1);
  * the reference inflates them one by one on the host (samtools-0.1.19 bgzf.c:214-307).  Here
@@ -387,6 +419,16 @@ int hpn_comm_unique_id(uint8_t id[HPN_UNIQUE_ID_BYTES]);
 int hpn_comm_init(hpn_ctx *ctx, int rank, int n_ranks, const uint8_t id[HPN_UNIQUE_ID_BYTES]);
 int hpn_comm_destroy(hpn_ctx *ctx);
 int hpn_allreduce_u64(hpn_ctx *ctx, uint64_t *d_vec, size_t n);
+/* The same for ONE process that owns several contexts (the C tools sharding one input over the node's
+ * GPUs): hpn_comm_init_all builds one communicator per context (ncclCommInitAll; the contexts must sit
+ * on n distinct devices, else HPN_E_ARG and nothing is made -- callers then add the vectors on the
+ * host), hpn_allreduce_u64_all sums d_vecs[i] (on ctxs[i]'s device) in place into every one of them in
+ * one RCCL group, each on its context's stream; the call returns when all have finished.  This is where
+ * reduceStats' element-wise sum goes (fastq_count_kthread.c:180-210).  hpn_comm_library: the path of
+ * the RCCL library the binding resolved to ("" before the first use / when none could be loaded). */
+int hpn_comm_init_all(hpn_ctx **ctxs, int n);
+int hpn_allreduce_u64_all(hpn_ctx **ctxs, uint64_t **d_vecs, int n, size_t n_words);
+const char *hpn_comm_library(void);
 
 /* ---- synthetic inputs, generated in HBM -----------------------------------
  * Counter-based: byte k of record r depends only on (seed, r, k), so any shard

@@ -72,6 +72,68 @@ def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
         assert open(tmp_path / f, "rb").read() == expected(case, f), f
 
 
+# ONE FASTQ input over several GPUs (host/text_shard.hpp): the input's bytes go in pieces cut anywhere to one
+# context per device, every lane frames and tallies / trims the records its pieces own, the lanes' count vectors are summed
+# where reduceStats sums files (fastq_count_kthread.c:180-210), trimmed slabs are written in piece order.  HPN_NGPU forces
+# that many lanes on whatever devices exist, so the route runs on a one-GPU box: the bytes must be the reference's, and
+# regular plain / host-inflated text must really have taken the route.
+SHARDED_REGULAR = {"count_a1", "count_a1_gz", "count_empty", "count_crlf", "count_multi", "count_syn_var_a", "count_syn_var_b",
+                   "count_syn_100", "count_to_file", "kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty",
+                   "trim_a1_file", "trim_syn_var", "trim_syn_100", "trim_crlf"}
+
+
+@pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_TEXT_CHUNK": "8192"}, {"HPN_NGPU": "5", "HPN_TEXT_CHUNK": "20000"}],
+                         ids=["2lanes", "3lanes-8k", "5lanes-20k"])
+@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("count_", "kthread_", "trim_"))])
+def test_drop_in_one_fastq_over_several_lanes(manifest, case, env, tmp_path):
+    c = manifest[case]
+    args = list(c["args"])
+    if c["tool"] == "fastq_count" and "-t" not in args:
+        args = ["-t", "1"] + args
+    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, {**env, "HPN_TIMING": "1"})
+    assert p.returncode == c["returncode"], p.stderr.decode()
+    assert p.stdout == expected(case), p.stderr.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    took = p.stderr.count(f"one input over {env['HPN_NGPU']} lanes".encode())
+    if case in SHARDED_REGULAR:
+        assert took >= 1 and b"abandoned" not in p.stderr, p.stderr.decode()
+        assert b"(lanes share a device)" in p.stderr       # and said how the sum was made
+    if c["tool"] == "fastq_trim" and "-o" not in args:
+        assert took == 0                                    # output to stdout cannot be rewound: one context
+
+
+def test_sharded_route_on_a_larger_file(tmp_path):
+    """5e5 reads (~160 MB): 4 lanes, 1 MiB pieces -> ~160 pieces racing through the board; the three tools' outputs equal
+    the one-context route's, which the goldens pin to the reference."""
+    n, L = 500000, 150
+    seq, qual, off = orc.synth_soa(777, 0, n, L, L)
+    s, q = seq.reshape(n, L), qual.reshape(n, L)
+    with open(tmp_path / "big.fq", "wb") as fh:
+        for i in range(n):
+            fh.write(b"@read%d/1\n" % i + s[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n")
+    outs = {}
+    for tag, env in (("one", {}), ("four", {"HPN_NGPU": "4", "HPN_TEXT_CHUNK": str(1 << 20), "HPN_TIMING": "1"})):
+        d = tmp_path / tag
+        d.mkdir()
+        e = {**os.environ, **env}
+        a = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "../big.fq"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        b = subprocess.run([os.path.join(BIN, "fastq_count_kthread"), "-L", "../big.fq"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        t = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", "../big.fq", "-s", "5", "-e", "140", "-o", "t"], cwd=d, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=e)
+        assert a.returncode == 0 and b.returncode == 0 and t.returncode == 0, (a.stderr, b.stderr, t.stderr)
+        if tag == "four":
+            for r in (a, b, t):
+                assert b"one input over 4 lanes" in r.stderr and b"abandoned" not in r.stderr, r.stderr.decode()
+        outs[tag] = (a.stdout, b.stdout, open(d / "big.fq.0.tsv", "rb").read(), open(d / "t.trim.fastq", "rb").read(),
+                     [l for l in t.stderr.split(b"\n") if l.startswith(b"Total_reads")])
+    assert outs["one"] == outs["four"]
+    assert outs["one"][4] == [b"Total_reads: %d" % n]
+    row = outs["one"][0].decode().split("\n")[1].split("\t")
+    assert int(row[1]) == n and int(row[2]) == n * L
+
+
 # The BAM tools inflate BGZF blocks and walk the records on the GPU when every block starts at a
 # record boundary (as samtools writes them), else on the host: both routes, and compressed
 # chunks that cut blocks every 64 KiB, must give the reference's bytes.
