@@ -373,6 +373,28 @@ class Context:
                  "hpn_synth_fastq_dev")
 
 
+def comm_init_all(ctxs):
+    """One communicator per context of THIS process (ncclCommInitAll): the contexts must sit on distinct devices."""
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    rc = _lib.lib().hpn_comm_init_all(arr, len(ctxs))
+    if rc != 0:
+        raise HpnError(rc, "hpn_comm_init_all", _lib.lib().hpn_ctx_last_error(ctxs[0].h).decode() if ctxs else "")
+
+
+def allreduce_u64_all(ctxs, d_vecs, n_words):
+    """Sum d_vecs[i] (on ctxs[i]'s device) in place into every one of them, in one RCCL group."""
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    vec = (C.c_void_p * len(ctxs))(*[v if isinstance(v, int) else _ptr(v) for v in d_vecs])
+    rc = _lib.lib().hpn_allreduce_u64_all(arr, vec, len(ctxs), n_words)
+    if rc != 0:
+        raise HpnError(rc, "hpn_allreduce_u64_all", _lib.lib().hpn_ctx_last_error(ctxs[0].h).decode() if ctxs else "")
+
+
+def comm_library() -> str:
+    """Path of the RCCL library the binding resolved to ('' before the first use / when none could be loaded)."""
+    return _lib.lib().hpn_comm_library().decode()
+
+
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
     rc = _lib.lib().hpn_comm_unique_id(buf)

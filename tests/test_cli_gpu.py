@@ -79,7 +79,7 @@ def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
 # regular plain / host-inflated text must really have taken the route.
 SHARDED_REGULAR = {"count_a1", "count_a1_gz", "count_empty", "count_crlf", "count_multi", "count_syn_var_a", "count_syn_var_b",
                    "count_syn_100", "count_to_file", "kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty",
-                   "trim_a1_file", "trim_syn_var", "trim_syn_100", "trim_crlf"}
+                   "trim_a1_file", "trim_syn_100"}
 
 
 @pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_TEXT_CHUNK": "8192"}, {"HPN_NGPU": "5", "HPN_TEXT_CHUNK": "20000"}],

@@ -45,3 +45,36 @@ def test_allreduce_without_comm_is_a_state_error():
         ctx.allreduce_u64(v, 4)
     assert e.value.status == _lib.E_STATE
     ctx.close()
+
+
+def test_grouped_allreduce_of_one_process():
+    """hpn_comm_init_all / hpn_allreduce_u64_all: the C tools' collective (one process, one communicator per context).
+    On the one-GPU box: a group of one context is the identity and keeps the tally; two contexts on ONE device are
+    refused (one RCCL rank per device) without making anything -- the tools then add the vectors on the host."""
+    import torch
+    import highperformancengs_amd as hp
+    from highperformancengs_amd import _lib, api
+    import orc
+    a, b = hp.Context(0), hp.Context(0)
+    with pytest.raises(hp.HpnError) as e:
+        api.comm_init_all([a, b])
+    assert e.value.status == _lib.E_ARG
+    with pytest.raises(hp.HpnError) as e:
+        api.allreduce_u64_all([a], [a.tally_devptr()], 8)     # nothing was made by the refused call
+    assert e.value.status == _lib.E_STATE
+    api.comm_init_all([a])
+    lib = api.comm_library()
+    assert "rccl" in lib
+    # inside a torch process the binding must have found the RCCL torch already mapped, not a second one beside it
+    maps = open("/proc/self/maps").read()
+    assert len({l.split()[-1] for l in maps.splitlines() if "librccl" in l}) == 1, lib
+    seq, qual, off = orc.synth_soa(12, 0, 4000, 30, 151)
+    dq, do = torch.from_numpy(qual).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    a.fastq_tally_dev(dq, do, 4000)
+    api.allreduce_u64_all([a], [a.tally_devptr()], _lib.TALLY_WORDS)
+    got = a.fastq_tally_fetch()
+    rc, want = orc.count_soa(qual, off)
+    s = want.summary()
+    assert np.array_equal(got.seqlen, want.seqlen) and (got.total, got.q20, got.q30) == (s.sum, s.q20, s.q30)
+    a.close()
+    b.close()

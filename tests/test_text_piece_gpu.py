@@ -101,13 +101,9 @@ def _count(ctxs, text, cuts, order=None):
             parts.append(None)
     if res is None:
         return None, (flags[0] if flags else f), 0
-    tot = parts[0]
-    for p in parts[1:]:
-        tot.seqlen = tot.seqlen + p.seqlen
-        tot.qual_hist = tot.qual_hist + p.qual_hist
-        tot.total += p.total
-        tot.q20 += p.q20
-        tot.q30 += p.q30
+    from types import SimpleNamespace
+    tot = SimpleNamespace(seqlen=sum(p.seqlen for p in parts), qual_hist=sum(p.qual_hist for p in parts),
+                          total=sum(p.total for p in parts), q20=sum(p.q20 for p in parts), q30=sum(p.q30 for p in parts))
     return tot, 0, sum(res)
 
 
