@@ -157,6 +157,8 @@ def main():
     if allreduce == "torch.distributed" and rank == 0:
         print(f"[bench] native RCCL init failed on some rank ({getattr(job, 'why', 'another rank')}); using torch.distributed",
               file=sys.stderr)
+    from highperformancengs_amd import api as _api
+    rccl_lib = _api.comm_library() if allreduce.startswith("rccl") or world == 1 else None   # which librccl the native binding resolved to
     kernel_ms = []
 
     def step():
@@ -210,13 +212,16 @@ def main():
         alg_bytes = n * L + (n + 1) * 8  # 1 B per base + 8 B per record, per launch
         k_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if measured
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so this is the figure of the
+        # separate `--pmc` passes over this same command, kept in profiles/traffic.json (traffic_source says which run)
+        traffic, traffic_source = None, None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
                 t = json.load(open(tj))
                 if t.get("reads_per_launch") == n and t.get("read_len") == L and not a.full_matrix:
                     traffic = t.get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, round {t.get('round')}; not measured by this run)"
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
@@ -228,9 +233,10 @@ def main():
                                    f"(BASELINE configs[1]; gzip inflate is host work, excluded)",
                        "reads_per_gpu": n, "read_len": L, "kernel": "k_tally_hist" if a.full_matrix else "k_tally_scan",
                        "outputs": "SeqLen[512], sum, Q20, Q30" + (", Quality[128][512]" if a.full_matrix else ""),
-                       "parallelism": f"record-block shard x{world}", "allreduce": allreduce},
+                       "parallelism": f"record-block shard x{world}", "allreduce": allreduce,
+                       "rccl_library": rccl_lib},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:

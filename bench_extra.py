@@ -28,10 +28,16 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 PEAK = 8000.0
 
 
-def _leg(name, ms, alg_bytes, **more):
+def _leg(name, ms, alg_bytes, bytes_touched=None, **more):
+    """algorithmic_bytes: SURVEY.md 8(d)'s formula for the kernel, the figure `frac` is computed from.  bytes_touched: what
+    the kernel really has to move where that differs (wider offsets, fields 8(d) does not count) -- reported, not priced."""
     gbs = alg_bytes / ms / 1e6
-    return {"kernel": name, "kernel_ms": round(ms, 4), "algorithmic_bytes": int(alg_bytes), "achieved_GBps": round(gbs, 1),
-            "frac": round(gbs / PEAK, 4), **more}
+    leg = {"kernel": name, "kernel_ms": round(ms, 4), "algorithmic_bytes": int(alg_bytes), "achieved_GBps": round(gbs, 1),
+           "frac": round(gbs / PEAK, 4), **more}
+    if bytes_touched is not None:
+        leg["bytes_touched"] = int(bytes_touched)
+        leg["frac_bytes_touched"] = round(bytes_touched / ms / 1e6 / PEAK, 4)
+    return leg
 
 
 def _median_ms(ctx, fn, family, reps):
@@ -118,8 +124,10 @@ def kernel_legs(ctx, reps=5):
     ob = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
     oo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     ms = _median_ms(ctx, lambda: ctx.fastq_trim_dev(db, dq, do, n, S, E, ob, oq, oo), 1, reps)
+    # 8(d): read 2*Sum(len) + 8n, write 2*Sum(newlen) + 8n; the kernels read the 8-byte offsets twice (scan, then copy)
     legs.append(_leg("K2 k_trim_scan + k_trim_copy: fastq_trim -s 5 -e 140, one mate", ms,
-                     2 * n * L + 16 * n + 2 * n * (E - S) + 8 * n, reads=n, read_len=L))
+                     2 * n * L + 8 * n + 2 * n * (E - S) + 8 * n, bytes_touched=2 * n * L + 16 * n + 2 * n * (E - S) + 8 * n,
+                     reads=n, read_len=L))
     # trimmed output = strided view of the input (exact, on the device)
     assert int(oo[-1].item()) == n * (E - S)
     k = 1_000_003
@@ -204,7 +212,7 @@ def kernel_legs(ctx, reps=5):
         del blk, hi, lo, per
     assert int(gc.sum()) == want_gc, (int(gc.sum()), want_gc)
     legs.append(_leg("K5 k_window_add: per-window count / GC / length (bam_sliding_count fetch_func + cal_GC)",
-                     statistics.median(ts5), n * (20 + (L + 1) // 2), records=n))
+                     statistics.median(ts5), n * (12 + (L + 1) // 2), bytes_touched=n * (20 + (L + 1) // 2), records=n))   # 8(d): n x (12 B + ceil(l_qseq / 2)); the SoA view also holds flag and the 8-byte seq_off
     del d, tid, pos, fl, cigar, cigar_off, m_per
     torch.cuda.empty_cache()
     return legs
@@ -326,6 +334,86 @@ def _outputs(d, inputs):
     return sorted(f for f in os.listdir(d) if f not in inputs and not f.endswith("_hits.png"))
 
 
+def _steady_state_legs(ctx, cores, td, pair, L):
+    """Inputs large enough that start-up (HIP init + context + exit, measured on a one-record file and reported as
+    startup_s) is a few per cent of the wall: what the tools sustain from the page cache over one PCIe link."""
+    import torch
+    legs = []
+    free = shutil.disk_usage(td).free
+    n_small, n_big = 13_000_000, 52_000_000                     # 4.1 GB and 16.3 GB of text
+    if free < 60 << 30:
+        return [{"leg": "steady state", "skipped": f"{free >> 30} GiB free in {td}"}]
+    rec = 14 + 2 * L
+    with open(os.path.join(td, "one.fq"), "wb") as f:
+        f.write(_fastq_text(ctx, 1, L, 5).tobytes())
+    t_start = min(_timed([os.path.join(BIN, "fastq_count"), "one.fq"], td)[0] for _ in range(3))
+    # 16.3 GB as four generator blocks (host memory stays near 4 GB); the first block alone is small.fq
+    with open(os.path.join(td, "big.fq"), "wb") as fb, open(os.path.join(td, "small.fq"), "wb") as fs:
+        for k in range(4):
+            blk = _fastq_text(ctx, n_small, L, 40 + k)
+            fb.write(blk.data)
+            if k == 0:
+                fs.write(blk.data)
+            del blk
+    torch.cuda.empty_cache()
+    names8 = [f"s{i}.fq" for i in range(8)]
+    for nm in names8:
+        os.symlink(os.path.join(td, "small.fq"), os.path.join(td, nm))
+
+    def ours_only(label, tool, args, inputs, unit_bases, env=None, compare_to=None):
+        wd = tempfile.mkdtemp(prefix="ours_", dir=td)
+        for i in inputs:
+            os.symlink(os.path.join(td, i), os.path.join(wd, i))
+        _timed([os.path.join(BIN, tool)] + args, wd, env)
+        for f in _outputs(wd, inputs):
+            os.unlink(os.path.join(wd, f))
+        dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
+        res = {"leg": label, "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode},
+               "reference": None, "startup_s": round(t_start, 3), "startup_share": round(t_start / dt, 3)}
+        out = {f: open(os.path.join(wd, f), "rb").read() for f in _outputs(wd, inputs)}
+        if compare_to is not None:
+            res["outputs_identical_to"] = compare_to[0]
+            res["outputs_identical"] = bool(out == compare_to[1])
+        shutil.rmtree(wd, ignore_errors=True)
+        return res, out
+
+    big_bases, small_bases = n_big * L, n_small * L
+    # (fastq_count_kthread: fastq_count prints its rows in completion order, which no two runs share)
+    r = pair(f"fastq_count_kthread -t 8, 8 plain files x {n_small:.1e} x {L} bp ({8 * n_small * rec / 1e9:.1f} GB)", "fastq_count_kthread",
+             lambda wd: ["-t", "8", "-o", "m.tsv"] + names8, names8, 8 * small_bases)
+    r["startup_s"] = round(t_start, 3)
+    legs.append(r)
+    r = pair(f"fastq_count, ONE plain file {n_big:.1e} x {L} bp ({n_big * rec / 1e9:.1f} GB)", "fastq_count",
+             lambda wd: ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases)
+    r["startup_s"] = round(t_start, 3)
+    legs.append(r)
+    # the same file by record block over lanes (host/text_shard.hpp): on this box the lanes share the one device and
+    # its one PCIe link, so this shows the route's overhead, not a gain
+    base, base_out = ours_only("fastq_count, the same ONE file on one context (again, for the comparison below)", "fastq_count",
+                               ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases)
+    lanes, _ = ours_only("fastq_count, the same ONE file by record block over 4 lanes (HPN_NGPU=4, lanes share the device)", "fastq_count",
+                         ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases, env={"HPN_NGPU": "4"}, compare_to=("one context", base_out))
+    legs.extend([base, lanes])
+    os.unlink(os.path.join(td, "big.fq"))
+    # gzip, one member, 4.1 GB of text x 3 members' worth would take the reference minutes: ours only, checked against the
+    # plain-text run of the same reads (which the pair above ties to the reference)
+    raw = open(os.path.join(td, "small.fq"), "rb").read()
+    with open(os.path.join(td, "gz3.fq.gz"), "wb") as f:
+        one = _gz_single_member(raw, 256, cores)
+        for _ in range(3):
+            f.write(one)
+        gz_bytes = 3 * len(one)
+    del raw, one
+    gz, gz_out = ours_only(f"fastq_count, gzip: 3 members x {n_small:.1e} x {L} bp ({gz_bytes / 1e9:.1f} GB compressed, {3 * n_small * rec / 1e9:.1f} GB of text)",
+                           "fastq_count", ["-o", "rep.txt", "gz3.fq.gz"], ["gz3.fq.gz"], 3 * small_bases)
+    row = gz_out.get("rep.txt", b"").decode().split("\t")
+    gz["counts_closed_form"] = bool(len(row) > 2 and int(row[1]) == 3 * n_small and float(row[2]) == 3 * small_bases)
+    legs.append(gz)
+    for nm in names8 + ["small.fq", "gz3.fq.gz", "one.fq"]:
+        os.unlink(os.path.join(td, nm))
+    return legs
+
+
 def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
     legs = []
     td = tempfile.mkdtemp(prefix="hpn_e2e_")
@@ -378,6 +466,10 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
                          lambda wd: ["-i", "plain.fq", "-s", "5", "-e", "140", "-o", "t"], ["plain.fq"], bases))
         for f in ("plain.fq", "members.fq.gz", "single.fq.gz"):
             os.unlink(os.path.join(td, f))
+        try:
+            legs.extend(_steady_state_legs(ctx, cores, td, pair, L))
+        except Exception as e:  # noqa: BLE001  (disk or memory of the box: the short legs above stand)
+            legs.append({"leg": "steady state", "failed": str(e)[:300]})
         # ---- BAM --------------------------------------------------------------------------------------------------
         synth = os.path.join(td, "bam_synth")
         subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "scripts", "bam_synth.cpp"), "-o", synth, "-lz", "-lpthread"])
