@@ -480,6 +480,59 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
         for tool, args in (("bam2depth", ["-o", "d", "s.bam"]), ("bam2wig", ["-o", "w", "s.bam"]), ("bam_sliding_count", ["-o", "s", "s.bam"])):
             legs.append(pair(f"{tool}, {bam_reads:.0e} x 150 bp over 2 x {contig / 1e6:.0f} Mb (30x), BAM {bsz / 1e6:.0f} MB -> reports", tool,
                              lambda wd, a=args: a, ins, bam_reads * 150))
+        try:
+            legs.extend(_c4_file_legs(cores, td))
+        except Exception as e:  # noqa: BLE001
+            legs.append({"leg": "C4 as files", "failed": str(e)[:300]})
     finally:
         shutil.rmtree(td, ignore_errors=True)
+    return legs
+
+
+def _c4_file_legs(cores, td):
+    """BASELINE configs[3] as a FILE: the 25 hg38 primary contigs at their true lengths (30x on chr21 + chrM, 3x on the
+    rest: 7.0e7 reads, ~10 GB of BAM -- the full 30x file is ~90 GB, more than the box's disk) through the built binaries,
+    every output byte against the oracle run on the generator's own records (tests/c4.py; checker use).  The reference
+    binaries would need ~3 minutes each on this file: not timed here (their rate is in the 4e6-read legs above)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import c4
+    if shutil.disk_usage(td).free < 40 << 30:
+        return [{"leg": "C4 as files", "skipped": "less than 40 GiB free"}]
+    tg = c4.targets(lambda n, l: 30.0 if n in ("chr21", "chrM") else 3.0)
+    n_reads = sum(r for _, _, r in tg)
+    t0 = time.perf_counter()
+    bam, prefix = c4.synth(td, "hg38.bam", tg, max(2, cores - 1))
+    t_synth = time.perf_counter() - t0
+    soa = c4.Soa(prefix, len(tg))
+    for ext in (".tid", ".pos", ".flag", ".kind", ".seq4"):
+        os.unlink(prefix + ext)
+    W, legs = 20000, []
+    shape = f"{n_reads:.2e} x 150 bp over the 25 hg38 contigs (30x chr21 + chrM, 3x the rest), BAM {os.path.getsize(bam) / 1e9:.1f} GB"
+    for tool, args, env in (("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {}),
+                            ("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {"HPN_NGPU": "3"}),
+                            ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {}),
+                            ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "3"})):
+        wd = tempfile.mkdtemp(prefix="c4_", dir=td)
+        os.symlink(bam, os.path.join(wd, "hg38.bam")), os.symlink(bam + ".bai", os.path.join(wd, "hg38.bam.bai"))
+        dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
+        leg = {"leg": f"{tool} -w {W}{' on 3 workers (HPN_NGPU=3, one device)' if env else ''}, {shape}",
+               "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(n_reads * 150 / dt / 1e9, 3), "rc": p.returncode}, "reference": None}
+        if tool == "bam2depth":
+            ok, n_runs = True, 0
+            with open(os.path.join(wd, "hg38.bam.1.bedGraph"), "rb") as fb, open(os.path.join(wd, "d.1.depth"), "rb") as fd:
+                for t, (name, tlen, _) in enumerate(tg):
+                    runs, bins = c4.oracle_depth_target(soa, tg, t, W)
+                    bed, dep = c4.oracle_target_text(name, tlen, W, runs, bins)
+                    ok = ok and fb.read(len(bed)) == bed and fd.read(len(dep)) == dep
+                    n_runs += len(runs)
+                ok = ok and fb.read(1) == b"" and fd.read(1) == b""
+            leg["outputs_identical_to"], leg["outputs_identical"], leg["bedgraph_lines"] = "oracle (orc_depth_target per target)", bool(ok), n_runs
+        else:
+            leg["outputs_identical_to"] = "oracle (orc_window_add + float32 replay)"
+            leg["outputs_identical"] = bool(open(os.path.join(wd, "s.txt"), "rb").read() == c4.oracle_window_report(soa, tg, W))
+        shutil.rmtree(wd, ignore_errors=True)
+        legs.append(leg)
+    legs[0]["input_made_in_s"] = round(t_synth, 1)
+    os.unlink(bam), os.unlink(bam + ".bai")
     return legs

@@ -107,7 +107,7 @@ def test_hg38_shaped_bam_through_the_tools(tmp_path):
             runs_total += len(runs)
             del runs, bins, bed, dep, got
         assert fb.read(1) == b"" and fd.read(1) == b""
-    assert runs_total > 1.0e8                                     # ~1.2e8 lines: the writer's volume is part of the shape
+    assert runs_total > 3.0e7                                     # (evenly spaced starts: a read start often meets a read end; random starts would give ~1.2e8)
     # ---- bam2depth over three workers: the same files ------------------------------------------------------------------
     d3 = tmp_path / "three"
     d3.mkdir()
