@@ -15,6 +15,7 @@ W_SEQLEN, W_TOTAL, W_Q20, W_Q30, W_BAD, W_QUAL = 0, 512, 513, 514, 515, 516
 W_NUC = W_QUAL + QUAL_ROWS * LEN_BINS
 TALLY_WORDS = W_NUC + NUC_CODES * LEN_BINS
 TALLY_QUAL_HIST, TALLY_NUC_HIST = 1, 2
+DEPTH_ANY_ORDER = 0x80000000
 UNIQUE_ID_BYTES = 128
 
 OK, E_NODEVICE, E_HIP, E_ARG, E_DOMAIN, E_NOMEM, E_STATE, E_RCCL, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -117,6 +118,7 @@ SYMBOLS = [
     ("hpn_depth_add_raw_dev", _int, [_vp, _vp]),
     ("hpn_window_add_raw_dev", _int, [_vp, _vp]),
     ("hpn_depth_begin", _int, [_vp, _i32, _u32, _u32]),
+    ("hpn_depth_begin_w", _int, [_vp, _i32, _u32, _u32, _u32]),
     ("hpn_depth_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_add_dev", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_finish", _int, [_vp, _u32, _vp, _u64, C.POINTER(_u64), _vp]),

@@ -202,7 +202,7 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
                 claimed[(size_t)j] = 1, ++next, outstanding += estimate(j);
             }
             TargetOut &o = out[(size_t)j];
-            int rc = hpn_depth_begin(ctx, j, hdr.target_len[j], mask);
+            int rc = hpn_depth_begin_w(ctx, j, hdr.target_len[j], mask, want_win ? window : 0u);
             if (rc == HPN_OK && first[(size_t)j] != ~0ull) {
                 ok = gs.seek(first[(size_t)j]);
                 hpn_raw_info info;

@@ -8,15 +8,20 @@
 namespace hpn {
 hipError_t launch_depth_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
                             const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots,
-                            void *ws, uint32_t *bad, int n_cu, hipStream_t st);
+                            void *ws, void *sws, hpn_run *runs, uint64_t runs_cap, u64 *win_sw, uint32_t target_len, uint32_t W,
+                            uint32_t *bad, int n_cu, hipStream_t st);
 hipError_t launch_depth_add_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
-                                uint64_t slots, void *ws, uint32_t *bad, int n_cu, hipStream_t st);
+                                uint64_t slots, void *ws, void *sws, hpn_run *runs, uint64_t runs_cap, u64 *win_sw, uint32_t target_len,
+                                uint32_t W, uint32_t *bad, int n_cu, hipStream_t st);
+size_t depth_sweep_bytes(uint64_t slots);
+hipError_t depth_sweep_reset(void *sws, uint64_t slots, bool enabled, hipStream_t st);
+hipError_t launch_win_from_runs(const hpn_run *runs, uint64_t n_runs, uint32_t target_len, uint32_t W, u64 *win_sum, int n_cu, hipStream_t st);
 size_t depth_index_bytes(uint64_t slots);
 hipError_t depth_index_reset(void *ws, uint64_t slots, hipStream_t st);
 const uint32_t *depth_written(void *ws, uint64_t slots);
 size_t depth_scan_bytes(uint64_t slots);
 hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
-                             uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st);
+                             uint64_t runs_cap, u64 *win_sum, void *ws, void *sws, hipStream_t st);
 uint64_t bedgraph_text_bound(uint64_t n_runs, int name_len);
 size_t bedgraph_ws_bytes(uint64_t n_runs);
 hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char *name, int name_len, const uint8_t *d_long_name,
@@ -55,36 +60,53 @@ extern "C" {
 
 // ---- bam2depth -------------------------------------------------------------------------
 
-int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_mask)
+int hpn_depth_begin_w(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_mask, uint32_t W)
 {
     if (!c || tid < 0) return HPN_E_ARG;
     HPN_HIP(c, hipSetDevice(c->device));
     uint64_t slots = (uint64_t)target_len + 1 + kOverhang;
     if (slots > kPosLimit) slots = kPosLimit;
+    const bool sweeping = !(flag_mask & HPN_DEPTH_ANY_ORDER);
     int rc = scratch_reserve(c, c->d_diff, slots * sizeof(int32_t) + 64);
     if (rc != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->d_ws, depth_scan_bytes(slots) + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->d_tidx, depth_index_bytes(slots) + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->d_sw, depth_sweep_bytes(slots) + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->w_misc, 64)) != HPN_OK) return rc;
+    // The sweep writes runs while the records come and cannot be run again: the buffer holds the most a target can have
+    // (a run needs a position; 12 B x 2^28 = 3 GB for chr1, of 288 GB).  The two-pass route grows its buffer on demand.
+    if (sweeping && (rc = scratch_reserve(c, c->d_runs, slots * sizeof(hpn_run) + 64)) != HPN_OK) return rc;
+    if (sweeping && W) {
+        const uint64_t windows = (uint64_t)target_len / W + 1;
+        if ((rc = scratch_reserve(c, c->d_win_sw, windows * sizeof(u64) + 64)) != HPN_OK) return rc;
+        HPN_HIP(c, hipMemsetAsync(c->d_win_sw.p, 0, windows * sizeof(u64), c->stream));
+    }
     // the 1 GB array is NOT cleared: K3 writes whole tiles and a per-tile word says which ones hold data
     HPN_HIP(c, depth_index_reset(c->d_tidx.p, slots, c->stream));
+    HPN_HIP(c, depth_sweep_reset(c->d_sw.p, slots, sweeping, c->stream));
     HPN_HIP(c, hipMemsetAsync(c->w_misc.p, 0, 64, c->stream));  // word 0: domain flag of the scatter
     c->depth_open = true;
     c->depth_tid = tid;
     c->depth_len = target_len;
-    c->depth_mask = flag_mask;
+    c->depth_mask = flag_mask & ~HPN_DEPTH_ANY_ORDER;
     c->depth_slots = slots;
     c->depth_scanned = false;
     c->depth_text_bytes = 0;
+    c->depth_W = sweeping ? W : 0;
+    c->depth_sweeping = sweeping;
     return HPN_OK;
 }
+
+int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_mask) { return hpn_depth_begin_w(c, tid, target_len, flag_mask, 0); }
 
 static int depth_add_common(hpn_ctx *c, const hpn_bam_batch *b)
 {
     if (b->n > 0xfffffff0ull) return fail(c, HPN_E_ARG, "more than 2^32 records in one hpn_depth_add call");
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
     HPN_HIP(c, launch_depth_add(b->tid, b->pos, b->flag, b->cigar_off, b->cigar, b->n, c->depth_tid, c->depth_mask,
-                                (int32_t *)c->d_diff.p, c->depth_slots, c->d_tidx.p, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
+                                (int32_t *)c->d_diff.p, c->depth_slots, c->d_tidx.p, c->d_sw.p, (hpn_run *)c->d_runs.p,
+                                c->d_runs.cap / sizeof(hpn_run), (u64 *)c->d_win_sw.p, c->depth_len, c->depth_W, (uint32_t *)c->w_misc.p,
+                                c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
     c->ev_valid[kFamDepth] = true;
     c->depth_scanned = false;
@@ -130,27 +152,43 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
     if (rc != HPN_OK) return rc;
     if (c->d_runs.cap == 0 && (rc = scratch_reserve(c, c->d_runs, (1u << 20) * sizeof(hpn_run))) != HPN_OK) return rc;
     struct { uint32_t ticket, err; u64 n_runs; } head;
-    uint32_t bad = 0;
+    uint32_t bad = 0, sw_ctl[8] = {0};
+    // What the sweep did while the records came (k_depth_sweep) stands: runs and, for window size depth_W, window sums of
+    // everything in front of its frontier.  k_depth_scan does the rest from the frontier on; with another window size than
+    // the sweep was told, the window sums of the whole target are taken from the runs instead.
+    const bool sums_ride = c->depth_sweeping && W == c->depth_W;            // the sweep's sums are for this W: k_depth_scan adds the rest
+    const bool sums_from_runs = c->depth_sweeping && !sums_ride && win_sum;  // (bam2wig takes no window sums at all)
     for (int attempt = 0; attempt < 2; ++attempt) {
         const uint64_t dev_cap = c->d_runs.cap / sizeof(hpn_run);
-        HPN_HIP(c, hipMemsetAsync(c->d_win.p, 0, windows * sizeof(u64), c->stream));
+        if (sums_ride) HPN_HIP(c, hipMemcpyAsync(c->d_win.p, c->d_win_sw.p, windows * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        else HPN_HIP(c, hipMemsetAsync(c->d_win.p, 0, windows * sizeof(u64), c->stream));
         HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
         HPN_HIP(c, launch_depth_scan((const int32_t *)c->d_diff.p, depth_written(c->d_tidx.p, c->depth_slots), c->depth_slots,
-                                     c->depth_len, W, (hpn_run *)c->d_runs.p, dev_cap, (u64 *)c->d_win.p, c->d_ws.p, c->stream));
+                                     c->depth_len, sums_from_runs ? 0u : W, (hpn_run *)c->d_runs.p, dev_cap, (u64 *)c->d_win.p,
+                                     c->d_ws.p, c->d_sw.p, c->stream));
         HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
         c->ev_valid[kFamDepth] = true;
         HPN_HIP(c, hipMemcpyAsync(&head, c->d_ws.p, sizeof head, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipMemcpyAsync(&bad, c->w_misc.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipMemcpyAsync(sw_ctl, c->d_sw.p, sizeof sw_ctl, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipStreamSynchronize(c->stream));
         if (bad)
             return fail(c, HPN_E_DOMAIN, "a CIGAR M block ends at or beyond position %llu (2^28 key limit of the reference, "
                         "or more than %llu bases past the contig end)", (unsigned long long)c->depth_slots,
                         (unsigned long long)kOverhang);
-        if (head.err & 1u) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
-        if (head.err & 2u) return fail(c, HPN_E_DOMAIN, "coverage of 2^30 or more on this target");
+        if (sw_ctl[1])   // kSwLate
+            return fail(c, HPN_E_STATE, "records of the target arrived behind positions already swept (tile %u): hpn_depth_add expects "
+                        "coordinate order across calls; begin again with HPN_DEPTH_ANY_ORDER in flag_mask for input in any order", sw_ctl[0]);
+        if ((head.err | sw_ctl[3]) & 1u) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
+        if ((head.err | sw_ctl[3]) & 2u) return fail(c, HPN_E_DOMAIN, "coverage of 2^30 or more on this target");
         if (head.n_runs <= dev_cap) break;
-        // device buffer too small for this chromosome: grow it and redo the pass (diff is read-only)
+        // device buffer too small for this chromosome (two-pass route only: the sweep's buffer holds any target): grow it and
+        // redo the pass (diff is read-only)
+        if (sw_ctl[0]) return fail(c, HPN_E_NOMEM, "runs buffer of the sweep too small");
         if ((rc = scratch_reserve(c, c->d_runs, head.n_runs * sizeof(hpn_run))) != HPN_OK) return rc;
+    }
+    if (sums_from_runs) {
+        HPN_HIP(c, launch_win_from_runs((const hpn_run *)c->d_runs.p, head.n_runs, c->depth_len, W, (u64 *)c->d_win.p, c->n_cu, c->stream));
     }
     c->depth_scanned = true;
     c->depth_nruns = head.n_runs;
@@ -255,7 +293,8 @@ int hpn_depth_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
     HPN_HIP(c, hipSetDevice(c->device));
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
     HPN_HIP(c, launch_depth_add_raw(d_raw, (const uint64_t *)c->r_off.p, c->r_n, c->depth_tid, c->depth_mask, (int32_t *)c->d_diff.p,
-                                    c->depth_slots, c->d_tidx.p, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
+                                    c->depth_slots, c->d_tidx.p, c->d_sw.p, (hpn_run *)c->d_runs.p, c->d_runs.cap / sizeof(hpn_run),
+                                    (u64 *)c->d_win_sw.p, c->depth_len, c->depth_W, (uint32_t *)c->w_misc.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
     c->ev_valid[kFamDepth] = true;
     c->depth_scanned = false;

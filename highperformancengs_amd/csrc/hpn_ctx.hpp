@@ -42,6 +42,7 @@ struct hpn_ctx {
     hpn::u64 *h_acc = nullptr;  // pinned mirror
     hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;  // staging of host batches
     hpn::Scratch d_diff, d_runs, d_win, d_ws, d_tidx, d_text;     // bam2depth: difference array, runs, window sums, scan workspace, tile index
+    hpn::Scratch d_sw, d_win_sw;                                  // the sweep's state (frontier, chain) and the window sums of what it has swept
     hpn::Scratch w_off, w_bins, w_len, w_gc, w_misc;      // bam_sliding_count accumulators
     hipEvent_t ev_beg[hpn::kFamCount] = {};
     hipEvent_t ev_end[hpn::kFamCount] = {};
@@ -55,6 +56,8 @@ struct hpn_ctx {
     uint64_t depth_nruns = 0;
     uint64_t depth_runs_cap = 0;  // entries the device runs buffer holds
     uint64_t depth_text_bytes = 0;  // bedGraph text formatted on the device (hpn_depth_bedgraph_format)
+    bool depth_sweeping = false;    // batches in coordinate order are swept as they come (k_depth_sweep)
+    uint32_t depth_W = 0;           // window size the sweep takes its window sums for (0: none; hpn_depth_begin_w)
     // bam_sliding_count state
     bool win_open = false;
     int32_t win_targets = 0;

@@ -59,6 +59,11 @@ struct SoaRecs {
         cig = cigar + c0, n = c1 - c0;
         return t == want && !(f & mask);                          // bam2depth.c:90
     }
+    __device__ __forceinline__ void cigar_of(uint64_t r, const uint32_t *&cig, uint32_t &n) const
+    {
+        const uint32_t c0 = cigar_off[r], c1 = cigar_off[r + 1];
+        cig = cigar + c0, n = c1 - c0;
+    }
     // (the pointer went through a select with nullptr and lost its address space: say it again, a flat load waits on the LDS counter too)
     static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k) { return ((const __attribute__((address_space(1))) uint32_t *)cig)[k]; }
 };
@@ -88,6 +93,12 @@ struct RawRecs {
         n = flag_nc & 0xffffu;
         return (int32_t)t == want && !((flag_nc >> 16) & mask);
     }
+    __device__ __forceinline__ void cigar_of(uint64_t r, const uint32_t *&cig, uint32_t &n) const
+    {
+        const uint8_t *q = raw + rec_off[r];
+        cig = reinterpret_cast<const uint32_t *>(q + 36u + q[12]);
+        n = ld32u(q + 16) & 0xffffu;
+    }
     static __device__ __forceinline__ uint32_t word(const uint32_t *cig, uint32_t k)
     {
         uint32_t v;
@@ -100,8 +111,24 @@ struct RawRecs {
 // K3
 // ---------------------------------------------------------------------------
 // head[]: per-add state, cleared before k_depth_index
-enum { kHdFlags = 0, kHdFar = 1, kHdR0 = 2, kHdR1 = 3, kHdPmin = 4, kHdPmax = 5, kHdWords = 8 };
+enum { kHdFlags = 0, kHdFar = 1, kHdR0 = 2, kHdR1 = 3, kHdPmin = 4, kHdPmax = 5, kHdReach = 6, kHdWords = 8 };
 constexpr uint32_t kUnsorted = 1u;
+constexpr uint32_t kLate = 2u;      // a record of the target lies in front of the sweep's frontier
+
+// The sweep (k_depth_sweep): state that lives from hpn_depth_begin to hpn_depth_finish, across hpn_depth_add calls.
+//   ctl[kSwFrontier]  first tile not yet swept: everything in front of it has become runs / window sums, its difference
+//                     array is never looked at again
+//   ctl[kSwLate]      records arrived behind the frontier (input not in coordinate order across calls): the result is void
+//   ctl[kSwTicket]    tiles handed out in the current call (start order; reset by k_depth_commit)
+//   ctl[kSwErr]       look-back timed out (1) / coverage >= 2^30 (2), as k_depth_scan's err word
+//   ctl[kSwEnabled]   0: every batch takes the two-pass route (HPN_DEPTH_ANY_ORDER)
+//   status            the look-back chain, ONE entry per tile of kTile positions (k_depth_scan's format), kept across calls:
+//                     the entry of tile frontier - 1 is where the next call, and finally k_depth_scan, pick the chain up
+enum { kSwFrontier = 0, kSwLate = 1, kSwTicket = 2, kSwErr = 3, kSwEnabled = 4, kSwWords = 16 };
+struct SweepState {
+    uint32_t *ctl;
+    u64 *status;
+};
 
 struct TileIndex {
     uint32_t *head;       // [kHdWords]
@@ -119,10 +146,16 @@ constexpr int kIdxThreads = 256;
 
 constexpr int kIdxUnroll = HPN_IDX_UNROLL;   // records per thread whose keys are loaded side by side (one at a time: a dependent round trip each)
 
+// ... and, for the sweep: the batch's REACH = the largest distance of an M block's end from its record's pos (walked from
+// the CIGARs: a batch whose breakpoints all lie within kReach of their records' pos has no "far" breakpoints, which is what
+// lets a tile be swept by the workgroup that gathered it), and whether a record of the target lies behind the frontier.
 template <typename Recs>
-__global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t n, int32_t want, TileIndex ix)
+__global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t n, int32_t want, TileIndex ix, SweepState sw)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kIdxThreads;
+    const bool sweeping = sw.ctl[kSwEnabled] != 0;
+    const u64 swept = (u64)sw.ctl[kSwFrontier] * kTile;     // positions in front of this are final
+    uint32_t reach = 0;
     for (uint64_t i0 = (uint64_t)blockIdx.x * kIdxThreads + threadIdx.x; i0 < n; i0 += stride * kIdxUnroll) {
         int32_t t[kIdxUnroll], tp[kIdxUnroll], tn[kIdxUnroll];
         uint32_t p[kIdxUnroll], pp[kIdxUnroll], pn[kIdxUnroll];
@@ -146,6 +179,20 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
                 if (ka > kb) atomicOr(&ix.head[kHdFlags], kUnsorted);
             }
             if (t[u] != want) continue;
+            if (sweeping) {
+                if (p[u] < swept) atomicOr(&ix.head[kHdFlags], kLate);
+                const uint32_t *cig;
+                uint32_t nc;
+                recs.cigar_of(i, cig, nc);
+                uint32_t q = 0, last = 0;                        // relative to pos; saturating is not needed below 2^32 / op
+                for (uint32_t k = 0; k < nc; ++k) {
+                    const uint32_t w = Recs::word(cig, k), op = w & 0xfu, len = w >> 4;
+                    if (op == 0u) q += len, last = q;
+                    else if (op == 2u || op == 3u) q += len;
+                    if (q > (1u << 30)) break;                   // (absurd: reported as a far batch; the two-pass route has the domain check)
+                }
+                reach = last > reach ? last : reach;
+            }
             const bool first = i == 0 || tp[u] != want;
             const bool last = i + 1 == n || tn[u] != want;
             if (first) ix.head[kHdR0] = (uint32_t)i, ix.head[kHdPmin] = p[u];
@@ -158,6 +205,20 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
             }
         }
     }
+    if (sweeping) {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const uint32_t other = __shfl_xor(reach, o, kWave);
+            reach = other > reach ? other : reach;
+        }
+        if (lane_id() == 0 && reach) atomicMax(&ix.head[kHdReach], reach);
+    }
+}
+
+// Does this batch go through the sweep?  The same answer in every kernel of the call (it is a function of the head).
+__device__ __forceinline__ bool sweep_takes(const TileIndex &ix, const SweepState &sw)
+{
+    return sw.ctl[kSwEnabled] != 0 && !(ix.head[kHdFlags] & (kUnsorted | kLate)) && ix.head[kHdReach] <= kReach;
 }
 
 // first record of the wanted target with pos >= thr (thr in positions): the head's values, or the table entry `tab`
@@ -171,10 +232,11 @@ __device__ __forceinline__ uint32_t first_at(uint32_t tab, u64 thr, uint32_t r0,
 
 template <typename Recs>
 __global__ __launch_bounds__(kTileThreads) void k_depth_tiles(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff,
-                                                             uint64_t slots, TileIndex ix, uint32_t *__restrict__ bad)
+                                                             uint64_t slots, TileIndex ix, SweepState sw, uint32_t *__restrict__ bad)
 {
     __shared__ int32_t s_d[kTile];
     const uint32_t t = blockIdx.x;
+    if (sweep_takes(ix, sw)) return;             // k_depth_sweep did the batch
     // head and table entries in ONE round trip (the table words are garbage outside the batch's position range and then unused)
     const uint32_t h_flags = ix.head[kHdFlags], h_r0 = ix.head[kHdR0], h_r1 = ix.head[kHdR1], h_pmin = ix.head[kHdPmin], h_pmax = ix.head[kHdPmax];
     const uint32_t t_lo = ix.first_lo[t], t_hi = ix.first_hi[t], t_hi1 = ix.first_hi[t + 1], was_written = ix.written[t];
@@ -260,9 +322,10 @@ __global__ __launch_bounds__(kTileThreads) void k_depth_tiles(Recs recs, int32_t
 }
 
 // tiles a far breakpoint targets (or every tile, for an unsorted batch) that have never been written: zero them
-__global__ __launch_bounds__(256) void k_depth_fill(int32_t *__restrict__ diff, uint64_t slots, TileIndex ix)
+__global__ __launch_bounds__(256) void k_depth_fill(int32_t *__restrict__ diff, uint64_t slots, TileIndex ix, SweepState sw)
 {
     const uint32_t t = blockIdx.x;
+    if (sweep_takes(ix, sw) || t < sw.ctl[kSwFrontier]) return;   // (swept tiles are never read again)
     const bool all = ix.head[kHdFlags] & kUnsorted;
     if (ix.written[t] || !(all || ix.need[t])) return;
     const u64 lo = (u64)t * kTile;
@@ -280,8 +343,9 @@ __global__ __launch_bounds__(256) void k_depth_fill(int32_t *__restrict__ diff, 
 constexpr int kFarThreads = 256;
 template <typename Recs>
 __global__ __launch_bounds__(kFarThreads) void k_depth_far(Recs recs, uint64_t n, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff,
-                                                          uint64_t slots, TileIndex ix, uint32_t *__restrict__ bad)
+                                                          uint64_t slots, TileIndex ix, SweepState sw, uint32_t *__restrict__ bad)
 {
+    if (sweep_takes(ix, sw)) return;
     const bool all = ix.head[kHdFlags] & kUnsorted;
     if (!all && ix.head[kHdFar] == 0) return;
     for (uint64_t r = (uint64_t)blockIdx.x * kFarThreads + threadIdx.x; r < n; r += (uint64_t)gridDim.x * kFarThreads) {
@@ -656,12 +720,25 @@ constexpr int kDsSub = 4;                        // with 1024 threads, 1 / 2 / 3
 constexpr int kDsGroup = kDsSub * kDsTile;       // positions per workgroup = per chain entry
 static_assert(kDsSub * (kDsThreads / kWave) <= kWave, "wave 0 scans one (sub-tile, wave) total per lane");
 
+// Starts at the sweep's frontier (position pos0 = frontier * kTile; 0 when nothing was swept): the chain entry of the tile in
+// front of it (sw.status, decoded by ds_load_prefix) is what the first group here continues from.
+__device__ __forceinline__ DepthSum ds_load_prefix(const u64 *status, uint64_t tile)
+{
+    const u64 h0 = __hip_atomic_load(&status[kStStride * tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 h1 = __hip_atomic_load(&status[kStStride * tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return DepthSum{sext31((uint32_t)(h0 >> 31) & 0x7fffffffu), sext31((uint32_t)h0 & 0x7fffffffu), (uint32_t)(h1 >> 31) & 0x7fffffffu,
+                    (uint32_t)h1 & 0x7fffffffu};
+}
+
 __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__restrict__ diff, const uint32_t *__restrict__ written,
                                                           uint64_t slots, uint32_t target_len, uint32_t W, DepthOut out,
                                                           u64 *__restrict__ status, uint32_t *__restrict__ ticket,
-                                                          uint32_t *__restrict__ err)
+                                                          uint32_t *__restrict__ err, SweepState sw)
 {
     constexpr int kWaves = kDsThreads / kWave;
+    const uint32_t frontier = sw.ctl[kSwFrontier];
+    const uint64_t pos0 = (uint64_t)frontier * kTile;
+    if (pos0 + (uint64_t)blockIdx.x * kDsGroup >= slots) return;   // the grid is sized for the whole target
     __shared__ DepthSum s_w[kDsSub * kWaves + 1]; // [sub][wave]: in stream order; the last one: the whole group
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kStageWords];
     __shared__ DepthSum s_lb[kLbWaves];
@@ -677,7 +754,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     uint64_t p0[kDsSub];
 #pragma unroll
     for (int sb = 0; sb < kDsSub; ++sb) {
-        p0[sb] = tile * kDsGroup + (uint64_t)sb * kDsTile + (uint64_t)tid * kDsPer;  // this lane's first position in the sub-tile
+        p0[sb] = pos0 + tile * kDsGroup + (uint64_t)sb * kDsTile + (uint64_t)tid * kDsPer;  // this lane's first position in the sub-tile
         const bool have = p0[sb] < slots && written[p0[sb] / kTile] != 0;
         if (!have) {                             // never touched by K3: zeros, nothing to load
 #pragma unroll
@@ -718,6 +795,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
     // takes 3.3 us under streaming load (two 512-thread workgroups per CU overlap each other's).  Wider hops
     // (more tiles per lane, several polling waves), more workgroups per CU and larger tiles were all measured slower.
     DepthSum exclusive = ds_identity();               // of tiles 0 .. tile-1; the same in every thread
+    if (tile == 0 && frontier > 0) exclusive = ds_load_prefix(sw.status, frontier - 1u);   // what the sweep left
 #ifdef DIAG_NOCHAIN
     if (false) {
 #else
@@ -760,14 +838,243 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
         const DepthSum upto0 = s_w[sb * kWaves];                             // everything before the sub-tile
         const DepthSum upto = s_w[(sb + 1) * kWaves];                        // everything up to its end
         const uint32_t base = ds_starts(upto0, 0);                           // runs started before the sub-tile
-        idx = scan_emit(d[sb], before, p0[sb], tile * kDsGroup + (uint64_t)sb * kDsTile, target_len, W, Wm, out, err, s_stage, base);
+        idx = scan_emit(d[sb], before, p0[sb], pos0 + tile * kDsGroup + (uint64_t)sb * kDsTile, target_len, W, Wm, out, err, s_stage, base);
         __syncthreads();
 #ifndef DIAG_NOFLUSH
         scan_flush(s_stage, base, ds_starts(upto, 0), upto0.s > 0 && upto.nz != upto0.nz, upto.s, out);
 #endif
         if (sb + 1 < kDsSub) __syncthreads();     // the image is written again
     }
-    if (tile == (slots - 1) / kDsGroup && tid == kDsThreads - 1) *out.n_runs = idx;   // (< 2^28: one run needs a position)
+    if (tile == (slots - 1 - pos0) / kDsGroup && tid == kDsThreads - 1) *out.n_runs = idx;   // (< 2^28: one run needs a position)
+}
+
+// ---------------------------------------------------------------------------
+// K3 + K4 in one: the sweep
+// ---------------------------------------------------------------------------
+// The difference array's round trip through HBM -- written by k_depth_tiles, read back by k_depth_scan: 2 GB of the two
+// kernels' 3.3 GB per chr1 -- is what is left between them and their roofline.  In a coordinate-sorted input a tile that the
+// batch's LAST record lies beyond can receive nothing more: the workgroup that gathered it (as k_depth_tiles does) goes
+// straight on and sweeps it from LDS (as k_depth_scan does): prefix sum, runs, window sums, with the look-back chain kept
+// across hpn_depth_add calls.  Only the tile the batch ends in (and the few behind it its last records reach) go to HBM, to be
+// completed by the next call; hpn_depth_finish's k_depth_scan starts at the frontier and sees only those.
+// Takes a batch that is sorted, has no far breakpoints (reach <= kReach, proven by k_depth_index from the CIGARs) and
+// does not start behind the frontier; every other batch goes the two-pass way as before, whenever it comes.
+// LDS image of the tile, laid out for what comes after the gather: lane l of sub-tile sb holds positions 16 l .. 16 l + 15
+// as four quads, and quad j of all lanes lies together (conflict-free 16-byte reads):
+//   position p -> word (p & ~8191) | (((p >> 2 & 3) * 512 + ((p & 8191) >> 4)) << 2) | (p & 3)
+constexpr int kSwSub = kTile / kDsTile;
+static_assert(kSwSub * kDsTile == kTile && kStageWords <= (uint32_t)kTile, "the tile image doubles as the runs' staging area");
+__device__ __forceinline__ uint32_t sw_word(uint32_t p) { return (p & ~8191u) | (((((p >> 2) & 3u) << 9) + ((p & 8191u) >> 4)) << 2) | (p & 3u); }
+
+template <typename Recs>
+__global__ __launch_bounds__(kDsThreads) void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff,
+                                                           uint64_t slots, TileIndex ix, SweepState sw, uint32_t target_len, uint32_t W,
+                                                           DepthOut out, uint32_t *__restrict__ bad)
+{
+    constexpr int kWaves = kDsThreads / kWave;
+    __shared__ __attribute__((aligned(16))) int32_t s_d[kTile];
+    __shared__ DepthSum s_w[kSwSub * kWaves + 1];
+    __shared__ DepthSum s_lb;
+    __shared__ uint32_t s_lbp, s_tile;
+    const int tid = threadIdx.x;
+    if (!sweep_takes(ix, sw)) return;
+    const uint32_t h_r0 = ix.head[kHdR0], h_r1 = ix.head[kHdR1], h_pmin = ix.head[kHdPmin], h_pmax = ix.head[kHdPmax];
+    if (h_r0 == h_r1) return;                                  // no record of the target in this batch
+    const uint32_t frontier = sw.ctl[kSwFrontier];
+    // tiles in front of `closed` end before the batch's last record: final.  The target's last tile is always left to k_depth_scan.
+    uint32_t closed = h_pmax / kTile, t_end = (uint32_t)(((u64)h_pmax + kReach) / kTile);
+    closed = closed < ix.ntiles - 1u ? closed : ix.ntiles - 1u;
+    t_end = t_end < ix.ntiles - 1u ? t_end : ix.ntiles - 1u;
+    if (blockIdx.x > t_end - frontier) return;                 // (frontier <= tile of pmin <= t_end: the batch is not late)
+    if (tid == 0) s_tile = atomicAdd(&sw.ctl[kSwTicket], 1u);   // tiles in start order: the look-back only waits on running workgroups
+    __syncthreads();
+    const uint32_t t = frontier + s_tile;
+    const uint32_t t_lo = ix.first_lo[t], t_hi = ix.first_hi[t], t_hi1 = ix.first_hi[t + 1], was_written = ix.written[t];
+    const u64 lo = (u64)t * kTile, hi = lo + kTile;
+    const uint32_t r_first = first_at(t_lo, lo > kReach ? lo - kReach : 0, h_r0, h_r1, h_pmin, h_pmax);
+    const uint32_t r_end = t + 1 == ix.ntiles ? h_r1 : first_at(t_hi1, hi, h_r0, h_r1, h_pmin, h_pmax);
+    (void)t_hi;
+    const bool sweep = t < closed, gather = r_first < r_end;
+    if (!sweep && !gather) return;                             // an open tile nothing lands in
+    if (gather) {
+        u32 *z = reinterpret_cast<u32 *>(s_d);
+#pragma unroll
+        for (int k = 0; k < kTile / 4 / kDsThreads; ++k) z[k * kDsThreads + tid] = u32{0, 0, 0, 0};
+        __syncthreads();
+        for (uint32_t base = r_first; base < r_end; base += kTileUnroll * kDsThreads) {
+            uint32_t p[kTileUnroll], n[kTileUnroll], w0[kTileUnroll], w1[kTileUnroll];
+            const uint32_t *cig[kTileUnroll];
+#pragma unroll
+            for (int u = 0; u < kTileUnroll; ++u) {
+                const uint32_t r = base + u * kDsThreads + tid;
+                n[u] = 0, p[u] = 0, cig[u] = nullptr;
+                if (r < r_end && !recs.open(r, want, flag_mask, p[u], cig[u], n[u])) n[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < kTileUnroll; ++u) {
+                w0[u] = n[u] > 0 ? Recs::word(cig[u], 0) : 0u;
+                w1[u] = n[u] > 1 ? Recs::word(cig[u], 1) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kTileUnroll; ++u) {
+                u64 q = p[u];
+                for (uint32_t k = 0; k < n[u]; ++k) {
+                    const uint32_t w = k == 0 ? w0[u] : k == 1 ? w1[u] : Recs::word(cig[u], k), op = w & 0xfu, len = w >> 4;
+                    if (op == 2u || op == 3u) {          // D, N: advance only
+                        q += len;
+                    } else if (op == 0u) {               // M: +1 at the block start, -1 one past its end (bam2depth.c:94-107)
+                        const u64 e = q + len;
+                        if (e >= slots) {                // breakpoint beyond the dense array (>= 2^28 or huge overhang)
+                            if (p[u] >= lo) atomicOr(bad, 1u);
+                            break;
+                        }
+                        if (q >= lo && q < hi) __hip_atomic_fetch_add(&s_d[sw_word((uint32_t)(q - lo))], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (e >= lo && e < hi) __hip_atomic_fetch_add(&s_d[sw_word((uint32_t)(e - lo))], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        q = e;
+                    }                                    // I, S, H, P, =, X: neither counted nor advanced
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!sweep) {
+        // the batch's records do not end beyond this tile: to HBM in natural order (+ what earlier calls left), for the next call
+        if (hi <= slots) {
+            u32 *g = reinterpret_cast<u32 *>(diff + lo);
+#pragma unroll
+            for (int k = 0; k < kTile / 4 / kDsThreads; ++k) {
+                const uint32_t Q = (uint32_t)(k * kDsThreads + tid);
+                u32 v = *reinterpret_cast<const u32 *>(&s_d[sw_word(4u * Q)]);
+                if (was_written) v += g[Q];
+                g[Q] = v;
+            }
+        } else {
+            for (u64 q = lo + tid; q < slots; q += kDsThreads) diff[q] = s_d[sw_word((uint32_t)(q - lo))] + (was_written ? diff[q] : 0);
+        }
+        if (tid == 0) ix.written[t] = 1u;
+        return;
+    }
+    // ---- sweep: this lane's 2 x 16 positions out of LDS (+ the tile's earlier content in HBM), then k_depth_scan's steps ----
+    int32_t d[kSwSub][kDsPer];
+    uint64_t p0[kSwSub];
+#pragma unroll
+    for (int sb = 0; sb < kSwSub; ++sb) {
+        p0[sb] = lo + (uint64_t)sb * kDsTile + (uint64_t)tid * kDsPer;
+#pragma unroll
+        for (int j = 0; j < kDsPer / 4; ++j) {
+            u32 q = u32{0, 0, 0, 0};
+            if (gather) q = reinterpret_cast<const u32 *>(s_d)[sb * (kDsTile / 4) + j * kDsThreads + tid];
+            d[sb][4 * j] = (int32_t)q[0], d[sb][4 * j + 1] = (int32_t)q[1], d[sb][4 * j + 2] = (int32_t)q[2], d[sb][4 * j + 3] = (int32_t)q[3];
+        }
+        if (was_written) {                                     // (closed tiles lie wholly inside the array: the last tile is never swept)
+            const u32 *v = reinterpret_cast<const u32 *>(diff + p0[sb]);
+#pragma unroll
+            for (int j = 0; j < kDsPer / 4; ++j) {
+                const u32 q = v[j];
+                d[sb][4 * j] += (int32_t)q[0], d[sb][4 * j + 1] += (int32_t)q[1], d[sb][4 * j + 2] += (int32_t)q[2], d[sb][4 * j + 3] += (int32_t)q[3];
+            }
+        }
+    }
+    uint32_t *const s_stage = reinterpret_cast<uint32_t *>(s_d);   // the image is in registers: its LDS stages the runs
+    DepthSum lanes_before[kSwSub];
+#pragma unroll
+    for (int sb = 0; sb < kSwSub; ++sb) {
+        const DepthSum inc = ds_wave_inclusive(scan_lane_sum(d[sb]));
+        lanes_before[sb] = ds_lane_before(inc);
+        if (lane_id() == kWave - 1) s_w[sb * kWaves + wave_id()] = inc;
+    }
+    __syncthreads();                                           // (also: every lane has read its quads)
+    DepthSum excl = ds_identity(), agg = ds_identity();        // (wave 0 only)
+    if (wave_id() == 0) {
+        const DepthSum w = ds_wave_inclusive(lane_id() < kSwSub * kWaves ? s_w[lane_id()] : ds_identity());
+        agg = DepthSum{__shfl(w.s, kSwSub * kWaves - 1, kWave), __shfl(w.m, kSwSub * kWaves - 1, kWave),
+                       __shfl(w.z, kSwSub * kWaves - 1, kWave), __shfl(w.nz, kSwSub * kWaves - 1, kWave)};
+        excl = ds_lane_before(w);
+        if (t > 0 && lane_id() == 0) ds_publish(sw.status, t, kScanAggregate, agg);
+    }
+    DepthSum exclusive = ds_identity();                        // of tiles 0 .. t-1 (earlier calls' included); the same in every thread
+    if (t > 0) {
+        int64_t newest = (int64_t)t - 1;
+        for (;;) {
+            if (wave_id() == 0) {
+                bool hp = false;
+                const DepthSum win = ds_window(sw.status, newest, &hp, &sw.ctl[kSwErr]);
+                if (lane_id() == 0) s_lb = win, s_lbp = hp ? 1u : 0u;
+            }
+            __syncthreads();
+            exclusive = ds_compose(s_lb, exclusive);           // older windows come first
+            if (s_lbp) break;
+            newest -= kWave;
+            __syncthreads();                                   // s_lb is written again
+        }
+    }
+    if (wave_id() == 0) {
+        if (lane_id() == 0) {
+            const DepthSum all = ds_compose(exclusive, agg);
+            ds_publish(sw.status, t, kScanPrefix, all);
+            s_w[kSwSub * kWaves] = all;
+        }
+        if (lane_id() < kSwSub * kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before (sub-tile, wave) `lane`
+    }
+    __syncthreads();
+    const uint32_t Wm = W ? 0xffffffffu / W : 0u;
+#pragma unroll
+    for (int sb = 0; sb < kSwSub; ++sb) {
+        const DepthSum before = ds_compose(s_w[sb * kWaves + wave_id()], lanes_before[sb]);
+        const DepthSum upto0 = s_w[sb * kWaves];
+        const DepthSum upto = s_w[(sb + 1) * kWaves];
+        const uint32_t base = ds_starts(upto0, 0);
+        (void)scan_emit(d[sb], before, p0[sb], lo + (uint64_t)sb * kDsTile, target_len, W, Wm, out, &sw.ctl[kSwErr], s_stage, base);
+        __syncthreads();
+        scan_flush(s_stage, base, ds_starts(upto, 0), upto0.s > 0 && upto.nz != upto0.nz, upto.s, out);
+        if (sb + 1 < kSwSub) __syncthreads();                  // the image is written again
+    }
+}
+
+// After the sweep of a call: the frontier moves up to the tile the batch's last record lies in, the tickets start over.
+__global__ void k_depth_commit(TileIndex ix, SweepState sw)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ix.head[kHdFlags] & kLate) sw.ctl[kSwLate] = 1u;
+    if (sweep_takes(ix, sw) && ix.head[kHdR0] != ix.head[kHdR1]) {
+        uint32_t closed = ix.head[kHdPmax] / kTile;
+        closed = closed < ix.ntiles - 1u ? closed : ix.ntiles - 1u;
+        if (closed > sw.ctl[kSwFrontier]) sw.ctl[kSwFrontier] = closed;
+    }
+    sw.ctl[kSwTicket] = 0u;
+}
+
+// Window sums of coverage from the runs (what overlap() does, bam2depth.c:132-176), for a window size other than the one
+// the sweep was told: sum over runs of depth x overlap with [kW, min((k+1)W, target_len)).  Runs are sorted, so the 64 runs
+// under a wave mostly lie in one window: one atomic per wave then, else per lane and window.
+__global__ __launch_bounds__(256) void k_win_from_runs(const hpn_run *__restrict__ runs, uint64_t n_runs, uint32_t target_len, uint32_t W,
+                                                      u64 *__restrict__ win_sum)
+{
+    const uint32_t Wm = 0xffffffffu / W;
+    for (uint64_t r0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) & ~(uint64_t)(kWave - 1); r0 < n_runs; r0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = r0 + lane_id();
+        uint32_t s = 0, e = 0, dp = 0;
+        if (r < n_runs) {
+            typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+            const i32x3 v = *reinterpret_cast<const i32x3 *>(&runs[r]);
+            s = (uint32_t)v[0], e = (uint32_t)v[1], dp = (uint32_t)v[2];
+            e = e < target_len ? e : target_len;               // windows are clipped at the contig end (:132-176); runs may overhang it
+            if (s >= e) s = e = 0, dp = 0;
+        }
+        const uint32_t k0 = div_by(s, W, Wm), k1 = e > s ? div_by(e - 1u, W, Wm) : k0;
+        const uint32_t w_first = __shfl(k0, 0, kWave);
+        if (__ballot(dp != 0 && (k0 != w_first || k1 != w_first)) == 0) {
+            u64 tot = (u64)(e - s) * dp;
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+            if (lane_id() == 0 && tot) atomicAdd(&win_sum[w_first], tot);
+        } else if (dp) {
+            for (uint32_t k = k0; k <= k1; ++k) {
+                const uint32_t a = s > k * W ? s : k * W, b = e < (k + 1) * W ? e : (k + 1) * W;
+                if (b > a) atomicAdd(&win_sum[k], (u64)(b - a) * dp);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1002,42 +1309,84 @@ hipError_t depth_index_reset(void *ws, uint64_t slots, hipStream_t st)
 
 const uint32_t *depth_written(void *ws, uint64_t slots) { return tile_index(ws, slots).written; }
 
+// the sweep's state (SweepState): ctl words, then one chain entry per tile
+size_t depth_sweep_bytes(uint64_t slots) { return kSwWords * sizeof(uint32_t) + kStStride * depth_tiles(slots) * sizeof(u64); }
+static SweepState sweep_state(void *sws) { return SweepState{(uint32_t *)sws, (u64 *)((uint32_t *)sws + kSwWords)}; }
+
+// hpn_depth_begin: nothing swept, no chain entry published; enabled = 0 keeps every batch on the two-pass route
+hipError_t depth_sweep_reset(void *sws, uint64_t slots, bool enabled, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(sws, 0, depth_sweep_bytes(slots), st);
+    if (e != hipSuccess || !enabled) return e;
+    static const uint32_t one = 1u;
+    return hipMemcpyAsync((uint32_t *)sws + kSwEnabled, &one, sizeof one, hipMemcpyHostToDevice, st);
+}
+
+// what the sweep writes besides the chain: runs (all of the target's, capacity runs_cap) and, when the window size is
+// known while the records come (W != 0), the window sums of the swept part
+struct SweepOut {
+    hpn_run *runs;
+    uint64_t runs_cap;
+    u64 *win_sum;
+    uint32_t target_len, W;
+};
+
 template <typename Recs>
 static hipError_t depth_add(const Recs &recs, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots, void *ws,
-                            uint32_t *bad, int n_cu, hipStream_t st)
+                            void *sws, const SweepOut &so, uint32_t *bad, int n_cu, hipStream_t st)
 {
     if (n == 0 || tid < 0) return hipSuccess;    // tid < 0 never matches (bam2depth.c:90)
     const TileIndex ix = tile_index(ws, slots);
+    const SweepState sw = sweep_state(sws);
     hipError_t e = hipMemsetAsync(ix.head, 0, kHdWords * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     const uint64_t cap = (uint64_t)n_cu * 8;
     const uint64_t wi = (n + kIdxThreads - 1) / kIdxThreads, wf = (n + kFarThreads - 1) / kFarThreads;
-    hipLaunchKernelGGL(k_depth_index<Recs>, dim3((unsigned)(wi < cap * 4 ? wi : cap * 4)), dim3(kIdxThreads), 0, st, recs, n, tid, ix);
-    hipLaunchKernelGGL(k_depth_tiles<Recs>, dim3(ix.ntiles), dim3(kTileThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, bad);
-    hipLaunchKernelGGL(k_depth_fill, dim3(ix.ntiles), dim3(256), 0, st, diff, slots, ix);
+    hipLaunchKernelGGL(k_depth_index<Recs>, dim3((unsigned)(wi < cap * 4 ? wi : cap * 4)), dim3(kIdxThreads), 0, st, recs, n, tid, ix, sw);
+    // the sweep takes the batch (sorted, no far breakpoint, not behind the frontier) or leaves it to the three kernels behind it
+    const DepthOut out{so.runs, so.runs_cap, nullptr, so.W ? so.win_sum : nullptr};
+    hipLaunchKernelGGL(k_depth_sweep<Recs>, dim3(ix.ntiles), dim3(kDsThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, sw, so.target_len,
+                       so.W, out, bad);
+    hipLaunchKernelGGL(k_depth_tiles<Recs>, dim3(ix.ntiles), dim3(kTileThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, sw, bad);
+    hipLaunchKernelGGL(k_depth_fill, dim3(ix.ntiles), dim3(256), 0, st, diff, slots, ix, sw);
     hipLaunchKernelGGL(k_depth_far<Recs>, dim3((unsigned)(wf < cap ? wf : cap)), dim3(kFarThreads), 0, st, recs, n, tid, flag_mask, diff,
-                       slots, ix, bad);
+                       slots, ix, sw, bad);
+    hipLaunchKernelGGL(k_depth_commit, dim3(1), dim3(64), 0, st, ix, sw);
     return hipGetLastError();
 }
 
 hipError_t launch_depth_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const uint32_t *cigar_off,
                             const uint32_t *cigar, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots,
-                            void *ws, uint32_t *bad, int n_cu, hipStream_t st)
+                            void *ws, void *sws, hpn_run *runs, uint64_t runs_cap, u64 *win_sw, uint32_t target_len, uint32_t W,
+                            uint32_t *bad, int n_cu, hipStream_t st)
 {
-    return depth_add(SoaRecs{tid_a, pos, flag, cigar_off, cigar}, n, tid, flag_mask, diff, slots, ws, bad, n_cu, st);
+    return depth_add(SoaRecs{tid_a, pos, flag, cigar_off, cigar}, n, tid, flag_mask, diff, slots, ws, sws,
+                     SweepOut{runs, runs_cap, win_sw, target_len, W}, bad, n_cu, st);
 }
 
 hipError_t launch_depth_add_raw(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff,
-                                uint64_t slots, void *ws, uint32_t *bad, int n_cu, hipStream_t st)
+                                uint64_t slots, void *ws, void *sws, hpn_run *runs, uint64_t runs_cap, u64 *win_sw, uint32_t target_len,
+                                uint32_t W, uint32_t *bad, int n_cu, hipStream_t st)
 {
-    return depth_add(RawRecs{raw, rec_off}, n, tid, flag_mask, diff, slots, ws, bad, n_cu, st);
+    return depth_add(RawRecs{raw, rec_off}, n, tid, flag_mask, diff, slots, ws, sws, SweepOut{runs, runs_cap, win_sw, target_len, W}, bad,
+                     n_cu, st);
+}
+
+// window sums of all `n_runs` runs for window size W, added into win_sum
+hipError_t launch_win_from_runs(const hpn_run *runs, uint64_t n_runs, uint32_t target_len, uint32_t W, u64 *win_sum, int n_cu, hipStream_t st)
+{
+    if (n_runs == 0) return hipSuccess;
+    const uint64_t want = (n_runs + 255) / 256, cap = (uint64_t)n_cu * 8;
+    hipLaunchKernelGGL(k_win_from_runs, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, runs, n_runs, target_len, W, win_sum);
+    return hipGetLastError();
 }
 
 // ws: [0] ticket, [1] err (uint32 each), then u64 n_runs, then status[2 * tiles]
 size_t depth_scan_bytes(uint64_t slots) { return 16 + kStStride * scan_tiles(slots) * sizeof(u64); }
 
+// sws: the sweep's state -- the scan starts at its frontier and continues its chain (a frontier of 0: the whole target)
 hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint64_t slots, uint32_t target_len, uint32_t W, hpn_run *runs,
-                             uint64_t runs_cap, u64 *win_sum, void *ws, hipStream_t st)
+                             uint64_t runs_cap, u64 *win_sum, void *ws, void *sws, hipStream_t st)
 {
     const uint64_t tiles = scan_tiles(slots);
     hipError_t e = hipMemsetAsync(ws, 0, depth_scan_bytes(slots), st);
@@ -1047,7 +1396,7 @@ hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint6
     u64 *status = (u64 *)ws + 2;
     DepthOut out{runs, runs_cap, n_runs, win_sum};
     hipLaunchKernelGGL(k_depth_scan, dim3((unsigned)tiles), dim3(kDsThreads), 0, st, diff, written, slots, target_len, W, out, status,
-                       ticket, ticket + 1);
+                       ticket, ticket + 1, sweep_state(sws));
     return hipGetLastError();
 }
 

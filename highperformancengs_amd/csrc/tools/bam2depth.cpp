@@ -150,7 +150,7 @@ int main(int argc, char *argv[])
         for (int32_t j = 0; j < hdr.n_targets() && !redo; ++j) {
             const uint32_t tlen = hdr.target_len[j];
             const char *name = hdr.target_name[j].c_str();
-            if ((rc = hpn_depth_begin(ctx, j, tlen, BAM_DEF_MASK)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");
+            if ((rc = hpn_depth_begin_w(ctx, j, tlen, BAM_DEF_MASK, (uint32_t)window)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");   // sorted input: swept while it streams
             t0 = wall_s();
             rc = bam.feed(j);
             t_feed += wall_s() - t0;

@@ -358,6 +358,17 @@ typedef struct hpn_run {
 } hpn_run;
 
 int hpn_depth_begin(hpn_ctx *ctx, int32_t tid, uint32_t target_len, uint32_t flag_mask);
+/* The same, telling the window size hpn_depth_finish will be called with.  A BAM that bam2depth can read is coordinate-
+ * sorted (it needs the index, bam2depth.c:112-119), and on sorted input the work is done WHILE the records come: every
+ * stretch of the target that the records of an hpn_depth_add call have moved beyond is swept at once -- prefix sum, runs,
+ * window sums, in the workgroup that gathered its breakpoints -- and never goes through memory as a difference array.
+ * Window sums can only ride along if W is known by then; with W = 0 (hpn_depth_begin) or another W at hpn_depth_finish
+ * they are taken from the runs afterwards (same numbers, one more pass over the runs).
+ * This expects the records of the target in coordinate order ACROSS calls (inside a call any order is handled).  A record
+ * that arrives behind positions already swept makes hpn_depth_finish fail with HPN_E_STATE; callers with input in any
+ * order put HPN_DEPTH_ANY_ORDER into flag_mask: nothing is swept early then. */
+#define HPN_DEPTH_ANY_ORDER 0x80000000u
+int hpn_depth_begin_w(hpn_ctx *ctx, int32_t tid, uint32_t target_len, uint32_t flag_mask, uint32_t W);
 int hpn_depth_add(hpn_ctx *ctx, const hpn_bam_batch *host_batch);
 int hpn_depth_add_dev(hpn_ctx *ctx, const hpn_bam_batch *dev_batch);
 /* runs: caller buffer of runs_cap entries; *n_runs receives the number found

@@ -174,11 +174,14 @@ def test_depth_batches_overlap_and_mix_sorted_with_unsorted(ctx):
              make_soa(30_000, refs, 43, sort=True, cigars=FAR_CIGARS, max_start_frac=0.9),
              make_soa(5, refs, 44, sort=True, cigars=["150M"], max_start_frac=0.9)]
     L, keep = ctx.L, []
-    assert L.hpn_depth_begin(ctx.h, 0, refs[0][1], 0x704) == 0
+    from highperformancengs_amd import _lib
+    # calls in no coordinate order: nothing may be swept early (HPN_DEPTH_ANY_ORDER) ...
+    assert L.hpn_depth_begin(ctx.h, 0, refs[0][1], 0x704 | _lib.DEPTH_ANY_ORDER) == 0
     for part in parts:
         bb = ctx._batch(part, keep)
         assert L.hpn_depth_add(ctx.h, C.byref(bb)) == 0
     runs, win = ctx.depth_finish(refs[0][1], 1000)
+    # (what happens without the flag once something HAS been swept: tests/test_depth_sweep_gpu.py::test_late_records_are_reported)
     whole = bamio.BamSoA(refs=refs, tid=np.concatenate([p.tid for p in parts]), pos=np.concatenate([p.pos for p in parts]),
                          flag=np.concatenate([p.flag for p in parts]), l_qseq=np.concatenate([p.l_qseq for p in parts]),
                          cigar_off=np.concatenate([[0], np.cumsum(np.concatenate([np.diff(p.cigar_off.astype(np.int64)) for p in parts]))]).astype(np.uint32),
