@@ -77,9 +77,17 @@ def plain_traffic():
     return out
 
 
-def kernel_legs(ctx, reps=5):
+def kernel_legs(ctx, reps=5, fastq=True):
     import torch
     legs = []
+    if fastq:
+        _fastq_kernel_legs(ctx, reps, legs)
+    _bam_kernel_legs(ctx, reps, legs)
+    return legs
+
+
+def _fastq_kernel_legs(ctx, reps, legs):
+    import torch
     # ---- FASTQ: K1L and K2 on 2e8 x 150 bp ------------------------------------------------------------------
     n, L = 200_000_000, 150
     dq = torch.empty(n * L, dtype=torch.uint8, device="cuda")
@@ -135,6 +143,9 @@ def kernel_legs(ctx, reps=5):
     del dq, db, do, oq, ob, oo
     torch.cuda.empty_cache()
 
+
+def _bam_kernel_legs(ctx, reps, legs):
+    import torch
     # ---- BAM: chr1-sized target at 30x (SURVEY §8d CIGAR / flag mix) ------------------------------------------
     TL, L = 248_956_422, 150
     n = 30 * TL // L
@@ -164,9 +175,10 @@ def kernel_legs(ctx, reps=5):
     d.seq_off = torch.arange(n + 1, device="cuda", dtype=torch.int64) * ((L + 1) // 2)
     d.seq4 = torch.randint(0, 256, (n * ((L + 1) // 2),), device="cuda", generator=g, dtype=torch.uint8)
     n_ops, n_m = int(cigar.numel()), int(((cigar & 15) == 0).sum().item())
-    keep_alive, ts3, ts4 = [], [], []
+    keep_alive, ts3, ts4, tsw, tsf_ = [], [], [], [], []
+    ANY = 0x80000000            # HPN_DEPTH_ANY_ORDER: nothing swept early -> the two kernels of round 2, timed on their own
     for r in range(reps + 1):
-        ctx._ck(ctx.L.hpn_depth_begin(ctx.h, 0, TL, 0x704), "hpn_depth_begin")
+        ctx._ck(ctx.L.hpn_depth_begin(ctx.h, 0, TL, 0x704 | ANY), "hpn_depth_begin")
         b = ctx._batch(d, keep_alive)
         ctx._ck(ctx.L.hpn_depth_add_dev(ctx.h, C.byref(b)), "hpn_depth_add_dev")
         ctx.sync()
@@ -176,10 +188,29 @@ def kernel_legs(ctx, reps=5):
         if r:
             ts3.append(t3), ts4.append(t4)
     slots = TL + 1 + (1 << 21)
-    legs.append(_leg("K3 k_depth_index + k_depth_tiles: CIGAR-M difference array (bam2depth fetch_func)",
-                     statistics.median(ts3), n * 16 + 4 * n_ops + 8 * n_m, records=n, cigar_ops=n_ops, target_len=TL))
-    legs.append(_leg("K4 k_depth_scan: prefix sum + runs + window sums (hash2BedGraph, overlap)", statistics.median(ts4),
-                     slots * 4 + 12 * len(runs) + 8 * len(win), positions=slots, runs=len(runs)))
+    k3_bytes, k4_bytes = n * 16 + 4 * n_ops + 8 * n_m, slots * 4 + 12 * len(runs) + 8 * len(win)
+    legs.append(_leg("K3 k_depth_index + k_depth_tiles: CIGAR-M difference array (bam2depth fetch_func), two-pass route (input in any order)",
+                     statistics.median(ts3), k3_bytes, records=n, cigar_ops=n_ops, target_len=TL))
+    legs.append(_leg("K4 k_depth_scan: prefix sum + runs + window sums (hash2BedGraph, overlap), two-pass route", statistics.median(ts4),
+                     k4_bytes, positions=slots, runs=len(runs)))
+    # the default on coordinate-sorted input: tiles the batch has moved beyond are swept by the workgroup that gathered them
+    # (k_depth_index + k_depth_sweep in hpn_depth_add, k_depth_scan over what is left in hpn_depth_finish); same results
+    for r in range(reps + 1):
+        ctx._ck(ctx.L.hpn_depth_begin_w(ctx.h, 0, TL, 0x704, 20000), "hpn_depth_begin_w")
+        b = ctx._batch(d, keep_alive)
+        ctx._ck(ctx.L.hpn_depth_add_dev(ctx.h, C.byref(b)), "hpn_depth_add_dev")
+        ctx.sync()
+        t3 = ctx.last_kernel_ms(2)
+        runs2, win2 = ctx.depth_finish(TL, 20000, runs_cap=1 << 27)
+        t4 = ctx.last_kernel_ms(2)
+        if r:
+            tsw.append(t3), tsf_.append(t4)
+    assert np.array_equal(runs2, runs) and np.array_equal(win2, win)
+    del runs2, win2
+    legs.append(_leg("K3+K4 k_depth_index + k_depth_sweep (+ k_depth_scan over the last tiles): bam2depth's fetch_func, hash2BedGraph and overlap in one pass "
+                     "over sorted records, no difference array through HBM", statistics.median(tsw) + statistics.median(tsf_), k3_bytes + k4_bytes,
+                     add_ms=round(statistics.median(tsw), 4), finish_ms=round(statistics.median(tsf_), 4), records=n, runs=len(runs),
+                     identical_to_two_pass_route=True))
     tsf = []
     for r in range(reps + 1):
         text_bytes = ctx.depth_bedgraph_format("chr1")
@@ -215,7 +246,6 @@ def kernel_legs(ctx, reps=5):
                      statistics.median(ts5), n * (12 + (L + 1) // 2), bytes_touched=n * (20 + (L + 1) // 2), records=n))   # 8(d): n x (12 B + ceil(l_qseq / 2)); the SoA view also holds flag and the 8-byte seq_off
     del d, tid, pos, fl, cigar, cigar_off, m_per
     torch.cuda.empty_cache()
-    return legs
 
 
 # --------------------------------------------------------------------------------------------------------------

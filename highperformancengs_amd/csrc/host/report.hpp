@@ -224,9 +224,28 @@ inline void print_wig_bins_d(FILE *out, const char *chr, uint32_t target_len, ui
 // ---- bam_sliding_count ---------------------------------------------------------------------
 
 // calc_winGC + output_count_GC (bam_sliding_count.c:126-164).  The reference keeps GC[k]
-// as float32 and adds an unsigned short per record; an integer sum converts to the
+// as float32 and adds an unsigned short per record (:119-121); an integer sum converts to the
 // same float as long as it stays below 2^24 (always, for windows up to ~100 kb at WGS
-// depth).  The per-chromosome running sums are replayed here in float32, window order.
+// depth).  From 2^24 on the reference's value depends on the ORDER of its additions (every
+// += rounds), which integer sums taken in parallel -- and, over several GPUs, out of file
+// order -- cannot give back: such a window is outside the domain, and window_gc_in_domain()
+// says so before anything is printed (the tool then stops with HPN_E_DOMAIN's exit code
+// instead of printing other digits than the reference).
+// The per-chromosome running sums are replayed here in float32, window order.
+inline bool window_gc_in_domain(const std::vector<uint32_t> &tlen, const uint64_t *win_off, const uint64_t *gc, const uint8_t *touched,
+                                size_t *bad_target, uint64_t *bad_window)
+{
+    for (size_t t = 0; t < tlen.size(); ++t) {
+        if (!touched[t]) continue;
+        for (uint64_t s = win_off[t]; s < win_off[t + 1]; ++s)
+            if (gc[s] >= (1ull << 24)) {
+                *bad_target = t, *bad_window = s - win_off[t];
+                return false;
+            }
+    }
+    return true;
+}
+
 inline void print_window_report(FILE *out, const std::vector<std::string> &names, const std::vector<uint32_t> &tlen,
                                 uint32_t W, const uint64_t *win_off, const uint32_t *bins, const uint64_t *gc,
                                 const uint32_t *len, const uint8_t *touched)

@@ -140,7 +140,7 @@ struct TileIndex {
 };
 
 #ifndef HPN_IDX_UNROLL
-#define HPN_IDX_UNROLL 2
+#define HPN_IDX_UNROLL 4
 #endif
 constexpr int kIdxThreads = 256;
 
@@ -159,15 +159,22 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
     for (uint64_t i0 = (uint64_t)blockIdx.x * kIdxThreads + threadIdx.x; i0 < n; i0 += stride * kIdxUnroll) {
         int32_t t[kIdxUnroll], tp[kIdxUnroll], tn[kIdxUnroll];
         uint32_t p[kIdxUnroll], pp[kIdxUnroll], pn[kIdxUnroll];
+        const uint32_t *cg[kIdxUnroll];
+        uint32_t nc[kIdxUnroll], w0[kIdxUnroll];
 #pragma unroll
         for (int u = 0; u < kIdxUnroll; ++u) {
             const uint64_t i = i0 + u * stride;
-            t[u] = tp[u] = tn[u] = 0, p[u] = pp[u] = pn[u] = 0;
+            t[u] = tp[u] = tn[u] = 0, p[u] = pp[u] = pn[u] = 0, cg[u] = nullptr, nc[u] = 0;
             if (i < n) {
                 recs.key(i, t[u], p[u]);
                 if (i) recs.key(i - 1, tp[u], pp[u]);
                 if (i + 1 < n) recs.key(i + 1, tn[u], pn[u]);
+                if (sweeping) recs.cigar_of(i, cg[u], nc[u]);     // (where the CIGAR lies: issued beside the keys, not behind them)
             }
+        }
+        if (sweeping) {
+#pragma unroll
+            for (int u = 0; u < kIdxUnroll; ++u) w0[u] = nc[u] ? Recs::word(cg[u], 0) : 0u;   // the first operations of all records side by side
         }
 #pragma unroll
         for (int u = 0; u < kIdxUnroll; ++u) {
@@ -181,12 +188,9 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
             if (t[u] != want) continue;
             if (sweeping) {
                 if (p[u] < swept) atomicOr(&ix.head[kHdFlags], kLate);
-                const uint32_t *cig;
-                uint32_t nc;
-                recs.cigar_of(i, cig, nc);
                 uint32_t q = 0, last = 0;                        // relative to pos; saturating is not needed below 2^32 / op
-                for (uint32_t k = 0; k < nc; ++k) {
-                    const uint32_t w = Recs::word(cig, k), op = w & 0xfu, len = w >> 4;
+                for (uint32_t k = 0; k < nc[u]; ++k) {
+                    const uint32_t w = k ? Recs::word(cg[u], k) : w0[u], op = w & 0xfu, len = w >> 4;
                     if (op == 0u) q += len, last = q;
                     else if (op == 2u || op == 3u) q += len;
                     if (q > (1u << 30)) break;                   // (absurd: reported as a far batch; the two-pass route has the domain check)
@@ -211,7 +215,8 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
             const uint32_t other = __shfl_xor(reach, o, kWave);
             reach = other > reach ? other : reach;
         }
-        if (lane_id() == 0 && reach) atomicMax(&ix.head[kHdReach], reach);
+        // (one atomic per wave on ONE word is 32 K serialised atomics per chr1, ~0.4 ms: nearly every wave finds its value there already)
+        if (lane_id() == 0 && reach > __hip_atomic_load(&ix.head[kHdReach], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ix.head[kHdReach], reach);
     }
 }
 
@@ -528,6 +533,8 @@ __device__ __forceinline__ int32_t stage_origin(uint32_t base) { return ((int32_
 
 // Runs and window sums of one lane's 16 positions (first one p0), given everything before them.  Returns the number of
 // runs started up to and including these positions.
+// (kRuns: runs the staging area holds -- kStageRuns for k_depth_scan's sub-tiles, kSwStageRuns for a tile of the sweep)
+template <uint32_t kRuns = kStageRuns>
 __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const DepthSum &before, uint64_t p0, uint64_t sub_first,
                                               uint32_t target_len, uint32_t W, uint32_t Wm, const DepthOut &out, uint32_t *__restrict__ err,
                                               uint32_t *__restrict__ stage, uint32_t base)
@@ -544,7 +551,7 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
     // ---- change points -> runs ------------------------------------------------------------
     // A run [s, e) of depth c: at s coverage becomes c > 0; at e it changes again.  With idx = number
     // of runs started before position p: a start at p is run idx, a run ending at p is run idx-1.
-    if (__ballot(idx + kDsPer - base > kStageRuns) == 0) {
+    if (__ballot(idx + kDsPer - base > kRuns) == 0) {
         // every piece lies inside the image: no branches, three predicated LDS stores per position
         uint32_t *q = stage + ((int32_t)(3u * idx) - 2 - origin);   // `end` of run idx-1; run idx starts two words on
         uint32_t *const q0 = q;
@@ -583,7 +590,7 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
                 const int32_t p = pb + k;
                 if (prev > 0) {
                     const uint32_t r = idx - 1u;               // >= base - 1
-                    if (r + 1u - base <= kStageRuns) {
+                    if (r + 1u - base <= kRuns) {
                         uint32_t *q = stage + ((int32_t)(3u * r) - origin);
                         if (pending) q[0] = (uint32_t)rs, q[2] = (uint32_t)rd;
                         q[1] = (uint32_t)p;
@@ -601,7 +608,7 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
         }
         if (pending) {
             const uint32_t r = idx - 1u;
-            if (r + 1u - base <= kStageRuns) {
+            if (r + 1u - base <= kRuns) {
                 uint32_t *q = stage + ((int32_t)(3u * r) - origin);
                 q[0] = (uint32_t)rs, q[2] = (uint32_t)rd;
             } else if (r < cap32) {
@@ -686,11 +693,12 @@ __device__ __forceinline__ uint32_t scan_emit(const int32_t (&d)[kDsPer], const 
 // The staged runs [base, next) of a sub-tile -> memory, 16 bytes per lane, consecutive lanes consecutive pieces.  Left alone:
 // the `end` of a run still open where the sub-tile ends (cov_end > 0; whoever sees the next change point writes it), and of
 // run base-1 all but its `end`, and that only when the sub-tile closed it (closes_prev).
+template <int kThreads = kDsThreads, uint32_t kRuns = kStageRuns>
 __device__ __forceinline__ void scan_flush(const uint32_t *__restrict__ stage, uint32_t base, uint32_t next, bool closes_prev,
                                            int32_t cov_end, const DepthOut &out)
 {
     uint32_t n = next - base;
-    n = n < kStageRuns ? n : kStageRuns;
+    n = n < kRuns ? n : kRuns;
     const int32_t origin = stage_origin(base);
     const int32_t g_lo = (int32_t)(3u * base);                           // in dwords of runs[]; < 2^30
     const uint64_t lim = 3ull * out.runs_cap;
@@ -698,9 +706,9 @@ __device__ __forceinline__ void scan_flush(const uint32_t *__restrict__ stage, u
     if ((uint64_t)g_hi > lim) g_hi = (int32_t)lim;
     const int32_t prev_end = closes_prev && (uint64_t)g_lo <= lim ? g_lo - 2 : -8;
     if (g_hi <= g_lo && prev_end < 0) return;
-    const int32_t skip = (cov_end > 0 && next - base - 1u < kStageRuns) ? (int32_t)(3u * (next - 1u)) + 1 : -8;
+    const int32_t skip = (cov_end > 0 && next - base - 1u < kRuns) ? (int32_t)(3u * (next - 1u)) + 1 : -8;
     uint32_t *__restrict__ dst = reinterpret_cast<uint32_t *>(out.runs);
-    for (int32_t g = origin + 4 * (int32_t)threadIdx.x; g < g_hi; g += 4 * kDsThreads) {
+    for (int32_t g = origin + 4 * (int32_t)threadIdx.x; g < g_hi; g += 4 * kThreads) {
         const u32 v = *reinterpret_cast<const u32 *>(stage + (g - origin));
         if (g >= g_lo && g + 4 <= g_hi && (uint32_t)(skip - g) >= 4u) {
             *reinterpret_cast<u32 *>(dst + g) = v;
@@ -862,18 +870,30 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
 // LDS image of the tile, laid out for what comes after the gather: lane l of sub-tile sb holds positions 16 l .. 16 l + 15
 // as four quads, and quad j of all lanes lies together (conflict-free 16-byte reads):
 //   position p -> word (p & ~8191) | (((p >> 2 & 3) * 512 + ((p & 8191) >> 4)) << 2) | (p & 3)
-constexpr int kSwSub = kTile / kDsTile;
-static_assert(kSwSub * kDsTile == kTile && kStageWords <= (uint32_t)kTile, "the tile image doubles as the runs' staging area");
-__device__ __forceinline__ uint32_t sw_word(uint32_t p) { return (p & ~8191u) | (((((p >> 2) & 3u) << 9) + ((p & 8191u) >> 4)) << 2) | (p & 3u); }
+// One workgroup of kTile / 16 = 1024 threads per tile, 16 positions per lane, two workgroups per CU (64 KB of LDS and <= 64
+// VGPRs each): 32 waves per CU keep the record loads of the gather in flight, as k_depth_tiles does.
+//   position p -> word (((p >> 2 & 3) * 1024 + (p >> 4)) << 2) | (p & 3)
+constexpr int kSwThreads = kTile / kDsPer;
+constexpr uint32_t kSwStageRuns = (kTile - 8) / 3 - 1;       // runs of one tile the image's LDS can stage (5457; a tile at 30x holds ~4400)
+static_assert(kSwThreads == kTileThreads && 3 * (kSwStageRuns + 1) + 8 <= (uint32_t)kTile, "the tile image doubles as the runs' staging area");
+__device__ __forceinline__ uint32_t sw_word(uint32_t p) { return (((((p >> 2) & 3u) << 10) + (p >> 4)) << 2) | (p & 3u); }
 
 template <typename Recs>
-__global__ __launch_bounds__(kDsThreads) void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff,
-                                                           uint64_t slots, TileIndex ix, SweepState sw, uint32_t target_len, uint32_t W,
-                                                           DepthOut out, uint32_t *__restrict__ bad)
+__global__ __launch_bounds__(kSwThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restrict__ diff, uint64_t slots, TileIndex ix, SweepState sw,
+                   uint32_t target_len, uint32_t W, DepthOut out, uint32_t *__restrict__ bad)
 {
-    constexpr int kWaves = kDsThreads / kWave;
+    constexpr int kWaves = kSwThreads / kWave;
+#ifdef DIAG_SWEEP_STAMPS
+    uint64_t st_[8];
+    int st_n = 0;
+#define SW_STAMP() st_[st_n++] = wall_clock64()
+#else
+#define SW_STAMP()
+#endif
+    SW_STAMP();
     __shared__ __attribute__((aligned(16))) int32_t s_d[kTile];
-    __shared__ DepthSum s_w[kSwSub * kWaves + 1];
+    __shared__ DepthSum s_w[kWaves + 1];
     __shared__ DepthSum s_lb;
     __shared__ uint32_t s_lbp, s_tile;
     const int tid = threadIdx.x;
@@ -889,24 +909,24 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_sweep(Recs recs, int32_t w
     if (tid == 0) s_tile = atomicAdd(&sw.ctl[kSwTicket], 1u);   // tiles in start order: the look-back only waits on running workgroups
     __syncthreads();
     const uint32_t t = frontier + s_tile;
-    const uint32_t t_lo = ix.first_lo[t], t_hi = ix.first_hi[t], t_hi1 = ix.first_hi[t + 1], was_written = ix.written[t];
+    const uint32_t t_lo = ix.first_lo[t], t_hi1 = ix.first_hi[t + 1], was_written = ix.written[t];
     const u64 lo = (u64)t * kTile, hi = lo + kTile;
     const uint32_t r_first = first_at(t_lo, lo > kReach ? lo - kReach : 0, h_r0, h_r1, h_pmin, h_pmax);
     const uint32_t r_end = t + 1 == ix.ntiles ? h_r1 : first_at(t_hi1, hi, h_r0, h_r1, h_pmin, h_pmax);
-    (void)t_hi;
     const bool sweep = t < closed, gather = r_first < r_end;
     if (!sweep && !gather) return;                             // an open tile nothing lands in
+    SW_STAMP();
     if (gather) {
         u32 *z = reinterpret_cast<u32 *>(s_d);
 #pragma unroll
-        for (int k = 0; k < kTile / 4 / kDsThreads; ++k) z[k * kDsThreads + tid] = u32{0, 0, 0, 0};
+        for (int k = 0; k < kTile / 4 / kSwThreads; ++k) z[k * kSwThreads + tid] = u32{0, 0, 0, 0};
         __syncthreads();
-        for (uint32_t base = r_first; base < r_end; base += kTileUnroll * kDsThreads) {
+        for (uint32_t base = r_first; base < r_end; base += kTileUnroll * kSwThreads) {
             uint32_t p[kTileUnroll], n[kTileUnroll], w0[kTileUnroll], w1[kTileUnroll];
             const uint32_t *cig[kTileUnroll];
 #pragma unroll
             for (int u = 0; u < kTileUnroll; ++u) {
-                const uint32_t r = base + u * kDsThreads + tid;
+                const uint32_t r = base + u * kSwThreads + tid;
                 n[u] = 0, p[u] = 0, cig[u] = nullptr;
                 if (r < r_end && !recs.open(r, want, flag_mask, p[u], cig[u], n[u])) n[u] = 0;
             }
@@ -925,7 +945,7 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_sweep(Recs recs, int32_t w
                     } else if (op == 0u) {               // M: +1 at the block start, -1 one past its end (bam2depth.c:94-107)
                         const u64 e = q + len;
                         if (e >= slots) {                // breakpoint beyond the dense array (>= 2^28 or huge overhang)
-                            if (p[u] >= lo) atomicOr(bad, 1u);
+                            atomicOr(bad, 1u);
                             break;
                         }
                         if (q >= lo && q < hi) __hip_atomic_fetch_add(&s_d[sw_word((uint32_t)(q - lo))], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -942,56 +962,49 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_sweep(Recs recs, int32_t w
         if (hi <= slots) {
             u32 *g = reinterpret_cast<u32 *>(diff + lo);
 #pragma unroll
-            for (int k = 0; k < kTile / 4 / kDsThreads; ++k) {
-                const uint32_t Q = (uint32_t)(k * kDsThreads + tid);
+            for (int k = 0; k < kTile / 4 / kSwThreads; ++k) {
+                const uint32_t Q = (uint32_t)(k * kSwThreads + tid);
                 u32 v = *reinterpret_cast<const u32 *>(&s_d[sw_word(4u * Q)]);
                 if (was_written) v += g[Q];
                 g[Q] = v;
             }
         } else {
-            for (u64 q = lo + tid; q < slots; q += kDsThreads) diff[q] = s_d[sw_word((uint32_t)(q - lo))] + (was_written ? diff[q] : 0);
+            for (u64 q = lo + tid; q < slots; q += kSwThreads) diff[q] = s_d[sw_word((uint32_t)(q - lo))] + (was_written ? diff[q] : 0);
         }
         if (tid == 0) ix.written[t] = 1u;
         return;
     }
-    // ---- sweep: this lane's 2 x 16 positions out of LDS (+ the tile's earlier content in HBM), then k_depth_scan's steps ----
-    int32_t d[kSwSub][kDsPer];
-    uint64_t p0[kSwSub];
+    SW_STAMP();
+    // ---- sweep: this lane's 16 positions out of LDS (+ the tile's earlier content in HBM), then k_depth_scan's steps ----
+    int32_t d[kDsPer];
+    const uint64_t p0 = lo + (uint64_t)tid * kDsPer;
 #pragma unroll
-    for (int sb = 0; sb < kSwSub; ++sb) {
-        p0[sb] = lo + (uint64_t)sb * kDsTile + (uint64_t)tid * kDsPer;
+    for (int j = 0; j < kDsPer / 4; ++j) {
+        u32 q = u32{0, 0, 0, 0};
+        if (gather) q = reinterpret_cast<const u32 *>(s_d)[j * kSwThreads + tid];
+        d[4 * j] = (int32_t)q[0], d[4 * j + 1] = (int32_t)q[1], d[4 * j + 2] = (int32_t)q[2], d[4 * j + 3] = (int32_t)q[3];
+    }
+    if (was_written) {                                         // (closed tiles lie wholly inside the array: the last tile is never swept)
+        const u32 *v = reinterpret_cast<const u32 *>(diff + p0);
 #pragma unroll
         for (int j = 0; j < kDsPer / 4; ++j) {
-            u32 q = u32{0, 0, 0, 0};
-            if (gather) q = reinterpret_cast<const u32 *>(s_d)[sb * (kDsTile / 4) + j * kDsThreads + tid];
-            d[sb][4 * j] = (int32_t)q[0], d[sb][4 * j + 1] = (int32_t)q[1], d[sb][4 * j + 2] = (int32_t)q[2], d[sb][4 * j + 3] = (int32_t)q[3];
-        }
-        if (was_written) {                                     // (closed tiles lie wholly inside the array: the last tile is never swept)
-            const u32 *v = reinterpret_cast<const u32 *>(diff + p0[sb]);
-#pragma unroll
-            for (int j = 0; j < kDsPer / 4; ++j) {
-                const u32 q = v[j];
-                d[sb][4 * j] += (int32_t)q[0], d[sb][4 * j + 1] += (int32_t)q[1], d[sb][4 * j + 2] += (int32_t)q[2], d[sb][4 * j + 3] += (int32_t)q[3];
-            }
+            const u32 q = v[j];
+            d[4 * j] += (int32_t)q[0], d[4 * j + 1] += (int32_t)q[1], d[4 * j + 2] += (int32_t)q[2], d[4 * j + 3] += (int32_t)q[3];
         }
     }
     uint32_t *const s_stage = reinterpret_cast<uint32_t *>(s_d);   // the image is in registers: its LDS stages the runs
-    DepthSum lanes_before[kSwSub];
-#pragma unroll
-    for (int sb = 0; sb < kSwSub; ++sb) {
-        const DepthSum inc = ds_wave_inclusive(scan_lane_sum(d[sb]));
-        lanes_before[sb] = ds_lane_before(inc);
-        if (lane_id() == kWave - 1) s_w[sb * kWaves + wave_id()] = inc;
-    }
+    const DepthSum inc = ds_wave_inclusive(scan_lane_sum(d));
+    const DepthSum lanes_before = ds_lane_before(inc);
+    if (lane_id() == kWave - 1) s_w[wave_id()] = inc;
     __syncthreads();                                           // (also: every lane has read its quads)
     DepthSum excl = ds_identity(), agg = ds_identity();        // (wave 0 only)
     if (wave_id() == 0) {
-        const DepthSum w = ds_wave_inclusive(lane_id() < kSwSub * kWaves ? s_w[lane_id()] : ds_identity());
-        agg = DepthSum{__shfl(w.s, kSwSub * kWaves - 1, kWave), __shfl(w.m, kSwSub * kWaves - 1, kWave),
-                       __shfl(w.z, kSwSub * kWaves - 1, kWave), __shfl(w.nz, kSwSub * kWaves - 1, kWave)};
+        const DepthSum w = ds_wave_inclusive(lane_id() < kWaves ? s_w[lane_id()] : ds_identity());
+        agg = DepthSum{__shfl(w.s, kWaves - 1, kWave), __shfl(w.m, kWaves - 1, kWave), __shfl(w.z, kWaves - 1, kWave), __shfl(w.nz, kWaves - 1, kWave)};
         excl = ds_lane_before(w);
         if (t > 0 && lane_id() == 0) ds_publish(sw.status, t, kScanAggregate, agg);
     }
+    SW_STAMP();
     DepthSum exclusive = ds_identity();                        // of tiles 0 .. t-1 (earlier calls' included); the same in every thread
     if (t > 0) {
         int64_t newest = (int64_t)t - 1;
@@ -1012,23 +1025,28 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_sweep(Recs recs, int32_t w
         if (lane_id() == 0) {
             const DepthSum all = ds_compose(exclusive, agg);
             ds_publish(sw.status, t, kScanPrefix, all);
-            s_w[kSwSub * kWaves] = all;
+            s_w[kWaves] = all;
         }
-        if (lane_id() < kSwSub * kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before (sub-tile, wave) `lane`
+        if (lane_id() < kWaves) s_w[lane_id()] = ds_compose(exclusive, excl);   // everything before wave `lane`
     }
     __syncthreads();
+    SW_STAMP();
     const uint32_t Wm = W ? 0xffffffffu / W : 0u;
-#pragma unroll
-    for (int sb = 0; sb < kSwSub; ++sb) {
-        const DepthSum before = ds_compose(s_w[sb * kWaves + wave_id()], lanes_before[sb]);
-        const DepthSum upto0 = s_w[sb * kWaves];
-        const DepthSum upto = s_w[(sb + 1) * kWaves];
-        const uint32_t base = ds_starts(upto0, 0);
-        (void)scan_emit(d[sb], before, p0[sb], lo + (uint64_t)sb * kDsTile, target_len, W, Wm, out, &sw.ctl[kSwErr], s_stage, base);
-        __syncthreads();
-        scan_flush(s_stage, base, ds_starts(upto, 0), upto0.s > 0 && upto.nz != upto0.nz, upto.s, out);
-        if (sb + 1 < kSwSub) __syncthreads();                  // the image is written again
-    }
+    const DepthSum before = ds_compose(s_w[wave_id()], lanes_before);
+    const DepthSum upto0 = s_w[0];
+    const DepthSum upto = s_w[kWaves];
+    const uint32_t base = ds_starts(upto0, 0);
+    (void)scan_emit<kSwStageRuns>(d, before, p0, lo, target_len, W, Wm, out, &sw.ctl[kSwErr], s_stage, base);
+    __syncthreads();
+    SW_STAMP();
+    scan_flush<kSwThreads, kSwStageRuns>(s_stage, base, ds_starts(upto, 0), upto0.s > 0 && upto.nz != upto0.nz, upto.s, out);
+#ifdef DIAG_SWEEP_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    SW_STAMP();
+    if (tid == 0 && (t & 1023u) == 7u)
+        printf("tile %u: setup %llu gather %llu scan %llu lookback %llu emit %llu flush %llu (x10 ns) records %u\n", t, st_[1] - st_[0], st_[2] - st_[1],
+               st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], r_end - r_first);
+#endif
 }
 
 // After the sweep of a call: the frontier moves up to the tile the batch's last record lies in, the tickets start over.
@@ -1345,7 +1363,7 @@ static hipError_t depth_add(const Recs &recs, uint64_t n, int32_t tid, uint32_t 
     hipLaunchKernelGGL(k_depth_index<Recs>, dim3((unsigned)(wi < cap * 4 ? wi : cap * 4)), dim3(kIdxThreads), 0, st, recs, n, tid, ix, sw);
     // the sweep takes the batch (sorted, no far breakpoint, not behind the frontier) or leaves it to the three kernels behind it
     const DepthOut out{so.runs, so.runs_cap, nullptr, so.W ? so.win_sum : nullptr};
-    hipLaunchKernelGGL(k_depth_sweep<Recs>, dim3(ix.ntiles), dim3(kDsThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, sw, so.target_len,
+    hipLaunchKernelGGL(k_depth_sweep<Recs>, dim3(ix.ntiles), dim3(kSwThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, sw, so.target_len,
                        so.W, out, bad);
     hipLaunchKernelGGL(k_depth_tiles<Recs>, dim3(ix.ntiles), dim3(kTileThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, sw, bad);
     hipLaunchKernelGGL(k_depth_fill, dim3(ix.ntiles), dim3(256), 0, st, diff, slots, ix, sw);

@@ -253,6 +253,16 @@ int main(int argc, char *argv[])
         fprintf(stderr, "%lu\n", (unsigned long)n_count0);  // databuf->n_count: always the first file's (:414)
     }
     if (n_in > 0) {
+        size_t bt = 0;
+        uint64_t bw = 0;
+        if (!window_gc_in_domain(hdr0.target_len, off0.data(), gc0.data(), touched0.data(), &bt, &bw)) {
+            // GC[tid][w] += gc is a float32 sum in the reference (bam_sliding_count.c:121): from 2^24 on its value depends on
+            // the order of the additions, which this build does not keep -- refuse rather than print other digits
+            fprintf(stderr, "bam_sliding_count: window %llu of %s holds %llu G/C bases (2^24 or more): the reference's float32 sum is "
+                    "order-dependent there; use a smaller -w\n", (unsigned long long)(bw + 1), hdr0.target_name[bt].c_str(),
+                    (unsigned long long)gc0[off0[bt] + bw]);
+            return 2;
+        }
         std::string path = std::string(outfile) + ".txt";
         FILE *out = fopen(path.c_str(), "wb");
         if (!out) err(1, "Failed to open file (%s)", path.c_str());

@@ -131,3 +131,22 @@ def test_hg38_shaped_bam_through_the_tools(tmp_path):
             assert b"GPU ingest on 3 workers" in p.stderr and b"abandoned" not in p.stderr, p.stderr.decode()
     rows = want.split(b"\n")
     assert len(rows) == 1 + 25 + 1 and rows[1].startswith(b"chr1\t248956422\t")
+
+
+def test_gc_window_beyond_the_float32_domain_is_refused(tmp_path):
+    """A window whose G/C sum reaches 2^24: the reference's float32 accumulation (bam_sliding_count.c:119-121) is order-
+    dependent there (pinned against the reference in tests/test_c4_synth.py); the tool stops with the domain error's exit
+    code instead of printing other digits, on every route; a window size that keeps the sums exact gives the oracle's bytes."""
+    tg = [("chrBig", 2_000_000, 260_000), ("chrS", 50_000, 1000)]
+    bam, prefix = c4.synth(str(tmp_path), "g.bam", tg, 4)
+    soa = c4.Soa(prefix, len(tg))
+    for env in ({}, {"HPN_NGPU": "2"}, {"HPN_BAM_GPU": "0"}):
+        d = tmp_path / ("r" + "".join(env.values()))
+        d.mkdir()
+        os.symlink(bam, d / "g.bam"), os.symlink(bam + ".bai", d / "g.bam.bai")
+        e = {**os.environ, **env}
+        p = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", "3000000", "-o", "s", "g.bam"], cwd=d, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 2 and b"order-dependent" in p.stderr and not os.path.exists(d / "s.txt"), p.stderr.decode()
+        p = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", "100000", "-o", "s", "g.bam"], cwd=d, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        assert open(d / "s.txt", "rb").read() == c4.oracle_window_report(soa, tg, 100000)
