@@ -119,6 +119,7 @@ SYMBOLS = [
     ("hpn_window_add_raw_dev", _int, [_vp, _vp]),
     ("hpn_depth_begin", _int, [_vp, _i32, _u32, _u32]),
     ("hpn_depth_begin_w", _int, [_vp, _i32, _u32, _u32, _u32]),
+    ("hpn_depth_progress", _int, [_vp, C.POINTER(_u64)]),
     ("hpn_depth_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_add_dev", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_depth_finish", _int, [_vp, _u32, _vp, _u64, C.POINTER(_u64), _vp]),

@@ -99,6 +99,18 @@ int hpn_depth_begin_w(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t fla
 
 int hpn_depth_begin(hpn_ctx *c, int32_t tid, uint32_t target_len, uint32_t flag_mask) { return hpn_depth_begin_w(c, tid, target_len, flag_mask, 0); }
 
+int hpn_depth_progress(hpn_ctx *c, uint64_t *swept_positions)
+{
+    if (!c || !swept_positions) return HPN_E_ARG;
+    if (!c->depth_open) return fail(c, HPN_E_STATE, "hpn_depth_progress before hpn_depth_begin");
+    HPN_HIP(c, hipSetDevice(c->device));
+    uint32_t frontier = 0;
+    HPN_HIP(c, hipMemcpyAsync(&frontier, c->d_sw.p, sizeof frontier, hipMemcpyDeviceToHost, c->stream));   // ctl[kSwFrontier]
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
+    *swept_positions = (uint64_t)frontier * 16384u;   // kTile
+    return HPN_OK;
+}
+
 static int depth_add_common(hpn_ctx *c, const hpn_bam_batch *b)
 {
     if (b->n > 0xfffffff0ull) return fail(c, HPN_E_ARG, "more than 2^32 records in one hpn_depth_add call");

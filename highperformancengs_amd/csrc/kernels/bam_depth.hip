@@ -48,6 +48,9 @@ constexpr int kTileUnroll = 4;              // records per lane in flight in k_d
 
 // ---- record accessors: SoA batch (hpn_bam_batch) or records in place in inflated BGZF blocks ----------
 struct SoaRecs {
+    // the CIGAR operations of a batch lie in one array: the reach is BOUNDED by (most operations of a record) x (longest M / D / N
+    // operation of the batch) from two streaming passes, instead of walked record by record
+    static constexpr bool kCigarArray = true;
     const int32_t *tid, *pos;
     const uint32_t *flag, *cigar_off, *cigar;
     __device__ __forceinline__ void key(uint64_t r, int32_t &t, uint32_t &p) const { t = tid[r], p = (uint32_t)pos[r]; }
@@ -77,6 +80,7 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
 
 // bam1_core_t on disk behind block_size (bam.h:178-187): refID @4, pos @8, l_read_name @12, n_cigar_op @16, flag @18
 struct RawRecs {
+    static constexpr bool kCigarArray = false;
     const uint8_t *raw;
     const uint64_t *rec_off;
     __device__ __forceinline__ void key(uint64_t r, int32_t &t, uint32_t &p) const
@@ -111,7 +115,7 @@ struct RawRecs {
 // K3
 // ---------------------------------------------------------------------------
 // head[]: per-add state, cleared before k_depth_index
-enum { kHdFlags = 0, kHdFar = 1, kHdR0 = 2, kHdR1 = 3, kHdPmin = 4, kHdPmax = 5, kHdReach = 6, kHdWords = 8 };
+enum { kHdFlags = 0, kHdFar = 1, kHdR0 = 2, kHdR1 = 3, kHdPmin = 4, kHdPmax = 5, kHdReach = 6, kHdNcig = 7, kHdOplen = 8, kHdWords = 12 };
 constexpr uint32_t kUnsorted = 1u;
 constexpr uint32_t kLate = 2u;      // a record of the target lies in front of the sweep's frontier
 
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
                 if (sweeping) recs.cigar_of(i, cg[u], nc[u]);     // (where the CIGAR lies: issued beside the keys, not behind them)
             }
         }
-        if (sweeping) {
+        if (sweeping && !Recs::kCigarArray) {
 #pragma unroll
             for (int u = 0; u < kIdxUnroll; ++u) w0[u] = nc[u] ? Recs::word(cg[u], 0) : 0u;   // the first operations of all records side by side
         }
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
             if (sweeping) {
                 if (p[u] < swept) atomicOr(&ix.head[kHdFlags], kLate);
                 uint32_t q = 0, last = 0;                        // relative to pos; saturating is not needed below 2^32 / op
-                for (uint32_t k = 0; k < nc[u]; ++k) {
+                if (Recs::kCigarArray) last = nc[u];             // (only counted here: k_depth_oplen has the lengths)
+                else for (uint32_t k = 0; k < nc[u]; ++k) {
                     const uint32_t w = k ? Recs::word(cg[u], k) : w0[u], op = w & 0xfu, len = w >> 4;
                     if (op == 0u) q += len, last = q;
                     else if (op == 2u || op == 3u) q += len;
@@ -216,14 +221,43 @@ __global__ __launch_bounds__(kIdxThreads) void k_depth_index(Recs recs, uint64_t
             reach = other > reach ? other : reach;
         }
         // (one atomic per wave on ONE word is 32 K serialised atomics per chr1, ~0.4 ms: nearly every wave finds its value there already)
-        if (lane_id() == 0 && reach > __hip_atomic_load(&ix.head[kHdReach], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ix.head[kHdReach], reach);
+        uint32_t *word = &ix.head[Recs::kCigarArray ? kHdNcig : kHdReach];
+        if (lane_id() == 0 && reach > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, reach);
     }
+}
+
+// longest M / D / N operation among cigar[cigar_off[0] .. cigar_off[n]) (SoA batches): one streaming pass
+__global__ __launch_bounds__(256) void k_depth_oplen(const uint32_t *__restrict__ cigar_off, const uint32_t *__restrict__ cigar, uint64_t n,
+                                                    TileIndex ix, SweepState sw)
+{
+    if (sw.ctl[kSwEnabled] == 0) return;
+    const uint32_t c0 = cigar_off[0], c1 = cigar_off[n];
+    uint32_t best = 0;
+    for (uint64_t i = (uint64_t)c0 + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < c1; i += (uint64_t)gridDim.x * 256 * 4) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (i + 4 <= c1) __builtin_memcpy(w, cigar + i, 16);
+        else
+            for (uint64_t k = i; k < c1; ++k) w[k - i] = cigar[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t op = w[k] & 0xfu, len = w[k] >> 4;
+            if ((op == 0u || op == 2u || op == 3u) && len > best) best = len;
+        }
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(best, o, kWave);
+        best = other > best ? other : best;
+    }
+    if (lane_id() == 0 && best > __hip_atomic_load(&ix.head[kHdOplen], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ix.head[kHdOplen], best);
 }
 
 // Does this batch go through the sweep?  The same answer in every kernel of the call (it is a function of the head).
 __device__ __forceinline__ bool sweep_takes(const TileIndex &ix, const SweepState &sw)
 {
-    return sw.ctl[kSwEnabled] != 0 && !(ix.head[kHdFlags] & (kUnsorted | kLate)) && ix.head[kHdReach] <= kReach;
+    // reach: walked exactly (records in place), or bounded by operations x longest operation (SoA)
+    return sw.ctl[kSwEnabled] != 0 && !(ix.head[kHdFlags] & (kUnsorted | kLate)) && ix.head[kHdReach] <= kReach &&
+           (u64)ix.head[kHdNcig] * ix.head[kHdOplen] <= kReach;
 }
 
 // first record of the wanted target with pos >= thr (thr in positions): the head's values, or the table entry `tab`
@@ -874,6 +908,10 @@ __global__ __launch_bounds__(kDsThreads) void k_depth_scan(const int32_t *__rest
 // VGPRs each): 32 waves per CU keep the record loads of the gather in flight, as k_depth_tiles does.
 //   position p -> word (((p >> 2 & 3) * 1024 + (p >> 4)) << 2) | (p & 3)
 constexpr int kSwThreads = kTile / kDsPer;
+#ifndef HPN_SW_LB_WAVES
+#define HPN_SW_LB_WAVES 1
+#endif
+constexpr int kSwLbWaves = HPN_SW_LB_WAVES;                  // waves of a tile's workgroup that look back side by side
 constexpr uint32_t kSwStageRuns = (kTile - 8) / 3 - 1;       // runs of one tile the image's LDS can stage (5457; a tile at 30x holds ~4400)
 static_assert(kSwThreads == kTileThreads && 3 * (kSwStageRuns + 1) + 8 <= (uint32_t)kTile, "the tile image doubles as the runs' staging area");
 __device__ __forceinline__ uint32_t sw_word(uint32_t p) { return (((((p >> 2) & 3u) << 10) + (p >> 4)) << 2) | (p & 3u); }
@@ -885,7 +923,7 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
 {
     constexpr int kWaves = kSwThreads / kWave;
 #ifdef DIAG_SWEEP_STAMPS
-    uint64_t st_[8];
+    uint64_t st_[12];
     int st_n = 0;
 #define SW_STAMP() st_[st_n++] = wall_clock64()
 #else
@@ -894,8 +932,9 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
     SW_STAMP();
     __shared__ __attribute__((aligned(16))) int32_t s_d[kTile];
     __shared__ DepthSum s_w[kWaves + 1];
-    __shared__ DepthSum s_lb;
-    __shared__ uint32_t s_lbp, s_tile;
+    __shared__ DepthSum s_lb[kSwLbWaves];
+    __shared__ uint32_t s_lbp[kSwLbWaves];
+    __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     if (!sweep_takes(ix, sw)) return;
     const uint32_t h_r0 = ix.head[kHdR0], h_r1 = ix.head[kHdR1], h_pmin = ix.head[kHdPmin], h_pmax = ix.head[kHdPmax];
@@ -922,7 +961,7 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
         for (int k = 0; k < kTile / 4 / kSwThreads; ++k) z[k * kSwThreads + tid] = u32{0, 0, 0, 0};
         __syncthreads();
         for (uint32_t base = r_first; base < r_end; base += kTileUnroll * kSwThreads) {
-            uint32_t p[kTileUnroll], n[kTileUnroll], w0[kTileUnroll], w1[kTileUnroll];
+            uint32_t p[kTileUnroll], n[kTileUnroll], w0[kTileUnroll], w1[kTileUnroll], w2[kTileUnroll];
             const uint32_t *cig[kTileUnroll];
 #pragma unroll
             for (int u = 0; u < kTileUnroll; ++u) {
@@ -930,26 +969,43 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
                 n[u] = 0, p[u] = 0, cig[u] = nullptr;
                 if (r < r_end && !recs.open(r, want, flag_mask, p[u], cig[u], n[u])) n[u] = 0;
             }
+#ifdef DIAG_SWEEP_STAMPS
+            { uint32_t sink = 0;
+              for (int u = 0; u < kTileUnroll; ++u) sink += n[u] + p[u];
+              if (sink == 0xdeadbeefu) st_[11] = 1; }
+            uint64_t g1 = wall_clock64();
+#endif
 #pragma unroll
             for (int u = 0; u < kTileUnroll; ++u) {
                 w0[u] = n[u] > 0 ? Recs::word(cig[u], 0) : 0u;
                 w1[u] = n[u] > 1 ? Recs::word(cig[u], 1) : 0u;
+                w2[u] = n[u] > 2 ? Recs::word(cig[u], 2) : 0u;   // (a third operation loaded inside the walk is a memory round trip per record and lane, one after the other)
             }
+#ifdef DIAG_SWEEP_STAMPS
+            { uint32_t sink = 0;
+              for (int u = 0; u < kTileUnroll; ++u) sink += w0[u] + w1[u] + w2[u];
+              if (sink == 0xdeadbeefu) st_[11] = 2; }
+            uint64_t g2 = wall_clock64();
+            st_[8] = g1, st_[9] = g2;
+#endif
+        // positions in 32 bits: slots <= 2^28 and an operation is shorter than 2^28, so q + len cannot wrap while q is kept below 2^31
+        const uint32_t lo32 = (uint32_t)lo, slots32 = (uint32_t)slots;
 #pragma unroll
             for (int u = 0; u < kTileUnroll; ++u) {
-                u64 q = p[u];
+                uint32_t q = p[u] < 0x80000000u ? p[u] : 0x80000000u;
                 for (uint32_t k = 0; k < n[u]; ++k) {
-                    const uint32_t w = k == 0 ? w0[u] : k == 1 ? w1[u] : Recs::word(cig[u], k), op = w & 0xfu, len = w >> 4;
+                    const uint32_t w = k == 0 ? w0[u] : k == 1 ? w1[u] : k == 2 ? w2[u] : Recs::word(cig[u], k), op = w & 0xfu, len = w >> 4;
                     if (op == 2u || op == 3u) {          // D, N: advance only
                         q += len;
+                        q = q < 0x80000000u ? q : 0x80000000u;
                     } else if (op == 0u) {               // M: +1 at the block start, -1 one past its end (bam2depth.c:94-107)
-                        const u64 e = q + len;
-                        if (e >= slots) {                // breakpoint beyond the dense array (>= 2^28 or huge overhang)
+                        const uint32_t e = q + len;
+                        if (e >= slots32) {              // breakpoint beyond the dense array (>= 2^28 or huge overhang)
                             atomicOr(bad, 1u);
                             break;
                         }
-                        if (q >= lo && q < hi) __hip_atomic_fetch_add(&s_d[sw_word((uint32_t)(q - lo))], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (e >= lo && e < hi) __hip_atomic_fetch_add(&s_d[sw_word((uint32_t)(e - lo))], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (q - lo32 < (uint32_t)kTile) __hip_atomic_fetch_add(&s_d[sw_word(q - lo32)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (e - lo32 < (uint32_t)kTile) __hip_atomic_fetch_add(&s_d[sw_word(e - lo32)], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         q = e;
                     }                                    // I, S, H, P, =, X: neither counted nor advanced
                 }
@@ -1007,17 +1063,27 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
     SW_STAMP();
     DepthSum exclusive = ds_identity();                        // of tiles 0 .. t-1 (earlier calls' included); the same in every thread
     if (t > 0) {
+        // A tile's aggregate exists only after its gather (~10 us in), so the 512 tiles in flight reach this point at about the same
+        // time and wait for each other: 10-15 us per tile on average, the sweep's longest step (stamps in profiles/r03).  More
+        // waves looking back side by side (64 tiles each) only add polling traffic: 1 / 2 / 4 / 16 waves: 0.94 / 0.96 / 0.99 / 1.14 ms.
         int64_t newest = (int64_t)t - 1;
         for (;;) {
-            if (wave_id() == 0) {
+            if (wave_id() < kSwLbWaves) {
                 bool hp = false;
-                const DepthSum win = ds_window(sw.status, newest, &hp, &sw.ctl[kSwErr]);
-                if (lane_id() == 0) s_lb = win, s_lbp = hp ? 1u : 0u;
+                const DepthSum win = ds_window(sw.status, newest - (int64_t)kWave * wave_id(), &hp, &sw.ctl[kSwErr]);
+                if (lane_id() == 0) s_lb[wave_id()] = win, s_lbp[wave_id()] = hp ? 1u : 0u;
             }
             __syncthreads();
-            exclusive = ds_compose(s_lb, exclusive);           // older windows come first
-            if (s_lbp) break;
-            newest -= kWave;
+            bool found = false;
+#pragma unroll
+            for (int v = 0; v < kSwLbWaves; ++v) {
+                if (!found) {
+                    exclusive = ds_compose(s_lb[v], exclusive);   // older windows come first
+                    found = s_lbp[v] != 0;
+                }
+            }
+            if (found) break;
+            newest -= (int64_t)kWave * kSwLbWaves;
             __syncthreads();                                   // s_lb is written again
         }
     }
@@ -1044,8 +1110,8 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
     __builtin_amdgcn_s_waitcnt(0);
     SW_STAMP();
     if (tid == 0 && (t & 1023u) == 7u)
-        printf("tile %u: setup %llu gather %llu scan %llu lookback %llu emit %llu flush %llu (x10 ns) records %u\n", t, st_[1] - st_[0], st_[2] - st_[1],
-               st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], r_end - r_first);
+        printf("tile %u: setup %llu gather %llu [fields %llu words %llu walk %llu] scan %llu lookback %llu emit %llu flush %llu (x10 ns) records %u\n", t, st_[1] - st_[0], st_[2] - st_[1],
+               st_[8] - st_[1], st_[9] - st_[8], st_[2] - st_[9], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], r_end - r_first);
 #endif
 }
 
@@ -1349,6 +1415,13 @@ struct SweepOut {
     uint32_t target_len, W;
 };
 
+static void launch_oplen(const SoaRecs &recs, uint64_t n, const TileIndex &ix, const SweepState &sw, uint64_t cap, hipStream_t st)
+{
+    const uint64_t want = (n / 4 + 255) / 256 + 1;       // ~1.25 operations per record
+    hipLaunchKernelGGL(k_depth_oplen, dim3((unsigned)(want < cap * 2 ? want : cap * 2)), dim3(256), 0, st, recs.cigar_off, recs.cigar, n, ix, sw);
+}
+static void launch_oplen(const RawRecs &, uint64_t, const TileIndex &, const SweepState &, uint64_t, hipStream_t) {}
+
 template <typename Recs>
 static hipError_t depth_add(const Recs &recs, uint64_t n, int32_t tid, uint32_t flag_mask, int32_t *diff, uint64_t slots, void *ws,
                             void *sws, const SweepOut &so, uint32_t *bad, int n_cu, hipStream_t st)
@@ -1361,6 +1434,7 @@ static hipError_t depth_add(const Recs &recs, uint64_t n, int32_t tid, uint32_t 
     const uint64_t cap = (uint64_t)n_cu * 8;
     const uint64_t wi = (n + kIdxThreads - 1) / kIdxThreads, wf = (n + kFarThreads - 1) / kFarThreads;
     hipLaunchKernelGGL(k_depth_index<Recs>, dim3((unsigned)(wi < cap * 4 ? wi : cap * 4)), dim3(kIdxThreads), 0, st, recs, n, tid, ix, sw);
+    launch_oplen(recs, n, ix, sw, cap, st);
     // the sweep takes the batch (sorted, no far breakpoint, not behind the frontier) or leaves it to the three kernels behind it
     const DepthOut out{so.runs, so.runs_cap, nullptr, so.W ? so.win_sum : nullptr};
     hipLaunchKernelGGL(k_depth_sweep<Recs>, dim3(ix.ntiles), dim3(kSwThreads), 0, st, recs, tid, flag_mask, diff, slots, ix, sw, so.target_len,

@@ -369,6 +369,9 @@ int hpn_depth_begin(hpn_ctx *ctx, int32_t tid, uint32_t target_len, uint32_t fla
  * order put HPN_DEPTH_ANY_ORDER into flag_mask: nothing is swept early then. */
 #define HPN_DEPTH_ANY_ORDER 0x80000000u
 int hpn_depth_begin_w(hpn_ctx *ctx, int32_t tid, uint32_t target_len, uint32_t flag_mask, uint32_t W);
+/* How far the target has been swept by the hpn_depth_add calls so far: positions [0, *swept_positions) are final (waits for the
+ * calls' kernels).  0 with HPN_DEPTH_ANY_ORDER, or while no batch could be taken that way. */
+int hpn_depth_progress(hpn_ctx *ctx, uint64_t *swept_positions);
 int hpn_depth_add(hpn_ctx *ctx, const hpn_bam_batch *host_batch);
 int hpn_depth_add_dev(hpn_ctx *ctx, const hpn_bam_batch *dev_batch);
 /* runs: caller buffer of runs_cap entries; *n_runs receives the number found

@@ -14,7 +14,10 @@ from highperformancengs_amd import _lib, bamio
 
 pytestmark = pytest.mark.gpu
 FAR = ["150M", "50M2047N50M", "50M2048N50M", "30M1999D20M100N40M", "10M20000N10M30000N10M", "5M100000D5M"]
-NEAR = ["150M", "40M2I108M", "60M5D90M", "10S140M", "50M1900N50M", "1M", "70M500D70M", "5=5X", "20M3000I20M"]
+# (SoA batches are taken by the sweep when (most operations of a record) x (longest M / D / N operation) <= 2048: NEAR keeps
+# that bound, EDGE breaks it although no breakpoint is far -- such batches must simply go the two-pass way)
+NEAR = ["150M", "40M2I108M", "60M5D90M", "10S140M", "1M", "70M500D70M", "5=5X", "20M3000I20M", "600M"]
+EDGE = ["150M", "40M2I108M", "50M1900N50M", "70M500D70M", "5=5X"]
 
 
 @pytest.fixture(scope="module")
@@ -43,6 +46,12 @@ def _feed(ctx, soa, tid, cuts, W_begin, mask=0x704, dev=False):
     return keep
 
 
+def _swept(ctx):
+    v = C.c_uint64(0)
+    assert ctx.L.hpn_depth_progress(ctx.h, C.byref(v)) == 0
+    return v.value
+
+
 def _check(ctx, soa, tid, W, mask=0x704):
     runs, win = ctx.depth_finish(soa.refs[tid][1], W)
     rc, wruns, wbins = orc.depth_target(soa, tid, W, mask)
@@ -61,9 +70,11 @@ def test_sorted_stream_any_batching(ctx, n, seed, W, pieces):
     for tid in (0, 1):
         cuts = [0] + sorted(int(x) for x in rng.integers(0, n, pieces - 1)) + [n]      # (cuts anywhere: other targets' records ride along)
         _feed(ctx, soa, tid, cuts, W)
+        # the sweep really took place: everything in front of the tile the last record of the target lies in is final already
+        mine = soa.pos[soa.tid == tid]
+        assert _swept(ctx) == (min(int(mine.max()), refs[tid][1] + (1 << 21) - 16384) // 16384) * 16384, (tid, pieces)
         runs = _check(ctx, soa, tid, W)
         assert len(runs) > 0
-        # the sweep really took place: with pieces > 1 most tiles were final before hpn_depth_finish
         # another window size on the same result: sums from the runs
         _check(ctx, soa, tid, 777)
         _check(ctx, soa, tid, W)
@@ -73,6 +84,19 @@ def test_sorted_stream_any_batching(ctx, n, seed, W, pieces):
         # bam2wig's filter
         _feed(ctx, soa, tid, cuts, W, mask=0x4)
         _check(ctx, soa, tid, W, mask=0x4)
+
+
+def test_a_batch_beyond_the_reach_bound_goes_the_two_pass_way(ctx):
+    refs = [("chrA", 2_000_000)]
+    soa = make_soa(100_000, refs, 51, cigars=EDGE)
+    _feed(ctx, soa, 0, [0, 30_000, 100_000], 20000)
+    assert _swept(ctx) == 0
+    _check(ctx, soa, 0, 20000)
+    # ... and with HPN_DEPTH_ANY_ORDER nothing is swept whatever the batch
+    soa = make_soa(100_000, refs, 52, cigars=NEAR)
+    _feed(ctx, soa, 0, [0, 30_000, 100_000], 20000, mask=0x704 | _lib.DEPTH_ANY_ORDER)
+    assert _swept(ctx) == 0
+    _check(ctx, soa, 0, 20000)
 
 
 def test_batches_the_sweep_must_leave_alone(ctx):
