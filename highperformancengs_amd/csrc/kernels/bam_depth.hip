@@ -1066,15 +1066,30 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
         // A tile's aggregate exists only after its gather (~10 us in), so the 512 tiles in flight reach this point at about the same
         // time and wait for each other: 10-15 us per tile on average, the sweep's longest step (stamps in profiles/r03).  More
         // waves looking back side by side (64 tiles each) only add polling traffic: 1 / 2 / 4 / 16 waves: 0.94 / 0.96 / 0.99 / 1.14 ms.
+        // A tile's aggregate exists only after its gather (~10 us in), so the 512 tiles in flight reach this point at about the same
+        // time and wait for each other: 10-15 us per tile, the sweep's longest step (stamps in profiles/r03/sweep_stamps.txt).
+        // Step 1, one wave: the 64 tiles in front of this one, polled until each has at least its aggregate.  Step 2, only when none
+        // of them holds a prefix yet: kSwLbWaves waves look further back side by side.  Measured per chr1 (index + sweep): all
+        // windows polled by 1 / 2 / 4 / 16 waves from the start 0.94 / 0.96 / 0.99 / 1.14 ms; this two-step form with 8 waves 0.97:
+        // the wait is for the aggregates themselves, not for the prefix to travel, and more polling only takes from the gathers.
         int64_t newest = (int64_t)t - 1;
-        for (;;) {
+        if (wave_id() == 0) {
+            bool hp = false;
+            const DepthSum win = ds_window(sw.status, newest, &hp, &sw.ctl[kSwErr]);
+            if (lane_id() == 0) s_lb[0] = win, s_lbp[0] = hp ? 1u : 0u;
+        }
+        __syncthreads();
+        exclusive = s_lb[0];
+        bool found = s_lbp[0] != 0;
+        newest -= kWave;
+        while (!found) {
+            __syncthreads();                                   // s_lb is written again
             if (wave_id() < kSwLbWaves) {
                 bool hp = false;
                 const DepthSum win = ds_window(sw.status, newest - (int64_t)kWave * wave_id(), &hp, &sw.ctl[kSwErr]);
                 if (lane_id() == 0) s_lb[wave_id()] = win, s_lbp[wave_id()] = hp ? 1u : 0u;
             }
             __syncthreads();
-            bool found = false;
 #pragma unroll
             for (int v = 0; v < kSwLbWaves; ++v) {
                 if (!found) {
@@ -1082,9 +1097,7 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
                     found = s_lbp[v] != 0;
                 }
             }
-            if (found) break;
             newest -= (int64_t)kWave * kSwLbWaves;
-            __syncthreads();                                   // s_lb is written again
         }
     }
     if (wave_id() == 0) {
