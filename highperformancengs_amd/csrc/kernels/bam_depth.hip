@@ -1347,6 +1347,10 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
             piece += s_w[sb][w];
         }
         uint32_t at = (uint32_t)before + wex[sb];             // this lane's first line inside the piece
+        // (Round 3 tried lines built in registers -- digits shifted to the front with v_alignbyte, fields written with two overlapping
+        // exact-length 8- / 4- / 2-byte stores at their own byte offsets: 270 M instead of 313 M vector instructions per chr1, but the
+        // unaligned stores stall in LDS (SQ_LDS_UNALIGNED_STALL 394 M cycles: 1.15 ms against 1.03) and are worse still straight to
+        // memory (2.27 ms): profiles/r03/bedgraph_text_variants.txt.  The byte-wise line stays.)
         if (name_len <= kFmtMaxName) {                        // staged: build in LDS, copy out in 16-byte pieces
 #pragma unroll
             for (int k = 0; k < kFmtPer; ++k) {

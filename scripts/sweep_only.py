@@ -51,3 +51,9 @@ for mode in ("sweep", "two-pass"):
         ctx._ck(ctx.L.hpn_depth_finish(ctx.h, 20000, None, 0, C.byref(nr), None), "finish")
         t_fin = ctx.last_kernel_ms(2)
     print(f"{mode}: add {t_add:.3f} ms  finish {t_fin:.3f} ms  runs {nr.value}")
+    if mode == "sweep":
+        ts = []
+        for r in range(reps + 1):
+            ctx.depth_bedgraph_format("chr1")
+            ts.append(ctx.last_kernel_ms(2))
+        print(f"bedgraph text: {min(ts):.3f} ms")
