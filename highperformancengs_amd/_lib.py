@@ -114,6 +114,8 @@ SYMBOLS = [
     ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("hpn_gz_inflate_dev", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
     ("hpn_gz_members", _int, [_vp, _vp, _u32, C.POINTER(_u32)]),
+    ("hpn_crc32_dev", _int, [_vp, _vp, _vp, _u32, _vp]),
+    ("hpn_crc32_join", _u32, [_u32, _u32, _u64]),
     ("hpn_bam_raw_index_dev", _int, [_vp, _vp, _vp, _u64, _u32, _vp, C.POINTER(RawInfo)]),
     ("hpn_depth_add_raw_dev", _int, [_vp, _vp]),
     ("hpn_window_add_raw_dev", _int, [_vp, _vp]),

@@ -267,6 +267,14 @@ class Context:
         self._ck(self.L.hpn_gz_members(self.h, buf.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "hpn_gz_members")
         return [(int(r["text_end"]), int(r["isize"])) for r in buf]
 
+    def crc32_dev(self, d_data, spans):
+        """CRC-32 of d_data[off : off + len) for every (off, len) in spans (hpn_crc32_dev) -> list of ints."""
+        n = len(spans)
+        arr = np.array(spans, np.uint64).reshape(-1, 2) if n else np.zeros((0, 2), np.uint64)
+        out = np.zeros(max(n, 1), np.uint32)
+        self._ck(self.L.hpn_crc32_dev(self.h, _ptr(d_data), _ptr(arr) if n else None, n, _ptr(out)), "hpn_crc32_dev")
+        return [int(x) for x in out[:n]]
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

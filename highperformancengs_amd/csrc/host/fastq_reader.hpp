@@ -53,6 +53,14 @@ struct InStream {
     // (the text front end hands an irregular stream back to the exact framer this way)
     std::shared_ptr<const std::vector<char>> pre;
     size_t pre_pos = 0;
+    // exact: the stream is zlib's own gzFile with its default buffers, read in requests small enough to go through them, as
+    // the reference's gzgets does (IO_stream.h:122-136): on a damaged file the bytes handed out before the error are then the
+    // reference's, buffer for buffer (open_input_stream_exact)
+    bool exact = false;
+    bool gz_error = false;
+    // a reader noticed that the stream is not sound (CRC-32, ISIZE, a data error): what it delivered may differ from what
+    // gzgets hands out, and the caller reads the input again through open_input_stream_exact
+    bool damaged() const { return gz_error || (pz && pz->damaged()) || (mz && mz->damaged()); }
     int read(void *dst, unsigned n)
     {
         if (pre && pre_pos < pre->size()) {
@@ -61,7 +69,12 @@ struct InStream {
             pre_pos += k;
             return (int)k;
         }
-        return bz ? (int)bz->read(dst, n) : mz ? (int)mz->read(dst, n) : pz ? (int)pz->read(dst, n) : gzread(gz, dst, n);
+        if (bz) return (int)bz->read(dst, n);
+        if (mz) return (int)mz->read(dst, n);
+        if (pz) return (int)pz->read(dst, n);
+        const int k = gzread(gz, dst, exact && n > 8192u ? 8192u : n);   // (below 2 x 8192 zlib serves a request from its own buffer)
+        if (k < 0) gz_error = true;
+        return k;
     }
     void close()
     {
@@ -154,8 +167,19 @@ inline InStream open_input_stream(const char *name)
             }
         }
     }
+    in.gz = gzdopen(fd, "rb");   // zlib itself: default buffers and small requests, so that even a damaged stream reads as in the reference
+    in.exact = true;
+    return in;
+}
+
+// The reference's own reader and nothing else: gzdopen on the file, default buffers (see InStream::exact).
+inline InStream open_input_stream_exact(const char *name)
+{
+    InStream in;
+    const int fd = strncmp(name, "-", 1) == 0 || !strcmp(name, "") ? STDIN_FILENO : open(name, O_CREAT | O_RDONLY, 0666);
+    if (fd == -1) fprintf(stderr, "Failed to create input file (%s)", name);
     in.gz = gzdopen(fd, "rb");
-    if (in.gz) gzbuffer(in.gz, 1u << 20);
+    in.exact = true;
     return in;
 }
 
@@ -171,11 +195,27 @@ public:
     char *gets(char *dst, int len, size_t *n = nullptr)
     {
         if (len < 1) return nullptr;
+        if (f_.exact && f_.gz && !f_.pre) {
+            // zlib's own gzgets on zlib's own buffers: the reference's call, so a damaged stream ends for us where it ends for the
+            // reference (gzread in pieces does not: a request that straddles two of zlib's buffers loses the part already copied)
+            const z_off_t before = gztell(f_.gz);
+            char *r = gzgets(f_.gz, dst, len);
+            if (n) *n = (size_t)(gztell(f_.gz) - before);
+            past_ = gzeof(f_.gz) != 0;
+            return r;
+        }
         unsigned left = (unsigned)len - 1;
         char *out = dst;
         bool eol = false;
         while (left && !eol) {
             if (have_ == 0 && !fill()) {
+                // gzgets: "if (state->x.have == 0 && gz_fetch(state) == -1) return NULL" -- an ERROR of the stream ends the call at
+                // once, whatever part of a line has been copied (it stays in dst, unterminated: the callers' stale-buffer rules see
+                // it); a clean end of data ends the line with what there is
+                if (error_) {
+                    if (n) *n = (size_t)(out - dst);
+                    return nullptr;
+                }
                 past_ = true;
                 break;
             }
@@ -202,6 +242,7 @@ private:
         int n = f_.read(buf_.data(), (unsigned)buf_.size());
         if (n <= 0) {
             done_ = true;
+            error_ = n < 0;   // gzread's -1: Z_DATA_ERROR / Z_BUF_ERROR (damaged or truncated gzip)
             return false;
         }
         cur_ = buf_.data();
@@ -212,7 +253,7 @@ private:
     std::vector<char> buf_;
     const char *cur_ = nullptr;
     size_t have_ = 0;
-    bool done_ = false, past_ = false;
+    bool done_ = false, past_ = false, error_ = false;
 };
 
 // One batch of records as structure of arrays (what hpn_fastq_tally / hpn_fastq_trim take).

@@ -10,8 +10,8 @@
 //
 // Exactness is by construction as in the host reader: stretch 0 starts at the member's first
 // block, and the device accepts a stretch only if it ends on the next one's first bit at a block
-// boundary.  The member must end the file (trailer + nothing else) and its ISIZE must match.
-// Anything else -- several members, trailing bytes, a block start the trial decoder got wrong,
+// boundary.  The last member must end the file (trailer + nothing else); every member's ISIZE and CRC-32 (hpn_crc32_dev over
+// the inflated text) must match, as gzread demands.  Anything else -- trailing bytes, a block start the trial decoder got wrong,
 // more than 8x expansion, damage -- makes next() return -1 and the caller reads the file
 // through the host readers from its first byte.
 #pragma once
@@ -226,7 +226,10 @@ public:
             return give_up(why_buf_) - 1;
         }
         ++batch_;
-        {   // members that ended inside this batch (cat a.gz b.gz): every one's ISIZE against the bytes it produced
+        {   // members that ended inside this batch (cat a.gz b.gz): every one's ISIZE against the bytes it produced, and its
+            // CRC-32 against the text (gzread checks both, and the reference counts nothing of a member's last buffers if they
+            // fail: such a file is read again through zlib itself, tally_file).  The text of a member may span batches: the CRC
+            // of each piece is taken while its text is on the device and folded into the member's (hpn_crc32_join).
             uint32_t nm = 0;
             int rc = hpn_gz_members(ctx_, nullptr, 0, &nm);
             if (rc == HPN_E_CAPACITY) {
@@ -234,12 +237,23 @@ public:
                 rc = hpn_gz_members(ctx_, members_.data(), nm, &nm);
             }
             if (rc != HPN_OK) return give_up("member list") - 1;
+            spans_.clear();
+            uint64_t at = 0;
+            for (uint32_t k = 0; k < nm; ++k) spans_.push_back(hpn_span{at, members_[k].text_end - at}), at = members_[k].text_end;
+            spans_.push_back(hpn_span{at, info.n_bytes - at});          // the piece of the member that goes on in the next batch
+            crcs_.resize(spans_.size());
+            if (check_crc_ && hpn_crc32_dev(ctx_, (const uint8_t *)d_text_, spans_.data(), (uint32_t)spans_.size(), crcs_.data()) != HPN_OK)
+                return give_up("CRC-32 kernel") - 1;
             for (uint32_t k = 0; k < nm; ++k) {
                 const uint64_t end = total_ + members_[k].text_end;
                 if (members_[k].isize != (uint32_t)(end - member_start_)) return give_up("ISIZE mismatch in a member") - 1;
+                member_crc_ = hpn_crc32_join(member_crc_, crcs_[k], spans_[k].len);
+                if (check_crc_ && member_crc_ != members_[k].crc32) return give_up("CRC-32 mismatch in a member") - 1;
+                member_crc_ = 0;
                 member_start_ = end;
                 ++n_members_;
             }
+            member_crc_ = hpn_crc32_join(member_crc_, crcs_.back(), spans_.back().len);
         }
         total_ += info.n_bytes;
         *n_bytes = info.n_bytes;
@@ -248,9 +262,11 @@ public:
             if (info.final_chunk != n) return give_up("the member ends before the file does") - 1;
             const uint64_t trailer = ((starts_[n - 1] & ~(uint64_t)7) + info.end_bit) >> 3;
             if (trailer + 8 != size_) return give_up("bytes behind the member") - 1;
-            uint32_t isize;
+            uint32_t isize, crc;
+            memcpy(&crc, data_ + trailer, 4);
             memcpy(&isize, data_ + trailer + 4, 4);
             if (isize != (uint32_t)(total_ - member_start_)) return give_up("ISIZE mismatch") - 1;
+            if (check_crc_ && crc != member_crc_) return give_up("CRC-32 mismatch") - 1;
             ++n_members_;
             done_ = true;
         } else {
@@ -329,6 +345,10 @@ private:
     uint64_t first_bit_ = 0, next_start_ = 0, total_ = 0;
     uint64_t member_start_ = 0, n_members_ = 0;   // text offset where the current member began; members finished
     std::vector<hpn_gz_member> members_;
+    std::vector<hpn_span> spans_;
+    std::vector<uint32_t> crcs_;
+    uint32_t member_crc_ = 0;                       // CRC-32 of the current member's text so far
+    const bool check_crc_ = !(getenv("HPN_GZ_CRC") && getenv("HPN_GZ_CRC")[0] == '0');   // (timing experiments only)
     bool done_ = false, grown_ = false;
     double ratio_ = 4.0;
     const char *why_ = "";

@@ -87,6 +87,9 @@ public:
         if (fd_ >= 0) close(fd_);
     }
 
+    // zlib refused the stream (a member's CRC-32 / ISIZE / data): what was delivered is NOT what the reference's gzgets hands out
+    bool damaged() const { return damaged_; }
+
     // Up to n bytes of the uncompressed stream; fewer only at its end (or at an error, like gzread).
     size_t read(void *dst, size_t n)
     {
@@ -96,6 +99,7 @@ public:
             if (fallback_) {
                 const size_t ask = n - got < ((size_t)1 << 30) ? n - got : (size_t)1 << 30;
                 const int k = gzread(fallback_, out + got, (unsigned)ask);
+                if (k < 0) damaged_ = true;   // zlib's verdict on the stream: the caller re-reads it the reference's way (InStream::damaged)
                 if (k <= 0) break;
                 got += (size_t)k;
                 continue;
@@ -500,6 +504,7 @@ private:
             uint64_t skip = delivered_;
             while (skip) {
                 const int k = gzread(fallback_, sink.data(), (unsigned)(skip < sink.size() ? skip : sink.size()));
+                if (k < 0) damaged_ = true;
                 if (k <= 0) break;
                 skip -= (uint64_t)k;
             }
@@ -526,6 +531,7 @@ private:
     std::condition_variable cv_;
     bool stop_ = false;
     gzFile fallback_ = nullptr;
+    bool damaged_ = false;
 };
 
 }  // namespace hpn

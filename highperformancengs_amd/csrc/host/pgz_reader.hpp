@@ -239,6 +239,7 @@ public:
             if (fallback_) {
                 const size_t ask = n - got < ((size_t)1 << 30) ? n - got : (size_t)1 << 30;
                 const int k = gzread(fallback_, out + got, (unsigned)ask);
+                if (k < 0) damaged_ = true;   // zlib's verdict on the stream: the caller re-reads it the reference's way (InStream::damaged)
                 if (k <= 0) break;
                 got += (size_t)k;
                 continue;
@@ -255,6 +256,8 @@ public:
         return got;
     }
     bool crc_failed() const { return crc_failed_; }
+    // CRC-32 / ISIZE of a member wrong, or zlib refused the stream: what was delivered is NOT what the reference's gzgets hands out
+    bool damaged() const { return crc_failed_ || damaged_; }
     // how the stream was produced (tests, HPN_TIMING)
     uint64_t chunks_accepted() const { return n_accepted_; }
     uint64_t gaps_decoded() const { return n_gaps_; }
@@ -628,6 +631,7 @@ private:
         while (left) {
             const unsigned ask = left < sink.size() ? (unsigned)left : (unsigned)sink.size();
             const int k = gzread(fallback_, sink.data(), ask);
+            if (k < 0) damaged_ = true;
             if (k <= 0) return false;
             left -= (uint64_t)k;
         }
@@ -663,6 +667,7 @@ private:
     uint32_t member_crc_ = 0;
     bool crc_failed_ = false;
     gzFile fallback_ = nullptr;
+    bool damaged_ = false;
 };
 
 }  // namespace hpn

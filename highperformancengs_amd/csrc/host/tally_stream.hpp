@@ -100,6 +100,10 @@ inline int tally_text_stream(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
     if (timing)
         fprintf(stderr, "[hpn] %s: %.1f MB  setup %.3f s  waiting for the reader %.3f s  copy+frame+tally %.3f s\n", path,
                 bytes / 1e6, t_setup, t_wait, t_gpu);
+    if (rc == HPN_OK && !*irregular && pump.damaged()) {   // a damaged gzip stream: only zlib's own reader hands out the reference's bytes
+        if (timing) fprintf(stderr, "[hpn] %s: the gzip stream is damaged: read again the reference's way\n", path);
+        *irregular = true;
+    }
     if (*irregular || rc != HPN_OK) {  // drop whatever earlier chunks added on the device
         hpn_tally scratch;
         memset(&scratch, 0, sizeof scratch);
@@ -256,7 +260,27 @@ inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_
         const int rc = tally_text_stream(ctx, path, acc, &irregular);
         if (!irregular) return rc;
     }
-    InStream fq = open_input_stream(path);
+    // the exact route: the 4 x gzgets framer on the host, over zlib's own reader (what the reference reads with).  With the text
+    // front end switched off (HPN_TEXT=0) the threaded inflaters are tried first; a stream they find damaged is read again.
+    if (!text_path_enabled() && !is_stdin) {
+        InStream fq = open_input_stream(path);
+        hpn_tally tmp;
+        memset(&tmp, 0, sizeof tmp);
+        std::vector<uint64_t> qh;
+        if (acc->qual_hist) qh.assign((size_t)HPN_QUAL_ROWS * HPN_LEN_BINS, 0), tmp.qual_hist = qh.data();
+        const int rc = tally_stream(ctx, fq, &tmp, too_long);
+        const bool damaged = fq.damaged();
+        fq.close();
+        if (!damaged || rc != HPN_OK) {
+            for (int l = 0; l < HPN_LEN_BINS; ++l) acc->seqlen[l] += tmp.seqlen[l];
+            acc->total += tmp.total, acc->q20 += tmp.q20, acc->q30 += tmp.q30;
+            if (acc->qual_hist)
+                for (size_t k = 0; k < qh.size(); ++k) acc->qual_hist[k] += qh[k];
+            return rc;
+        }
+        *too_long = false;
+    }
+    InStream fq = open_input_stream_exact(path);
     const int rc = tally_stream(ctx, fq, acc, too_long);
     fq.close();
     return rc;

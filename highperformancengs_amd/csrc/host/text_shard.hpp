@@ -212,7 +212,7 @@ public:
     }
     bool ok() const { return pump_.ok(); }
     size_t piece_bytes() const { return pump_.chunk_bytes(); }
-    bool irregular() const { return irregular_; }
+    bool irregular() const { return irregular_ || pump_.damaged(); }   // (a damaged gzip stream is for zlib's own reader: tally_file / fastq_trim)
     int status() const { return rc_; }
     hpn_ctx *failing_ctx() const { return bad_ctx_; }
     uint64_t pieces() const { return n_pieces_; }

@@ -118,6 +118,9 @@ public:
     bool ok() const { return ok_; }
     size_t chunk_bytes() const { return cap_; }
     bool plain_file() const { return fd_ >= 0; }
+    // the reader met a CRC-32 / ISIZE / data error (valid once the eof chunk is out): the caller reads the input again through
+    // open_input_stream_exact, whose bytes are the reference's even then
+    bool damaged() const { return in_.damaged(); }
 
     // Start over at file offset `pos` with the same pinned buffers (plain / raw files only): what was read ahead is dropped.
     bool restart(uint64_t pos)

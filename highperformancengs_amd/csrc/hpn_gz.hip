@@ -16,6 +16,10 @@ hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_me
                              uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st);
 hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
                                uint8_t *d_text, hipStream_t st);
+uint32_t crc_block_bytes();
+hipError_t launch_crc32_blocks(const uint8_t *d_data, const void *d_blocks, uint32_t n_blocks, uint32_t *d_out, hipStream_t st);
+uint32_t crc_fold_blocks(const uint32_t *crcs, uint64_t n_blocks, uint64_t total_len);
+uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 }
 
 using namespace hpn;
@@ -62,7 +66,7 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     if (n_bounds && !summary[1]) {   // members that ended inside stretches: where in this call's text, and their ISIZE
         if (n_bounds > kBounds) n_bounds = kBounds;
         struct Meta { uint32_t n_out, status, final_block, reserved; uint64_t end_bit, text_off; };
-        struct Bound { uint32_t chunk, n_out, isize, reserved; };
+        struct Bound { uint32_t chunk, n_out, isize, crc; };
         std::vector<Meta> metas(n_chunks);
         std::vector<Bound> bounds(n_bounds);
         HPN_HIP(c, hipMemcpyAsync(metas.data(), c->g_meta.p, (size_t)n_chunks * 32, hipMemcpyDeviceToHost, c->stream));
@@ -72,7 +76,7 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
         // `cat a.gz empty.gz b.gz`) ends at the same text offset as its predecessor, so text_end alone does not order them
         std::stable_sort(bounds.begin(), bounds.end(), [](const Bound &a, const Bound &b) { return a.chunk != b.chunk ? a.chunk < b.chunk : a.n_out < b.n_out; });
         for (const Bound &b : bounds)
-            if (b.chunk < n_chunks) c->gz_members.push_back(hpn_gz_member{metas[b.chunk].text_off + b.n_out, b.isize, 0u});
+            if (b.chunk < n_chunks) c->gz_members.push_back(hpn_gz_member{metas[b.chunk].text_off + b.n_out, b.isize, b.crc});
     }
     const double t2 = now();
     info->n_bytes = summary[0];
@@ -105,5 +109,39 @@ int hpn_gz_members(hpn_ctx *c, hpn_gz_member *out, uint32_t cap, uint32_t *n)
     if (*n) memcpy(out, c->gz_members.data(), (size_t)*n * sizeof(hpn_gz_member));
     return HPN_OK;
 }
+
+int hpn_crc32_dev(hpn_ctx *c, const uint8_t *d_data, const hpn_span *spans, uint32_t n_spans, uint32_t *crc)
+{
+    if (!c || (n_spans && (!spans || !crc))) return HPN_E_ARG;
+    HPN_HIP(c, hipSetDevice(c->device));
+    struct Block { uint64_t off; uint32_t len, reserved; };
+    const uint64_t B = crc_block_bytes();
+    std::vector<Block> blocks;
+    for (uint32_t k = 0; k < n_spans; ++k) {
+        if (spans[k].len && !d_data) return HPN_E_ARG;
+        for (uint64_t at = 0; at < spans[k].len; at += B)
+            blocks.push_back(Block{spans[k].off + at, (uint32_t)(spans[k].len - at < B ? spans[k].len - at : B), 0u});
+    }
+    if (blocks.size() > 0x7fffffffull) return fail(c, HPN_E_ARG, "hpn_crc32_dev: more than 2^31 blocks of 64 KiB");
+    int rc;
+    if ((rc = scratch_reserve(c, c->g_crc, blocks.size() * (sizeof(Block) + sizeof(uint32_t)) + 64)) != HPN_OK) return rc;
+    uint32_t *d_out = (uint32_t *)((uint8_t *)c->g_crc.p + blocks.size() * sizeof(Block));
+    std::vector<uint32_t> out(blocks.size());
+    if (!blocks.empty()) {
+        HPN_HIP(c, hipMemcpyAsync(c->g_crc.p, blocks.data(), blocks.size() * sizeof(Block), hipMemcpyHostToDevice, c->stream));
+        HPN_HIP(c, launch_crc32_blocks(d_data, c->g_crc.p, (uint32_t)blocks.size(), d_out, c->stream));
+        HPN_HIP(c, hipMemcpyAsync(out.data(), d_out, blocks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HPN_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    size_t at = 0;
+    for (uint32_t k = 0; k < n_spans; ++k) {
+        const uint64_t nb = (spans[k].len + B - 1) / B;
+        crc[k] = crc_fold_blocks(out.data() + at, nb, spans[k].len);
+        at += nb;
+    }
+    return HPN_OK;
+}
+
+uint32_t hpn_crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return crc_join(crc_a, crc_b, len_b); }
 
 }  // extern "C"

@@ -31,7 +31,7 @@ struct GzChunk {  // = hpn_gz_chunk
 };
 struct GzBound {   // a member that ended inside a stretch, and went on with the next member
     uint32_t chunk, n_out;   // symbols of the stretch that belong to members up to and including this one
-    uint32_t isize, reserved; // ISIZE of its trailer
+    uint32_t isize, crc;      // ISIZE and CRC-32 of its trailer
 };
 struct GzMeta {
     uint32_t n_out, status, final_block, reserved;
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
                         refill(s, b, in, in_len);
                         return take(b, 8);
                     };
-                    uint32_t isize = 0, hdr_ok = 1;
-                    for (int k = 0; k < 4; ++k) (void)byte();
+                    uint32_t isize = 0, crc = 0, hdr_ok = 1;
+                    for (int k = 0; k < 4; ++k) crc |= byte() << (8 * k);
                     for (int k = 0; k < 4; ++k) isize |= byte() << (8 * k);
                     hdr_ok = byte() == 0x1fu;
                     hdr_ok = (byte() == 0x8bu) && hdr_ok;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
                         if (slot >= bounds_cap) {
                             err = 23;                                       // more members than the caller made room for
                         } else {
-                            if (lane == 0) bounds[slot] = GzBound{ci, op, isize, 0u};
+                            if (lane == 0) bounds[slot] = GzBound{ci, op, isize, crc};
                             last = false;                                   // the next member's first block
                         }
                     } else {

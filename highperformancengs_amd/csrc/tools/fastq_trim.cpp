@@ -229,8 +229,21 @@ int main(int argc, char *argv[])
         if (getenv("HPN_TIMING"))
             fprintf(stderr, "[hpn] waiting for reader / writer %.3f s  copy+frame+trim+copy back %.3f s  final drain %.3f s\n", t_wait,
                     t_gpu, wall_s() - t4);
+        if (!exact && pump.damaged()) {
+            // A gzip member failed its CRC-32 / ISIZE / a data error: zlib -- hence the reference -- does not hand out the bytes of
+            // the buffer it was filling when it noticed; the threaded inflaters delivered them.  Output to a file is done again
+            // through zlib's own reader; output that cannot be taken back is refused rather than left different.
+            if (!to_file) {
+                fprintf(stderr, "fastq_trim: %s is a damaged gzip file (CRC-32 / ISIZE / data error) and the output cannot be rewound: "
+                        "write to a file (-o) to get the reference's bytes\n", infile);
+                return 2;
+            }
+            start_over();
+            in = open_input_stream_exact(infile);
+            exact = true;
+        }
     } else {
-        in = open_input_stream(infile);
+        in = open_input_stream_exact(infile);
     }
     if (exact && !done) {
         TrimFramer framer(in, start, end);

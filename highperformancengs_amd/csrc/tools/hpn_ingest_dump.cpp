@@ -24,12 +24,14 @@ static void put(const std::vector<T> &v)
 int main(int argc, char **argv)
 {
     if (argc != 3) {
-        fprintf(stderr, "usage: %s count|trim|cat|crc|bam FILE\n", argv[0]);
+        fprintf(stderr, "usage: %s count|trim|cat|crc|bam FILE   (count-exact / trim-exact / cat-exact: through zlib's own reader)\n", argv[0]);
         return 1;
     }
-    const std::string mode = argv[1];
+    std::string mode = argv[1];
+    const bool exact = mode.size() > 6 && mode.compare(mode.size() - 6, 6, "-exact") == 0;   // the stream the tools read a damaged gzip file with
+    if (exact) mode.resize(mode.size() - 6);
     if (mode == "count" || mode == "trim") {
-        InStream f = open_input_stream(argv[2]);
+        InStream f = exact ? open_input_stream_exact(argv[2]) : open_input_stream(argv[2]);
         // small batches on purpose: the dump is the concatenation of many refills
         FastqBatch b;
         if (!b.init(1u << 16, 1u << 10, true)) return 4;
@@ -61,7 +63,7 @@ int main(int argc, char **argv)
         return 0;
     }
     if (mode == "cat") {
-        InStream f = open_input_stream(argv[2]);
+        InStream f = exact ? open_input_stream_exact(argv[2]) : open_input_stream(argv[2]);
         std::vector<uint8_t> buf(1u << 20);
         for (;;) {
             const int n = f.read(buf.data(), (unsigned)buf.size());
@@ -73,6 +75,7 @@ int main(int argc, char **argv)
                     f.pz ? "pgz" : f.mz ? "mgz" : f.bz ? "bgzf" : "zlib", f.pz ? (unsigned long)f.pz->chunks_accepted() : 0ul,
                     f.pz ? (unsigned long)f.pz->gaps_decoded() : 0ul, f.pz ? (int)f.pz->fell_back() : 0, f.pz ? (int)f.pz->crc_failed() : 0,
                     f.pz ? f.pz->seconds_find() : 0.0, f.pz ? f.pz->seconds_decode() : 0.0, f.pz ? f.pz->seconds_translate() : 0.0);
+        if (f.damaged()) fprintf(stderr, "damaged\n");   // (what makes the tools read the file again, the reference's way)
         f.close();
         return 0;
     }

@@ -319,12 +319,22 @@ typedef struct hpn_gz_info {
 } hpn_gz_info;
 typedef struct hpn_gz_member {
     uint64_t text_end;
-    uint32_t isize, reserved;
+    uint32_t isize, crc32; /* the two fields of the member's trailer (RFC 1952) */
 } hpn_gz_member;
 int hpn_gz_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks,
                        uint32_t sym_cap, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap,
                        uint8_t *d_window_out, hpn_gz_info *info);
 int hpn_gz_members(hpn_ctx *ctx, hpn_gz_member *out, uint32_t cap, uint32_t *n); /* HPN_E_CAPACITY: *n tells how many */
+
+/* CRC-32 (RFC 1952) of byte ranges of a device buffer: crc[k] of d_data[spans[k].off .. + spans[k].len).  gzread, which the
+ * reference reads every input through (IO_stream.h:122-136), verifies each gzip member's CRC-32 and stops handing out bytes
+ * where one fails; a member inflated on the device is verified with this (in pieces, as the text comes: hpn_crc32_join folds
+ * CRC(A), CRC(B), |B| into CRC(A || B)).  spans and crc are host arrays.  Synchronous. */
+typedef struct hpn_span {
+    uint64_t off, len;
+} hpn_span;
+int hpn_crc32_dev(hpn_ctx *ctx, const uint8_t *d_data, const hpn_span *spans, uint32_t n_spans, uint32_t *crc);
+uint32_t hpn_crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),

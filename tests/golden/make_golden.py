@@ -128,6 +128,24 @@ def make_fastq_inputs():
     assert orc.orc_synth_write_fastq(f"{FQ}/syn_var_a.fq".encode(), 12345, 0, 1500, 30, 151, 0) == 0
     assert orc.orc_synth_write_fastq(f"{FQ}/syn_var_b.fq.gz".encode(), 12345, 1500, 1500, 30, 151, 3) == 0
     assert orc.orc_synth_write_fastq(f"{FQ}/syn_100.fq.gz".encode(), 777, 0, 4000, 100, 100, 4) == 0
+    # damaged gzip files: zlib's gzread (behind the reference's gzgets, IO_stream.h:122-136) checks every member's CRC-32 and
+    # ISIZE and, when they fail, does not hand out the bytes of the internal buffer it was filling: how much the reference
+    # counts depends on zlib's 16 KiB buffering.  Text of ~100 KB, so that several buffers are involved.
+    tmp = f"{FQ}/_plain.tmp"
+    assert orc.orc_synth_write_fastq(tmp.encode(), 4242, 0, 520, 40, 151, 0) == 0
+    text = open(tmp, "rb").read()
+    os.unlink(tmp)
+    third = text[:len(text) // 3 // 4 * 4]          # (not a record boundary: members are cut anywhere)
+    member = lambda b: gzip.compress(b, 6, mtime=0)
+    m = bytearray(member(text))
+    m[-8] ^= 0x5a                                    # CRC-32 of the only member
+    w(f"{FQ}/badcrc.fq.gz", bytes(m))
+    a, b, c = member(text[:40000]), bytearray(member(text[40000:90000])), member(text[90000:])
+    b[-7] ^= 0x01                                    # CRC-32 of the middle member of three
+    w(f"{FQ}/badcrc_mid.fq.gz", a + bytes(b) + c)
+    m = bytearray(member(text))
+    m[-4] ^= 0x10                                    # ISIZE
+    w(f"{FQ}/badisize.fq.gz", bytes(m))
 
 
 def make_bam_inputs():
@@ -242,6 +260,11 @@ def main():
     run_case("trim_stale_30_31", "fastq_trim", ["-i", "stale.fq", "-s", "30", "-e", "31", "-o", "st"], [fq("stale.fq")])
     run_case("trim_stale_a1", "fastq_trim", ["-i", "t.fq", "-s", "12", "-e", "30"], [fq("t.fq")])
     run_case("count_stale", "fastq_count", ["-H", "-L", "stale.fq"], [fq("stale.fq")])
+    for n in ("badcrc", "badcrc_mid", "badisize"):
+        run_case("count_" + n, "fastq_count", ["-H", "-L", n + ".fq.gz"], [fq(n + ".fq.gz")])
+    run_case("kthread_badcrc", "fastq_count_kthread", ["-L", "-o", "-", "badcrc_mid.fq.gz", "t.fq"], [fq("badcrc_mid.fq.gz"), fq("t.fq")])
+    run_case("trim_badcrc", "fastq_trim", ["-i", "badcrc.fq.gz", "-s", "3", "-e", "60"], [fq("badcrc.fq.gz")])
+    run_case("trim_badcrc_mid_file", "fastq_trim", ["-i", "badcrc_mid.fq.gz", "-s", "0", "-e", "100", "-o", "bc"], [fq("badcrc_mid.fq.gz")])
     # ---- bam2depth ---------------------------------------------------------
     bm = lambda n: os.path.join(BAM, n)  # noqa: E731
     run_case("depth_a3", "bam2depth", ["-w", "100", "-o", "d", "e.bam"], [bm("e.bam")])

@@ -21,6 +21,8 @@ CASES = ["count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "
          "trim_a1", "trim_a1_default", "trim_a1_file", "trim_nonl", "trim_short", "trim_crlf", "trim_syn_var",
          "trim_syn_100", "trim_multi", "trim_empty", "trim_stale_8_40", "trim_stale_15_400", "trim_stale_30_31",
          "trim_stale_a1", "count_stale",
+         # damaged gzip members (CRC-32 / ISIZE): the reference counts what zlib's gzgets hands out before it fails
+         "count_badcrc", "count_badcrc_mid", "count_badisize", "kthread_badcrc", "trim_badcrc_mid_file",
          "depth_a3", "depth_a3_wig", "depth_a3_stdout", "depth_rand", "depth_rand_w1000", "depth_two_files",
          "wig_a3", "wig_a3_w7", "wig_rand", "wig_rand_w1000", "wig_rand_w37",
          "sliding_a3", "sliding_rand", "sliding_rand_w700", "sliding_rand_w37", "sliding_region", "sliding_region_chr",
@@ -77,6 +79,7 @@ def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
 # where reduceStats sums files (fastq_count_kthread.c:180-210), trimmed slabs are written in piece order.  HPN_NGPU forces
 # that many lanes on whatever devices exist, so the route runs on a one-GPU box: the bytes must be the reference's, and
 # regular plain / host-inflated text must really have taken the route.
+# (the damaged gzip files leave the route -- the reader reports the damage -- and are read again through zlib's own reader)
 SHARDED_REGULAR = {"count_a1", "count_a1_gz", "count_empty", "count_crlf", "count_multi", "count_syn_var_a", "count_syn_var_b",
                    "count_syn_100", "count_to_file", "kthread_a1", "kthread_syn", "kthread_plain", "kthread_empty",
                    "trim_a1_file", "trim_syn_100"}
@@ -132,6 +135,17 @@ def test_sharded_route_on_a_larger_file(tmp_path):
     assert outs["one"][4] == [b"Total_reads: %d" % n]
     row = outs["one"][0].decode().split("\n")[1].split("\t")
     assert int(row[1]) == n and int(row[2]) == n * L
+
+
+def test_trim_of_a_damaged_gzip_to_stdout_is_refused(manifest, tmp_path):
+    """fastq_trim writes while it reads; when a gzip member then fails its CRC-32, text the reference never prints is already
+    out and stdout cannot be rewound: exit code 2 and a message (to a file, -o, the output is made again: trim_badcrc_mid_file)."""
+    c = manifest["trim_badcrc"]
+    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path)
+    assert p.returncode == 2 and b"damaged gzip" in p.stderr, p.stderr.decode()
+    # with the text front end off the tool reads through zlib alone and prints the reference's bytes
+    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, {"HPN_TEXT": "0"})
+    assert p.returncode == 0 and p.stdout == expected("trim_badcrc")
 
 
 # The BAM tools inflate BGZF blocks and walk the records on the GPU when every block starts at a

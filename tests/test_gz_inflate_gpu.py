@@ -270,3 +270,27 @@ def test_damaged_files_of_several_members_never_pass_silently(ctx):
             # zlib also checks CRC-32 and ISIZE (the caller's job here): a flip there makes zlib fail where this call does not
             if want is not None:
                 assert got == want, (trial, pos)
+
+
+# ---- CRC-32 of device-resident text (hpn_crc32_dev): what gzread checks per member ------------------------------------------
+def test_crc32_of_spans_equals_zlib():
+    import zlib
+    import torch
+    import highperformancengs_amd as hp
+    from highperformancengs_amd import _lib
+    ctx = hp.Context(0)
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, 3_000_000, dtype=np.uint8)
+    data[100_000:400_000] = 0                       # (zeros: the register must still move)
+    d = torch.from_numpy(data).cuda()
+    spans = [(0, 0), (0, 1), (7, 255), (1, 256), (3, 257), (13, 65535), (0, 65536), (5, 65537), (100_001, 1_048_579), (0, len(data)),
+             (2_999_999, 1), (65536 * 3, 65536 * 4), (123, 4 * 65536 + 255)]
+    got = ctx.crc32_dev(d, spans)
+    for (o, n), c in zip(spans, got):
+        assert c == zlib.crc32(data[o:o + n].tobytes()), (o, n)
+    # folding: CRC(A || B) from CRC(A), CRC(B), |B|
+    L = _lib.lib()
+    for cut in (0, 1, 65536, 1_000_003, len(data)):
+        a, b = zlib.crc32(data[:cut].tobytes()), zlib.crc32(data[cut:].tobytes())
+        assert L.hpn_crc32_join(a, b, len(data) - cut) == zlib.crc32(data.tobytes())
+    ctx.close()

@@ -328,3 +328,37 @@ def test_two_pass_parallel_inflate_of_one_member_equals_zlib(tmp_path):
         short, long_ = sorted((outs[0], ref), key=len)
         assert long_.startswith(short) and len(long_) - len(short) <= (1 << 20) + 400000, (trial, len(ref), len(outs[0]))
         assert len(outs[0]) >= len(big) * (pos - 200000) // len(good) - (1 << 20), trial
+
+
+# ---- damaged gzip files: CRC-32 / ISIZE of a member wrong (goldens count_badcrc*, made by the reference binary) -------------
+# zlib's gzread -- behind the reference's gzgets (IO_stream.h:122-136) -- does not hand out the bytes of the internal buffer it
+# was filling when a member fails its check; the threaded inflaters deliver every byte and REPORT the damage, and the tools then
+# read the file again through zlib's own reader with its default buffers (open_input_stream_exact).
+
+DAMAGED = ["badcrc.fq.gz", "badcrc_mid.fq.gz", "badisize.fq.gz"]
+
+
+@pytest.mark.parametrize("name", DAMAGED)
+def test_damaged_gzip_exact_reader_hands_out_the_reference_bytes(name):
+    path = golden_path("fastq", name)
+    raw = _dump("count-exact", path)
+    n = struct.unpack_from("<Q", raw)[0]
+    off = np.frombuffer(raw, np.uint64, n + 1, 8)
+    qual = np.frombuffer(raw, np.uint8, int(off[-1]), 8 + 8 * (n + 1))
+    rc, a = orc.count_soa(qual, off)
+    rc2, b = orc.count_stream(path)
+    assert rc == 0 and rc2 == 0 and np.array_equal(a.seqlen, b.seqlen) and np.array_equal(a.quality, b.quality)
+    # ... which is what the reference binary printed
+    row = [l for l in expected("count_" + name.split(".")[0]).decode().split("\n") if l and not l.startswith("#")][0].split("\t")
+    assert int(row[1]) == n and int(row[2]) == int(off[-1])
+
+
+@pytest.mark.parametrize("name", DAMAGED)
+@pytest.mark.parametrize("env", [{"HPN_PGZ_FORCE": "1", "HPN_GZ_THREADS": "3"}, {"HPN_NO_PGZ": "1"}, {}], ids=["two-pass", "member-parallel", "default"])
+def test_damaged_gzip_is_reported_by_the_threaded_readers(name, env):
+    path = golden_path("fastq", name)
+    p = subprocess.run([DUMP, "cat", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **env})
+    assert p.returncode == 0 and b"damaged" in p.stderr, p.stderr
+    # (how many bytes a threaded reader hands out before it notices is its own business: the tools drop them and read again)
+    sound = subprocess.run([DUMP, "cat", golden_path("fastq", "multi.fq.gz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **env})
+    assert b"damaged" not in sound.stderr

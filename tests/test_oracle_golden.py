@@ -26,7 +26,7 @@ def _args_flags(case):
 @pytest.mark.parametrize("case", [
     "count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "count_multi", "count_short",
     "count_len0", "count_allzero", "count_trunc", "count_longname", "count_syn_var_a", "count_syn_var_b",
-    "count_syn_100"])
+    "count_syn_100", "count_badcrc", "count_badcrc_mid", "count_badisize"])   # (damaged gzip: what zlib's gzgets hands out before it fails)
 def test_fastq_count_stdout(manifest, case):
     c = manifest[case]
     header, detail = _args_flags(c)
