@@ -263,8 +263,7 @@ def main():
     for n in ("badcrc", "badcrc_mid", "badisize"):
         run_case("count_" + n, "fastq_count", ["-H", "-L", n + ".fq.gz"], [fq(n + ".fq.gz")])
     run_case("kthread_badcrc", "fastq_count_kthread", ["-L", "-o", "-", "badcrc_mid.fq.gz", "t.fq"], [fq("badcrc_mid.fq.gz"), fq("t.fq")])
-    run_case("trim_badcrc", "fastq_trim", ["-i", "badcrc.fq.gz", "-s", "3", "-e", "60"], [fq("badcrc.fq.gz")])
-    run_case("trim_badcrc_mid_file", "fastq_trim", ["-i", "badcrc_mid.fq.gz", "-s", "0", "-e", "100", "-o", "bc"], [fq("badcrc_mid.fq.gz")])
+    # (fastq_trim on these files: the reference dereferences the NULL of the failed gzgets and dies with SIGSEGV -- no golden)
     # ---- bam2depth ---------------------------------------------------------
     bm = lambda n: os.path.join(BAM, n)  # noqa: E731
     run_case("depth_a3", "bam2depth", ["-w", "100", "-o", "d", "e.bam"], [bm("e.bam")])
