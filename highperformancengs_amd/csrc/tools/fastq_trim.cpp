@@ -246,30 +246,44 @@ int main(int argc, char *argv[])
         in = open_input_stream_exact(infile);
     }
     if (exact && !done) {
-        TrimFramer framer(in, start, end);
-        FastqBatch b;
-        const size_t kBytes = 64u << 20, kRecs = 1u << 20;
-        if (!b.init(kBytes, kRecs, true)) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
-        std::vector<uint8_t> oseq(kBytes + kLineBuf), oqual(kBytes + kLineBuf);
-        std::vector<uint64_t> ooff(kRecs + 1);
-        bool more = true;
-        while (more) {
-            b.clear();
-            more = framer.fill(b);
-            const uint64_t n = b.n();
-            if (!n) continue;
-            rc = hpn_fastq_trim(ctx, b.seq, b.qual, b.off, n, start, end, oseq.data(), oqual.data(), ooff.data());
-            if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_trim");
-            for (uint64_t i = 0; i < n; ++i) {  // fprintf("%s\n%s\n+\n%s\n") (:101): each cut ends at its first NUL
-                const uint64_t a = ooff[i], len = ooff[i + 1] - a;
-                fputs(b.names[i].c_str(), out);
-                fputc('\n', out);
-                fwrite(oseq.data() + a, 1, strnlen((const char *)oseq.data() + a, len), out);
-                fputs("\n+\n", out);
-                fwrite(oqual.data() + a, 1, strnlen((const char *)oqual.data() + a, len), out);
-                fputc('\n', out);
+        for (int pass = 0; pass < 2; ++pass) {
+            TrimFramer framer(in, start, end);
+            FastqBatch b;
+            const size_t kBytes = 64u << 20, kRecs = 1u << 20;
+            if (!b.init(kBytes, kRecs, true)) die_hpn(ctx, HPN_E_NOMEM, "fastq_trim");
+            std::vector<uint8_t> oseq(kBytes + kLineBuf), oqual(kBytes + kLineBuf);
+            std::vector<uint64_t> ooff(kRecs + 1);
+            bool more = true;
+            while (more) {
+                b.clear();
+                more = framer.fill(b);
+                const uint64_t n = b.n();
+                if (!n) continue;
+                rc = hpn_fastq_trim(ctx, b.seq, b.qual, b.off, n, start, end, oseq.data(), oqual.data(), ooff.data());
+                if (rc != HPN_OK) die_hpn(ctx, rc, "hpn_fastq_trim");
+                for (uint64_t i = 0; i < n; ++i) {  // fprintf("%s\n%s\n+\n%s\n") (:101): each cut ends at its first NUL
+                    const uint64_t a = ooff[i], len = ooff[i + 1] - a;
+                    fputs(b.names[i].c_str(), out);
+                    fputc('\n', out);
+                    fwrite(oseq.data() + a, 1, strnlen((const char *)oseq.data() + a, len), out);
+                    fputs("\n+\n", out);
+                    fwrite(oqual.data() + a, 1, strnlen((const char *)oqual.data() + a, len), out);
+                    fputc('\n', out);
+                }
+                reads += n;
             }
-            reads += n;
+
+            // the stream came from a threaded inflater that met a damaged gzip member: only zlib's own reader stops where the
+            // reference's gzgets stops (see above)
+            if (pass == 1 || in.exact || !in.damaged()) break;
+            if (!to_file) {
+                fprintf(stderr, "fastq_trim: %s is a damaged gzip file (CRC-32 / ISIZE / data error) and the output cannot be rewound: "
+                        "write to a file (-o) to get the reference's bytes\n", infile);
+                return 2;
+            }
+            start_over();
+            in.close();
+            in = open_input_stream_exact(infile);
         }
     }
     fprintf(stderr, "Total_reads: %lu\nFinished in %.3f s\n", reads, (double)(usec() - begin) / CLOCKS_PER_SEC);

@@ -389,3 +389,21 @@ def test_bam2depth_requires_index(tmp_path):
     p = subprocess.run([os.path.join(BIN, "bam2depth"), "-o", "d", "e.bam"], cwd=tmp_path, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"BAM indexing file is not available" in p.stderr
+
+
+@pytest.mark.parametrize("case,why", [("count_badcrc", b"CRC-32 mismatch"), ("count_badcrc_mid", b"CRC-32 mismatch in a member"),
+                                      ("count_badisize", b"ISIZE mismatch")])
+def test_gzip_on_the_gpu_checks_every_member_like_gzread(manifest, case, why, tmp_path):
+    """The device inflate route takes the CRC-32 of each member's text (hpn_crc32_dev) and compares it and ISIZE with the
+    trailer, as zlib's gzread does behind the reference's gzgets; a member that fails sends the file to zlib's own reader,
+    whose bytes -- up to the buffer the failure was noticed in -- are the reference's (goldens made by the reference binary)."""
+    c = manifest[case]
+    for env in ({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000"}):
+        p, files = _run(c["tool"], ["-t", "1"] + list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, {**env, "HPN_TIMING": "1"})
+        assert p.returncode == 0 and p.stdout == expected(case), p.stderr.decode()
+        assert b"gzip route on the GPU abandoned" in p.stderr and why in p.stderr, p.stderr.decode()
+    # and a sound file passes the same checks
+    c = manifest["count_multi"]
+    p, files = _run(c["tool"], ["-t", "1"] + list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path,
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_TIMING": "1"})
+    assert p.stdout == expected("count_multi") and b"gzip on the GPU: inflate + frame + tally" in p.stderr, p.stderr.decode()
