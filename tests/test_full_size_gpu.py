@@ -48,41 +48,61 @@ def test_c2_fastq_count_1e9_reads_exact(ctx):
 
 
 def test_c3_fastq_trim_one_mate_full_size(ctx):
+    """BASELINE configs[2]: 5e8 reads of 150 bp per mate.  In + out of a whole mate (150 + 4 + 135 GB) do not fit the 288 GB of
+    one device together, so the mate goes through in two slabs of 2.5e8 reads (the second slab's generator continues where the
+    first one's ended; the first slab's output is checked and freed before the second is made): offsets in closed form, every
+    output byte against the strided view of its input on the device, the oracle on windows at both ends of each slab, across
+    the 2^32-byte mark, and ACROSS THE SEAM (the last reads of slab 0 and the first of slab 1 against the oracle run on the CPU
+    generator's records for that stretch)."""
     import torch
-    n, L, S, E = 250_000_000, 150, 5, 140
-    dq = torch.empty(n * L, dtype=torch.uint8, device="cuda")
-    db = torch.empty(n * L, dtype=torch.uint8, device="cuda")
-    do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    ctx.synth_fastq_dev(4242, 0, n, L, dq, db, do)
-    oq = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
-    ob = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
-    oo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    ctx.fastq_trim_dev(db, dq, do, n, S, E, ob, oq, oo)
-    ctx.sync()
-    # offsets: closed form (beyond 2^32 bytes: 3.4e10)
-    assert int(oo[0].item()) == 0 and int(oo[-1].item()) == n * (E - S) > 1 << 34
-    step = torch.arange(0, n + 1, 1 << 16, device="cuda", dtype=torch.int64)
-    assert torch.equal(oo[step], step * (E - S))
-    assert bool((oo[1:] - oo[:-1] == E - S).all())
-    # every output byte = the strided view of the input, compared on the device in slabs
-    slab = 10_000_000
-    for a in range(0, n, slab):
-        b = min(n, a + slab)
-        assert torch.equal(oq[a * (E - S):b * (E - S)].view(b - a, E - S), dq[a * L:b * L].view(b - a, L)[:, S:E])
-        assert torch.equal(ob[a * (E - S):b * (E - S)].view(b - a, E - S), db[a * L:b * L].view(b - a, L)[:, S:E])
-    # oracle on windows (first, one straddling the 2^32-byte mark of the input, last)
+    n_mate, L, S, E, seed = 500_000_000, 150, 5, 140, 4242
+    n = n_mate // 2
     w = 100_000
-    for a in (0, (1 << 32) // L - w // 2, n - w):
-        seq = db[a * L:(a + w) * L].cpu().numpy()
-        qual = dq[a * L:(a + w) * L].cpu().numpy()
-        off = (do[a:a + w + 1] - do[a]).cpu().numpy().astype(np.uint64)
-        rc, wseq, wqual, woff = orc.trim_soa(seq, qual, off, S, E)
-        assert rc == 0
-        assert np.array_equal(oq[a * (E - S):(a + w) * (E - S)].cpu().numpy(), wqual)
-        assert np.array_equal(ob[a * (E - S):(a + w) * (E - S)].cpu().numpy(), wseq)
-        assert np.array_equal((oo[a:a + w + 1] - oo[a]).cpu().numpy().astype(np.uint64), woff)
-    del dq, db, do, oq, ob, oo
-    torch.cuda.empty_cache()
+    seam = {}
+    for slab_no in (0, 1):
+        first = slab_no * n
+        dq = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+        db = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+        do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        ctx.synth_fastq_dev(seed, first, n, L, dq, db, do)
+        oq = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
+        ob = torch.empty(n * (E - S), dtype=torch.uint8, device="cuda")
+        oo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        ctx.fastq_trim_dev(db, dq, do, n, S, E, ob, oq, oo)
+        ctx.sync()
+        # offsets: closed form (beyond 2^32 bytes: 3.4e10)
+        assert int(oo[0].item()) == 0 and int(oo[-1].item()) == n * (E - S) > 1 << 34
+        step = torch.arange(0, n + 1, 1 << 16, device="cuda", dtype=torch.int64)
+        assert torch.equal(oo[step], step * (E - S))
+        assert bool((oo[1:] - oo[:-1] == E - S).all())
+        # every output byte = the strided view of the input, compared on the device in pieces
+        piece = 10_000_000
+        for a in range(0, n, piece):
+            b = min(n, a + piece)
+            assert torch.equal(oq[a * (E - S):b * (E - S)].view(b - a, E - S), dq[a * L:b * L].view(b - a, L)[:, S:E])
+            assert torch.equal(ob[a * (E - S):b * (E - S)].view(b - a, E - S), db[a * L:b * L].view(b - a, L)[:, S:E])
+        # oracle on windows (first, one straddling the 2^32-byte mark of the input, last)
+        for a in (0, (1 << 32) // L - w // 2, n - w):
+            seq = db[a * L:(a + w) * L].cpu().numpy()
+            qual = dq[a * L:(a + w) * L].cpu().numpy()
+            off = (do[a:a + w + 1] - do[a]).cpu().numpy().astype(np.uint64)
+            rc, wseq, wqual, woff = orc.trim_soa(seq, qual, off, S, E)
+            assert rc == 0
+            assert np.array_equal(oq[a * (E - S):(a + w) * (E - S)].cpu().numpy(), wqual)
+            assert np.array_equal(ob[a * (E - S):(a + w) * (E - S)].cpu().numpy(), wseq)
+            assert np.array_equal((oo[a:a + w + 1] - oo[a]).cpu().numpy().astype(np.uint64), woff)
+        # what lies at the seam: the last w / 2 reads of slab 0, the first w / 2 of slab 1
+        h = w // 2
+        lo, hi = (n - h, n) if slab_no == 0 else (0, h)
+        seam[slab_no] = (oq[lo * (E - S):hi * (E - S)].cpu().numpy(), ob[lo * (E - S):hi * (E - S)].cpu().numpy())
+        del dq, db, do, oq, ob, oo
+        torch.cuda.empty_cache()
+    # the seam window from the CPU generator (records n - w/2 .. n + w/2 of the mate) through the oracle
+    seq, qual, off = orc.synth_soa(seed, n - w // 2, w, L, L)
+    rc, wseq, wqual, woff = orc.trim_soa(seq, qual, off, S, E)
+    assert rc == 0 and int(woff[-1]) == w * (E - S)
+    assert np.array_equal(np.concatenate([seam[0][0], seam[1][0]]), wqual)
+    assert np.array_equal(np.concatenate([seam[0][1], seam[1][1]]), wseq)
 
 
 def _chr1_soa():
