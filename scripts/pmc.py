@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 sep = sys.argv.index("--")
-needle, groups, cmd = sys.argv[1], sys.argv[2:sep], sys.argv[sep + 1:]
+needles, groups, cmd = sys.argv[1].split(","), sys.argv[2:sep], sys.argv[sep + 1:]   # several kernels: a,b,c (one pass serves all)
 os.environ.setdefault("TMPDIR", "/tmp")
 for gi, g in enumerate(groups):
     d = f"gpurun_out/pmc_{os.getpid()}_{gi}"
@@ -20,10 +20,11 @@ for gi, g in enumerate(groups):
     tot, cnt = {}, {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if needle in row["Kernel_Name"]:
-                k = row["Counter_Name"]
-                tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
-                cnt[k] = cnt.get(k, 0) + 1
+            for needle in needles:
+                if needle in row["Kernel_Name"]:
+                    k = (needle, row["Counter_Name"])
+                    tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
+                    cnt[k] = cnt.get(k, 0) + 1
     for k in sorted(tot):
-        print(f"{k} {tot[k] / cnt[k]:.0f} per launch ({needle}, {cnt[k]} launches)", flush=True)
+        print(f"{k[1]} {tot[k] / cnt[k]:.0f} per launch ({k[0]}, {cnt[k]} launches)", flush=True)
     shutil.rmtree(d, ignore_errors=True)
