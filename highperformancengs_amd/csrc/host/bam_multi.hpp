@@ -106,31 +106,22 @@ inline int multi_gpu_workers()
     return n;
 }
 
-// ... and for one file handed out in batches: no more workers than the file has batches' worth of bytes (a context costs
-// ~0.1 s to make; a 600 MB BAM is seven batches of 88 MB)
+// ... and for one file: no more workers than the file has batches' worth of bytes (a context costs ~0.1 s to make; a 600 MB
+// BAM is seven batches of 88 MB).  With ONE device a file of 2 GiB or more still gets three workers on it: one's upload and
+// block-table walk run beside another's inflate and a third's record kernels (hg38-shaped 10.6 GB BAM: bam_sliding_count 1.80 ->
+// 1.24-1.31 s, bam2depth 1.88 -> 1.77 s; profiles/r03/bench.json).
 inline int multi_gpu_workers_for(const char *path)
 {
     int n = multi_gpu_workers();
-    if (n > 1 && !getenv("HPN_NGPU")) {
+    if (!getenv("HPN_NGPU")) {
         struct stat sb;
         if (stat(path, &sb) == 0) {
+            if (n == 1 && sb.st_size >= ((off_t)2 << 30)) n = 3;
             const long batches = (long)(sb.st_size / ((off_t)88 << 20)) + 1;
             if (batches < n) n = (int)batches;
         }
     }
     return n;
-}
-
-// Worker contexts live for the whole process and are reused across input files: a depth context keeps several GB of
-// scratch for a chr1-sized target, and bam2depth / bam2wig / bam_sliding_count come here once per file.
-inline hpn_ctx *pooled_worker_ctx(int worker, int device)
-{
-    static std::mutex m;
-    static std::vector<hpn_ctx *> pool;
-    std::lock_guard<std::mutex> lk(m);
-    if ((size_t)worker >= pool.size()) pool.resize((size_t)worker + 1, nullptr);
-    if (!pool[(size_t)worker] && hpn_ctx_create(device, &pool[(size_t)worker]) != HPN_OK) pool[(size_t)worker] = nullptr;
-    return pool[(size_t)worker];
 }
 
 struct TargetOut {

@@ -140,11 +140,14 @@ private:
 // How many lanes for this input.  HPN_NGPU=n: n, whatever the input.  Otherwise plain regular files only (compressed
 // input is bounded by its inflate, which has its own routes), one lane per 2 GiB -- a context costs 15-30 ms to make
 // and one lane already streams at the PCIe rate of its link --, at most `devices_for_me`.
-inline int shard_lanes_for(const char *path, int devices_for_me)
+// pair_on_one_device (the count tools): with a single device, a plain file of 4 GiB or more still gets TWO lanes on it -- one lane's
+// copy over PCIe then runs beside the other's framing and tally (15.2 GB: 0.42 s against 0.49-0.53 s on one context; three or
+// four lanes only add contexts: scripts/e2e_lanes.sh).
+inline int shard_lanes_for(const char *path, int devices_for_me, bool pair_on_one_device = false)
 {
     if (!text_path_enabled()) return 1;
     if (const char *e = getenv("HPN_NGPU")) return atoi(e) > 1 ? atoi(e) : 1;
-    if (devices_for_me < 2) return 1;
+    if (devices_for_me < 2 && !pair_on_one_device) return 1;
     struct stat sb;
     if (strncmp(path, "-", 1) == 0 || !strcmp(path, "") || stat(path, &sb) != 0 || !S_ISREG(sb.st_mode)) return 1;
     uint8_t magic[2] = {0, 0};
@@ -153,6 +156,7 @@ inline int shard_lanes_for(const char *path, int devices_for_me)
     if (fd >= 0) close(fd);
     if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return 1;
     const long long lanes = (long long)(sb.st_size >> 31) + 1;
+    if (devices_for_me < 2) return lanes >= 3 ? 2 : 1;
     return (int)(lanes < devices_for_me ? lanes : devices_for_me);
 }
 
@@ -170,10 +174,13 @@ public:
     static int device_of(int ndev, int workers, int w) { return (w * (getenv("HPN_NGPU") ? 1 : cap(ndev, workers))) % ndev; }
 
     // own sits on device base + rel of the ndev devices base .. base + ndev - 1
-    WorkerLanes(hpn_ctx *own, int base, int rel, int ndev, int cap) : own_(own), base_(base), rel_(rel), ndev_(ndev), cap_(cap) {}
+    WorkerLanes(hpn_ctx *own, int base, int rel, int ndev, int cap, bool pair_on_one_device = false)
+        : own_(own), base_(base), rel_(rel), ndev_(ndev), cap_(cap), pair_(pair_on_one_device)
+    {
+    }
     LaneGroup *for_file(const char *path)
     {
-        const int want = shard_lanes_for(path, cap_);
+        const int want = shard_lanes_for(path, cap_, pair_);
         if (want < 2) return nullptr;
         if (!group_) group_.reset(new LaneGroup(own_, base_, rel_, ndev_, want));   // sized by the first input that is sharded, kept for the others
         return group_.get();
@@ -182,6 +189,7 @@ public:
 private:
     hpn_ctx *own_;
     int base_, rel_, ndev_, cap_;
+    bool pair_;
     std::unique_ptr<LaneGroup> group_;
 };
 

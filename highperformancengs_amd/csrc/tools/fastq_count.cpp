@@ -75,7 +75,7 @@ static void worker(int slot, int workers, FILE *out)
     const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
     if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] worker %d: context %.3f s\n", slot, wall_s() - t0);
-    WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers));
+    WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers), workers == 1);
     for (int i; (i = g_next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, g.infiles[i], out);
 }
 

@@ -1,0 +1,23 @@
+set -e
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import numpy as np, os, sys
+sys.path.insert(0,'tests'); import orc
+n, L = 2000000, 150
+seq, qual, off = orc.synth_soa(99, 0, n, L, L)
+s, q = seq.reshape(n, L), qual.reshape(n, L)
+nl = np.full((n,1), 10, np.uint8)
+names = np.frombuffer(b"".join(b"@r%09d" % i for i in range(n)), np.uint8).reshape(n, 11)
+plus = np.tile(np.frombuffer(b"\n+\n", np.uint8), (n,1))
+rec = np.concatenate([names, nl, s, plus, q, nl], axis=1).tobytes()
+with open('/tmp/big.fq','wb') as fh:
+    for _ in range(24): fh.write(rec)
+PY
+B=highperformancengs_amd/bin
+cat /tmp/big.fq > /dev/null
+HPN_TIMING=1 $B/fastq_count /tmp/big.fq > /dev/null 2>&1
+for l in 1 2 3 4; do for t in 6 8 12; do for c in 16777216 33554432; do
+  echo -n "lanes $l threads $t chunk $c: "; HPN_NGPU=$l HPN_READ_THREADS=$t HPN_TEXT_CHUNK=$c HPN_TIMING=1 $B/fastq_count /tmp/big.fq 2>&1 | grep -E "Finished" | tr '\n' ' '; echo
+done; done; done
+echo trim; for l in 1 2 3; do echo -n "lanes $l: "; HPN_NGPU=$l HPN_READ_THREADS=8 $B/fastq_trim -i /tmp/big.fq -s 5 -e 140 -o /tmp/t$l 2>&1 | grep Finished; done
+cmp /tmp/t1.trim.fastq /tmp/t2.trim.fastq && cmp /tmp/t1.trim.fastq /tmp/t3.trim.fastq && echo trims identical
