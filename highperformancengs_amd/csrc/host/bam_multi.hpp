@@ -124,6 +124,18 @@ inline int multi_gpu_workers_for(const char *path)
     return n;
 }
 
+// Worker contexts live for the whole process and are reused across input files: a depth context keeps several GB of
+// scratch for a chr1-sized target, and bam2depth / bam2wig / bam_sliding_count come here once per file.
+inline hpn_ctx *pooled_worker_ctx(int worker, int device)
+{
+    static std::mutex m;
+    static std::vector<hpn_ctx *> pool;
+    std::lock_guard<std::mutex> lk(m);
+    if ((size_t)worker >= pool.size()) pool.resize((size_t)worker + 1, nullptr);
+    if (!pool[(size_t)worker] && hpn_ctx_create(device, &pool[(size_t)worker]) != HPN_OK) pool[(size_t)worker] = nullptr;
+    return pool[(size_t)worker];
+}
+
 struct TargetOut {
     std::vector<hpn_run> runs;
     std::vector<char> text;      // bedGraph lines formatted on the device (text_name given), instead of runs
