@@ -413,14 +413,15 @@ def _steady_state_legs(ctx, cores, td, pair, L):
              lambda wd: ["-t", "8", "-o", "m.tsv"] + names8, names8, 8 * small_bases)
     r["startup_s"] = round(t_start, 3)
     legs.append(r)
-    r = pair(f"fastq_count, ONE plain file {n_big:.1e} x {L} bp ({n_big * rec / 1e9:.1f} GB)", "fastq_count",
+    r = pair(f"fastq_count, ONE plain file {n_big:.1e} x {L} bp ({n_big * rec / 1e9:.1f} GB; default route: two lanes on the one device)", "fastq_count",
              lambda wd: ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases)
     r["startup_s"] = round(t_start, 3)
     legs.append(r)
-    # the same file by record block over lanes (host/text_shard.hpp): on this box the lanes share the one device and
-    # its one PCIe link, so this shows the route's overhead, not a gain
-    base, base_out = ours_only("fastq_count, the same ONE file on one context (again, for the comparison below)", "fastq_count",
-                               ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases)
+    # the same file by record block over lanes (host/text_shard.hpp).  On this box the lanes share the one device and its one
+    # PCIe link; the default above already uses TWO of them for a file of this size (one lane's copy runs beside the other's
+    # kernels), HPN_NGPU=1 is the single-context route, HPN_NGPU=4 shows what more lanes on one link cost
+    base, base_out = ours_only("fastq_count, the same ONE file on ONE context (HPN_NGPU=1)", "fastq_count",
+                               ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases, env={"HPN_NGPU": "1"})
     lanes, _ = ours_only("fastq_count, the same ONE file by record block over 4 lanes (HPN_NGPU=4, lanes share the device)", "fastq_count",
                          ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases, env={"HPN_NGPU": "4"}, compare_to=("one context", base_out))
     legs.extend([base, lanes])
@@ -546,13 +547,13 @@ def _c4_file_legs(cores, td):
         return want[t]
     shape = f"{n_reads:.2e} x 150 bp over the 25 hg38 contigs (30x chr21 + chrM, 3x the rest), BAM {os.path.getsize(bam) / 1e9:.1f} GB"
     for tool, args, env in (("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {}),
-                            ("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {"HPN_NGPU": "3"}),
+                            ("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {"HPN_NGPU": "1"}),
                             ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {}),
-                            ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "3"})):
+                            ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "1"})):
         wd = tempfile.mkdtemp(prefix="c4_", dir=td)
         os.symlink(bam, os.path.join(wd, "hg38.bam")), os.symlink(bam + ".bai", os.path.join(wd, "hg38.bam.bai"))
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
-        leg = {"leg": f"{tool} -w {W}{' on 3 workers (HPN_NGPU=3, one device)' if env else ''}, {shape}",
+        leg = {"leg": f"{tool} -w {W}{' on ONE worker (HPN_NGPU=1)' if env else ' (default: three workers on the one device)'}, {shape}",
                "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(n_reads * 150 / dt / 1e9, 3), "rc": p.returncode}, "reference": None}
         if tool == "bam2depth":
             ok, n_runs = True, 0
