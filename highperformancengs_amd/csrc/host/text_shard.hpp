@@ -215,8 +215,18 @@ public:
     };
 
     PieceRun(LaneGroup &g, const char *path, size_t piece_bytes)
-        : g_(g), pump_(g.ctx(0), path, piece_bytes, g.lanes() + 2, false, 0, HPN_TEXT_PIECE_TAIL + 64)
+        : g_(g), pump_(g.ctx(0), path, piece_bytes, g.lanes() + 2, false, 0, HPN_TEXT_PIECE_TAIL + 64, reader_threads(g.lanes()))
     {
+    }
+    // ONE reader feeds every lane: four pread threads per lane (a lane's PCIe link takes ~25 GB/s, a thread copies ~7 GB/s out
+    // of the page cache), within this worker's share of the host's CPUs
+    static int reader_threads(int lanes)
+    {
+        const long share = usable_cpus() / text_workers_in_flight();
+        long n = 4L * lanes;
+        n = n < 6 ? 6 : n;
+        n = n > share ? share : n;
+        return (int)(n < 1 ? 1 : n);
     }
     bool ok() const { return pump_.ok(); }
     size_t piece_bytes() const { return pump_.chunk_bytes(); }

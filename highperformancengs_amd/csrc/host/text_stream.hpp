@@ -75,8 +75,9 @@ public:
     // raw: deliver the file's own bytes whatever they are (compressed BGZF for the device inflater)
     // start: file offset the stream begins at (plain / raw files only)
     // pad: writable bytes in front of and behind every chunk (text_shard.hpp puts a piece's head byte and tail there)
-    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false, uint64_t start = 0, size_t pad = 0)
-        : ctx_(ctx), cap_(chunk), pad_(pad), pos_(start)
+    // read_threads: pread threads of a plain file (0: HPN_READ_THREADS, else 6 shared among the workers in flight)
+    TextPump(hpn_ctx *ctx, const char *path, size_t chunk, int nbuf = 3, bool raw = false, uint64_t start = 0, size_t pad = 0, int read_threads = 0)
+        : ctx_(ctx), cap_(chunk), pad_(pad), pos_(start), read_threads_(read_threads)
     {
         struct stat sb;
         uint8_t magic[2] = {0, 0};
@@ -184,12 +185,13 @@ private:
     size_t fill(uint8_t *dst)
     {
         if (fd_ >= 0) {  // plain file: a few threads pull disjoint pieces out of the page cache
-            static const int kThreads = [] {
+            static const int kDefault = [] {
                 const char *e = getenv("HPN_READ_THREADS");
                 long n = e ? atol(e) : 6;   // (15.2 GB from the page cache: 4 / 6 / 8 / 12 threads 0.51 / 0.47 / 0.45-0.49 / 0.49-0.51 s)
                 if (!e && n > usable_cpus() / text_workers_in_flight()) n = usable_cpus() / text_workers_in_flight();
                 return (int)(n < 1 ? 1 : n > 32 ? 32 : n);
             }();
+            const int kThreads = read_threads_ > 0 && !getenv("HPN_READ_THREADS") ? (read_threads_ > 32 ? 32 : read_threads_) : kDefault;
             const size_t piece = (cap_ / (size_t)kThreads + 4095) & ~(size_t)4095;
             std::vector<size_t> got((size_t)kThreads, 0);
             auto pull = [&](int t) {
@@ -257,6 +259,7 @@ private:
     size_t cap_, pad_;
     int fd_ = -1;
     uint64_t pos_ = 0;   // (declared after cap_, pad_: the constructor initialises them in this order)
+    int read_threads_ = 0;
     InStream in_;
     bool ok_ = false, handed_over_ = false;
     std::vector<uint8_t *> buf_;
