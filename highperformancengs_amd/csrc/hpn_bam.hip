@@ -164,7 +164,7 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
     if (rc != HPN_OK) return rc;
     if (c->d_runs.cap == 0 && (rc = scratch_reserve(c, c->d_runs, (1u << 20) * sizeof(hpn_run))) != HPN_OK) return rc;
     struct { uint32_t ticket, err; u64 n_runs; } head;
-    uint32_t bad = 0, sw_ctl[8] = {0};
+    uint32_t bad = 0, sw_ctl[16] = {0};
     // What the sweep did while the records came (k_depth_sweep) stands: runs and, for window size depth_W, window sums of
     // everything in front of its frontier.  k_depth_scan does the rest from the frontier on; with another window size than
     // the sweep was told, the window sums of the whole target are taken from the runs instead.
@@ -184,6 +184,24 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
         HPN_HIP(c, hipMemcpyAsync(&bad, c->w_misc.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipMemcpyAsync(sw_ctl, c->d_sw.p, sizeof sw_ctl, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipStreamSynchronize(c->stream));
+        if (getenv("HPN_SWEEP_DIAG") && sw_ctl[0]) {   // (DIAG_SWEEP_STAMPS builds leave eight words per swept tile in its stretch of d_diff)
+            const uint32_t nt = sw_ctl[0];
+            std::vector<uint32_t> st((size_t)nt * 8);
+            if (hipMemcpy2D(st.data(), 32, c->d_diff.p, 16384 * 4, 32, nt, hipMemcpyDeviceToHost) == hipSuccess) {
+                double sum[8] = {0}, mx[8] = {0};
+                uint32_t n = 0, late = 0;
+                for (uint32_t t = 0; t < nt; ++t) {
+                    const uint32_t *o = &st[(size_t)t * 8];
+                    if (o[0] != 0x5354414du) continue;
+                    ++n, late += o[4] > 2000u;
+                    for (int k = 1; k < 8; ++k) sum[k] += o[k], mx[k] = o[k] > mx[k] ? o[k] : mx[k];
+                }
+                if (n)
+                    fprintf(stderr, "[sweep] %u tiles, mean (max) in us: setup %.2f (%.1f), gather %.2f (%.1f), scan %.2f, look-back %.2f (%.1f; %u tiles > 20 us; %.2f polls), "
+                            "emit %.2f, flush %.2f (%.1f)\n", n, sum[1] / n / 100, mx[1] / 100, sum[2] / n / 100, mx[2] / 100, sum[3] / n / 100, sum[4] / n / 100, mx[4] / 100, late,
+                            sum[7] / n, sum[5] / n / 100, sum[6] / n / 100, mx[6] / 100);
+            }
+        }
         if (bad)
             return fail(c, HPN_E_DOMAIN, "a CIGAR M block ends at or beyond position %llu (2^28 key limit of the reference, "
                         "or more than %llu bases past the contig end)", (unsigned long long)c->depth_slots,

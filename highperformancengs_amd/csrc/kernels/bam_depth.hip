@@ -487,6 +487,9 @@ __device__ __forceinline__ int32_t sext31(uint32_t x) { return (int32_t)(x << 1)
 // published at least their aggregate, then returns (in every lane) the composition, oldest first, of the tiles from
 // the nearest one that holds a full prefix up to `newest`; *has_prefix = such a tile exists in the window.
 // Tiles before 0 count as the empty prefix.
+#ifdef DIAG_SWEEP_STAMPS
+__device__ uint32_t g_diag_polls[1024];   // polls per tile slot (tile & 1023): one writer at a time, summed by the reader
+#endif
 __device__ __forceinline__ DepthSum ds_window(u64 *status, int64_t newest, bool *has_prefix, uint32_t *err)
 {
     const int64_t t = newest - lane_id();
@@ -506,6 +509,9 @@ __device__ __forceinline__ DepthSum ds_window(u64 *status, int64_t newest, bool 
         }
         __builtin_amdgcn_s_sleep(1);
     }
+#ifdef DIAG_SWEEP_STAMPS
+    if (lane_id() == 0) g_diag_polls[(newest + 1) & 1023] = spins + 1u;
+#endif
     const u64 pfx = __ballot((h0 >> 62) == kScanPrefix);
     const int stop = pfx ? __builtin_ctzll(pfx) : kWave;                      // lane of the nearest full prefix
     DepthSum v = ds_identity();
@@ -923,9 +929,9 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
 {
     constexpr int kWaves = kSwThreads / kWave;
 #ifdef DIAG_SWEEP_STAMPS
-    uint64_t st_[12];
+    uint32_t st_[12];      // (32-bit stamps in registers, totals by atomics at the end: a printf in the kernel quadruples its time)
     int st_n = 0;
-#define SW_STAMP() st_[st_n++] = wall_clock64()
+#define SW_STAMP() st_[st_n++] = (uint32_t)wall_clock64()
 #else
 #define SW_STAMP()
 #endif
@@ -973,7 +979,7 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
             { uint32_t sink = 0;
               for (int u = 0; u < kTileUnroll; ++u) sink += n[u] + p[u];
               if (sink == 0xdeadbeefu) st_[11] = 1; }
-            uint64_t g1 = wall_clock64();
+            uint32_t g1 = (uint32_t)wall_clock64();
 #endif
 #pragma unroll
             for (int u = 0; u < kTileUnroll; ++u) {
@@ -985,7 +991,7 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
             { uint32_t sink = 0;
               for (int u = 0; u < kTileUnroll; ++u) sink += w0[u] + w1[u] + w2[u];
               if (sink == 0xdeadbeefu) st_[11] = 2; }
-            uint64_t g2 = wall_clock64();
+            uint32_t g2 = (uint32_t)wall_clock64();
             st_[8] = g1, st_[9] = g2;
 #endif
         // positions in 32 bits: slots <= 2^28 and an operation is shorter than 2^28, so q + len cannot wrap while q is kept below 2^31
@@ -1122,9 +1128,13 @@ void k_depth_sweep(Recs recs, int32_t want, uint32_t flag_mask, int32_t *__restr
 #ifdef DIAG_SWEEP_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     SW_STAMP();
-    if (tid == 0 && (t & 1023u) == 7u)
-        printf("tile %u: setup %llu gather %llu [fields %llu words %llu walk %llu] scan %llu lookback %llu emit %llu flush %llu (x10 ns) records %u\n", t, st_[1] - st_[0], st_[2] - st_[1],
-               st_[8] - st_[1], st_[9] - st_[8], st_[2] - st_[9], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], r_end - r_first);
+    // (the tile's stretch of the difference array is free once it is swept: the stamps go there, plain stores, nothing shared;
+    // hpn_depth_finish reads them back when HPN_SWEEP_DIAG is set)
+    if (tid == 0) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(diff + lo);
+        o[0] = 0x5354414du, o[1] = st_[1] - st_[0], o[2] = st_[2] - st_[1], o[3] = st_[3] - st_[2], o[4] = st_[4] - st_[3], o[5] = st_[5] - st_[4],
+        o[6] = st_[6] - st_[5], o[7] = g_diag_polls[t & 1023u];
+    }
 #endif
 }
 
