@@ -50,8 +50,9 @@ def test_pieces_add_up_to_the_serial_pass(harness, tmp_path, lanes, chunk):
                        stderr=subprocess.PIPE, env=env)
     assert p.stdout.decode().strip() == "0 0 %d" % len(recs)
     assert (tmp_path / "t.out").read_bytes() == b"".join(b"%s\n%s\n+\n%s\n" % (n, s[S:E], q[S:E]) for n, s, q in recs)
-    # a stream that ends inside a record: the route is abandoned, nothing is added
-    (tmp_path / "trunc.fq").write_bytes(text[:len(text) // 2 + 11])
+    # a stream that ends inside a record's '+' line: the route is abandoned, nothing is added
+    half = b"".join(b"%s\n%s\n+\n%s\n" % r for r in recs[:2000])
+    (tmp_path / "trunc.fq").write_bytes(half + b"%s\n%s\n+" % recs[2000][:2])
     p = subprocess.run([harness["plain"], "count", str(tmp_path / "trunc.fq"), str(lanes)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.stdout.decode().strip() == "0 1 0 0"
 
