@@ -36,6 +36,45 @@ struct BgzfBlock {  // = hpn_bgzf_block
     uint64_t out_off;
 };
 
+// where the decoded bytes go: straight to global memory; a match reads its source back from there
+struct ByteSink {
+    uint8_t *out;
+    uint32_t out_len, op, safe;   // op: bytes decoded; output bytes below `safe` are known to have reached memory
+    __device__ __forceinline__ void pin_state() { op = uni(op), safe = uni(safe); }
+    // entry e: [23:16] the literal, [31:24] the second one of a pair
+    __device__ __forceinline__ void lits(bool mine, bool two, uint32_t at, uint32_t e)
+    {
+        if (mine) {
+            if (two) {
+                const uint16_t v = (uint16_t)(e >> 16);
+                __builtin_memcpy(out + at, &v, 2);              // (one store; `at` may be odd)
+            } else {
+                out[at] = (uint8_t)(e >> 16);
+            }
+        }
+    }
+    // (at + len <= out_len: checked by the caller)
+    __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t len, uint32_t dist)
+    {
+        if (dist > at) return 14;
+        const uint32_t start = at - dist, lane = (uint32_t)lane_id();
+        if (start + (len < dist ? len : dist) > safe) {
+            // the source reaches into bytes this wave stored a moment ago: wait for those stores
+            // (workgroup scope = this CU's vector cache: a counter wait, no cache invalidate)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            safe = at;
+        }
+        if (dist >= len) {  // the usual case: source and destination do not overlap
+            for (uint32_t i0 = 0; i0 < len; i0 += kWave)
+                if (i0 + lane < len) out[at + i0 + lane] = out[start + i0 + lane];
+        } else {  // overlapping match = periodic pattern: every source byte exists already
+            for (uint32_t i0 = 0; i0 < len; i0 += kWave)
+                if (i0 + lane < len) out[at + i0 + lane] = out[start + (i0 + lane) % dist];
+        }
+        return 0;
+    }
+};
+
 __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
                                                         uint32_t n_blocks, uint8_t *__restrict__ outbuf,
                                                         uint32_t *__restrict__ status)
@@ -50,9 +89,11 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
         Bits b;
         stage(s, b, in, in_len);
         stage(s, b, in, in_len);
-        uint32_t op = 0, safe = 0, err = 0;  // output bytes below `safe` are known to have reached memory
+        ByteSink sink{out, out_len, 0u, 0u};
+        uint32_t err = 0;
         bool last = false;
         while (!last && !err) {
+            pin(b), pin(err), sink.pin_state();
             refill(s, b, in, in_len);
             if (b.in_pos - (b.bc >> 3) > in_len) {  // ran past the payload (the ring would only repeat itself)
                 err = 17;
@@ -66,6 +107,7 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                 const uint32_t len = take(b, 16);
                 refill(s, b, in, in_len);
                 const uint32_t nlen = take(b, 16);
+                uint32_t &op = sink.op;
                 if ((len ^ nlen) != 0xffffu || op + len > out_len) {
                     err = 1;
                     break;
@@ -159,63 +201,14 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                 }
                 pair_literals(s.lit, kLitRoot);
             }
-            // ---- symbols of this block ------------------------------------------------------
-            // (every pass emits at least one byte -- bounded by out_len -- or leaves, so the loop ends on any
+            // ---- symbols of this block: 64 bit offsets at a time (decode_symbols, inflate_core.hpp) --------
+            // (every symbol emits at least one byte -- bounded by out_len -- or ends the block, so this ends on any
             // input; running past the payload is caught per block above)
-            for (;;) {
-                refill(s, b, in, in_len);
-                uint32_t e = lookup(s.lit, kLitRoot, b);
-                uint32_t kind = (e >> 4) & 15u;
-                // literal run: a loop of its own, so that the common case carries none of the match path's state;
-                // every lane stores the same byte(s) to the same address (no exec masking)
-                while (kind <= kLit2) {
-                    if (op + kind + 1u > out_len) {
-                        err = 12;
-                        break;
-                    }
-                    out[op] = (uint8_t)(e >> 16);
-                    if (kind) out[op + 1u] = (uint8_t)(e >> 24);
-                    op += kind + 1u;
-                    refill(s, b, in, in_len);
-                    e = lookup(s.lit, kLitRoot, b);
-                    kind = (e >> 4) & 15u;
-                }
-                if (err) break;
-                if (kind == kLen) {
-                    const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
-                    refill(s, b, in, in_len);
-                    const uint32_t d = lookup(s.dist, kDistRoot, b);
-                    if (((d >> 4) & 15u) != kDist) {
-                        err = 13;
-                        break;
-                    }
-                    const uint32_t dist = (d >> 16) + take(b, (d >> 8) & 255u);
-                    if (dist > op || op + len > out_len) {
-                        err = 14;
-                        break;
-                    }
-                    const uint32_t start = op - dist;
-                    if (start + (len < dist ? len : dist) > safe) {
-                        // the source reaches into bytes this wave stored a moment ago: wait for those stores
-                        // (workgroup scope = this CU's vector cache: a counter wait, no cache invalidate)
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        safe = op;
-                    }
-                    if (dist >= len) {  // the usual case: source and destination do not overlap
-                        for (uint32_t i = (uint32_t)lane; i < len; i += kWave) out[op + i] = out[start + i];
-                    } else {  // overlapping match = periodic pattern: every source byte exists already
-                        for (uint32_t i = (uint32_t)lane; i < len; i += kWave) out[op + i] = out[start + i % dist];
-                    }
-                    op += len;
-                } else if (kind == kEob) {
-                    break;
-                } else {
-                    err = 15;
-                    break;
-                }
-            }
+            Pos p = pos_of(b);
+            if (!decode_symbols(s, b, p, in, in_len, sink, err)) break;
+            seek(s, b, p, in, in_len);
         }
-        if (!err && op != out_len) err = 16;
+        if (!err && sink.op != out_len) err = 16;
         if (lane == 0) status[bi] = err;
     }
 }

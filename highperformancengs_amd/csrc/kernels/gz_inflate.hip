@@ -41,6 +41,47 @@ struct GzMeta {
 
 constexpr uint32_t kGzHist = 32768;
 
+// where the symbols go: 16 bits each, straight to global memory; a match reads its source back from there, or names the
+// byte of the 32 KiB in front of the stretch it would have copied
+struct SymSink {
+    uint16_t *out;
+    uint32_t out_len, op, safe;   // op: symbols decoded; symbols below `safe` are known to have reached memory
+    __device__ __forceinline__ void pin_state() { op = uni(op), safe = uni(safe); }
+    // entry e: [23:16] the literal, [31:24] the second one of a pair.  (Byte offsets in 32 bits: a stretch's symbols stay far
+    // below 2 GiB.)
+    __device__ __forceinline__ void lits(bool mine, bool two, uint32_t at, uint32_t e)
+    {
+        if (mine) {
+            uint8_t *to = (uint8_t *)out + (at << 1);
+            if (two) {
+                const uint32_t v = ((e >> 16) & 255u) | (e >> 24) << 16;
+                __builtin_memcpy(to, &v, 4);                    // (one store; `at` may be odd)
+            } else {
+                *(uint16_t *)to = (uint16_t)((e >> 16) & 255u);
+            }
+        }
+    }
+    // (at + len <= out_len: checked by the caller)
+    __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t len, uint32_t dist)
+    {
+        if (dist > at + kGzHist) return 14;
+        const int32_t start = (int32_t)at - (int32_t)dist;  // negative: in the history before this stretch
+        const uint32_t lane = (uint32_t)lane_id();
+        if (start + (int32_t)(len < dist ? len : dist) > (int32_t)safe) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            safe = at;
+        }
+        for (uint32_t i0 = 0; i0 < len; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            if (i < len) {
+                const int32_t idx = start + (int32_t)(dist >= len ? i : i % dist);
+                out[at + i] = idx < 0 ? (uint16_t)(256 + (int32_t)kGzHist + idx) : out[idx];
+            }
+        }
+        return 0;
+    }
+};
+
 __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
                                                           uint32_t n_chunks, uint16_t *__restrict__ symbuf, uint32_t sym_cap,
                                                           GzMeta *__restrict__ meta, GzBound *__restrict__ bounds, uint32_t bounds_cap,
@@ -59,9 +100,12 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
         stage(s, b, in, in_len);
         refill(s, b, in, in_len);
         drop(b, ck.start_bit);
-        uint32_t op = 0, safe = 0, err = 0;  // symbols below `safe` are known to have reached memory
+        SymSink sink{out, out_len, 0u, 0u};
+        uint32_t &op = sink.op;
+        uint32_t err = 0;
         bool last = false, arrived = false;
         while (!last && !err) {
+            pin(b), pin(err), sink.pin_state();
             const uint64_t pos = (uint64_t)b.in_pos * 8u - b.bc;  // a block boundary
             if (pos >= end_bit) {
                 if (pos == end_bit) arrived = true;
@@ -111,6 +155,7 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
                     err = 4;
                     break;
                 }
+                pair_literals(s.lit, kLitRoot);
             } else {  // dynamic codes
                 refill(s, b, in, in_len);
                 const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
@@ -167,53 +212,13 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
                     err = 11;
                     break;
                 }
+                pair_literals(s.lit, kLitRoot);
             }
-            // ---- symbols of this block ----
-            for (;;) {
-                refill(s, b, in, in_len);
-                uint32_t e = lookup(s.lit, kLitRoot, b);
-                uint32_t kind = (e >> 4) & 15u;
-                while (kind == kLit) {  // every lane stores the same symbol to the same address
-                    if (op + 1u > out_len) {
-                        err = 12;
-                        break;
-                    }
-                    out[op] = (uint16_t)((e >> 16) & 255u);
-                    op += 1u;
-                    refill(s, b, in, in_len);
-                    e = lookup(s.lit, kLitRoot, b);
-                    kind = (e >> 4) & 15u;
-                }
-                if (err) break;
-                if (kind == kLen) {
-                    const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
-                    refill(s, b, in, in_len);
-                    const uint32_t d = lookup(s.dist, kDistRoot, b);
-                    if (((d >> 4) & 15u) != kDist) {
-                        err = 13;
-                        break;
-                    }
-                    const uint32_t dist = (d >> 16) + take(b, (d >> 8) & 255u);
-                    if (dist > op + kGzHist || op + len > out_len) {
-                        err = 14;
-                        break;
-                    }
-                    const int32_t start = (int32_t)op - (int32_t)dist;  // negative: in the history before this stretch
-                    if (start + (int32_t)(len < dist ? len : dist) > (int32_t)safe) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        safe = op;
-                    }
-                    for (uint32_t i = (uint32_t)lane; i < len; i += kWave) {
-                        const int32_t idx = start + (int32_t)(dist >= len ? i : i % dist);
-                        out[op + i] = idx < 0 ? (uint16_t)(256 + (int32_t)kGzHist + idx) : out[idx];
-                    }
-                    op += len;
-                } else if (kind == kEob) {
-                    break;
-                } else {
-                    err = 15;
-                    break;
-                }
+            // ---- symbols of this block: 64 bit offsets at a time (decode_symbols, inflate_core.hpp) ----
+            {
+                Pos p = pos_of(b);
+                if (!decode_symbols(s, b, p, in, in_len, sink, err)) break;
+                seek(s, b, p, in, in_len);
             }
             // ---- the member's final block is done: does another member follow (cat a.gz b.gz, pigz -i ...)? ----
             // 8 bytes of trailer (CRC-32, ISIZE), then a gzip header (RFC 1952) and the next member's first block: the

@@ -33,6 +33,13 @@ struct Bits {  // wave-uniform bit reader over the LDS ring
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+// The decoder's state is the same in every lane and its loops are meant to run on the scalar unit (SGPR arithmetic, s_cbranch
+// instead of exec masks).  The compiler does that only for values it can PROVE uniform, and one doubtful value in a loop's cycle
+// (the error code, behind the table builds' lane-strided loops) moves the whole cycle into vector registers and its branches
+// under exec masks.  pin() re-states the uniformity at the head of a loop (v_readfirstlane; nothing for a value in an SGPR).
+__device__ __forceinline__ void pin(Bits &b) { b.bb = uni64(b.bb), b.bc = uni(b.bc), b.in_pos = uni(b.in_pos), b.filled = uni(b.filled); }
+__device__ __forceinline__ void pin(uint32_t &v) { v = uni(v); }
 
 // stage the next kRing/2 bytes of the block's compressed data (16 B per lane)
 __device__ __forceinline__ void stage(InfLds &s, Bits &b, const uint8_t *__restrict__ in, uint32_t in_len)
@@ -174,6 +181,193 @@ __device__ __forceinline__ uint32_t lookup(const uint32_t *tab, uint32_t root, B
     }
     drop(b, e & 15u);
     return e;
+}
+
+// ---- the symbols of a block, 64 bit offsets at a time ----------------------------------------------------------------------
+// The serial loop (refill; look the next code up in LDS; wait; readfirstlane; branch; store) is one instruction stream per
+// wave, and with 18 single-wave decoders per CU it is the CU's ONE scalar unit that has to carry them: 42 scalar
+// instructions per literal code kept it 70 % busy (SQ_ACTIVE_INST_SCA / SQ_BUSY_CU_CYCLES), and neither moving the loop's
+// arithmetic between the vector and the scalar unit, nor dropping the per-literal store, nor taking the LDS round trip off
+// the chain changed the kernel's time (round 3 A/B runs, profiles/r03/inflate_ab.txt).  So the work per symbol is moved to
+// the lanes, which were idle:
+//   * lane k looks up the code that WOULD start at bit k of the next 64 bits of the stream (one ring read and one table
+//     read per lane, for the literal/length table and for the distance table), and works out what that symbol would be:
+//     its literal(s), or its length, the distance code behind it (ds_bpermute from the lane where it starts) and the
+//     distance, and the offset of the code after it;
+//   * the wave follows the true chain of symbol starts through those offsets -- v_readlane + s_bitset1 per symbol, nothing else;
+//   * the lanes on the chain then take their places in the output with one prefix sum; the literals go out in one (two)
+//     store instruction(s) for the whole window, the matches are copied one after the other.
+// A symbol that does not fit the rest of the window starts the next window (it fits any window it starts: 15 + 5 + 15 +
+// 13 bits); a code longer than its root table (second-level look-up) is decoded by the serial reader, then windows resume.
+struct Pos {             // consumed position in the chunk: `bit` (0..7) bits into byte `byte`
+    uint32_t byte, bit;
+};
+__device__ __forceinline__ Pos pos_of(const Bits &b)
+{
+    return Pos{b.in_pos - ((b.bc + 7u) >> 3), (0u - b.bc) & 7u};
+}
+// the serial reader, restarted at p (the ring holds the bytes around it)
+__device__ __forceinline__ void seek(InfLds &s, Bits &b, Pos p, const uint8_t *__restrict__ in, uint32_t in_len)
+{
+    b.in_pos = p.byte, b.bb = 0, b.bc = 0;
+    refill(s, b, in, in_len);
+    drop(b, p.bit);
+}
+struct Win {
+    uint32_t raw;        // >= 25 bits of the stream from bit (p + lane) on
+    uint32_t el, ed;     // root entries of the literal/length and of the distance table for them
+};
+__device__ __forceinline__ Win window(InfLds &s, Bits &b, Pos p, const uint8_t *__restrict__ in, uint32_t in_len)
+{
+    if (b.filled - p.byte < 8u + kRing / 4) {        // (the window reads up to byte p.byte + 16)
+        if (b.filled < in_len + 8u) stage(s, b, in, in_len);
+    }
+    const uint32_t q = p.bit + (uint32_t)lane_id();
+    const uint32_t byte = p.byte + (q >> 3);
+    const uint32_t i0 = (byte >> 2) & (kRing / 4 - 1), i1 = (i0 + 1u) & (kRing / 4 - 1);
+    const uint32_t v = (uint32_t)((((u64)s.ring[i1] << 32) | s.ring[i0]) >> (8u * (byte & 3u)));   // 32 bits from `byte` on
+    Win w;
+    w.raw = v >> (q & 7u);
+    w.el = s.lit[w.raw & ((1u << kLitRoot) - 1u)];
+    w.ed = s.dist[w.raw & ((1u << kDistRoot) - 1u)];
+    return w;
+}
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t from_lane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
+// inclusive prefix sum over the lanes of a wave (DPP: shifts inside rows of 16, then row broadcasts; see wave_sum)
+__device__ __forceinline__ uint32_t wave_prefix(uint32_t v)
+{
+#define HPN_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
+    HPN_DPP_ADD(0x111, 0xf);
+    HPN_DPP_ADD(0x112, 0xf);
+    HPN_DPP_ADD(0x114, 0xf);
+    HPN_DPP_ADD(0x118, 0xf);
+    HPN_DPP_ADD(0x142, 0xa);
+    HPN_DPP_ADD(0x143, 0xc);
+#undef HPN_DPP_ADD
+    return v;
+}
+
+// One window.  -> how it ended; o = bits consumed (the symbol at o is still to be decoded, except behind an end-of-block code).
+// The sink: op / out_len -- symbols written / allowed; lits(mine, two, at, e) -- the lanes for which `mine` holds store the one
+// (two) literal(s) of THEIR entry e at symbol `at`; match(at, len, dist) -> 0 or an error code (wave-uniform arguments).
+enum { kWinNext = 0, kWinEob = 1, kWinSerial = 2, kWinError = 3 };
+template <typename Sink>
+__device__ __forceinline__ uint32_t walk(const Win &w, Sink &sink, uint32_t &o, uint32_t &err)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    const uint32_t kind = (w.el >> 4) & 15u, bits = w.el & 15u;
+    const bool is_lit = kind <= kLit2;
+    // what the symbol starting here would be, and where the one behind it starts
+    uint32_t nxt = lane + bits, len = 0, dist = 0, why = kWinError;
+    bool is_match = false;
+    const u64 len_lanes = __ballot(kind == kLen);
+    if (len_lanes) {                                  // (same in every lane: windows of literals skip the three exchanges)
+        const uint32_t xb = (w.el >> 8) & 15u, o2 = lane + bits + xb;              // o2: where the distance code starts
+        len = (w.el >> 16) + ((w.raw >> bits) & ((1u << xb) - 1u));
+        const uint32_t d = from_lane(w.ed, o2), dk = (d >> 4) & 15u, dxb = (d >> 8) & 15u, o3 = o2 + (d & 15u);   // o3: its extra bits
+        dist = (d >> 16) + (from_lane(w.raw, o3) & ((1u << dxb) - 1u));
+        if (kind == kLen) {
+            nxt = o3 + dxb;
+            is_match = o2 < (uint32_t)kWave && dk == kDist && o3 < (uint32_t)kWave;
+            // a length whose distance is not in reach: beyond the window -> the next window starts with this symbol; a
+            // distance code longer than the root table -> the serial reader; anything else is not a distance code
+            why = o2 >= (uint32_t)kWave ? kWinNext : dk == kSub ? kWinSerial : dk != kDist ? kWinError : kWinNext;
+        }
+    }
+    const bool emits = is_lit || is_match;
+    // the chain's fixed point: a lane whose symbol this window does not take, or whose symbol ends the window
+    const uint32_t hop = emits && nxt < (uint32_t)kWave ? nxt : lane;
+    u64 on = 1;
+    uint32_t f = 0;
+    for (;;) {
+        const uint32_t a = lane_of(hop, f), b = lane_of(hop, a), c = lane_of(hop, b), d = lane_of(hop, c);
+        on |= (1ull << a) | (1ull << b) | (1ull << c) | (1ull << d);
+        f = d;
+        if (d == c) break;
+    }
+    const u64 taken = on & __ballot(emits);
+    const bool mine = (taken >> lane) & 1u;
+    const uint32_t units = mine ? (is_lit ? kind + 1u : len) : 0u;
+    const uint32_t upto = wave_prefix(units), at = sink.op + upto - units, total = lane_of(upto, kWave - 1);
+    if (sink.op + total > sink.out_len) {
+        err = 12;
+        return kWinError;
+    }
+    sink.lits(mine && is_lit, kind != 0, at, w.el);
+    for (u64 mm = taken & len_lanes; mm; mm &= mm - 1) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(mm);
+        if ((err = sink.match(lane_of(at, k), lane_of(len, k), lane_of(dist, k))) != 0) return kWinError;
+    }
+    sink.op += total;
+    if ((taken >> f) & 1u) {                          // the last symbol ends in or behind the window's last bit
+        o = lane_of(nxt, f);
+        return kWinNext;
+    }
+    const uint32_t fe = lane_of(w.el, f), fk = (fe >> 4) & 15u;
+    o = f;
+    if (fk == kEob) {
+        o += fe & 15u;
+        return kWinEob;
+    }
+    if (fk == kSub) return kWinSerial;
+    if (fk == kLen) {
+        const uint32_t how = lane_of(why, f);
+        if (how == kWinError) err = 13;
+        return how;
+    }
+    err = 15;
+    return kWinError;
+}
+
+// Decodes symbols from p on until the block's end-of-block code (-> true: p is behind it) or an error (-> false, err set).
+template <typename Sink>
+__device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const uint8_t *__restrict__ in, uint32_t in_len, Sink &sink,
+                                               uint32_t &err)
+{
+    for (;;) {
+        p.byte = uni(p.byte), p.bit = uni(p.bit), b.filled = uni(b.filled), sink.pin_state();
+        const Win w = window(s, b, p, in, in_len);
+        uint32_t o;
+        const uint32_t how = walk(w, sink, o, err);
+        if (how == kWinError) return false;
+        p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
+        if (how == kWinEob) return true;
+        if (how == kWinSerial) {            // one symbol with a code longer than a root table, by the serial reader
+            seek(s, b, p, in, in_len);
+            const uint32_t e = lookup(s.lit, kLitRoot, b), kind = (e >> 4) & 15u;
+            if (kind <= kLit2) {
+                if (sink.op + kind + 1u > sink.out_len) {
+                    err = 12;
+                    return false;
+                }
+                sink.lits(lane_id() == 0, kind != 0, sink.op, e);
+                sink.op += kind + 1u;
+            } else if (kind == kLen) {
+                const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
+                refill(s, b, in, in_len);
+                const uint32_t d = lookup(s.dist, kDistRoot, b);
+                if (((d >> 4) & 15u) != kDist) {
+                    err = 13;
+                    return false;
+                }
+                const uint32_t dist = (d >> 16) + take(b, (d >> 8) & 255u);
+                if (sink.op + len > sink.out_len) {
+                    err = 14;
+                    return false;
+                }
+                if ((err = sink.match(sink.op, len, dist)) != 0) return false;
+                sink.op += len;
+            } else if (kind == kEob) {
+                p = pos_of(b);
+                return true;
+            } else {
+                err = 15;
+                return false;
+            }
+            p = pos_of(b);
+        }
+    }
 }
 
 // Two literals per lookup: where a root-table index starts with a literal code of l1 bits and the
