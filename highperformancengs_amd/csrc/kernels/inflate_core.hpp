@@ -217,11 +217,9 @@ struct Win {
     uint32_t raw;        // >= 25 bits of the stream from bit (p + lane) on
     uint32_t el, ed;     // root entries of the literal/length and of the distance table for them
 };
-__device__ __forceinline__ Win window(InfLds &s, Bits &b, Pos p, const uint8_t *__restrict__ in, uint32_t in_len)
+// (the ring holds the bytes the window reads, up to byte p.byte + 16: decode_symbols stages ahead of it)
+__device__ __forceinline__ Win window(const InfLds &s, Pos p)
 {
-    if (b.filled - p.byte < 8u + kRing / 4) {        // (the window reads up to byte p.byte + 16)
-        if (b.filled < in_len + 8u) stage(s, b, in, in_len);
-    }
     const uint32_t q = p.bit + (uint32_t)lane_id();
     const uint32_t byte = p.byte + (q >> 3);
     const uint32_t i0 = (byte >> 2) & (kRing / 4 - 1), i1 = (i0 + 1u) & (kRing / 4 - 1);
@@ -282,7 +280,7 @@ __device__ __forceinline__ uint32_t walk(const Win &w, Sink &sink, uint32_t &o, 
     uint32_t f = 0;
     for (;;) {
         const uint32_t a = lane_of(hop, f), b = lane_of(hop, a), c = lane_of(hop, b), d = lane_of(hop, c);
-        on |= (1ull << a) | (1ull << b) | (1ull << c) | (1ull << d);
+        asm("s_bitset1_b64 %0, %1\n\ts_bitset1_b64 %0, %2\n\ts_bitset1_b64 %0, %3\n\ts_bitset1_b64 %0, %4" : "+s"(on) : "s"(a), "s"(b), "s"(c), "s"(d));
         f = d;
         if (d == c) break;
     }
@@ -325,9 +323,18 @@ template <typename Sink>
 __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const uint8_t *__restrict__ in, uint32_t in_len, Sink &sink,
                                                uint32_t &err)
 {
+    // the ring is staged half a ring ahead of the windows: one compare per window (`ahead`: the byte position from which on
+    // the next half is due; none once the chunk's last bytes are in)
+    auto due = [&]() { return b.filled < in_len + 8u ? b.filled - (8u + kRing / 4) : 0xffffffffu; };
+    b.filled = uni(b.filled);
+    uint32_t ahead = due();
     for (;;) {
-        p.byte = uni(p.byte), p.bit = uni(p.bit), b.filled = uni(b.filled), sink.pin_state();
-        const Win w = window(s, b, p, in, in_len);
+        p.byte = uni(p.byte), p.bit = uni(p.bit), ahead = uni(ahead), sink.pin_state();
+        if (p.byte > ahead) {
+            stage(s, b, in, in_len);
+            b.filled = uni(b.filled), ahead = due();
+        }
+        const Win w = window(s, p);
         uint32_t o;
         const uint32_t how = walk(w, sink, o, err);
         if (how == kWinError) return false;
@@ -366,6 +373,7 @@ __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const
                 return false;
             }
             p = pos_of(b);
+            b.filled = uni(b.filled), ahead = due();
         }
     }
 }
