@@ -6,12 +6,13 @@
 // time once the per-record work is on the GPU.  Blocks are independent, and a file has one per
 // ~20 KB of compressed data, so here every block is decoded by its own wavefront:
 //
-//   * Huffman decoding is serial by nature; the 64 lanes run the decoder redundantly on
-//     wave-uniform state (bit buffer, positions), which keeps control flow scalar;
-//   * the lanes cooperate where there is data parallelism: staging the compressed bytes
-//     through an LDS ring (coalesced 16-byte loads), filling the decode tables, and copying an
-//     LZ77 match (lane i copies byte i; an overlapping match is a periodic pattern, so every
-//     source byte already exists);
+//   * a block's headers and code tables are handled by the wave as a whole on wave-uniform state (bit buffer, positions:
+//     scalar registers, scalar branches); the lanes cooperate where there is data parallelism: staging the compressed
+//     bytes through an LDS ring (coalesced 16-byte loads) and filling the decode tables;
+//   * the SYMBOLS are decoded 64 bit offsets at a time: lane k decodes the symbol that would start at bit k, the wave then
+//     follows the true chain of symbol starts through the lanes' results and the lanes on it write their literals in one
+//     store (decode_symbols, inflate_core.hpp); an LZ77 match is copied by the lanes (lane i copies byte i; an overlapping
+//     match is a periodic pattern, so every source byte already exists);
 //   * the output goes straight to global memory, and a match reads its source back from there:
 //     the 32 KiB history window does not have to live in LDS, which leaves two-level decode
 //     tables (10-bit root for literal/length, 8-bit for distance) and a 2 KiB input ring =
@@ -20,7 +21,8 @@
 //     wave stored since its last wait first waits for those stores (workgroup-scope fence: the
 //     CU's vector cache is coherent for its own waves, so that is a counter wait only).
 //
-// Bound: instruction issue of the serial symbol loop (dependent LDS table lookups), not memory.
+// Bound: instruction issue -- 18 single-wave decoders share the CU's one scalar unit and its four vector units; with the
+// per-symbol work in the lanes the two are about evenly loaded (SQ_ACTIVE_INST_SCA 0.58, VALU 0.5 of the busy CU cycles).
 // Like the reference's reader, the CRC32 of the trailer is not checked; the ISIZE is (the block
 // must produce exactly out_len bytes).
 //

@@ -15,8 +15,8 @@
 //                     stretch are the history of the next; also the running text offsets.
 //   k_gz_translate    symbols -> bytes through each stretch's history, compacted into one text.
 //
-// Bounds: k_gz_sym_inflate is bound by the scalar issue of the serial symbol loop like
-// k_bgzf_inflate; the other two are small streaming passes.  CRC-32 is not checked here (ISIZE is,
+// Bounds: k_gz_sym_inflate by instruction issue like k_bgzf_inflate (the same decoder: symbols 64 bit
+// offsets at a time, inflate_core.hpp); the other two are small streaming passes.  CRC-32 is not checked here (ISIZE is,
 // by the caller); anything malformed sets a status and the host readers take the file.
 #include "common.hpp"
 #include "inflate_core.hpp"
