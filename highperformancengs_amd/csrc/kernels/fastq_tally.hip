@@ -38,6 +38,8 @@
 // and one-length turns of 16384 records.  Timing-only builds of this form: without the LDS
 // atomics 6.2 ms, without the loads 4.9 ms, without both 3.0 ms: what bounds it is the memory
 // side at ~5 TB/s (K1 streams 6.9), not the atomics.  No MFMA: there is no contraction here.
+// Round 3, the nucleotide pass (2e8 x 150 bp, qualities + bases): 13.8 -> 12.2 ms with the five rows counted in packed
+// registers (stream_uniform): that pass was the one bound by LDS operations (a table read AND an atomic per base).
 #include <stdlib.h>
 
 #include "tally_util.hpp"
@@ -88,6 +90,7 @@ struct HistLds {
     uint32_t nh[HPN_NUC_CODES * kRowWords];
     uint32_t njunk[64];
     uint8_t nlut[256];       // nuc_code of every byte value: one LDS read per base instead of ten VALU operations
+    uint32_t nlut6[256];     // 1 << 6 * nuc_code(b): what a base adds to a lane's packed counters (stream_uniform)
     uint32_t loff[kHistRecs + 1];
     uint32_t lhist[HPN_LEN_BINS + 1];
     u64 red[3][kHistWaves];
@@ -221,8 +224,37 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
     // per chunk; the batch is then rejected) and the row index is masked to 7 bits so that the
     // LDS address stays in range: no compare, no exec-mask juggling per byte.
     uint32_t seen = 0, sink = 0;
+    // Nucleotides: five rows only.  A lane keeps the counts of its eight cycles in registers, five 6-bit counters to a word
+    // (what a base adds comes out of an LDS table: 1 << 6 * code), and adds them to the image every 56 items: one LDS read per
+    // base instead of a read and an atomic (the nucleotide pass took 7.6 ms beside the quality pass's 6.0 for the same
+    // bytes).  A slot behind the read (partial group) counts the next read's bytes and is dropped when the counters are poured.
+    uint32_t packed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto pour = [&]() {
+#pragma unroll
+        for (int b8 = 0; b8 < 8; ++b8) {
+            if (!kPartial || bmask[b8]) {
+#pragma unroll
+                for (int c = 0; c < HPN_NUC_CODES; ++c) {
+                    const uint32_t v = (packed[b8] >> (6 * c)) & 63u;
+                    if (v) atomicAdd(&hist[c * kRowWords + col[b8]], v);
+                }
+            }
+            packed[b8] = 0;
+        }
+    };
     auto tally_item = [&](const item_t d) {
         if (kQual) seen |= d[0] | d[1];   // (the bytes behind a partial group are the next read's: quality bytes as well)
+        if (!kQual) {
+#pragma unroll
+            for (int b8 = 0; b8 < 8; ++b8) {
+                const uint32_t w = d[b8 >> 2];
+                uint32_t at;                                           // 4 * byte: its word in nlut6
+                if (kRot) at = ((w >> shift[b8]) & 0xffu) << 2;
+                else at = (b8 & 3) == 0 ? (w << 2) & 0x3fcu : (w >> (8 * (b8 & 3) - 2)) & 0x3fcu;
+                packed[b8] += *(const uint32_t *)((const uint8_t *)s.nlut6 + at);
+            }
+            return;
+        }
 #pragma unroll
         for (int b8 = 0; b8 < 8; ++b8) {
             // bytes behind a partial group go to this lane's junk word behind the image (row 0): no branch per byte
@@ -255,14 +287,17 @@ __device__ __forceinline__ void stream_uniform(HistLds &s, const uint8_t *arr, u
 #pragma unroll
     for (int t = 0; t < kSets - 1; ++t)
         if (fetched < nsets) fetch(v[t], nv[t]), ++fetched;
+    uint32_t since = 0;                                   // sets tallied into `packed` (a 6-bit counter holds 63)
     for (uint32_t i = 0; i < nsets; i += kSets) {
 #pragma unroll
         for (int t = 0; t < kSets; ++t) {
             if (i + t >= nsets) break;
             if (fetched < nsets) fetch(v[(t + kSets - 1) % kSets], nv[(t + kSets - 1) % kSets]), ++fetched;
             tally(v[t], nv[t]);
+            if (!kQual && (since += kSpanRound) > 63u - kSpanRound) pour(), since = 0;
         }
     }
+    if (!kQual) pour();
     if (kPartial && last_mine) {                          // at most one lane of the batch's last chunk
         for (uint32_t b8 = 0; b8 < nvalid; ++b8) {
             const uint32_t byte = p0[last_off + b8];
@@ -359,6 +394,7 @@ __global__ __launch_bounds__(kHistThreads) void k_tally_hist(const uint8_t *__re
     for (int i = tid; i < HPN_NUC_CODES * kRowWords; i += kHistThreads) s.nh[i] = 0;
     for (int i = tid; i <= HPN_LEN_BINS; i += kHistThreads) s.lhist[i] = 0;
     if (tid < 256) s.nlut[tid] = (uint8_t)nuc_code((uint32_t)tid);
+    if (tid < 256) s.nlut6[tid] = 1u << (6u * nuc_code((uint32_t)tid));
     __syncthreads();
 
     uint32_t bad = 0;
