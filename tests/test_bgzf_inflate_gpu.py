@@ -167,3 +167,58 @@ def test_damaged_streams_are_reported_per_block(ctx):
             n_bad += 1
             assert z is None or len(z) != lens[i], i  # rejected: zlib rejects it as well (or the ISIZE check fails)
     assert n_bad >= 25
+
+
+def _fuzz_payload(rng, kind, n):
+    """Payloads that push the decoder's windows (inflate_core.hpp: symbols are decoded 64 bit offsets at a time) to their edges:
+    code lengths from 1 to 15 bits, second-level codes, symbols that straddle a window's end, every length / distance code."""
+    if kind == 0:     # geometric byte frequencies: literal codes of every length, the rare ones behind the 10-bit root table
+        q = float(rng.uniform(0.3, 0.9))
+        p = q ** np.arange(256)
+        return bytes(rng.choice(rng.permutation(256).astype(np.uint8), n, p=p / p.sum()))
+    if kind == 1:     # copies of earlier stretches at every distance and length, between literals
+        out = bytearray(rng.integers(0, 256, 300, dtype=np.uint8).tobytes())
+        while len(out) < n:
+            if rng.random() < 0.7:
+                d = int(min(len(out), rng.choice([1, 2, 3, 5, 17, 300, 1025, 4097, 16385, 32768]) + rng.integers(0, 40)))
+                l = int(rng.integers(3, 259))
+                s = len(out) - d
+                for i in range(l):
+                    out.append(out[s + i])
+            else:
+                out += rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tobytes()
+        return bytes(out[:n])
+    if kind == 2:     # few symbols: 1- and 2-bit codes, up to 64 symbols in a window, long runs of pairs
+        return bytes(rng.choice(np.frombuffer(b"AC", np.uint8), n, p=[0.9, 0.1]))
+    # FASTQ-like with mutated repeats of earlier reads (lengths and distances spread over all codes)
+    reads = [rng.choice(np.frombuffer(b"ACGT", np.uint8), 150).tobytes() for _ in range(40)]
+    out = bytearray()
+    i = 0
+    while len(out) < n:
+        r = bytearray(reads[int(rng.integers(0, len(reads)))])
+        for _ in range(int(rng.integers(0, 4))):
+            r[int(rng.integers(0, 150))] = int(rng.choice(np.frombuffer(b"ACGTN", np.uint8)))
+        out += b"@r%d\n%s\n+\n%s\n" % (i, bytes(r), bytes(rng.choice(np.frombuffer(b"FFFFF:,#", np.uint8), 150)))
+        i += 1
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_window_decoder_fuzz(ctx, seed):
+    rng = np.random.default_rng(9000 + seed)
+    payloads, streams = [], []
+    for k in range(48):
+        p = _fuzz_payload(rng, k % 4, int(rng.integers(1, 65000)))
+        level = int(rng.integers(1, 10))
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 6))]
+        payloads.append(p)
+        streams.append(raw_deflate(p, level, strategy, int(rng.integers(1, 10))))
+    got, st = run(ctx, streams, [len(p) for p in payloads])
+    assert not st.any(), np.flatnonzero(st)
+    for k, (g, p) in enumerate(zip(got, payloads)):
+        assert g == p, k
+    # the same streams with the room cut short by one byte, and with one byte too much: reported, nothing written beyond
+    got, st = run(ctx, streams[:8], [max(len(p) - 1, 0) for p in payloads[:8]])
+    assert all(s != 0 or len(p) == 0 for s, p in zip(st, payloads[:8]))
+    got, st = run(ctx, streams[:8], [len(p) + 1 for p in payloads[:8]])
+    assert st.all()

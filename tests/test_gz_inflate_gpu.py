@@ -294,3 +294,19 @@ def test_crc32_of_spans_equals_zlib():
         a, b = zlib.crc32(data[:cut].tobytes()), zlib.crc32(data[cut:].tobytes())
         assert L.hpn_crc32_join(a, b, len(data) - cut) == zlib.crc32(data.tobytes())
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_window_decoder_fuzz_with_unknown_history(ctx, seed):
+    """The payloads of tests/test_bgzf_inflate_gpu.py::test_window_decoder_fuzz as ONE stream cut at flush points: matches
+    reach in front of the stretches (history placeholders ride through the window decoder's match copies)."""
+    from test_bgzf_inflate_gpu import _fuzz_payload
+    rng = np.random.default_rng(9100 + seed)
+    pieces = [_fuzz_payload(rng, int(k % 4), int(rng.integers(1, 90000))) for k in range(14)]
+    level = int(rng.integers(1, 10))
+    comp, starts = _stream(pieces, level, zlib.Z_SYNC_FLUSH if seed % 2 else zlib.Z_FULL_FLUSH,
+                           [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_DEFAULT_STRATEGY][seed])
+    text = b"".join(pieces)
+    assert zlib.decompress(comp, -15) == text
+    info, got, wout = _run(ctx, comp, starts, pieces)
+    assert info.status == 0 and got == text and wout == (bytes(32768) + text)[-32768:]
