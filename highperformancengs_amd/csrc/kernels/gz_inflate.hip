@@ -307,26 +307,60 @@ __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__
     __syncthreads();
     u64 text = 0;
     uint32_t bad = 0, bad_at = 0, fin = 0;
+    // what position j0 of the history behind stretch k is, before the look-up: a symbol of the stretch's last 32 KiB, or --
+    // the stretch is shorter than that -- the history in front of it itself
+    // (a wave-uniform base + the lane's 32-bit j: one register per address)
+    auto tail = [&](uint32_t k, uint32_t j) -> uint32_t {
+        const int32_t d = (int32_t)meta[k].n_out - (int32_t)kGzHist;            // symbol j of the history = symbol d + j of the stretch
+        const uint16_t *base = symbuf + (uint64_t)k * sym_cap + (int64_t)d;
+        return (int32_t)j + d >= 0 ? (uint32_t)base[j] : 256u + (uint32_t)((int32_t)kGzHist + (int32_t)j + d);
+    };
+    if (kGzWinThreads >= 1024) {
+        // 32 positions per thread, ALL their symbols loaded while the stretch before is resolved (they do not depend on it):
+        // what is left on the chain per stretch is one round of look-ups, the stores and the barrier (~2.5 us; with the
+        // symbols loaded inside the step, in four batches, it was eight dependent round trips = 12.8 us, 59 ms for 4,608
+        // stretches beside 154 ms of inflating them)
+        constexpr int kPer = (int)(kGzHist / 1024);
+        uint32_t sv[kPer], nx[kPer / 2];                      // (the symbols in flight two to a register: 128 VGPRs are all there are)
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) sv[q] = n_chunks ? tail(0, (uint32_t)tid + (uint32_t)q * 1024u) : 0u;
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+            const uint32_t n = meta[k].n_out, st = meta[k].status;
+            if (st && !bad) bad = st, bad_at = k;
+            if (meta[k].final_block) fin = k + 1u;
+            if (tid == 0) meta[k].text_off = text;
+            text += n;
+            const uint8_t *cur = windows + (uint64_t)k * kGzHist;
+            uint8_t *nxt = windows + (uint64_t)(k + 1) * kGzHist;
+            if (k + 1 < n_chunks) {
+#pragma unroll
+                for (int q = 0; q < kPer / 2; ++q)
+                    nx[q] = tail(k + 1, (uint32_t)tid + (uint32_t)(2 * q) * 1024u) | tail(k + 1, (uint32_t)tid + (uint32_t)(2 * q + 1) * 1024u) << 16;
+            }
+            uint8_t v[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) v[q] = sv[q] < 256u ? (uint8_t)sv[q] : cur[sv[q] - 256u];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) nxt[(uint32_t)tid + (uint32_t)q * 1024u] = v[q];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) sv[q] = (q & 1) ? nx[q / 2] >> 16 : nx[q / 2] & 0xffffu;
+            __syncthreads();
+        }
+    } else {
     for (uint32_t k = 0; k < n_chunks; ++k) {
         const uint32_t n = meta[k].n_out, st = meta[k].status;
         if (st && !bad) bad = st, bad_at = k;
         if (meta[k].final_block) fin = k + 1u;
         if (tid == 0) meta[k].text_off = text;
         text += n;
-        const uint16_t *sym = symbuf + (uint64_t)k * sym_cap;
         const uint8_t *cur = windows + (uint64_t)k * kGzHist;
         uint8_t *nxt = windows + (uint64_t)(k + 1) * kGzHist;
         // 128 positions per thread, 16 at a time: 16 independent symbol loads, then 16 independent history look-ups
-        // (one position after the other this step took 67 us -- two dependent global loads x 128 -- and the whole walk
-        // 0.2 s for 2,800 stretches)
-        constexpr int kBatch = kGzWinThreads >= 1024 ? 8 : 16;
+        constexpr int kBatch = 16;
         for (uint32_t j0 = (uint32_t)tid; j0 < kGzHist; j0 += kGzWinThreads * kBatch) {
             uint32_t sv[kBatch];
 #pragma unroll
-            for (int q = 0; q < kBatch; ++q) {
-                const int64_t p = (int64_t)n - (int64_t)kGzHist + (int64_t)(j0 + (uint32_t)q * kGzWinThreads);
-                sv[q] = p >= 0 ? (uint32_t)sym[p] : 256u + (uint32_t)((int64_t)kGzHist + p);  // before the stretch: the history itself
-            }
+            for (int q = 0; q < kBatch; ++q) sv[q] = tail(k, j0 + (uint32_t)q * kGzWinThreads);
             uint8_t v[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) v[q] = sv[q] < 256u ? (uint8_t)sv[q] : cur[sv[q] - 256u];
@@ -334,6 +368,7 @@ __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__
             for (int q = 0; q < kBatch; ++q) nxt[j0 + (uint32_t)q * kGzWinThreads] = v[q];
         }
         __syncthreads();
+    }
     }
     if (window_out) {
         const uint8_t *last = windows + (uint64_t)n_chunks * kGzHist;
