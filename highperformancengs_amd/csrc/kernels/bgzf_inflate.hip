@@ -55,6 +55,22 @@ struct ByteSink {
             }
         }
     }
+    __device__ __forceinline__ bool in_reach(uint32_t at, uint32_t dist) const { return dist <= at; }
+    // output bytes at `from` (< base, the first position of the chunk being assembled) for the lanes that ask
+    __device__ __forceinline__ uint32_t fetch(bool ask, int32_t from, uint32_t base, uint32_t val)
+    {
+        if (__ballot(ask && (uint32_t)from >= safe)) {
+            // the source reaches into bytes this wave stored a moment ago: wait for those stores
+            // (workgroup scope = this CU's vector cache: a counter wait, no cache invalidate)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            safe = base;
+        }
+        return ask ? (uint32_t)out[(uint32_t)from] : val;
+    }
+    __device__ __forceinline__ void put(bool live, uint32_t at, uint32_t val)
+    {
+        if (live) out[at] = (uint8_t)val;
+    }
     // (at + len <= out_len: checked by the caller)
     __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t len, uint32_t dist)
     {

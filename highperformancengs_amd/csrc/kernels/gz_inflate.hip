@@ -61,6 +61,22 @@ struct SymSink {
             }
         }
     }
+    __device__ __forceinline__ bool in_reach(uint32_t at, uint32_t dist) const { return dist <= at + kGzHist; }
+    // symbols at `from` (< base, the first position of the chunk being assembled; negative: in the history in front of the
+    // stretch, whose byte this position will be) for the lanes that ask
+    __device__ __forceinline__ uint32_t fetch(bool ask, int32_t from, uint32_t base, uint32_t val)
+    {
+        if (__ballot(ask && from >= (int32_t)safe)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            safe = base;
+        }
+        if (ask) val = from < 0 ? 256u + kGzHist + (uint32_t)from : (uint32_t)out[from];
+        return val;
+    }
+    __device__ __forceinline__ void put(bool live, uint32_t at, uint32_t val)
+    {
+        if (live) *(uint16_t *)((uint8_t *)out + (at << 1)) = (uint16_t)val;
+    }
     // (at + len <= out_len: checked by the caller)
     __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t len, uint32_t dist)
     {

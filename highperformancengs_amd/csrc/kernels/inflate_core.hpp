@@ -246,12 +246,77 @@ __device__ __forceinline__ uint32_t wave_prefix(uint32_t v)
     return v;
 }
 
+// inclusive prefix maximum over the lanes of a wave (the same DPP moves as wave_prefix)
+__device__ __forceinline__ uint32_t wave_prefix_max(uint32_t v)
+{
+#define HPN_DPP_MAX(ctrl, rows)                                                                    \
+    {                                                                                              \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false); \
+        v = t > v ? t : v;                                                                         \
+    }
+    HPN_DPP_MAX(0x111, 0xf)
+    HPN_DPP_MAX(0x112, 0xf)
+    HPN_DPP_MAX(0x114, 0xf)
+    HPN_DPP_MAX(0x118, 0xf)
+    HPN_DPP_MAX(0x142, 0xa)
+    HPN_DPP_MAX(0x143, 0xc)
+#undef HPN_DPP_MAX
+    return v;
+}
+
+// The output of a window that holds matches, 64 positions at a time, one position per lane.  The symbols on the chain sit
+// in their lanes (`mine`): rel = where the symbol's output starts (from sink.op), el = its table entry (the literals), dist =
+// its distance, 0 for literals.  Every output position finds its symbol (the symbols' lane numbers written to their start
+// positions in 64 words of LDS, then a prefix maximum), takes the symbol's words from its lane (ds_bpermute) and is a
+// literal byte, or a copy of position - dist: of memory (sink.fetch: waits for this wave's stores first where they are
+// in the way; in front of a gzip stretch: a history placeholder), or of a lane of this very chunk -- those are followed by
+// pointer jumping, which is also what unrolls an overlapping match (distance < length: every position refers to the one
+// `dist` before it, in the same match).  One store instruction per chunk.  The serial form (per match: three v_readlane, a
+// dozen scalar compares and branches, a load, a wait and a store of its own) was half of k_bgzf_inflate's time on BAM blocks
+// (timing-only builds: 128 ms with, 66 ms without the matches; profiles/r03/inflate_ab.txt).
+template <typename Sink>
+__device__ __forceinline__ void assemble(InfLds &s, Sink &sink, bool mine, uint32_t rel, uint32_t el, uint32_t dist, uint32_t total)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t *spot = reinterpret_cast<uint32_t *>(s.lens);          // (the code lengths are not needed while symbols are decoded)
+    const uint32_t words = rel | dist << 16;                        // rel < 64 * 258, dist <= 32768
+    uint32_t carry = 0;                                             // the symbol the chunk before ended in
+    for (uint32_t c0 = 0; c0 < total; c0 += (uint32_t)kWave) {
+        spot[lane] = 0;
+        if (mine && rel - c0 < (uint32_t)kWave) spot[rel - c0] = lane + 1u;
+        // (what a lane reads next is what OTHER lanes of the wave wrote: without the fence the compiler forwards the lane's own 0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t x = spot[lane];
+        if (lane == 0 && carry > x) x = carry;
+        const uint32_t own = wave_prefix_max(x);                    // 1 + the lane of the symbol this position belongs to
+        carry = lane_of(own, kWave - 1);
+        const uint32_t w = from_lane(words, own - 1u), e = from_lane(el, own - 1u);
+        const uint32_t p = c0 + lane, i = p - (w & 0xffffu), d = w >> 16;
+        const bool live = p < total, copy = live && d != 0;
+        uint32_t val = (e >> (16u + 8u * (i & 1u))) & 255u;         // a literal: byte i of its entry
+        const int32_t from = (int32_t)(sink.op + p) - (int32_t)d;   // a copy: of this position (may lie in front of a gzip stretch)
+        const bool near = copy && from >= (int32_t)(sink.op + c0);
+        if (__ballot(copy && !near)) val = sink.fetch(copy && !near, from, sink.op + c0, val);
+        uint32_t ref = near ? (uint32_t)from - (sink.op + c0) : ~0u;   // lane of this chunk still to be copied from; ~0: val is final
+        while (__ballot(ref != ~0u)) {
+            const uint32_t rv = from_lane(val, ref), rr = from_lane(ref, ref);
+            if (ref != ~0u) {
+                if (rr == ~0u) val = rv, ref = ~0u;
+                else ref = rr;
+            }
+        }
+        sink.put(live, sink.op + p, val);
+    }
+}
+
 // One window.  -> how it ended; o = bits consumed (the symbol at o is still to be decoded, except behind an end-of-block code).
 // The sink: op / out_len -- symbols written / allowed; lits(mine, two, at, e) -- the lanes for which `mine` holds store the one
-// (two) literal(s) of THEIR entry e at symbol `at`; match(at, len, dist) -> 0 or an error code (wave-uniform arguments).
+// (two) literal(s) of THEIR entry e at symbol `at`; in_reach(at, dist) -- a match at `at` may refer `dist` back; fetch / put:
+// see assemble(); match(at, len, dist) -> 0 or an error code (wave-uniform arguments: the serial reader's matches).
 enum { kWinNext = 0, kWinEob = 1, kWinSerial = 2, kWinError = 3 };
 template <typename Sink>
-__device__ __forceinline__ uint32_t walk(const Win &w, Sink &sink, uint32_t &o, uint32_t &err)
+__device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, uint32_t &o, uint32_t &err)
 {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t kind = (w.el >> 4) & 15u, bits = w.el & 15u;
@@ -292,10 +357,14 @@ __device__ __forceinline__ uint32_t walk(const Win &w, Sink &sink, uint32_t &o, 
         err = 12;
         return kWinError;
     }
-    sink.lits(mine && is_lit, kind != 0, at, w.el);
-    for (u64 mm = taken & len_lanes; mm; mm &= mm - 1) {
-        const uint32_t k = (uint32_t)__builtin_ctzll(mm);
-        if ((err = sink.match(lane_of(at, k), lane_of(len, k), lane_of(dist, k))) != 0) return kWinError;
+    if ((taken & len_lanes) == 0) {
+        sink.lits(mine, kind != 0, at, w.el);
+    } else {
+        if (__ballot(mine && !is_lit && !sink.in_reach(at, dist))) {
+            err = 14;
+            return kWinError;
+        }
+        assemble(s, sink, mine, at - sink.op, w.el, is_lit ? 0u : dist, total);
     }
     sink.op += total;
     if ((taken >> f) & 1u) {                          // the last symbol ends in or behind the window's last bit
@@ -336,7 +405,7 @@ __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const
         }
         const Win w = window(s, p);
         uint32_t o;
-        const uint32_t how = walk(w, sink, o, err);
+        const uint32_t how = walk(s, w, sink, o, err);
         if (how == kWinError) return false;
         p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
         if (how == kWinEob) return true;
