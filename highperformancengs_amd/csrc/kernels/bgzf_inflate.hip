@@ -11,8 +11,8 @@
 //     bytes through an LDS ring (coalesced 16-byte loads) and filling the decode tables;
 //   * the SYMBOLS are decoded 64 bit offsets at a time: lane k decodes the symbol that would start at bit k, the wave then
 //     follows the true chain of symbol starts through the lanes' results and the lanes on it write their literals in one
-//     store (decode_symbols, inflate_core.hpp); an LZ77 match is copied by the lanes (lane i copies byte i; an overlapping
-//     match is a periodic pattern, so every source byte already exists);
+//     store; a window with LZ77 matches is put together by the lanes, one output position each (a literal byte, or a copy of
+//     position - distance out of memory or out of another lane: decode_symbols / assemble, inflate_core.hpp);
 //   * the output goes straight to global memory, and a match reads its source back from there:
 //     the 32 KiB history window does not have to live in LDS, which leaves two-level decode
 //     tables (10-bit root for literal/length, 8-bit for distance) and a 2 KiB input ring =
@@ -22,7 +22,7 @@
 //     CU's vector cache is coherent for its own waves, so that is a counter wait only).
 //
 // Bound: instruction issue -- 18 single-wave decoders share the CU's one scalar unit and its four vector units; with the
-// per-symbol work in the lanes the two are about evenly loaded (SQ_ACTIVE_INST_SCA 0.58, VALU 0.5 of the busy CU cycles).
+// per-symbol work in the lanes the two are about evenly loaded (SQ_ACTIVE_INST_SCA 0.54, VALU 0.52 of the busy CU cycles).
 // Like the reference's reader, the CRC32 of the trailer is not checked; the ISIZE is (the block
 // must produce exactly out_len bytes).
 //

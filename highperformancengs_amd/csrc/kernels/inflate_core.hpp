@@ -195,8 +195,8 @@ __device__ __forceinline__ uint32_t lookup(const uint32_t *tab, uint32_t root, B
 //     its literal(s), or its length, the distance code behind it (ds_bpermute from the lane where it starts) and the
 //     distance, and the offset of the code after it;
 //   * the wave follows the true chain of symbol starts through those offsets -- v_readlane + s_bitset1 per symbol, nothing else;
-//   * the lanes on the chain then take their places in the output with one prefix sum; the literals go out in one (two)
-//     store instruction(s) for the whole window, the matches are copied one after the other.
+//   * the lanes on the chain then take their places in the output with one prefix sum; a window of literals goes out in one
+//     (two) store instruction(s), a window with matches is assembled by the lanes, one output position each (assemble()).
 // A symbol that does not fit the rest of the window starts the next window (it fits any window it starts: 15 + 5 + 15 +
 // 13 bits); a code longer than its root table (second-level look-up) is decoded by the serial reader, then windows resume.
 struct Pos {             // consumed position in the chunk: `bit` (0..7) bits into byte `byte`
