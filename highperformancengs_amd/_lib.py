@@ -83,6 +83,7 @@ SYMBOLS = [
     ("hpn_ctx_destroy", _int, [_vp]),
     ("hpn_ctx_set_stream", _int, [_vp, _vp]),
     ("hpn_ctx_sync", _int, [_vp]),
+    ("hpn_ctx_device", _int, [_vp, C.POINTER(C.c_int)]),
     ("hpn_ctx_last_error", C.c_char_p, [_vp]),
     ("hpn_ctx_last_kernel_ms", _int, [_vp, _int, C.POINTER(C.c_float)]),
     ("hpn_dev_malloc", _int, [_vp, _sz, C.POINTER(_vp)]),
@@ -115,6 +116,7 @@ SYMBOLS = [
     ("hpn_gz_inflate_dev", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
     ("hpn_gz_members", _int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     ("hpn_crc32_dev", _int, [_vp, _vp, _vp, _u32, _vp]),
+    ("hpn_gz_find_starts_dev", _int, [_vp, _vp, C.c_uint64, _vp, _u32, _vp]),
     ("hpn_crc32_join", _u32, [_u32, _u32, _u64]),
     ("hpn_bam_raw_index_dev", _int, [_vp, _vp, _vp, _u64, _u32, _vp, C.POINTER(RawInfo)]),
     ("hpn_depth_add_raw_dev", _int, [_vp, _vp]),

@@ -275,6 +275,14 @@ class Context:
         self._ck(self.L.hpn_crc32_dev(self.h, _ptr(d_data), _ptr(arr) if n else None, n, _ptr(out)), "hpn_crc32_dev")
         return [int(x) for x in out[:n]]
 
+    def gz_find_starts_dev(self, d_comp, comp_bytes, slices):
+        """First block start (bit position in d_comp) in every (lo_bit, n_bits) slice, or 2^64 - 1 (hpn_gz_find_starts_dev)."""
+        n = len(slices)
+        arr = np.array(slices, np.uint64).reshape(-1, 2) if n else np.zeros((0, 2), np.uint64)
+        out = np.zeros(max(n, 1), np.uint64)
+        self._ck(self.L.hpn_gz_find_starts_dev(self.h, _ptr(d_comp), int(comp_bytes), _ptr(arr) if n else None, n, _ptr(out)), "hpn_gz_find_starts_dev")
+        return out[:n]
+
     # ---- BAM --------------------------------------------------------------
     @staticmethod
     def _batch(soa, keep):

@@ -8,6 +8,12 @@
 // with one wavefront, resolves the histories and writes one contiguous text per batch, which the
 // caller frames where it lies (hpn_fastq_text_count / _trim take device text).
 //
+// Two halves per batch, on two threads: PREPARE (block-start search on the pool, the compressed bytes through pinned chunks to
+// the device, the stretch table) needs nothing of the batch before it but where that one's last stretch ends, which the search
+// itself tells; RUN (inflate, histories, translation, member checks) needs the device.  A producer thread prepares batch k + 1
+// into the second set of buffers -- through a context of its own, so that its copies run beside the kernels -- while the caller
+// runs batch k and frames its text: the search and the upload (half of the route's wall on a 2.4 GB file) leave the path.
+//
 // Exactness is by construction as in the host reader: stretch 0 starts at the member's first
 // block, and the device accepts a stretch only if it ends on the next one's first bit at a block
 // boundary.  The last member must end the file (trailer + nothing else); every member's ISIZE and CRC-32 (hpn_crc32_dev over
@@ -16,6 +22,8 @@
 // through the host readers from its first byte.
 #pragma once
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "pgz_reader.hpp"
@@ -33,12 +41,21 @@ class GzGpuStream {
 public:
     ~GzGpuStream()
     {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (producer_.joinable()) producer_.join();
         pump_.reset();
         if (ctx_) {
-            hpn_dev_free(ctx_, d_comp_), hpn_dev_free(ctx_, d_chunks_), hpn_dev_free(ctx_, d_text_), hpn_dev_free(ctx_, d_win_[0]),
-                hpn_dev_free(ctx_, d_win_[1]);
-            if (h_chunks_) hpn_host_free(ctx_, h_chunks_);
+            for (Slot &s : slot_) {
+                hpn_dev_free(ctx_, s.d_comp), hpn_dev_free(ctx_, s.d_chunks);
+                if (s.h_chunks) hpn_host_free(ctx_, s.h_chunks);
+            }
+            hpn_dev_free(ctx_, d_text_), hpn_dev_free(ctx_, d_win_[0]), hpn_dev_free(ctx_, d_win_[1]);
         }
+        if (up_ctx_) hpn_ctx_destroy(up_ctx_);
         if (data_) munmap((void *)data_, size_);
         if (fd_ >= 0) close(fd_);
     }
@@ -59,6 +76,10 @@ public:
         const uint8_t *body = gzip_header_end(data_, data_ + size_);
         if (!body) return give_up("no gzip header");
         threads_ = threads < 1 ? 1 : threads;
+        {
+            const char *e = getenv("HPN_GZ_FIND");
+            search_on_device_ = e ? !strcmp(e, "device") : threads_ < 6;
+        }
         max_stretches_ = max_stretches < 1 ? 1 : max_stretches > 65535u ? 65535u : max_stretches;
         // symbols of scratch per stretch: from the expansion of the member's first megabytes (FASTQ is homogeneous; a
         // stretch that needs more is decoded again with twice the room)
@@ -80,7 +101,11 @@ public:
             // expands a lot: the symbol scratch is ~3 bytes per byte of text in flight
             uint64_t kMaxStretch = (uint64_t)((double)((uint64_t)3 << 19) * (ratio_ > 2.0 ? 2.0 / ratio_ : 1.0));
             if (kMaxStretch < ((uint64_t)512 << 10)) kMaxStretch = (uint64_t)512 << 10;
-            const uint64_t calls = (size_ + max_stretches_ * kMaxStretch - 1) / (max_stretches_ * kMaxStretch);
+            uint64_t calls = (size_ + max_stretches_ * kMaxStretch - 1) / (max_stretches_ * kMaxStretch);
+            // ... and where the DEVICE looks for the block starts (cheap per stretch), a file that can fill the chip more than once
+            // with stretches of 256 KiB is taken in up to four batches: the next batch's upload runs beside this one's device work
+            const uint64_t fills = size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10));
+            if (search_on_device_ && calls < (fills < 4 ? fills : 4)) calls = fills < 4 ? fills : 4;
             stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 65536) & ~(uint64_t)65535);
             if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
             if (!e && stretch_bytes > kMaxStretch) stretch_bytes = (size_t)kMaxStretch;  // (symbol scratch: ~12 bytes per compressed byte in flight)
@@ -92,7 +117,7 @@ public:
             // memory that is free now -- other processes may share the device
             uint64_t free_b = 0, total_b = 0;
             if (hpn_dev_mem_info(ctx_, &free_b, &total_b) == HPN_OK && free_b) {
-                const double per_stretch = 2.0 * cap_for(ratio_ * 3.0) + (double)stretch_ * (1.0 + ratio_ * 1.25 * 1.125);
+                const double per_stretch = 2.0 * cap_for(ratio_ * 3.0) + (double)stretch_ * (2.0 + ratio_ * 1.25 * 1.125);   // (two sets of compressed bytes)
                 const uint64_t fit = (uint64_t)((double)(free_b / 2) / per_stretch);
                 if (fit < max_stretches_) max_stretches_ = fit < 64 ? 64u : (uint32_t)fit;
             }
@@ -100,9 +125,12 @@ public:
         first_bit_ = (uint64_t)(body - data_) * 8;
         next_start_ = first_bit_;
         // the compressed bytes reach the device through pinned chunks read in parallel (the page cache is not pinned)
-        pump_.reset(new TextPump(ctx, path, (size_t)32 << 20, 3, true));
+        int device = 0;
+        if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) return give_up("no context for the uploads");
+        pump_.reset(new TextPump(up_ctx_, path, (size_t)32 << 20, 3, true));
         if (!pump_->ok()) return give_up("reader not available");
         if (hpn_dev_malloc(ctx_, 32768, &d_win_[0]) != HPN_OK || hpn_dev_malloc(ctx_, 32768, &d_win_[1]) != HPN_OK) return give_up("device memory");
+        producer_ = std::thread([this] { produce(); });
         return true;
     }
     const uint8_t *d_text() const { return (const uint8_t *)d_text_; }
@@ -121,87 +149,22 @@ public:
     {
         *n_bytes = 0;
         if (done_) return 0;
-        // ---- the batch's stretches: starts found in [lo, hi) slices of the compressed file, by the pool, while this
-        // thread moves the batch's compressed bytes to the device ----
-        const uint64_t base_byte = next_start_ >> 3;
-        const uint64_t left = (size_ - base_byte + stretch_ - 1) / stretch_;
-        const uint64_t calls = (left + max_stretches_ - 1) / max_stretches_;
-        uint64_t slices = (left + calls - 1) / calls;  // even shares: no call is left with a sliver
-        bool last_batch = calls <= 1;
-        if (last_batch) slices = left;
-        const double t0 = wall_s();
-        std::vector<uint64_t> found((size_t)slices + 1, kGzNone);
-        found[0] = next_start_;
-        std::atomic<uint64_t> take{1};
-        auto work = [&] {
-            for (;;) {
-                const uint64_t k = take.fetch_add(1);
-                if (k > slices || (k == slices && last_batch)) return;
-                const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
-                found[(size_t)k] = find_start(lo, hi < size_ * 8 ? hi : size_ * 8);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads_; ++t) pool.emplace_back(work);
-        const uint64_t body_end = last_batch || base_byte + slices * stretch_ > size_ ? size_ : base_byte + slices * stretch_;
-        bool up_ok = reserve(d_comp_, cap_comp_, (size_t)((slices + 3) * stretch_ + 8192 + 256));
-        if (up_ok) up_ok = upload(base_byte, body_end, base_byte);
-        t_upload_ += wall_s() - t0;
-        for (auto &t : pool) t.join();
-        if (!up_ok) return give_up("upload failed") - 1;
-        // the slice after the batch tells where its last stretch ends; nothing found there: one more slice ...
-        uint64_t end_bit = kGzNone;
-        if (!last_batch) {
-            uint64_t k = slices;
-            end_bit = found[(size_t)slices];
-            while (end_bit == kGzNone && k < slices + 1 && (base_byte + (k + 1) * stretch_) < size_) {  // (a slice without a dynamic block)
-                ++k;
-                const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
-                end_bit = find_start(lo, hi < size_ * 8 ? hi : size_ * 8);
-            }
-            if (end_bit == kGzNone) {
-                if ((base_byte + (k + 1) * stretch_) < size_) return give_up("no block start where one is expected") - 1;
-                last_batch = true;  // ... or, at the end of the file, run to the final block
-            }
+        Slot &sl = slot_[batch_ & 1];
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return sl.state != 0; });
         }
-        t_find_ += wall_s() - t0;
-        starts_.clear();
-        for (uint64_t k = 0; k < slices; ++k)
-            if (found[(size_t)k] != kGzNone) starts_.push_back(found[(size_t)k]);
-        const uint32_t n = (uint32_t)starts_.size();
-        // text compressed the usual way has a block start in every slice; a file where most slices show none is not
-        // what this route is for (one wavefront would crawl through megabytes)
-        if (slices >= 8 && (uint64_t)n * 2 < slices) return give_up("hardly any block starts found: not gzip'ed text") - 1;
-        // ---- the rest of the compressed bytes, up to a little beyond the batch's end ----
-        const uint64_t stop_byte = last_batch ? size_ : ((end_bit >> 3) + 4096 < size_ ? (end_bit >> 3) + 4096 : size_);
-        const uint64_t comp_bytes = stop_byte - base_byte;
-        if (comp_bytes + 256 > cap_comp_) return give_up("a stretch without a block start") - 1;
-        if (stop_byte > body_end && !upload(body_end, stop_byte, base_byte)) return give_up("upload failed") - 1;
-        // ---- stretch table ----
-        if (n > h_chunks_cap_) {
-            if (h_chunks_) hpn_host_free(ctx_, h_chunks_);
-            h_chunks_cap_ = n + n / 2 + 64;
-            void *p = nullptr;
-            if (hpn_host_malloc(ctx_, h_chunks_cap_ * sizeof(hpn_gz_chunk), &p) != HPN_OK) return give_up("pinned memory") - 1;
-            h_chunks_ = (hpn_gz_chunk *)p;
-        }
-        for (uint32_t k = 0; k < n; ++k) {
-            hpn_gz_chunk &c = h_chunks_[k];
-            const uint64_t s = starts_[k], e = k + 1 < n ? starts_[k + 1] : end_bit;
-            c.in_off = (s >> 3) - base_byte;
-            c.start_bit = (uint32_t)(s & 7);
-            c.end_bit = e == kGzNone ? kGzNone : e - (s & ~(uint64_t)7);
-            const uint64_t room = stop_byte - (s >> 3);
-            c.in_len = room > 0x7fffff00ull ? 0x7fffff00u : (uint32_t)room;  // (the kernel adds small constants to it in 32 bits)
-        }
-        if (!reserve(d_chunks_, cap_chunks_, (size_t)n * sizeof(hpn_gz_chunk))) return give_up("device memory") - 1;
-        if (hpn_memcpy_h2d(ctx_, d_chunks_, h_chunks_, (size_t)n * sizeof(hpn_gz_chunk)) != HPN_OK) return give_up("copy failed") - 1;
+        if (sl.state < 0) return give_up(sl.why) - 1;
+        const uint32_t n = sl.n;
+        const uint64_t comp_bytes = sl.comp_bytes, end_bit = sl.end_bit;
+        const bool last_batch = sl.last;
+        void *const d_comp_ = sl.d_comp, *const d_chunks_ = sl.d_chunks;
         const double t2 = wall_s();
         // ---- inflate, resolve, translate ----
         uint64_t want = (uint64_t)((double)comp_bytes * ratio_ * 1.25) + ((uint64_t)8 << 20);
         hpn_gz_info info;
         for (int attempt = 0;; ++attempt) {
-            if (!reserve(d_text_, cap_text_, want + 64)) return give_up("device memory (text)") - 1;
+            if (!reserve(ctx_, d_text_, cap_text_, want + 64)) return give_up("device memory (text)") - 1;
             const int rc = hpn_gz_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
                                               batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
                                               (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
@@ -225,6 +188,12 @@ public:
             snprintf(why_buf_, sizeof why_buf_, "stretch %u of %u: decoder status %u", info.bad_chunk, n, info.status);
             return give_up(why_buf_) - 1;
         }
+        const uint64_t last_start = sl.starts[n - 1];
+        {   // the compressed bytes are done with: the producer may fill this set again
+            std::lock_guard<std::mutex> g(mu_);
+            sl.state = 0;
+        }
+        cv_.notify_all();
         ++batch_;
         {   // members that ended inside this batch (cat a.gz b.gz): every one's ISIZE against the bytes it produced, and its
             // CRC-32 against the text (gzread checks both, and the reference counts nothing of a member's last buffers if they
@@ -260,7 +229,7 @@ public:
         if (last_batch) {
             // the last member must end the file: final block in the last stretch, 8-byte trailer, nothing behind, ISIZE right
             if (info.final_chunk != n) return give_up("the member ends before the file does") - 1;
-            const uint64_t trailer = ((starts_[n - 1] & ~(uint64_t)7) + info.end_bit) >> 3;
+            const uint64_t trailer = ((last_start & ~(uint64_t)7) + info.end_bit) >> 3;
             if (trailer + 8 != size_) return give_up("bytes behind the member") - 1;
             uint32_t isize, crc;
             memcpy(&crc, data_ + trailer, 4);
@@ -271,12 +240,179 @@ public:
             done_ = true;
         } else {
             if (info.final_chunk) return give_up("the member ends inside the file") - 1;  // more members or garbage follow
-            next_start_ = end_bit;
+            (void)end_bit;
         }
         return 1;
     }
 
 private:
+    // one batch's compressed side: filled by the producer (state 0 -> 1, or -1 with `why`), released by next() (-> 0)
+    struct Slot {
+        void *d_comp = nullptr, *d_chunks = nullptr;
+        size_t cap_comp = 0, cap_chunks = 0, h_cap = 0;
+        hpn_gz_chunk *h_chunks = nullptr;
+        std::vector<uint64_t> starts;
+        uint32_t n = 0;
+        uint64_t comp_bytes = 0, end_bit = kGzNone;
+        bool last = false;
+        int state = 0;
+        const char *why = "";
+    };
+    bool fail(Slot &sl, const char *why)
+    {
+        sl.why = why;
+        return false;
+    }
+    void produce()
+    {
+        for (uint32_t k = 0;; ++k) {
+            Slot &sl = slot_[k & 1];
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return sl.state == 0 || stop_; });
+                if (stop_) return;
+            }
+            const bool ok = prepare(sl);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                sl.state = ok ? 1 : -1;
+            }
+            cv_.notify_all();
+            if (!ok || sl.last) return;
+        }
+    }
+    // search + upload + stretch table of the batch that starts at next_start_ (producer thread, its own context)
+    bool prepare(Slot &sl)
+    {
+        // ---- the batch's stretches: starts found in [lo, hi) slices of the compressed file, by the pool, while this
+        // thread moves the batch's compressed bytes to the device ----
+        const uint64_t base_byte = next_start_ >> 3;
+        const uint64_t left = (size_ - base_byte + stretch_ - 1) / stretch_;
+        const uint64_t calls = (left + max_stretches_ - 1) / max_stretches_;
+        uint64_t slices = (left + calls - 1) / calls;  // even shares: no call is left with a sliver
+        bool last_batch = calls <= 1;
+        if (last_batch) slices = left;
+        const double t0 = wall_s();
+        std::vector<uint64_t> found((size_t)slices + 1, kGzNone);
+        found[0] = next_start_;
+        const uint64_t n_search = last_batch ? slices - 1 : slices;              // slices 1 .. n_search are searched
+        auto slice_bits = [&](uint64_t k, uint64_t &lo, uint64_t &hi) {
+            lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
+            if (hi > size_ * 8) hi = size_ * 8;
+        };
+        bool up_ok = reserve(up_ctx_, sl.d_comp, sl.cap_comp, (size_t)((slices + 3) * stretch_ + 8192 + 256));
+        uint64_t body_end;
+        if (search_on_device_) {
+            // the compressed bytes first -- the batch and two slices behind it: the slice that tells where the batch ends, and
+            // what a trial decode at its end reads --, then the search where they lie (k_gz_find_starts); what the device does not
+            // find in a slice (a member's first block is a final block: files of many small members) the cores look for
+            body_end = base_byte + (slices + 2) * stretch_;
+            if (last_batch || body_end > size_) body_end = size_;
+            if (up_ok) up_ok = upload(sl, base_byte, body_end, base_byte);
+            t_upload_ += wall_s() - t0;
+            if (!up_ok) return fail(sl, "upload failed");
+            std::vector<hpn_span> spans;
+            for (uint64_t k = 1; k <= n_search; ++k) {
+                uint64_t lo, hi;
+                slice_bits(k, lo, hi);
+                const uint64_t cap = (size_ - 8) * 8;                              // (the trailer is not deflate data)
+                if (hi > cap) hi = cap;
+                spans.push_back(hpn_span{lo - base_byte * 8, hi > lo ? hi - lo : 0});
+            }
+            if (!spans.empty()) {
+                if (hpn_gz_find_starts_dev(up_ctx_, (const uint8_t *)sl.d_comp, body_end - base_byte, spans.data(), (uint32_t)spans.size(), found.data() + 1) != HPN_OK)
+                    return fail(sl, "block-start search on the device");
+                for (uint64_t k = 1; k <= n_search; ++k)
+                    if (found[(size_t)k] != kGzNone) found[(size_t)k] += base_byte * 8;
+            }
+            std::atomic<uint64_t> take{1};
+            auto rest = [&] {
+                for (;;) {
+                    const uint64_t k = take.fetch_add(1);
+                    if (k > n_search) return;
+                    if (found[(size_t)k] != kGzNone) continue;
+                    uint64_t lo, hi;
+                    slice_bits(k, lo, hi);
+                    found[(size_t)k] = find_start(lo, hi);
+                }
+            };
+            uint64_t missing = 0;
+            for (uint64_t k = 1; k <= n_search; ++k) missing += found[(size_t)k] == kGzNone;
+            if (missing) {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < threads_ && (uint64_t)t < missing; ++t) pool.emplace_back(rest);
+                for (auto &t : pool) t.join();
+            }
+        } else {
+            std::atomic<uint64_t> take{1};
+            auto work = [&] {
+                for (;;) {
+                    const uint64_t k = take.fetch_add(1);
+                    if (k > n_search) return;
+                    uint64_t lo, hi;
+                    slice_bits(k, lo, hi);
+                    found[(size_t)k] = find_start(lo, hi);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads_; ++t) pool.emplace_back(work);
+            body_end = last_batch || base_byte + slices * stretch_ > size_ ? size_ : base_byte + slices * stretch_;
+            if (up_ok) up_ok = upload(sl, base_byte, body_end, base_byte);
+            t_upload_ += wall_s() - t0;
+            for (auto &t : pool) t.join();
+            if (!up_ok) return fail(sl, "upload failed");
+        }
+        // the slice after the batch tells where its last stretch ends; nothing found there: one more slice ...
+        uint64_t end_bit = kGzNone;
+        if (!last_batch) {
+            uint64_t k = slices;
+            end_bit = found[(size_t)slices];
+            while (end_bit == kGzNone && k < slices + 1 && (base_byte + (k + 1) * stretch_) < size_) {  // (a slice without a dynamic block)
+                ++k;
+                const uint64_t lo = (base_byte + k * stretch_) * 8, hi = (base_byte + (k + 1) * stretch_) * 8;
+                end_bit = find_start(lo, hi < size_ * 8 ? hi : size_ * 8);
+            }
+            if (end_bit == kGzNone) {
+                if ((base_byte + (k + 1) * stretch_) < size_) return fail(sl, "no block start where one is expected");
+                last_batch = true;  // ... or, at the end of the file, run to the final block
+            }
+        }
+        t_find_ += wall_s() - t0;
+        sl.starts.clear();
+        for (uint64_t k = 0; k < slices; ++k)
+            if (found[(size_t)k] != kGzNone) sl.starts.push_back(found[(size_t)k]);
+        const uint32_t n = (uint32_t)sl.starts.size();
+        // text compressed the usual way has a block start in every slice; a file where most slices show none is not
+        // what this route is for (one wavefront would crawl through megabytes)
+        if (slices >= 8 && (uint64_t)n * 2 < slices) return fail(sl, "hardly any block starts found: not gzip'ed text");
+        // ---- the rest of the compressed bytes, up to a little beyond the batch's end ----
+        const uint64_t stop_byte = last_batch ? size_ : ((end_bit >> 3) + 4096 < size_ ? (end_bit >> 3) + 4096 : size_);
+        const uint64_t comp_bytes = stop_byte - base_byte;
+        if (comp_bytes + 256 > sl.cap_comp) return fail(sl, "a stretch without a block start");
+        if (stop_byte > body_end && !upload(sl, body_end, stop_byte, base_byte)) return fail(sl, "upload failed");
+        // ---- stretch table ----
+        if (n > sl.h_cap) {
+            if (sl.h_chunks) hpn_host_free(up_ctx_, sl.h_chunks);
+            sl.h_cap = n + n / 2 + 64;
+            void *p = nullptr;
+            if (hpn_host_malloc(up_ctx_, sl.h_cap * sizeof(hpn_gz_chunk), &p) != HPN_OK) return fail(sl, "pinned memory");
+            sl.h_chunks = (hpn_gz_chunk *)p;
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            hpn_gz_chunk &c = sl.h_chunks[k];
+            const uint64_t s = sl.starts[k], e = k + 1 < n ? sl.starts[k + 1] : end_bit;
+            c.in_off = (s >> 3) - base_byte;
+            c.start_bit = (uint32_t)(s & 7);
+            c.end_bit = e == kGzNone ? kGzNone : e - (s & ~(uint64_t)7);
+            const uint64_t room = stop_byte - (s >> 3);
+            c.in_len = room > 0x7fffff00ull ? 0x7fffff00u : (uint32_t)room;  // (the kernel adds small constants to it in 32 bits)
+        }
+        if (!reserve(up_ctx_, sl.d_chunks, sl.cap_chunks, (size_t)n * sizeof(hpn_gz_chunk))) return fail(sl, "device memory");
+        if (hpn_memcpy_h2d(up_ctx_, sl.d_chunks, sl.h_chunks, (size_t)n * sizeof(hpn_gz_chunk)) != HPN_OK || hpn_ctx_sync(up_ctx_) != HPN_OK) return fail(sl, "copy failed");
+        sl.n = n, sl.comp_bytes = comp_bytes, sl.end_bit = end_bit, sl.last = last_batch;
+        if (!last_batch) next_start_ = end_bit;
+        return true;
+    }
     // a block that is not its member's last, or -- files of many one-block members -- a member's first block
     uint64_t find_start(uint64_t lo, uint64_t hi) const
     {
@@ -293,21 +429,23 @@ private:
         why_ = why;
         return false;
     }
-    bool reserve(void *&p, size_t &cap, size_t bytes)
+    bool reserve(hpn_ctx *ctx, void *&p, size_t &cap, size_t bytes)    // (ctx: the calling thread's)
     {
         if (bytes <= cap) return true;
-        if (p) hpn_dev_free(ctx_, p);
+        if (p) hpn_dev_free(ctx, p);
         p = nullptr, cap = 0;
         const size_t want = bytes + bytes / 8 + 4096;
-        if (hpn_dev_malloc(ctx_, want, &p) != HPN_OK) return false;
+        if (hpn_dev_malloc(ctx, want, &p) != HPN_OK) return false;
         cap = want;
         return true;
     }
     // file bytes [from, to) -> d_comp_[0 ..).  The pump delivers the file once, in order, in pinned chunks; a chunk that
     // reaches beyond `to` stays current for the next batch.  Batches overlap by a few KiB at their seams (a stretch may be
     // read a little past its end): bytes the pump has already let go of are taken from the mapped file.
-    bool upload(uint64_t from, uint64_t to, uint64_t origin)
+    bool upload(Slot &sl, uint64_t from, uint64_t to, uint64_t origin)
     {
+        void *const d_comp_ = sl.d_comp;
+        hpn_ctx *const ctx_ = up_ctx_;      // (the producer's context: its copies run beside the caller's kernels)
         uint64_t at = from;
         if (at < pump_off_) {
             const uint64_t e = to < pump_off_ ? to : pump_off_;
@@ -335,7 +473,16 @@ private:
         return hpn_ctx_sync(ctx_) == HPN_OK;
     }
 
-    hpn_ctx *ctx_ = nullptr;
+    hpn_ctx *ctx_ = nullptr, *up_ctx_ = nullptr;
+    // who looks for the block starts: the cores (0.4 ms per stretch and core, beside the upload and the batch before: with 16
+    // cores that keeps up with the device), or the device (HPN_GZ_FIND=device; ~15 ms per batch, but behind the upload and not
+    // beside an inflate kernel, which fills the CUs' LDS) -- the default where the process has few cores
+    bool search_on_device_ = false;
+    Slot slot_[2];
+    std::thread producer_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
     int fd_ = -1;
     const uint8_t *data_ = nullptr;
     uint64_t size_ = 0;
@@ -358,11 +505,8 @@ private:
     TextPump::Chunk cur_;
     bool have_chunk_ = false;
     uint64_t pump_off_ = 0;  // file offset of cur_'s first byte
-    std::vector<uint64_t> starts_;
-    void *d_comp_ = nullptr, *d_chunks_ = nullptr, *d_text_ = nullptr, *d_win_[2] = {nullptr, nullptr};
-    size_t cap_comp_ = 0, cap_chunks_ = 0, cap_text_ = 0;
-    hpn_gz_chunk *h_chunks_ = nullptr;
-    size_t h_chunks_cap_ = 0;
+    void *d_text_ = nullptr, *d_win_[2] = {nullptr, nullptr};
+    size_t cap_text_ = 0;
 };
 
 }  // namespace hpn

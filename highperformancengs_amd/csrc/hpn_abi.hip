@@ -121,6 +121,13 @@ int hpn_ctx_sync(hpn_ctx *c)
     return HPN_OK;
 }
 
+int hpn_ctx_device(const hpn_ctx *c, int *device)
+{
+    if (!c || !device) return HPN_E_ARG;
+    *device = c->device;
+    return HPN_OK;
+}
+
 const char *hpn_ctx_last_error(const hpn_ctx *c) { return c ? c->err : "null context"; }
 
 int hpn_ctx_last_kernel_ms(hpn_ctx *c, int family, float *ms)

@@ -16,6 +16,8 @@ hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_me
                              uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st);
 hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
                                uint8_t *d_text, hipStream_t st);
+hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const void *d_slices, uint32_t n, uint64_t *d_found, int n_cu,
+                                 hipStream_t st);
 uint32_t crc_block_bytes();
 hipError_t launch_crc32_blocks(const uint8_t *d_data, const void *d_blocks, uint32_t n_blocks, uint32_t *d_out, hipStream_t st);
 uint32_t crc_fold_blocks(const uint32_t *crcs, uint64_t n_blocks, uint64_t total_len);
@@ -98,6 +100,23 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
         fprintf(stderr, "[hpn_gz] %u stretches: scratch %.3f s, inflate + histories %.3f s (inflate kernel %.1f ms), translate %.3f s, %.1f MB of text\n",
                 n_chunks, t1 - t0, t2 - t1, ms, now() - t2, info->n_bytes / 1e6);
     }
+    return HPN_OK;
+}
+
+int hpn_gz_find_starts_dev(hpn_ctx *c, const uint8_t *d_comp, uint64_t comp_bytes, const hpn_span *slices, uint32_t n, uint64_t *found)
+{
+    if (!c || (n && (!d_comp || !slices || !found))) return HPN_E_ARG;
+    if (n == 0) return HPN_OK;
+    HPN_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = scratch_reserve(c, c->g_meta, (size_t)n * 24 + 64)) != HPN_OK) return rc;
+    uint64_t *d_sl = (uint64_t *)c->g_meta.p, *d_found = d_sl + (size_t)2 * n;
+    std::vector<uint64_t> lohi((size_t)2 * n);
+    for (uint32_t k = 0; k < n; ++k) lohi[2 * k] = slices[k].off, lohi[2 * k + 1] = slices[k].off + slices[k].len;
+    HPN_HIP(c, hipMemcpyAsync(d_sl, lohi.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HPN_HIP(c, launch_gz_find_starts(d_comp, comp_bytes, d_sl, n, d_found, c->n_cu, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(found, d_found, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipStreamSynchronize(c->stream));
     return HPN_OK;
 }
 

@@ -40,6 +40,7 @@ struct BgzfBlock {  // = hpn_bgzf_block
 
 // where the decoded bytes go: straight to global memory; a match reads its source back from there
 struct ByteSink {
+    static constexpr bool kDry = false;
     uint8_t *out;
     uint32_t out_len, op, safe;   // op: bytes decoded; output bytes below `safe` are known to have reached memory
     __device__ __forceinline__ void pin_state() { op = uni(op), safe = uni(safe); }
@@ -93,7 +94,7 @@ struct ByteSink {
     }
 };
 
-__global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
                                                         uint32_t n_blocks, uint8_t *__restrict__ outbuf,
                                                         uint32_t *__restrict__ status)
 {
@@ -151,74 +152,7 @@ __global__ __launch_bounds__(kWave) void k_bgzf_inflate(const uint8_t *__restric
                 err = 3;
                 break;
             }
-            if (type == 1) {  // fixed codes (RFC 1951 3.2.6)
-                for (uint32_t i = (uint32_t)lane; i < 288u; i += kWave) s.lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8;
-                for (uint32_t i = (uint32_t)lane; i < 32u; i += kWave) s.lens[288 + i] = 5;
-                if (!build(s, s.lit, kLitSize, kLitRoot, 0, 288, true, lit_payload) ||
-                    !build(s, s.dist, kDistSize, kDistRoot, 288, 32, true, dist_payload)) {  // 30 used + 2 reserved: complete
-                    err = 4;
-                    break;
-                }
-                pair_literals(s.lit, kLitRoot);
-            } else {  // dynamic codes
-                refill(s, b, in, in_len);
-                const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
-                if (hlit > 286u || hdist > 30u) {
-                    err = 5;
-                    break;
-                }
-                if (lane < 19) s.lens[lane] = 0;
-                for (uint32_t i = 0; i < hclen; ++i) {
-                    refill(s, b, in, in_len);
-                    const uint32_t v = take(b, 3);
-                    s.lens[kClOrder[i]] = (uint8_t)v;
-                }
-                // the code-length code decodes with the distance table's storage (7-bit root is enough)
-                if (!build(s, s.dist, kDistSize, 7, 0, 19, false, [](uint32_t sym, uint32_t nb) { return mk(sym, 0, kLit, nb); })) {
-                    err = 6;
-                    break;
-                }
-                uint32_t i = 0, prev = 0;
-                const uint32_t total = hlit + hdist;
-                while (i < total && !err) {
-                    refill(s, b, in, in_len);
-                    const uint32_t e = lookup(s.dist, 7, b);
-                    if (((e >> 4) & 15u) != kLit) {
-                        err = 7;
-                        break;
-                    }
-                    const uint32_t sym = e >> 16;
-                    uint32_t rep = 1, val = sym;
-                    if (sym == 16u) {
-                        if (i == 0) {
-                            err = 8;
-                            break;
-                        }
-                        rep = 3u + take(b, 2), val = prev;
-                    } else if (sym == 17u) {
-                        rep = 3u + take(b, 3), val = 0;
-                    } else if (sym == 18u) {
-                        rep = 11u + take(b, 7), val = 0;
-                    }
-                    if (i + rep > total) {
-                        err = 9;
-                        break;
-                    }
-                    for (uint32_t k = (uint32_t)lane; k < rep; k += kWave) s.lens[32 + i + k] = (uint8_t)val;
-                    i += rep, prev = val;
-                }
-                if (err) break;
-                if (s.lens[32 + 256] == 0) {  // no end-of-block code
-                    err = 10;
-                    break;
-                }
-                if (!build(s, s.lit, kLitSize, kLitRoot, 32, hlit, true, lit_payload) ||
-                    !build(s, s.dist, kDistSize, kDistRoot, 32 + hlit, hdist, true, dist_payload)) {
-                    err = 11;
-                    break;
-                }
-                pair_literals(s.lit, kLitRoot);
-            }
+            if ((err = block_tables(s, b, in, in_len, type)) != 0) break;
             // ---- symbols of this block: 64 bit offsets at a time (decode_symbols, inflate_core.hpp) --------
             // (every symbol emits at least one byte -- bounded by out_len -- or ends the block, so this ends on any
             // input; running past the payload is caught per block above)

@@ -44,6 +44,7 @@ constexpr uint32_t kGzHist = 32768;
 // where the symbols go: 16 bits each, straight to global memory; a match reads its source back from there, or names the
 // byte of the 32 KiB in front of the stretch it would have copied
 struct SymSink {
+    static constexpr bool kDry = false;
     uint16_t *out;
     uint32_t out_len, op, safe;   // op: symbols decoded; symbols below `safe` are known to have reached memory
     __device__ __forceinline__ void pin_state() { op = uni(op), safe = uni(safe); }
@@ -98,7 +99,7 @@ struct SymSink {
     }
 };
 
-__global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
                                                           uint32_t n_chunks, uint16_t *__restrict__ symbuf, uint32_t sym_cap,
                                                           GzMeta *__restrict__ meta, GzBound *__restrict__ bounds, uint32_t bounds_cap,
                                                           uint32_t *__restrict__ n_bounds)
@@ -163,73 +164,7 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
                 err = 3;
                 break;
             }
-            if (type == 1) {  // fixed codes
-                for (uint32_t i = (uint32_t)lane; i < 288u; i += kWave) s.lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8;
-                for (uint32_t i = (uint32_t)lane; i < 32u; i += kWave) s.lens[288 + i] = 5;
-                if (!build(s, s.lit, kLitSize, kLitRoot, 0, 288, true, lit_payload) ||
-                    !build(s, s.dist, kDistSize, kDistRoot, 288, 32, true, dist_payload)) {
-                    err = 4;
-                    break;
-                }
-                pair_literals(s.lit, kLitRoot);
-            } else {  // dynamic codes
-                refill(s, b, in, in_len);
-                const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
-                if (hlit > 286u || hdist > 30u) {
-                    err = 5;
-                    break;
-                }
-                if (lane < 19) s.lens[lane] = 0;
-                for (uint32_t i = 0; i < hclen; ++i) {
-                    refill(s, b, in, in_len);
-                    const uint32_t v = take(b, 3);
-                    s.lens[kClOrder[i]] = (uint8_t)v;
-                }
-                if (!build(s, s.dist, kDistSize, 7, 0, 19, false, [](uint32_t sym, uint32_t nb) { return mk(sym, 0, kLit, nb); })) {
-                    err = 6;
-                    break;
-                }
-                uint32_t i = 0, prev = 0;
-                const uint32_t total = hlit + hdist;
-                while (i < total && !err) {
-                    refill(s, b, in, in_len);
-                    const uint32_t e = lookup(s.dist, 7, b);
-                    if (((e >> 4) & 15u) != kLit) {
-                        err = 7;
-                        break;
-                    }
-                    const uint32_t sym = e >> 16;
-                    uint32_t rep = 1, val = sym;
-                    if (sym == 16u) {
-                        if (i == 0) {
-                            err = 8;
-                            break;
-                        }
-                        rep = 3u + take(b, 2), val = prev;
-                    } else if (sym == 17u) {
-                        rep = 3u + take(b, 3), val = 0;
-                    } else if (sym == 18u) {
-                        rep = 11u + take(b, 7), val = 0;
-                    }
-                    if (i + rep > total) {
-                        err = 9;
-                        break;
-                    }
-                    for (uint32_t k = (uint32_t)lane; k < rep; k += kWave) s.lens[32 + i + k] = (uint8_t)val;
-                    i += rep, prev = val;
-                }
-                if (err) break;
-                if (s.lens[32 + 256] == 0) {
-                    err = 10;
-                    break;
-                }
-                if (!build(s, s.lit, kLitSize, kLitRoot, 32, hlit, true, lit_payload) ||
-                    !build(s, s.dist, kDistSize, kDistRoot, 32 + hlit, hdist, true, dist_payload)) {
-                    err = 11;
-                    break;
-                }
-                pair_literals(s.lit, kLitRoot);
-            }
+            if ((err = block_tables(s, b, in, in_len, type)) != 0) break;
             // ---- symbols of this block: 64 bit offsets at a time (decode_symbols, inflate_core.hpp) ----
             {
                 Pos p = pos_of(b);
@@ -303,6 +238,104 @@ __global__ __launch_bounds__(kWave) void k_gz_sym_inflate(const uint8_t *__restr
             m.end_bit = pos, m.text_off = 0;
             meta[ci] = m;
         }
+    }
+}
+
+// ---- where do deflate blocks start? -----------------------------------------------------------------------------------------
+// The stretches of a member begin at block starts nobody marks: host/pgz_reader.hpp's gz_find_block_start looks for them by
+// trial (~0.4 ms per stretch and core: with 16 cores the search took as long as the device needed to inflate the file).  The
+// same trial on the device, one wavefront per slice of the compressed bytes: the lanes test 64 bit positions at a time for a
+// dynamic block's header (BFINAL 0, BTYPE 2, HLIT / HDIST in range, the code-length code complete: Kraft sum 1, RFC 1951 3.2.7),
+// and what passes is decoded by the wave with the decoder above into a sink that stores nothing and only asks whether the
+// literals are text: the block to its end, and the beginning of the one behind it.  Like every proposed start it is PROVEN only
+// by the stretch before it arriving there exactly (k_gz_sym_inflate, status 20 otherwise).
+struct GzSlice {       // bit positions in the compressed buffer
+    uint64_t lo, hi;
+};
+struct TextCheck {     // a sink that keeps nothing
+    static constexpr bool kDry = true;
+    uint32_t out_len, op, safe, bad;
+    __device__ __forceinline__ void pin_state() { op = uni(op), bad = uni(bad); }
+    static __device__ __forceinline__ bool texty(uint32_t v) { return (v >= 32u && v < 127u) || v == '\n' || v == '\r' || v == '\t'; }
+    __device__ __forceinline__ void lits(bool mine, bool two, uint32_t, uint32_t e)
+    {
+        if (__ballot(mine && !(texty((e >> 16) & 255u) && (!two || texty(e >> 24))))) bad = 1;
+    }
+    __device__ __forceinline__ bool in_reach(uint32_t at, uint32_t dist) const { return dist <= at + kGzHist; }
+    __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t, uint32_t dist) { return dist > at + kGzHist ? 14u : 0u; }
+};
+
+// does a dynamic block that decodes to text start at bit p, with something that begins like a block behind it?
+__device__ __forceinline__ bool gz_trial(InfLds &s, const uint8_t *__restrict__ comp, uint64_t comp_len, uint64_t p)
+{
+    const uint8_t *in = comp + (p >> 3);
+    const uint64_t room = comp_len - (p >> 3);
+    const uint32_t in_len = room > 0x7fffff00ull ? 0x7fffff00u : (uint32_t)room;
+    Bits b;
+    stage(s, b, in, in_len);
+    stage(s, b, in, in_len);
+    refill(s, b, in, in_len);
+    drop(b, (uint32_t)(p & 7u));
+    refill(s, b, in, in_len);
+    pin(b);
+    if (take(b, 1) != 0 || take(b, 2) != 2u) return false;
+    if (block_tables(s, b, in, in_len, 2) != 0) return false;
+    uint32_t err = 0;
+    TextCheck all{1u << 20, 0u, 0u, 0u};
+    Pos at = pos_of(b);
+    if (!decode_symbols(s, b, at, in, in_len, all, err) || all.op == 0 || all.bad) return false;
+    // ... and the next block must at least begin like one (header parses, tables build, the first symbols decode to text):
+    // decoding it to its end as well would double the cost for nothing -- whoever uses the start proves it anyway
+    seek(s, b, at, in, in_len);
+    refill(s, b, in, in_len);
+    pin(b);
+    if (b.in_pos - (b.bc >> 3) > in_len) return false;
+    (void)take(b, 1);
+    const uint32_t type = take(b, 2);
+    if (type == 3u) return false;
+    if (type == 0u) {
+        drop(b, b.bc & 7u);
+        refill(s, b, in, in_len);
+        const uint32_t len = take(b, 16);
+        refill(s, b, in, in_len);
+        return (len ^ take(b, 16)) == 0xffffu;
+    }
+    if (block_tables(s, b, in, in_len, type) != 0) return false;
+    TextCheck some{256u, 0u, 0u, 0u};
+    at = pos_of(b);
+    err = 0;
+    if (!decode_symbols(s, b, at, in, in_len, some, err) && err != 12u) return false;   // (12: the 256 symbols are through)
+    return !some.bad;
+}
+
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gz_find_starts(const uint8_t *__restrict__ comp, uint64_t comp_len, const GzSlice *__restrict__ slices,
+                                                          uint32_t n, uint64_t *__restrict__ found)
+{
+    __shared__ InfLds s;
+    const uint32_t lane = (uint32_t)lane_id();
+    for (uint32_t si = blockIdx.x; si < n; si += gridDim.x) {
+        const uint64_t lo = uni64(slices[si].lo), hi = uni64(slices[si].hi);
+        uint64_t hit = ~0ull;
+        for (uint64_t p0 = lo; p0 < hi && hit == ~0ull; p0 += kWave) {
+            const uint64_t p = p0 + lane;
+            uint64_t w0, w1;                          // 128 bits from the byte p lies in (the buffer is padded)
+            __builtin_memcpy(&w0, comp + (p >> 3), 8);
+            __builtin_memcpy(&w1, comp + (p >> 3) + 8, 8);
+            const uint32_t sh = (uint32_t)(p & 7u);
+            const uint64_t v0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+            bool ok = p < hi && (p >> 3) + 16 <= comp_len && (v0 & 7u) == 4u && ((v0 >> 3) & 31u) <= 29u && ((v0 >> 8) & 31u) <= 29u;
+            const uint32_t hclen = (uint32_t)(v0 >> 13 & 15u) + 4u;
+            uint64_t x = (v0 >> 17) | ((w1 >> sh) << 47);
+            uint32_t kraft = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 19u; ++i, x >>= 3) kraft += i < hclen ? (128u >> (x & 7u)) & 127u : 0u;   // length 0: unused
+            ok = ok && kraft == 128u;
+            for (uint64_t m = __ballot(ok); m && hit == ~0ull; m &= m - 1) {
+                const uint64_t q = p0 + (uint64_t)__builtin_ctzll(m);
+                if (gz_trial(s, comp, comp_len, q)) hit = q;
+            }
+        }
+        if (lane == 0) found[si] = hit;
     }
 }
 
@@ -436,6 +469,14 @@ hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, ui
     hipLaunchKernelGGL(k_gz_sym_inflate, dim3(n_chunks < cap ? n_chunks : cap), dim3(kWave), 0, st, d_comp, (const GzChunk *)d_chunks,
                        n_chunks, d_sym, sym_cap, (GzMeta *)d_meta, d_bounds ? (GzBound *)((uint8_t *)d_bounds + 16) : nullptr, bounds_cap,
                        (uint32_t *)d_bounds);
+    return hipGetLastError();
+}
+hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const void *d_slices, uint32_t n, uint64_t *d_found, int n_cu,
+                                 hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t cap = (uint32_t)n_cu * 18u;
+    hipLaunchKernelGGL(k_gz_find_starts, dim3(n < cap ? n : cap), dim3(kWave), 0, st, d_comp, comp_len, (const GzSlice *)d_slices, n, d_found);
     return hipGetLastError();
 }
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,

@@ -357,7 +357,13 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, ui
         err = 12;
         return kWinError;
     }
-    if ((taken & len_lanes) == 0) {
+    if constexpr (Sink::kDry) {                       // nothing is stored: the sink only looks at the literals
+        sink.lits(mine && is_lit, kind != 0, at, w.el);
+        if (__ballot(mine && !is_lit && !sink.in_reach(at, dist))) {
+            err = 14;
+            return kWinError;
+        }
+    } else if ((taken & len_lanes) == 0) {
         sink.lits(mine, kind != 0, at, w.el);
     } else {
         if (__ballot(mine && !is_lit && !sink.in_reach(at, dist))) {
@@ -407,6 +413,12 @@ __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const
         uint32_t o;
         const uint32_t how = walk(s, w, sink, o, err);
         if (how == kWinError) return false;
+        if constexpr (Sink::kDry) {
+            if (sink.bad) {                          // (a trial decode of something that is not text: no need to go on)
+                err = 16;
+                return false;
+            }
+        }
         p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
         if (how == kWinEob) return true;
         if (how == kWinSerial) {            // one symbol with a code longer than a root table, by the serial reader
@@ -468,6 +480,58 @@ __device__ __forceinline__ void pair_literals(uint32_t *tab, uint32_t root)
         if (l2 > rest) continue;  // its code would need bits beyond the index
         tab[i] = mk((e1 >> 16) | lit2 << 8, l1, kLit2, l1 + l2);
     }
+}
+
+// The code tables of a block whose three header bits have been taken: fixed (type 1, RFC 1951 3.2.6) or dynamic (type 2, 3.2.7)
+// codes, literal pairs included.  -> 0 or the decoder's error code.
+__device__ __forceinline__ uint32_t block_tables(InfLds &s, Bits &b, const uint8_t *__restrict__ in, uint32_t in_len, uint32_t type)
+{
+    const int lane = lane_id();
+    if (type == 1) {
+        for (uint32_t i = (uint32_t)lane; i < 288u; i += kWave) s.lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : 8;
+        for (uint32_t i = (uint32_t)lane; i < 32u; i += kWave) s.lens[288 + i] = 5;
+        if (!build(s, s.lit, kLitSize, kLitRoot, 0, 288, true, lit_payload) ||
+            !build(s, s.dist, kDistSize, kDistRoot, 288, 32, true, dist_payload))  // 30 used + 2 reserved: complete
+            return 4;
+    } else {
+        refill(s, b, in, in_len);
+        const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
+        if (hlit > 286u || hdist > 30u) return 5;
+        if (lane < 19) s.lens[lane] = 0;
+        for (uint32_t i = 0; i < hclen; ++i) {
+            refill(s, b, in, in_len);
+            const uint32_t v = take(b, 3);
+            s.lens[kClOrder[i]] = (uint8_t)v;
+        }
+        // the code-length code decodes with the distance table's storage (7-bit root is enough)
+        if (!build(s, s.dist, kDistSize, 7, 0, 19, false, [](uint32_t sym, uint32_t nb) { return mk(sym, 0, kLit, nb); })) return 6;
+        uint32_t i = 0, prev = 0;
+        const uint32_t total = hlit + hdist;
+        while (i < total) {
+            refill(s, b, in, in_len);
+            const uint32_t e = lookup(s.dist, 7, b);
+            if (((e >> 4) & 15u) != kLit) return 7;
+            const uint32_t sym = e >> 16;
+            uint32_t rep = 1, val = sym;
+            if (sym == 16u) {
+                if (i == 0) return 8;
+                rep = 3u + take(b, 2), val = prev;
+            } else if (sym == 17u) {
+                rep = 3u + take(b, 3), val = 0;
+            } else if (sym == 18u) {
+                rep = 11u + take(b, 7), val = 0;
+            }
+            if (i + rep > total) return 9;
+            for (uint32_t k = (uint32_t)lane; k < rep; k += kWave) s.lens[32 + i + k] = (uint8_t)val;
+            i += rep, prev = val;
+        }
+        if (s.lens[32 + 256] == 0) return 10;  // no end-of-block code
+        if (!build(s, s.lit, kLitSize, kLitRoot, 32, hlit, true, lit_payload) ||
+            !build(s, s.dist, kDistSize, kDistRoot, 32 + hlit, hdist, true, dist_payload))
+            return 11;
+    }
+    pair_literals(s.lit, kLitRoot);
+    return 0;
 }
 
 }  // namespace hpn

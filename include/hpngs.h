@@ -59,6 +59,8 @@ int hpn_ctx_destroy(hpn_ctx *ctx);
  * NULL restores the context's own stream. */
 int hpn_ctx_set_stream(hpn_ctx *ctx, void *hip_stream);
 int hpn_ctx_sync(hpn_ctx *ctx);
+/* The HIP ordinal the context was created on (a helper context for uploads beside it: host/gz_gpu.hpp). */
+int hpn_ctx_device(const hpn_ctx *ctx, int *device);
 const char *hpn_ctx_last_error(const hpn_ctx *ctx);
 /* Milliseconds the device spent in the most recent kernel launch group of the
  * given family, measured with hipEvents on the context's stream (valid after
@@ -335,6 +337,15 @@ typedef struct hpn_span {
 } hpn_span;
 int hpn_crc32_dev(hpn_ctx *ctx, const uint8_t *d_data, const hpn_span *spans, uint32_t n_spans, uint32_t *crc);
 uint32_t hpn_crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+
+/* Where deflate blocks start, by trial, on the device: found[k] = the first bit position in [slices[k].off, slices[k].off +
+ * slices[k].len) (bits, from d_comp) at which a non-final dynamic-Huffman block decodes to text and something that begins
+ * like a block follows, or ~0.  What the host's gz_find_block_start does on the cores (csrc/host/pgz_reader.hpp); a start
+ * found here is a proposal like one found there: it is proven by the stretch before it arriving exactly there
+ * (hpn_gz_inflate_dev, status 20 otherwise).  d_comp: comp_bytes bytes, readable for 256 more.  slices / found: host
+ * arrays.  Synchronous. */
+int hpn_gz_find_starts_dev(hpn_ctx *ctx, const uint8_t *d_comp, uint64_t comp_bytes, const hpn_span *slices, uint32_t n,
+                           uint64_t *found);
 
 /* ---- BAM record batches ---------------------------------------------------------------
  * What the reference's bam_fetch_f callback sees per record (bam.h:178-187,627),

@@ -353,8 +353,12 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
         (tmp_path / name).write_bytes(blob)
         ref = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", name], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              env={**os.environ, "HPN_NO_MGZ": "1", "HPN_NO_BGZF": "1"})
-        for env in ({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000"},
-                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "7"}):
+        # (HPN_GZ_FIND: the block starts looked for by the cores / by the device, k_gz_find_starts; several batches: the next
+        # one is prepared by the producer thread while this one is inflated)
+        for env in ({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000", "HPN_GZ_FIND": "host"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "7"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000", "HPN_GZ_FIND": "device"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "100000", "HPN_GZ_BATCH": "5", "HPN_GZ_FIND": "device"}):
             p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", name], cwd=tmp_path, stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, env={**os.environ, "HPN_TIMING": "1", **env})
             assert p.returncode == ref.returncode, p.stderr.decode()

@@ -310,3 +310,38 @@ def test_window_decoder_fuzz_with_unknown_history(ctx, seed):
     assert zlib.decompress(comp, -15) == text
     info, got, wout = _run(ctx, comp, starts, pieces)
     assert info.status == 0 and got == text and wout == (bytes(32768) + text)[-32768:]
+
+
+def test_block_starts_found_on_the_device(ctx):
+    """hpn_gz_find_starts_dev: in a stream cut at flush points the byte behind every flush is a block start; a slice that
+    begins there, a little in front of it or far in front of it must report that position (or an earlier TRUE block start:
+    zlib opens a new block every ~16 K symbols), and every reported start must decode from there to the stream's end."""
+    rng = np.random.default_rng(77)
+    text = _fastq(rng, 9000)
+    cuts = sorted(int(x) for x in rng.integers(200000, len(text) - 1000, 7))
+    pieces = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+    comp, starts = _stream(pieces, 6, zlib.Z_SYNC_FLUSH)
+    d_comp = torch.from_numpy(np.frombuffer(comp + bytes(512), np.uint8).copy()).cuda()
+    slices, want = [], []
+    assert comp[starts[-1]] & 1                         # the last piece is one FINAL block: not proposed (see below)
+    for s in starts[1:-1]:
+        for back in (0, 3, 5 * 8 + 1, 2000 * 8):
+            lo = s * 8 - back
+            slices.append((lo, 60000 * 8))
+            want.append(s * 8)
+    slices.append((len(comp) * 8 - 80, 64))            # nothing there
+    slices.append((starts[-1] * 8, 8 * (len(comp) - starts[-1] - 8)))   # a final block is not a stretch's end
+    found = ctx.gz_find_starts_dev(d_comp, len(comp), slices)
+    assert int(found[-1]) == (1 << 64) - 1 and int(found[-2]) == (1 << 64) - 1
+    for (lo, n), w, f in zip(slices, want, found[:-2]):
+        f = int(f)
+        assert lo <= f <= w, (lo, w, f)
+        if f != w:                                      # an earlier block start inside the slice: it must be a true one
+            d = zlib.decompressobj(-15)
+            # bit-unaligned start: shift the stream so that it begins on a byte (the decoder is fed from that bit on)
+            bits = np.unpackbits(np.frombuffer(comp, np.uint8), bitorder="little")[f:]
+            tail = np.packbits(bits, bitorder="little").tobytes()
+            try:
+                out = d.decompress(tail)
+            except zlib.error as e:                     # a match reaching in front of the start is the only excuse
+                assert "distance too far back" in str(e), e
