@@ -546,14 +546,18 @@ def _c4_file_legs(cores, td):
             want[t] = c4.oracle_target_text(tg[t][0], tg[t][1], W, runs, bins) + (len(runs),)
         return want[t]
     shape = f"{n_reads:.2e} x 150 bp over the 25 hg38 contigs (30x chr21 + chrM, 3x the rest), BAM {os.path.getsize(bam) / 1e9:.1f} GB"
+    # (defaults on one device: bam2depth reads the file front to back on one worker, four chunks under an inflate launch;
+    # bam_sliding_count's three workers take one reader's record batches in turn)
     for tool, args, env in (("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {}),
-                            ("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {"HPN_NGPU": "1"}),
+                            ("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {"HPN_NGPU": "3"}),
                             ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {}),
                             ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "1"})):
         wd = tempfile.mkdtemp(prefix="c4_", dir=td)
         os.symlink(bam, os.path.join(wd, "hg38.bam")), os.symlink(bam + ".bai", os.path.join(wd, "hg38.bam.bai"))
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
-        leg = {"leg": f"{tool} -w {W}{' on ONE worker (HPN_NGPU=1)' if env else ' (default: three workers on the one device)'}, {shape}",
+        how = {("bam2depth", ""): " (default: one worker)", ("bam2depth", "3"): " with the targets over three workers on the one device (HPN_NGPU=3)",
+               ("bam_sliding_count", ""): " (default: three workers on the one device)", ("bam_sliding_count", "1"): " on ONE worker (HPN_NGPU=1)"}[(tool, env.get("HPN_NGPU", ""))]
+        leg = {"leg": f"{tool} -w {W}{how}, {shape}",
                "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(n_reads * 150 / dt / 1e9, 3), "rc": p.returncode}, "reference": None}
         if tool == "bam2depth":
             ok, n_runs = True, 0

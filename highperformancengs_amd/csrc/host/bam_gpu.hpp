@@ -90,7 +90,70 @@ public:
         return info->flags ? -1 : 1;
     }
 
+    // The same in pieces: several chunks of the file under ONE inflate launch.  A launch of one round of the chip's 4,608
+    // decoder waves (an 88 MB chunk holds ~4,500 blocks) ends with its slowest block -- on a 10 GB BAM the 116 launches ran at
+    // 23.6 GB/s of inflated bytes where one launch over all blocks reaches 39.6 (rocprofv3: profiles/r03/kernel_stats_c4_*.csv) --;
+    // with four rounds under a launch the waves that finish early take the next blocks.  The pieces' compressed bytes are
+    // copied as they come (the pinned chunk is free again when add() returns), so the pinned memory stays three chunks.
+    bool begin(size_t comp_room)                     // comp_room: compressed bytes the launch may hold
+    {
+        pieces_.clear();
+        at_comp_ = 0, at_out_ = 0, first_off_ = 0, have_first_ = false;
+        return reserve<uint8_t>(d_comp_, cap_comp_, comp_room + 64);
+    }
+    bool add(const BgzfParsed &pb)
+    {
+        const size_t comp_bytes = pb.carry.size() + pb.body_len;
+        if (!pb.blocks.empty() && !have_first_) first_off_ = pb.first_off, have_first_ = true;
+        if (at_comp_ + comp_bytes + 64 > cap_comp_) return false;
+        if (!pb.carry.empty() && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + at_comp_, pb.carry.data(), pb.carry.size()) != HPN_OK) return false;
+        if (pb.body_len && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + at_comp_ + pb.carry.size(), pb.body, pb.body_len) != HPN_OK) return false;
+        for (hpn_bgzf_block b : pb.blocks) {
+            b.in_off += at_comp_, b.out_off += at_out_;
+            pieces_.push_back(b);
+        }
+        at_comp_ += comp_bytes, at_out_ += pb.out_bytes;
+        return hpn_ctx_sync(ctx_) == HPN_OK;           // (pageable carry, and the pinned chunk goes back to the reader)
+    }
+    size_t blocks_added() const { return pieces_.size(); }
+    int finish(bool text_mode, hpn_raw_info *info)
+    {
+        memset(info, 0, sizeof *info);
+        const size_t nb = pieces_.size();
+        if (!nb) return 1;
+        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) || !reserve<uint8_t>(d_out_, cap_out_, at_out_ + 64) ||
+            !reserve<uint32_t>(d_status_, cap_status_, nb))
+            return -1;
+        if (nb > h_blocks_cap_) {
+            if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
+            h_blocks_cap_ = nb + nb / 2 + 1024;
+            if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
+        }
+        memcpy(h_blocks_, pieces_.data(), nb * sizeof(hpn_bgzf_block));
+        if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
+        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
+                                 (uint32_t *)d_status_) != HPN_OK)
+            return -1;
+        if (text_mode) {  // no records: wait, check every block's status
+            status_.resize(nb);
+            if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
+            for (uint32_t st : status_)
+                if (st) return -1;
+            info->n_records = at_out_;
+            return 1;
+        }
+        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
+                                  (const uint32_t *)d_status_, info) != HPN_OK)
+            return -1;
+        return info->flags ? -1 : 1;
+    }
+
 private:
+    std::vector<hpn_bgzf_block> pieces_;
+    size_t at_comp_ = 0;
+    uint64_t at_out_ = 0;
+    uint32_t first_off_ = 0;
+    bool have_first_ = false;
     template <typename T>
     bool reserve(void *&p, size_t &cap, size_t n)
     {
@@ -185,6 +248,7 @@ public:
         if (!pump_ || !pump_->restart(voffset >> 16)) return false;
         first_off_ = (uint32_t)(voffset & 0xffff), skip_ = 0, eof_ = false;
         carry_.clear();
+        if (!rounds_env()) rounds_ = 1;
         return true;
     }
 
@@ -195,9 +259,13 @@ public:
     int next(hpn_raw_info *info)
     {
         memset(info, 0, sizeof *info);
-        for (;;) {
+        if (!dev_.begin((size_t)rounds_ * (chunk_ + 65536 + 64))) return -1;
+        for (int taken = 0; taken < rounds_;) {       // several chunks under one inflate launch (BgzfDevice::add)
             TextPump::Chunk c;
-            if (eof_ || !pump_->next(c)) return carry_.empty() ? 0 : -1;  // a partial block at the end: truncated file
+            if (eof_ || !pump_->next(c)) {
+                if (!carry_.empty()) return -1;              // a partial block at the end: truncated file
+                break;
+            }
             if (c.eof) eof_ = true;
             size_t at = 0;
             if (skip_) {  // chunks before the first record's block
@@ -206,15 +274,18 @@ public:
             }
             if (at == c.n) {
                 pump_->recycle(c);
-                if (eof_) return carry_.empty() ? 0 : -1;
+                if (eof_ && !carry_.empty()) return -1;
                 continue;
             }
             BgzfParsed pb;
             int r = parse(c, at, pb);
-            if (r == 1) r = dev_.run(pb, text_mode_, info);
+            if (r == 1 && !dev_.add(pb)) r = -1;
             pump_->recycle(c);
-            return r;
+            if (r != 1) return r;
+            ++taken;
         }
+        if (!dev_.blocks_added()) return eof_ ? 0 : 1;       // (a batch may be empty)
+        return dev_.finish(text_mode_, info);
     }
 
 private:
@@ -307,6 +378,15 @@ private:
     uint64_t start_ = 0, skip_ = 0;  // file offset of the block holding the first record
     uint32_t first_off_ = 0;         // ... and the record's offset inside it
     bool eof_ = false, text_mode_ = false;
+    // chunks per inflate launch: four when the file is read front to back; one behind a seek() -- a worker that reads ONE target
+    // (bam_multi.hpp) would inflate up to four chunks of its neighbours behind the target's last record (HPN_BAM_ROUNDS: both)
+    static int rounds_env()
+    {
+        const char *e = getenv("HPN_BAM_ROUNDS");
+        const int v = e ? atoi(e) : 0;
+        return v < 0 ? 0 : v > 64 ? 64 : v;
+    }
+    int rounds_ = rounds_env() ? rounds_env() : 4;
     std::vector<uint8_t> carry_;
     BgzfDevice dev_;
 

@@ -110,13 +110,18 @@ inline int multi_gpu_workers()
 // BAM is seven batches of 88 MB).  With ONE device a file of 2 GiB or more still gets three workers on it: one's upload and
 // block-table walk run beside another's inflate and a third's record kernels (hg38-shaped 10.6 GB BAM: bam_sliding_count 1.80 ->
 // 1.24-1.31 s, bam2depth 1.88 -> 1.77 s; profiles/r03/bench.json).
-inline int multi_gpu_workers_for(const char *path)
+// by_target: the tool hands whole TARGETS to its workers (bam2depth, bam2wig: each worker seeks to its targets and reads them with
+// a stream of its own).  On one device that no longer pays: a stream that reads the file front to back puts four chunks under
+// one inflate launch (BgzfGpuStream::next), which a per-target reader cannot (it would inflate its neighbours' blocks behind the
+// target's end) -- 10.6 GB BAM, bam2depth: one worker 1.42 s, three 1.56 s; bam_sliding_count's workers take record batches of
+// ONE reader in turn and stay at three (1.04 s against 1.19; scripts/e2e_bam_chunk.py).
+inline int multi_gpu_workers_for(const char *path, bool by_target = false)
 {
     int n = multi_gpu_workers();
     if (!getenv("HPN_NGPU")) {
         struct stat sb;
         if (stat(path, &sb) == 0) {
-            if (n == 1 && sb.st_size >= ((off_t)2 << 30)) n = 3;
+            if (n == 1 && !by_target && sb.st_size >= ((off_t)2 << 30)) n = 3;
             const long batches = (long)(sb.st_size / ((off_t)88 << 20)) + 1;
             if (batches < n) n = (int)batches;
         }

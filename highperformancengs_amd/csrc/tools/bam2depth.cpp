@@ -85,7 +85,7 @@ int main(int argc, char *argv[])
     // the bedGraph lines are formatted on the device (hpn_depth_bedgraph_format); HPN_BEDGRAPH_HOST=1: from the runs, on the host
     const bool dev_text = !(getenv("HPN_BEDGRAPH_HOST") && getenv("HPN_BEDGRAPH_HOST")[0] == '1');
     for (int i = 0; i < n_in; ++i) {
-      const int workers = multi_gpu_workers_for(infiles[i]);   // > 1: targets are spread over the GPUs -- or, for a large file, over three contexts of the one GPU (host/bam_multi.hpp)
+      const int workers = multi_gpu_workers_for(infiles[i], true);   // > 1: targets are spread over the GPUs (host/bam_multi.hpp)
       bool try_multi = workers > 1 && bam_gpu_enabled();
       // first with the BGZF inflate and the record walk on the GPU; a file that cannot be decoded
       // there (records straddling blocks, damaged block) is done again with the host reader

@@ -74,7 +74,7 @@ int main(int argc, char *argv[])
 
     char suffix[64];
     for (int i = 0; i < n_in; ++i) {
-      const int workers = multi_gpu_workers_for(infiles[i]);   // > 1: targets are spread over the GPUs -- or, for a large file, over three contexts of the one GPU (host/bam_multi.hpp)
+      const int workers = multi_gpu_workers_for(infiles[i], true);   // > 1: targets are spread over the GPUs (host/bam_multi.hpp)
       bool try_multi = workers > 1 && bam_gpu_enabled();
       for (int pass = bam_gpu_enabled() ? 0 : 1; pass < 2; ++pass) {  // GPU ingest first, host reader if the file needs it
         DepthFeeder bam;

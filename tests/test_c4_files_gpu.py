@@ -90,7 +90,7 @@ def test_hg38_shaped_bam_through_the_tools(tmp_path):
     d1 = tmp_path / "one"
     d1.mkdir()
     os.symlink(bam, d1 / "hg38.bam"), os.symlink(bam + ".bai", d1 / "hg38.bam.bai")
-    # (HPN_NGPU=1: one context; a file of this size would take three workers on the one device by itself)
+    # (HPN_NGPU=1: one context, which is also what bam2depth takes by itself on one device)
     p = subprocess.run([os.path.join(BIN, "bam2depth"), "-w", str(W), "-o", "d", "hg38.bam"], cwd=d1, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env={**os.environ, "HPN_NGPU": "1"})
     assert p.returncode == 0, p.stderr.decode()
