@@ -80,6 +80,8 @@ int main(int argc, char *argv[])
     hpn_ctx *ctx = nullptr;
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    const bool timing = getenv("HPN_TIMING") != nullptr;
+    if (timing) fprintf(stderr, "[hpn] context at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
 
     char suffix[64];
     // the bedGraph lines are formatted on the device (hpn_depth_bedgraph_format); HPN_BEDGRAPH_HOST=1: from the runs, on the host
@@ -98,6 +100,7 @@ int main(int argc, char *argv[])
         } else if (!bam.open(ctx, infiles[i], hdr, pass == 0)) {
             err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
         }
+        if (timing) fprintf(stderr, "[hpn] %s open at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
         std::string nm = infiles[i];
         snprintf(suffix, sizeof suffix, ".%u.bedGraph", i + 1);
         FILE *bedGraph = fcreat_outfile(basename(&nm[0]), suffix);
@@ -151,6 +154,7 @@ int main(int argc, char *argv[])
             const uint32_t tlen = hdr.target_len[j];
             const char *name = hdr.target_name[j].c_str();
             if ((rc = hpn_depth_begin_w(ctx, j, tlen, BAM_DEF_MASK, (uint32_t)window)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");   // sorted input: swept while it streams
+            if (timing && j == 0) fprintf(stderr, "[hpn] first target begun at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
             t0 = wall_s();
             rc = bam.feed(j);
             t_feed += wall_s() - t0;
