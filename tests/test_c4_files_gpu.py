@@ -58,7 +58,10 @@ def test_small_instance_every_route(tmp_path):
             cache[t] = c4.oracle_target_text(tg[t][0], tg[t][1], W, runs, bins)
         return cache[t]
     want_txt = c4.oracle_window_report(soa, tg, W)
-    for env in ({}, {"HPN_NGPU": "2"}, {"HPN_NGPU": "3"}, {"HPN_BAM_GPU": "0"}):
+    # (HPN_BAM_CHUNK / HPN_BAM_ROUNDS: small chunks, one / three / seven of them under an inflate launch -- blocks carried from
+    # chunk to chunk inside a launch and across launches)
+    for env in ({}, {"HPN_NGPU": "2"}, {"HPN_NGPU": "3"}, {"HPN_BAM_GPU": "0"}, {"HPN_BAM_CHUNK": "200000", "HPN_BAM_ROUNDS": "1"},
+                {"HPN_BAM_CHUNK": "150000", "HPN_BAM_ROUNDS": "3"}, {"HPN_BAM_CHUNK": "70000", "HPN_BAM_ROUNDS": "7", "HPN_NGPU": "1"}):
         d = tmp_path / ("run" + "".join(env.values()))
         d.mkdir()
         os.symlink(bam, d / "s.bam"), os.symlink(bam + ".bai", d / "s.bam.bai")
