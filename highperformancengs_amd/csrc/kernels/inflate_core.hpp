@@ -297,16 +297,24 @@ __device__ __forceinline__ void assemble(InfLds &s, Sink &sink, bool mine, uint3
         uint32_t val = (e >> (16u + 8u * (i & 1u))) & 255u;         // a literal: byte i of its entry
         const int32_t from = (int32_t)(sink.op + p) - (int32_t)d;   // a copy: of this position (may lie in front of a gzip stretch)
         const bool near = copy && from >= (int32_t)(sink.op + c0);
+#ifndef DIAG_NOFETCH
         if (__ballot(copy && !near)) val = sink.fetch(copy && !near, from, sink.op + c0, val);
+#endif
         uint32_t ref = near ? (uint32_t)from - (sink.op + c0) : ~0u;   // lane of this chunk still to be copied from; ~0: val is final
+#ifdef DIAG_NOJUMP
+        while (false) {
+#else
         while (__ballot(ref != ~0u)) {
+#endif
             const uint32_t rv = from_lane(val, ref), rr = from_lane(ref, ref);
             if (ref != ~0u) {
                 if (rr == ~0u) val = rv, ref = ~0u;
                 else ref = rr;
             }
         }
+#ifndef DIAG_NOPUT
         sink.put(live, sink.op + p, val);
+#endif
     }
 }
 
@@ -370,7 +378,9 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, ui
             err = 14;
             return kWinError;
         }
+#ifndef DIAG_NOASSEMBLE
         assemble(s, sink, mine, at - sink.op, w.el, is_lit ? 0u : dist, total);
+#endif
     }
     sink.op += total;
     if ((taken >> f) & 1u) {                          // the last symbol ends in or behind the window's last bit
