@@ -90,7 +90,7 @@ public:
         return info->flags ? -1 : 1;
     }
 
-    // The same in pieces: several chunks of the file under ONE inflate launch.  A launch of one round of the chip's 4,608
+    // The same in pieces: several chunks of the file under ONE inflate launch.  A launch of one round of the chip's ~5,000
     // decoder waves (an 88 MB chunk holds ~4,500 blocks) ends with its slowest block -- on a 10 GB BAM the 116 launches ran at
     // 23.6 GB/s of inflated bytes where one launch over all blocks reaches 39.6 (rocprofv3: profiles/r03/kernel_stats_c4_*.csv) --;
     // with four rounds under a launch the waves that finish early take the next blocks.  The pieces' compressed bytes are
@@ -219,7 +219,7 @@ public:
         }
         fclose(f);
         if (!ok) return false;
-        chunk_ = (size_t)88 << 20;  // ~4,500 blocks: one full round of the inflate kernel's 4,608 wave slots
+        chunk_ = (size_t)88 << 20;  // ~4,500 blocks: about one round of the inflate kernel's 5,120 wave slots
         if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
         pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         if (!pump_->ok()) return false;

@@ -107,7 +107,7 @@ public:
             const uint64_t fills = size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10));
             if (search_on_device_ && calls < (fills < 4 ? fills : 4)) calls = fills < 4 ? fills : 4;
             // (rounded up to 4 KiB, not more: a stretch 12 % longer than the share leaves 12 % of the wave slots empty AND makes
-            // the one launch 12 % longer -- 2.4 GB file: 4,097 stretches of 576 KiB where 4,590 of 516 fit)
+            // the one launch 12 % longer -- 2.4 GB file, 4,608 slots: 4,097 stretches of 576 KiB where 4,590 of 516 fit)
             stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 4096) & ~(uint64_t)4095);
             if (!e && stretch_bytes < ((size_t)256 << 10)) stretch_bytes = (size_t)256 << 10;
             if (!e && stretch_bytes > kMaxStretch) stretch_bytes = (size_t)kMaxStretch;  // (symbol scratch: ~12 bytes per compressed byte in flight)

@@ -185,7 +185,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
     *unusable = false;
     GzGpuStream gs;
     const long cpus = usable_cpus() / text_workers_in_flight();
-    uint32_t per_call = (uint32_t)(4608 / text_workers_in_flight());  // the chip runs 4,608 stretches at a time
+    uint32_t per_call = (uint32_t)(5120 / text_workers_in_flight());  // the chip runs 5,120 stretches at a time (20 decoder waves per CU)
     if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);  // (tests: several device calls per file)
     const double t0 = wall_s();
     if (!gs.open(ctx, path, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call)) {

@@ -15,9 +15,9 @@
 //     position - distance out of memory or out of another lane: decode_symbols / assemble, inflate_core.hpp);
 //   * the output goes straight to global memory, and a match reads its source back from there:
 //     the 32 KiB history window does not have to live in LDS, which leaves two-level decode
-//     tables (10-bit root for literal/length, 8-bit for distance) and a 2 KiB input ring =
-//     8.7 KiB per wave, 18 waves per CU, 4,608 blocks in flight on the chip (with the window in
-//     LDS it was 3 waves per CU and 2.9x slower).  A match whose source overlaps bytes this
+//     tables (9-bit root for literal/length, 8-bit for distance) and a 1 KiB input ring =
+//     7.1 KiB per wave = six of the CU's 1,280-byte LDS granules, 20 waves per CU, 5,120 blocks in flight on the chip (with the
+//     window in LDS it was 3 waves per CU and 2.9x slower).  A match whose source overlaps bytes this
 //     wave stored since its last wait first waits for those stores (workgroup-scope fence: the
 //     CU's vector cache is coherent for its own waves, so that is a counter wait only).
 //
@@ -169,7 +169,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *d_comp, const void *d_blocks, uint
                                int n_cu, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
-    const uint32_t cap = (uint32_t)n_cu * 18u;  // 18 single-wave workgroups (8.7 KiB of LDS each) per CU
+    const uint32_t cap = (uint32_t)n_cu * kInflateWavesPerCu;  // single-wave workgroups: 20 per CU (inflate_core.hpp)
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < cap ? n_blocks : cap), dim3(kWave), 0, st, d_comp, (const BgzfBlock *)d_blocks,
                        n_blocks, d_out, d_status);
     return hipGetLastError();

@@ -465,7 +465,7 @@ hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, ui
         hipError_t e = hipMemsetAsync(d_bounds, 0, 16, st);
         if (e != hipSuccess) return e;
     }
-    const uint32_t cap = (uint32_t)n_cu * 18u;
+    const uint32_t cap = (uint32_t)n_cu * kInflateWavesPerCu;
     hipLaunchKernelGGL(k_gz_sym_inflate, dim3(n_chunks < cap ? n_chunks : cap), dim3(kWave), 0, st, d_comp, (const GzChunk *)d_chunks,
                        n_chunks, d_sym, sym_cap, (GzMeta *)d_meta, d_bounds ? (GzBound *)((uint8_t *)d_bounds + 16) : nullptr, bounds_cap,
                        (uint32_t *)d_bounds);
@@ -475,7 +475,7 @@ hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const
                                  hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t cap = (uint32_t)n_cu * 18u;
+    const uint32_t cap = (uint32_t)n_cu * kInflateWavesPerCu;
     hipLaunchKernelGGL(k_gz_find_starts, dim3(n < cap ? n : cap), dim3(kWave), 0, st, d_comp, comp_len, (const GzSlice *)d_slices, n, d_found);
     return hipGetLastError();
 }

@@ -7,8 +7,14 @@
 namespace hpn {
 
 constexpr uint32_t kRing = 1024;             // compressed-input ring (bytes), refilled by halves
-constexpr uint32_t kLitRoot = 10, kDistRoot = 8;
-constexpr uint32_t kLitSize = 1024 + 384, kDistSize = 256 + 144;  // root + sub-tables (inftrees.c ENOUGH: 1332 for a 10-bit root)
+// Root bits and table sizes (root + sub-tables).  The sub-tables are sized like zlib's (inftrees.c: per root prefix, for the
+// longest code under it), so its bound holds: `enough 286 9 15` = 852 entries for the literal/length table; the distance table's
+// worst case is exactly 400 (30 symbols, 8-bit root: every length distribution enumerated).  A 9-bit literal root instead of
+// 10 bits: with 4 KiB instead of 5.5 for that table a decoder takes six of the CU's 1,280-byte LDS granules instead of seven
+// (scripts/micro/lds_occupancy.hip), 20 decoders per CU instead of 18 -- gz 44.0 -> 48.7, BGZF 39.5 -> 42.1 GB/s; codes longer
+// than the root are looked up a second time by the lanes that hold them (window()).
+constexpr uint32_t kLitRoot = 9, kDistRoot = 8;
+constexpr uint32_t kLitSize = 512 + 512, kDistSize = 256 + 144;
 
 // table entry: [31:16] value, [15:8] extra-bit count (or sub-table index bits), [7:4] kind, [3:0] code bits
 enum { kLit = 0, kLit2 = 1, kLen = 2, kEob = 3, kSub = 4, kDist = 5, kBad = 15 };  // literal kinds first: one compare
@@ -24,6 +30,9 @@ struct InfLds {
     uint8_t lens[384];     // code lengths being assembled (19 code-length codes | 286 + 30 lengths from offset 32)
     uint16_t count[16], first[16], next[16];
 };
+
+static_assert(sizeof(InfLds) <= 6 * 1280, "six LDS granules per decoder: 20 of them per CU (5 waves per SIMD at <= 96 VGPRs)");
+constexpr uint32_t kInflateWavesPerCu = 20;
 
 struct Bits {  // wave-uniform bit reader over the LDS ring
     u64 bb = 0;
@@ -228,6 +237,15 @@ __device__ __forceinline__ Win window(const InfLds &s, Pos p)
     w.raw = v >> (q & 7u);
     w.el = s.lit[w.raw & ((1u << kLitRoot) - 1u)];
     w.ed = s.dist[w.raw & ((1u << kDistRoot) - 1u)];
+    // codes longer than a root table: the lanes that hold one take the second-level entry themselves and count the root's bits
+    // into it -- the walk sees a plain entry of up to 15 bits (left to the serial reader, each such code on the chain is a
+    // detour of a thousand clocks: rare length codes and the 256-symbol alphabets of BAM blocks have them)
+    if (__ballot(((w.el >> 4) & 15u) == kSub)) {
+        if (((w.el >> 4) & 15u) == kSub) w.el = s.lit[(w.el >> 16) + ((w.raw >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
+    }
+    if (__ballot(((w.ed >> 4) & 15u) == kSub)) {
+        if (((w.ed >> 4) & 15u) == kSub) w.ed = s.dist[(w.ed >> 16) + ((w.raw >> kDistRoot) & ((1u << ((w.ed >> 8) & 15u)) - 1u))] + kDistRoot;
+    }
     return w;
 }
 __device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
