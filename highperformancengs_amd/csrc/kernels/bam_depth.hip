@@ -1194,8 +1194,11 @@ __global__ __launch_bounds__(256) void k_win_from_runs(const hpn_run *__restrict
 constexpr int kFmtThreads = 256, kFmtPer = 2, kFmtSub = kFmtThreads * kFmtPer;   // 512 runs are staged at a time ...
 constexpr int kFmtSubs = 8, kFmtTile = kFmtSub * kFmtSubs;   // ... and a workgroup takes 8 such pieces in a row: one chain entry
                                                              // per 4096 runs (one per 512 was 131 K entries x ~14 ns = 1.9 of 2.0 ms)
-constexpr int kFmtLds = 40960;                    // bytes of text a piece may stage (512 lines of up to 80 bytes)
-constexpr int kFmtMaxName = kFmtLds / kFmtSub - 34;   // longest target name the staged path takes (46)
+// bytes of text a piece may stage (512 lines of up to 78 bytes).  With the kernel's other ~600 bytes this stays within 32 of the
+// CU's LDS granules of 1,280 bytes (scripts/micro/lds_occupancy.hip): four workgroups per CU; 40,960 bytes of text were 33 granules
+// and three.
+constexpr int kFmtLds = 39936;
+constexpr int kFmtMaxName = kFmtLds / kFmtSub - 34;   // longest target name the staged path takes (44)
 
 __device__ __forceinline__ int dec_digits(uint32_t v)
 {

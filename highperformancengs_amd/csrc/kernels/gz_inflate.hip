@@ -18,6 +18,9 @@
 // Bounds: k_gz_sym_inflate by instruction issue like k_bgzf_inflate (the same decoder: symbols 64 bit
 // offsets at a time, inflate_core.hpp); the other two are small streaming passes.  CRC-32 is not checked here (ISIZE is,
 // by the caller); anything malformed sets a status and the host readers take the file.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.hpp"
 #include "inflate_core.hpp"
 
@@ -426,6 +429,85 @@ __global__ __launch_bounds__(kGzWinThreads) void k_gz_windows(const uint16_t *__
     if (tid == 0) summary[0] = text, summary[1] = bad, summary[2] = bad_at, summary[3] = fin;
 }
 
+// The same walk with the history in LDS, for a call that has the chip to itself (one worker: nobody else's decoders hold the
+// CUs' LDS, which is what made a 64 KiB workgroup wait for a whole stretch time when several contexts inflate side by side).
+// A thread takes eight groups of four consecutive positions: the four symbols in one 8-byte load (the NEXT stretch's, in flight
+// while this one is resolved), the placeholders among them looked up in LDS, the four bytes written as one dword to the other
+// half of the LDS image and to the global copy k_gz_translate reads: 5,120 stretches 25.5 -> 17 ms (3.3 us per stretch; the
+// prefetch's loads still end up on the chain: the compiler's s_waitcnt placement waits for the newest load where an older one
+// is used, whichever way the sets are rotated -- deeper prefetching by hand gave the same 17 ms or worse).
+__global__ __launch_bounds__(1024) void k_gz_windows_lds(const uint16_t *__restrict__ symbuf, uint32_t sym_cap, GzMeta *__restrict__ meta,
+                                                         uint32_t n_chunks, const uint8_t *__restrict__ window_in, uint8_t *windows,
+                                                         uint8_t *__restrict__ window_out, u64 *__restrict__ summary)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[2][kGzHist];
+    constexpr int kGroups = (int)(kGzHist / (1024 * 4));           // 8
+    const uint32_t tid = threadIdx.x;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+        uint32_t v = 0;
+        if (window_in) __builtin_memcpy(&v, window_in + j, 4);
+        *(uint32_t *)(s_win[0] + j) = v;
+        *(uint32_t *)(windows + j) = v;
+    }
+    // the four symbols of group g of the history behind stretch k, before the look-up (two to a register)
+    auto tail4 = [&](uint32_t k, uint32_t j) -> u32x2 {
+        const int32_t d = (int32_t)meta[k].n_out - (int32_t)kGzHist;   // symbol j of the history = symbol d + j of the stretch
+        const uint16_t *base = symbuf + (uint64_t)k * sym_cap + (int64_t)d;
+        u32x2 r;
+        if ((int32_t)j + d >= 0) {
+            __builtin_memcpy(&r, base + j, 8);
+        } else {
+            uint32_t e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = (int32_t)(j + i) + d >= 0 ? (uint32_t)base[j + i] : 256u + (uint32_t)((int32_t)kGzHist + (int32_t)(j + i) + d);
+            r = u32x2{e[0] | e[1] << 16, e[2] | e[3] << 16};
+        }
+        return r;
+    };
+    u32x2 sv[kGroups], nx[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) sv[g] = n_chunks ? tail4(0, ((uint32_t)g * 1024u + tid) * 4u) : u32x2{0, 0};
+    __syncthreads();
+    u64 text = 0;
+    uint32_t bad = 0, bad_at = 0, fin = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t n = meta[k].n_out, st = meta[k].status;
+        if (st && !bad) bad = st, bad_at = k;
+        if (meta[k].final_block) fin = k + 1u;
+        if (tid == 0) meta[k].text_off = text;
+        text += n;
+        const uint8_t *cur = s_win[k & 1];
+        uint8_t *nxt = s_win[(k + 1) & 1], *gout = windows + (uint64_t)(k + 1) * kGzHist;
+        if (k + 1 < n_chunks) {
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) nx[g] = tail4(k + 1, ((uint32_t)g * 1024u + tid) * 4u);
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+            const uint32_t e0 = sv[g][0] & 0xffffu, e1 = sv[g][0] >> 16, e2 = sv[g][1] & 0xffffu, e3 = sv[g][1] >> 16;
+            const uint32_t b0 = e0 < 256u ? e0 : cur[e0 - 256u], b1 = e1 < 256u ? e1 : cur[e1 - 256u];
+            const uint32_t b2 = e2 < 256u ? e2 : cur[e2 - 256u], b3 = e3 < 256u ? e3 : cur[e3 - 256u];
+            const uint32_t v = b0 | b1 << 8 | b2 << 16 | b3 << 24;
+            *(uint32_t *)(nxt + j) = v;
+            *(uint32_t *)(gout + j) = v;
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) sv[g] = nx[g];
+        __syncthreads();
+    }
+    if (window_out) {
+        const uint8_t *last = s_win[n_chunks & 1];
+        for (int g = 0; g < kGroups; ++g) {
+            const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+            *(uint32_t *)(window_out + j) = *(const uint32_t *)(last + j);
+        }
+    }
+    if (tid == 0) summary[0] = text, summary[1] = bad, summary[2] = bad_at, summary[3] = fin;
+}
+
 // symbols -> bytes: blockIdx.y = stretch, the x blocks stride over its symbols (8 per thread and step)
 constexpr int kGzTrThreads = 256;
 __global__ __launch_bounds__(kGzTrThreads) void k_gz_translate(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
@@ -482,7 +564,13 @@ hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
                              uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st)
 {
-    if (n_chunks > (uint32_t)n_cu * 6u)
+    // (a call of more than half a chip-fill of stretches comes from a worker that has the device to itself: tally_gz_on_gpu
+    // divides the chip's 5,120 slots among the workers in flight)
+    const char *how = getenv("HPN_GZ_WINDOWS");                  // lds / global: tests and A/B runs
+    if (how ? !strcmp(how, "lds") : n_chunks > (uint32_t)n_cu * 12u)
+        hipLaunchKernelGGL(k_gz_windows_lds, dim3(1), dim3(1024), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in, d_windows,
+                           d_window_out, d_summary);
+    else if (n_chunks > (uint32_t)n_cu * 6u)
         hipLaunchKernelGGL(k_gz_windows<1024>, dim3(1), dim3(1024), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in,
                            d_windows, d_window_out, d_summary);
     else

@@ -296,6 +296,27 @@ def test_crc32_of_spans_equals_zlib():
     ctx.close()
 
 
+@pytest.mark.parametrize("how", ["lds", "global"])
+def test_histories_in_lds_and_in_memory(ctx, how, monkeypatch):
+    """k_gz_windows_lds (calls that have the chip to themselves) and k_gz_windows walk the same chain: forced by HPN_GZ_WINDOWS
+    on a stream of many short stretches (placeholders ride from stretch to stretch; stretches shorter than 32 KiB hand the
+    history in front of them on), with and without a history handed in."""
+    monkeypatch.setenv("HPN_GZ_WINDOWS", how)
+    rng = np.random.default_rng(41)
+    text = _fastq(rng, 12000)
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(text), 60)) | {5, 9, 40000, 40010})
+    pieces = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+    comp, starts = _stream(pieces, 6, zlib.Z_SYNC_FLUSH)
+    info, got, wout = _run(ctx, comp, starts, pieces)
+    assert info.status == 0 and got == text and wout == text[-32768:]
+    half = len(pieces) // 2
+    n1 = starts[half]
+    info1, got1, w1 = _run_partial(ctx, comp, starts[:half], n1, pieces[:half])
+    assert info1.status == 0 and got1 == b"".join(pieces[:half])
+    info2, got2, w2 = _run(ctx, comp[n1:], [s - n1 for s in starts[half:]], pieces[half:], window=w1)
+    assert info2.status == 0 and got2 == b"".join(pieces[half:]) and w2 == text[-32768:]
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_window_decoder_fuzz_with_unknown_history(ctx, seed):
     """The payloads of tests/test_bgzf_inflate_gpu.py::test_window_decoder_fuzz as ONE stream cut at flush points: matches
