@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` IS the number of ranks.  Under a launcher (WORLD_SIZE in the environment) the rank checks WORLD_SIZE == N and
+stops otherwise; without one and N > 1 this process becomes the launcher: it starts N fresh rank processes (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), never touches a GPU itself, relays rank 0's JSON line and exits non-zero when any
+rank fails or the job times out.  N ranks need N devices: on a smaller node every rank stops with that message.
+
 The headline: a step = one pass of hpn_fastq_tally over the rank's resident batch of synthetic
 reads (BASELINE.json configs[1]: 1e9 x 150 bp per GPU, generated in HBM by the
 counter-based generator), plus -- for N > 1 -- the one sum all-reduce of the
@@ -42,7 +47,128 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip the exact check, the other kernels and the end-to-end legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--rank-timeout", type=float, default=3000.0, help="launcher: seconds the N ranks may take together")
     return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------
+# --gpus N without a launcher: this process starts the N ranks (and does nothing else)
+# --------------------------------------------------------------------------------------
+def launch_ranks(a):
+    """N fresh processes, one per GPU, each running this file as a rank; stands where reduceStats' caller starts its
+    workers (fastq_count_kthread.c:270, klib/kthread.c:48).  No exec, no GPU call in this process."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HPN_BENCH_LAUNCHER="bench.py")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # rank 0's pipe never fills
+    reader.start()
+    deadline = time.time() + a.rank_timeout
+    failed = None
+    live = set(range(a.gpus))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, f"exit code {rc}")
+                break
+        if live and failed is None:
+            if time.time() > deadline:
+                failed = (min(live), f"still running after {a.rank_timeout:.0f} s")
+            else:
+                time.sleep(0.2)
+    if failed is not None:
+        for r in live:   # exactly the processes started above, by pid
+            procs[r].kill()
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+        print(f"[bench] rank {failed[0]} of {a.gpus} failed ({failed[1]}): no result", file=sys.stderr)
+        return 1
+    reader.join(timeout=30)
+    lines = [l for l in (out0[0].decode() if out0 else "").splitlines() if l.startswith("{")]
+    if not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+class HipBackend:
+    """Where the ranks' buffers live and what makes their contexts: torch for device memory and torch.distributed, the
+    library's hpn_ctx for everything else.  (tests/stub/bench_backend.py is the CPU counterpart the launcher test injects
+    with HPN_BENCH_BACKEND; it is never used otherwise.)"""
+    name, device, dist_backend = "hip", "cuda", "nccl"
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+
+    def n_devices(self):
+        return self.torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+
+    def open(self, local):
+        import highperformancengs_amd as hp
+        if not self.torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        self.torch.cuda.set_device(local)
+        self.local = local
+        self.ctx = hp.Context(local)
+        return self.ctx
+
+    def dist_kwargs(self):
+        return {"device_id": self.torch.device("cuda", self.local)}
+
+    def unique_id(self):
+        import highperformancengs_amd as hp
+        return hp.comm_unique_id()
+
+    def resident_batch(self, n, L, rank):
+        from highperformancengs_amd import shard
+        torch = self.torch
+        free, _total = torch.cuda.mem_get_info()
+        need = n * (L + 8) + (1 << 30)
+        if need > free * 0.92:  # smaller HBM than expected: shrink the resident batch, say so
+            n = int(free * 0.92 - (1 << 30)) // (L + 8)
+        first = shard.weak_shard_first(rank, n)  # global record index of this shard (counter-based generator)
+        d_qual = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+        d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        self.ctx.synth_fastq_dev(12345, first, n, L, d_qual, None, d_off)
+        self.ctx.sync()
+        return d_qual, d_off, n, first
+
+    def sync(self):
+        self.ctx.sync()
+        self.torch.cuda.synchronize()
+
+    def rccl_ranks(self):
+        try:
+            return self.ctx.comm_count()
+        except Exception:  # noqa: BLE001
+            return None
+
+
+def make_backend():
+    spec = os.environ.get("HPN_BENCH_BACKEND")
+    if not spec:
+        return HipBackend()
+    import importlib
+    mod, _, attr = spec.partition(":")
+    return getattr(importlib.import_module(mod), attr or "Backend")()
 
 
 # --------------------------------------------------------------------------------------
@@ -122,43 +248,46 @@ def cpu_baseline(read_len, target_s):
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    import torch
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a {a.gpus}-GPU number "
+              f"from {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
+    import torch  # noqa: F401
     import torch.distributed as dist
-    import highperformancengs_amd as hp
-    from highperformancengs_amd import _lib, shard
+    import highperformancengs_amd as hp  # noqa: F401
+    from highperformancengs_amd import _lib, shard  # noqa: F401
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
+    be = make_backend()
+    have = be.n_devices()
+    if have < world:   # every rank sees the same count and stops here, before any rendezvous
+        print(f"bench.py: {world} ranks need {world} devices, this node has {have} (one process per GPU; "
+              f"ranks never share a device)", file=sys.stderr)
+        sys.exit(2)
+    ctx = be.open(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    ctx = hp.Context(local)
+        dist.init_process_group(be.dist_backend, rank=rank, world_size=world, **be.dist_kwargs())
 
     # ---- resident batch: this rank's shard of the N x 1e9-read job -------------------
     L = a.read_len
-    n = int(a.reads)
-    free, _total = torch.cuda.mem_get_info()
-    need = n * (L + 8) + (1 << 30)
-    if need > free * 0.92:  # smaller HBM than expected: shrink the resident batch, say so
-        n = int(free * 0.92 - (1 << 30)) // (L + 8)
-    first = shard.weak_shard_first(rank, n)  # global record index of this shard (counter-based generator)
-    d_qual = torch.empty(n * L, dtype=torch.uint8, device="cuda")
-    d_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    ctx.synth_fastq_dev(12345, first, n, L, d_qual, None, d_off)
-    ctx.sync()
+    d_qual, d_off, n, first = be.resident_batch(int(a.reads), L, rank)
 
     # ---- the one collective: native RCCL on the context's stream, else torch.distributed (shard.ShardedTally) --
-    job = shard.ShardedTally(ctx, rank, world, device="cuda", full_matrix=a.full_matrix)
-    allreduce = job.setup(hp.comm_unique_id)
+    job = shard.ShardedTally(ctx, rank, world, device=be.device, full_matrix=a.full_matrix)
+    allreduce = job.setup(be.unique_id)
     if allreduce == "torch.distributed" and rank == 0:
         print(f"[bench] native RCCL init failed on some rank ({getattr(job, 'why', 'another rank')}); using torch.distributed",
               file=sys.stderr)
     from highperformancengs_amd import api as _api
-    rccl_lib = _api.comm_library() if allreduce.startswith("rccl") or world == 1 else None   # which librccl the native binding resolved to
+    rccl_lib = _api.comm_library() if be.name == "hip" and (allreduce.startswith("rccl") or world == 1) else None   # which librccl the native binding resolved to
+    rccl_ranks = be.rccl_ranks() if allreduce.startswith("rccl") else None   # ncclCommCount of this rank's communicator
     kernel_ms = []
 
     def step():
@@ -167,11 +296,10 @@ def main():
         return out
 
     def fence():
-        ctx.sync()
-        torch.cuda.synchronize()
+        be.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.sync()
 
     for _ in range(a.warmup):
         out = step()
@@ -181,7 +309,9 @@ def main():
     for _ in range(a.steps):
         out = step()
     fence()
-    dt = shard.max_over_ranks(time.perf_counter() - t0, "cuda")
+    dt = shard.max_over_ranks(time.perf_counter() - t0, be.device)
+    k_mine = sum(kernel_ms) / max(1, len(kernel_ms))
+    k_ranks = shard.gather_floats(k_mine, be.device)   # every rank's mean kernel time, in rank order
 
     # ---- result checks (after the timed region) ------------------------------------------------
     # closed form: every record of every rank counted once, at its length
@@ -198,7 +328,8 @@ def main():
         if world == 1:
             assert (out["total"], out["q20"], out["q30"]) == (local["total"], local["q20"], local["q30"])
     del d_qual, d_off
-    torch.cuda.empty_cache()
+    if be.name == "hip":
+        torch.cuda.empty_cache()
     if world == 1 and not a.no_extra:
         extra["plain_traffic"] = bench_extra.plain_traffic()
         extra["kernel_legs"] = bench_extra.kernel_legs(ctx)
@@ -234,10 +365,13 @@ def main():
                        "reads_per_gpu": n, "read_len": L, "kernel": "k_tally_hist" if a.full_matrix else "k_tally_scan",
                        "outputs": "SeqLen[512], sum, Q20, Q30" + (", Quality[128][512]" if a.full_matrix else ""),
                        "parallelism": f"record-block shard x{world}", "allreduce": allreduce,
-                       "rccl_library": rccl_lib},
+                       "rccl_library": rccl_lib, "rccl_ranks": rccl_ranks, "ranks": world,
+                       "launcher": os.environ.get("HPN_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("none" if world == 1 else "external")),
+                       **({} if be.name == "hip" else {"backend": be.name})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": round(k_ms, 4), "kernel_ms_per_rank": [round(x, 4) for x in k_ranks],
+                         "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -18,7 +18,7 @@ TALLY_QUAL_HIST, TALLY_NUC_HIST = 1, 2
 DEPTH_ANY_ORDER = 0x80000000
 UNIQUE_ID_BYTES = 128
 
-OK, E_NODEVICE, E_HIP, E_ARG, E_DOMAIN, E_NOMEM, E_STATE, E_RCCL, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7, -8
+OK, E_NODEVICE, E_HIP, E_ARG, E_DOMAIN, E_NOMEM, E_STATE, E_RCCL, E_CAPACITY, E_PARTIAL = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 
 
 class HpnError(RuntimeError):
@@ -114,6 +114,8 @@ SYMBOLS = [
     ("hpn_fastq_text_piece_trim", _int, [_vp, _u64, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("hpn_gz_inflate_dev", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
+    ("hpn_gz_inflate_begin_dev", _int, [_vp, _vp, _vp, _u32, _u32]),
+    ("hpn_gz_inflate_finish_dev", _int, [_vp, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
     ("hpn_gz_members", _int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     ("hpn_crc32_dev", _int, [_vp, _vp, _vp, _u32, _vp]),
     ("hpn_gz_find_starts_dev", _int, [_vp, _vp, C.c_uint64, _vp, _u32, _vp]),
@@ -140,6 +142,7 @@ SYMBOLS = [
     ("hpn_comm_init_all", _int, [C.POINTER(_vp), _int]),
     ("hpn_allreduce_u64_all", _int, [C.POINTER(_vp), C.POINTER(_vp), _int, _sz]),
     ("hpn_comm_library", C.c_char_p, []),
+    ("hpn_comm_count", _int, [_vp, C.POINTER(_int)]),
     ("hpn_synth_fastq_dev", _int, [_vp, _u64, _u64, _u64, _u32, _vp, _vp, _vp]),
 ]
 

@@ -384,6 +384,12 @@ class Context:
     def allreduce_u64(self, d_vec, n):
         self._ck(self.L.hpn_allreduce_u64(self.h, _ptr(d_vec), n), "hpn_allreduce_u64")
 
+    def comm_count(self) -> int:
+        """Ranks of this context's communicator as RCCL reports them (ncclCommCount)."""
+        n = C.c_int(0)
+        self._ck(self.L.hpn_comm_count(self.h, C.byref(n)), "hpn_comm_count")
+        return n.value
+
     def synth_fastq_dev(self, seed, first, n, length, d_qual, d_base, d_off):
         self._ck(self.L.hpn_synth_fastq_dev(self.h, seed, first, n, length, _ptr(d_qual), _ptr(d_base), _ptr(d_off)),
                  "hpn_synth_fastq_dev")

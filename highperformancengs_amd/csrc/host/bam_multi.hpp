@@ -177,11 +177,12 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
     if (hpn_device_count(&devices) != HPN_OK || devices < 1) devices = 1;
     // Finished targets wait in host memory until every earlier one is written (a chr1 at 30x is ~2.6 GB of bedGraph
     // text): a worker takes a target only while the estimated bytes of everything claimed and not yet emitted stay
-    // within a budget -- except the lowest unclaimed target, which is always allowed (it is what the writer waits for).
+    // within a budget -- except the target the writer is waiting for, and anything at all when nothing is held back.
     const uint64_t budget = getenv("HPN_DEPTH_LOOKAHEAD") ? strtoull(getenv("HPN_DEPTH_LOOKAHEAD"), nullptr, 10) : (uint64_t)12 << 30;
     auto estimate = [&](int32_t j) { return (uint64_t)hdr.target_len[j] * 12u; };
     std::vector<char> claimed((size_t)nt, 0);
-    uint64_t outstanding = 0;
+    uint64_t outstanding = 0, peak_outstanding = 0, budget_waits = 0;
+    int32_t emit_at = 0;   // the target the writer will emit next
     auto work = [&](int w) {
         hpn_ctx *ctx = pooled_worker_ctx(w, w % devices);
         bool ok = ctx != nullptr;
@@ -195,19 +196,20 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
                 if (!ok) failed = true;
                 for (;;) {
                     if (failed || next >= order.size()) break;
-                    int32_t lowest = -1;
-                    for (int32_t t = 0; t < nt && lowest < 0; ++t)
-                        if (!claimed[(size_t)t]) lowest = t;
-                    for (int32_t t : order)   // largest first
-                        if (!claimed[(size_t)t] && (t == lowest || outstanding + estimate(t) <= budget)) {
-                            j = t;
-                            break;
-                        }
+                    // the target the writer is waiting for must be worked on whatever the budget says; so may anything when nothing
+                    // is held back; every other target only while it fits -- else wait until emit() has given bytes back
+                    if (emit_at < nt && !claimed[(size_t)emit_at]) j = emit_at;
+                    for (size_t k = 0; j < 0 && k < order.size(); ++k) {   // largest first
+                        const int32_t t = order[k];
+                        if (!claimed[(size_t)t] && (outstanding == 0 || outstanding + estimate(t) <= budget)) j = t;
+                    }
                     if (j >= 0) break;
+                    ++budget_waits;
                     cv.wait(lk);
                 }
                 if (j < 0) break;
                 claimed[(size_t)j] = 1, ++next, outstanding += estimate(j);
+                if (outstanding > peak_outstanding) peak_outstanding = outstanding;
             }
             TargetOut &o = out[(size_t)j];
             int rc = hpn_depth_begin_w(ctx, j, hdr.target_len[j], mask, want_win ? window : 0u);
@@ -273,6 +275,7 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
             {
                 std::lock_guard<std::mutex> lk(m);
                 outstanding -= estimate(j);
+                emit_at = j + 1;
             }
             cv.notify_all();
         }
@@ -283,6 +286,9 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
     }
     cv.notify_all();
     for (auto &t : th) t.join();
+    if (getenv("HPN_TIMING"))
+        fprintf(stderr, "[hpn] look-ahead: at most %.1f MB of estimated output claimed and not yet written (budget %.1f MB), %llu waits for the writer\n",
+                peak_outstanding / 1e6, budget / 1e6, (unsigned long long)budget_waits);
     return good;
 }
 

@@ -10,6 +10,7 @@
 #include "../host/gz_gpu.hpp"
 #include "../host/text_stream.hpp"
 #include "../host/text_shard.hpp"
+#include "../host/gz_shard.hpp"
 #include "hpngs.h"
 
 namespace hpn {
@@ -125,6 +126,11 @@ inline bool is_bgzf_file(const char *path)
     close(fd);
     return ok;
 }
+inline uint64_t bgzf_text_slice()   // HPN_BGZF_SLICE: tests cut small files into several calls
+{
+    const char *e = getenv("HPN_BGZF_SLICE");
+    return e && atoll(e) >= 4096 ? (uint64_t)atoll(e) : (uint64_t)256 << 20;
+}
 inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *unusable)
 {
     *unusable = false;
@@ -135,7 +141,6 @@ inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
     }
     const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
     int rc = hpn_fastq_text_begin(ctx);
-    bool sent_last = false;
     while (rc == HPN_OK && !*unusable) {
         hpn_raw_info bi;
         const int r = gs.next(&bi);
@@ -143,16 +148,20 @@ inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
             *unusable = true;
             break;
         }
-        hpn_text_info info;
         const bool last = r == 0 || gs.at_eof();
-        rc = hpn_fastq_text_count(ctx, gs.d_raw(), r == 0 ? 0 : bi.n_records, last, flags, &info);
-        if (rc == HPN_OK && info.irregular) *unusable = true;
-        if (last) {
-            sent_last = true;
-            break;
+        // One inflate launch covers up to four chunks of compressed bytes: at a ratio of 6 (binned qualities) that is past the
+        // 2 GiB one hpn_fastq_text_count call frames.  The text is cut anywhere, as on the gzip route below.
+        const uint64_t n = r == 0 ? 0 : bi.n_records, slice = bgzf_text_slice();
+        for (uint64_t at = 0; rc == HPN_OK && !*unusable && (at < n || (last && n == 0));) {
+            const uint64_t k = n - at < slice ? n - at : slice;
+            hpn_text_info info;
+            rc = hpn_fastq_text_count(ctx, (const uint8_t *)gs.d_raw() + at, k, last && at + k == n, flags, &info);
+            if (rc == HPN_OK && info.irregular) *unusable = true;
+            at += k;
+            if (n == 0) break;
         }
+        if (last) break;
     }
-    (void)sent_last;
     if (*unusable || rc != HPN_OK) {
         hpn_tally scratch;
         memset(&scratch, 0, sizeof scratch);
@@ -246,6 +255,11 @@ inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_
         if (!unusable) return rc;
     }
     if (text_path_enabled() && !is_stdin && gz_gpu_enabled() && !getenv("HPN_NO_MGZ") && !getenv("HPN_NO_PGZ") && is_plain_gzip_file(path)) {
+        if (group && group->lanes() > 1) {      // batches of its stretches over one context per device (host/gz_shard.hpp)
+            bool unusable = false;
+            const int rc = tally_gz_sharded(*group, path, acc, &unusable);
+            if (!unusable) return rc;
+        }
         bool unusable = false;
         const int rc = tally_gz_on_gpu(ctx, path, acc, &unusable);
         if (!unusable) return rc;

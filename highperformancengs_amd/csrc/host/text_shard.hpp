@@ -29,6 +29,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -98,6 +99,11 @@ public:
                 for (size_t k = 1; k < ctx_.size(); ++k) drop(ctx_[k]);
                 return rc;
             }
+            if (rc == HPN_E_PARTIAL) {   // some lanes may hold sums already: adding the vectors again would count records twice
+                fprintf(stderr, "[hpn] RCCL all-reduce failed half-way (%s): this input is abandoned\n", hpn_ctx_last_error(ctx_[0]));
+                drop_all();
+                return rc;
+            }
             fprintf(stderr, "[hpn] RCCL all-reduce failed (%s): the lanes' vectors are added on the host\n", hpn_ctx_last_error(ctx_[0]));
         }
         int rc = HPN_OK;
@@ -127,7 +133,10 @@ private:
     {
         const char *e = getenv("HPN_ALLREDUCE");
         if (e && !strcmp(e, "host")) return false;
-        return distinct_ && ctx_.size() > 1;   // one RCCL rank per device: lanes that share a device add on the host
+        // one RCCL rank per device: lanes that share a device add on the host (HPN_COMM_SHARED_DEVICE=1, tests: hpn_comm_init_all
+        // is asked all the same -- the RCCL stand-in of tests/stub accepts them, the real library refuses and the host adds)
+        const char *sh = getenv("HPN_COMM_SHARED_DEVICE");
+        return (distinct_ || (sh && sh[0] == '1')) && ctx_.size() > 1;
     }
     std::vector<hpn_ctx *> ctx_;
     int base_, rel_, ndev_;
@@ -154,7 +163,13 @@ inline int shard_lanes_for(const char *path, int devices_for_me, bool pair_on_on
     const int fd = open(path, O_RDONLY);
     const ssize_t k = fd >= 0 ? pread(fd, magic, 2, 0) : 0;
     if (fd >= 0) close(fd);
-    if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return 1;
+    if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        // gzip: the device inflate is the wall, and its batches spread over the devices (host/gz_shard.hpp, bam_gpu.hpp's
+        // block fan-out for BGZF) -- one lane per 512 MiB of compressed bytes, from 256 MiB on
+        if (devices_for_me < 2 || sb.st_size < ((off_t)256 << 20)) return 1;
+        const long long want = (long long)(sb.st_size >> 29) + 1;
+        return (int)(want < devices_for_me ? want : devices_for_me);
+    }
     const long long lanes = (long long)(sb.st_size >> 31) + 1;
     if (devices_for_me < 2) return lanes >= 3 ? 2 : 1;
     return (int)(lanes < devices_for_me ? lanes : devices_for_me);
@@ -236,6 +251,9 @@ public:
     uint64_t pieces() const { return n_pieces_; }
     uint64_t bytes() const { return n_bytes_; }
     uint64_t records() const { return n_records_; }
+    // Called once, by the lane that stops the route, after the reason is recorded: whatever ELSE a lane may be blocked in
+    // (fastq_trim: OrderedWriter::acquire behind a slab that will now never come) must be woken from here.
+    void on_stop(std::function<void()> f) { on_stop_ = std::move(f); }
 
     // second(lane, ctx, piece, lines_before, info): the piece's second half (count or trim + hand-over of its output);
     // returns an hpn status.  Runs until the stream ends or something stops the route.
@@ -304,16 +322,18 @@ private:
     }
     void stop(int rc, hpn_ctx *ctx, bool irregular)
     {
+        bool first = false;
         {
             std::lock_guard<std::mutex> lk(m_);
-            if (!stop_) {
-                stop_ = true;
+            if (!stop_) {   // the first reason stands: a lane woken by the stop reports HPN_E_STATE afterwards, which is not why
+                stop_ = first = true;
                 irregular_ = irregular;
                 rc_ = rc;
                 bad_ctx_ = ctx;
             }
         }
         cv_.notify_all();
+        if (first && on_stop_) on_stop_();
     }
 
     template <class Second>
@@ -371,6 +391,7 @@ private:
     bool closed_ = false, stop_ = false, irregular_ = false;
     int rc_ = HPN_OK;
     hpn_ctx *bad_ctx_ = nullptr;
+    std::function<void()> on_stop_;
     uint64_t n_pieces_ = 0, n_bytes_ = 0, n_records_ = 0;
 };
 
@@ -436,8 +457,8 @@ public:
     void *acquire(int lane, int *idx)
     {
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return !lane_free_[(size_t)lane].empty() || stop_; });
-        if (lane_free_[(size_t)lane].empty()) return nullptr;
+        cv_.wait(lk, [&] { return !lane_free_[(size_t)lane].empty() || stop_ || cancel_; });
+        if (cancel_ || lane_free_[(size_t)lane].empty()) return nullptr;
         *idx = lane_free_[(size_t)lane].front();
         lane_free_[(size_t)lane].pop_front();
         return buf_[(size_t)*idx];
@@ -455,6 +476,16 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             lane_free_[(size_t)lane].push_back(idx);
+        }
+        cv_.notify_all();
+    }
+    // The route is being abandoned: a lane waiting for a slab (both of its own queued behind a sequence number that
+    // will never be submitted) gets nullptr instead of waiting for ever; what is already in sequence is still written.
+    void cancel()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            cancel_ = true;
         }
         cv_.notify_all();
     }
@@ -492,7 +523,7 @@ private:
     }
     hpn_ctx *ctx_;
     FILE *out_;
-    bool ok_ = false, stop_ = false;
+    bool ok_ = false, stop_ = false, cancel_ = false;
     std::vector<void *> buf_;
     std::vector<std::deque<int>> lane_free_;
     std::map<uint64_t, Job> todo_;
@@ -517,6 +548,7 @@ inline int trim_text_sharded(LaneGroup &g, const char *path, int32_t S, int32_t 
     const size_t ocap = run.piece_bytes() + HPN_TEXT_PIECE_TAIL + 8192 + 64;
     OrderedWriter writer(g.ctx(0), out, ocap, g.lanes());
     if (!writer.ok()) return HPN_E_NOMEM;
+    run.on_stop([&writer] { writer.cancel(); });
     const double t1 = wall_s();
     run.run([&](int lane, hpn_ctx *ctx, const PieceRun::Piece &p, uint64_t before, hpn_text_info *info) {
         int oi = -1;

@@ -97,7 +97,10 @@ public:
         if (!is_stdin && stat(path, &sb) == 0 && S_ISREG(sb.st_mode)) {
             // small inputs get small buffers (pinning memory costs ~0.3 ms per MB): the whole
             // plain file + 1 byte, or 16 x the compressed size, rounded up to 64 KiB
-            const uint64_t guess = ((fd_ >= 0 ? (uint64_t)sb.st_size + 1 : (uint64_t)sb.st_size * 16) + 65535) & ~(uint64_t)65535;
+            // (never nothing: an input that did not exist has just been created empty -- open_input_stream's O_CREAT, the reference's
+            // IO_stream.h:127 -- and a reader with buffers of no bytes would hand out empty chunks for ever)
+            uint64_t guess = ((fd_ >= 0 ? (uint64_t)sb.st_size + 1 : (uint64_t)sb.st_size * 16) + 65535) & ~(uint64_t)65535;
+            if (guess < 65536) guess = 65536;
             if (guess < cap_) cap_ = (size_t)guess;
         }
         for (int i = 0; i < nbuf; ++i) {

@@ -29,7 +29,8 @@ hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
                              const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
-                             u64 *n_count, uint32_t *bad, int n_cu, hipStream_t st);
+                             u64 *n_count, uint32_t *bad, uint32_t *todo, int n_cu, hipStream_t st);
+size_t window_todo_words(uint64_t n);
 hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
                             uint32_t *counts, u64 *bases, int32_t *info, hipStream_t st);
 hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *counts,
@@ -393,11 +394,13 @@ int hpn_window_begin(hpn_ctx *c, int32_t n_targets, const uint64_t *win_off, uin
 static int window_add_common(hpn_ctx *c, const hpn_bam_batch *b, uint64_t seq_end)
 {
     uint8_t *m = (uint8_t *)c->w_misc.p;
+    const int rc = scratch_reserve(c, c->w_todo, window_todo_words(b->n) * sizeof(uint32_t));   // passes the fast kernel leaves to k_window_rest
+    if (rc != HPN_OK) return rc;
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamWindow], c->stream));
     HPN_HIP(c, launch_window_add(b->tid, b->pos, b->flag, b->l_qseq, b->seq_off, b->seq4, b->n, seq_end, c->win_W, c->win_targets,
                                  (const uint64_t *)c->w_off.p, (uint32_t *)c->w_bins.p, (u64 *)c->w_gc.p,
                                  (uint32_t *)c->w_len.p, (uint32_t *)(m + 64), (u64 *)(m + 8), (uint32_t *)(m + 16),
-                                 c->n_cu, c->stream));
+                                 (uint32_t *)c->w_todo.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamWindow], c->stream));
     c->ev_valid[kFamWindow] = true;
     return HPN_OK;

@@ -7,6 +7,7 @@
 // (and in processes) that never reduce across GPUs; inside a PyTorch process this
 // resolves to the librccl.so.1 torch already loaded.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -32,6 +33,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
@@ -66,6 +68,7 @@ void rccl_load(Rccl &r)
     r.GroupEnd = (int (*)())dlsym(r.h, "ncclGroupEnd");
     r.CommDestroy = (int (*)(ncclComm_t))dlsym(r.h, "ncclCommDestroy");
     r.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))dlsym(r.h, "ncclAllReduce");
+    r.CommCount = (int (*)(const ncclComm_t, int *))dlsym(r.h, "ncclCommCount");
     r.GetErrorString = (const char *(*)(int))dlsym(r.h, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
     Dl_info di;
@@ -128,13 +131,22 @@ int hpn_allreduce_u64(hpn_ctx *c, uint64_t *d_vec, size_t n)
 
 const char *hpn_comm_library(void) { return rccl().path; }
 
+// HPN_COMM_SHARED_DEVICE=1 (tests only): contexts that share a device are passed on to ncclCommInitAll.  RCCL itself refuses
+// them ("duplicate GPU"), so the switch changes nothing in production; with the test stand-in named by HPN_RCCL_LIB
+// (tests/stub/rccl_stub.cpp) it lets the grouped collective run with n = 2..8 "ranks" on a one-GPU box.
+static bool shared_device_allowed()
+{
+    const char *e = getenv("HPN_COMM_SHARED_DEVICE");
+    return e && e[0] == '1';
+}
+
 int hpn_comm_init_all(hpn_ctx **ctxs, int n)
 {
     if (!ctxs || n < 1 || n > 64) return HPN_E_ARG;
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i]) return HPN_E_ARG;
         if (ctxs[i]->comm) return fail(ctxs[i], HPN_E_STATE, "communicator already initialised");
-        for (int j = 0; j < i; ++j)
+        for (int j = 0; j < i && !shared_device_allowed(); ++j)
             if (ctxs[j]->device == ctxs[i]->device)
                 return fail(ctxs[0], HPN_E_ARG, "contexts %d and %d share device %d: one RCCL rank per device", j, i, ctxs[i]->device);
     }
@@ -149,6 +161,17 @@ int hpn_comm_init_all(hpn_ctx **ctxs, int n)
     return HPN_OK;
 }
 
+int hpn_comm_count(hpn_ctx *c, int *n_ranks)
+{
+    if (!c || !n_ranks) return HPN_E_ARG;
+    if (!c->comm) return fail(c, HPN_E_STATE, "no communicator on this context");
+    Rccl &r = rccl();
+    if (!r.CommCount) return fail(c, HPN_E_RCCL, "ncclCommCount not exported by %s", r.path);
+    const int e = r.CommCount((ncclComm_t)c->comm, n_ranks);
+    if (e != ncclSuccess) return fail(c, HPN_E_RCCL, "ncclCommCount: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
+    return HPN_OK;
+}
+
 int hpn_allreduce_u64_all(hpn_ctx **ctxs, uint64_t **d_vecs, int n, size_t n_words)
 {
     if (!ctxs || !d_vecs || n < 1 || n > 64) return HPN_E_ARG;
@@ -157,15 +180,27 @@ int hpn_allreduce_u64_all(hpn_ctx **ctxs, uint64_t **d_vecs, int n, size_t n_wor
         if (!ctxs[i]->comm) return fail(ctxs[i], HPN_E_STATE, "hpn_comm_init_all has not been called");
     }
     Rccl &r = rccl();
-    // one group: a single thread drives all ranks, so the n calls must be fused or the first would wait for peers forever
+    // one group: a single thread drives all ranks, so the n calls must be fused or the first would wait for peers forever.
+    // Nothing returns between GroupStart and GroupEnd: a group left open on this thread would swallow every later collective.
     int e = r.GroupStart();
-    for (int i = 0; e == ncclSuccess && i < n; ++i) {
-        HPN_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+    if (e != ncclSuccess) return fail(ctxs[0], HPN_E_RCCL, "ncclGroupStart: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
+    hipError_t he = hipSuccess;
+    int queued = 0;
+    for (int i = 0; e == ncclSuccess && he == hipSuccess && i < n; ++i) {
+        he = hipSetDevice(ctxs[i]->device);
+        if (he != hipSuccess) break;
         e = r.AllReduce(d_vecs[i], d_vecs[i], n_words, ncclUint64, ncclSum, (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream);
+        if (e == ncclSuccess) ++queued;
     }
     const int e2 = r.GroupEnd();
+    // with some of the all-reduces enqueued the vectors may or may not hold sums: HPN_E_PARTIAL tells the caller not to add them again
+    if (he != hipSuccess)
+        return fail(ctxs[0], queued ? HPN_E_PARTIAL : HPN_E_HIP, "hipSetDevice inside the group failed: %s (%d of %d all-reduces enqueued)",
+                    hipGetErrorString(he), queued, n);
     if (e == ncclSuccess) e = e2;
-    if (e != ncclSuccess) return fail(ctxs[0], HPN_E_RCCL, "grouped ncclAllReduce: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
+    if (e != ncclSuccess)
+        return fail(ctxs[0], queued ? HPN_E_PARTIAL : HPN_E_RCCL, "grouped ncclAllReduce: %s (%d of %d enqueued)",
+                    r.GetErrorString ? r.GetErrorString(e) : "?", queued, n);
     for (int i = 0; i < n; ++i) {
         HPN_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
         HPN_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));

@@ -43,7 +43,7 @@ struct hpn_ctx {
     hpn::Scratch s_a, s_b, s_c, s_d, s_e, s_f, s_g, s_h;  // staging of host batches
     hpn::Scratch d_diff, d_runs, d_win, d_ws, d_tidx, d_text;     // bam2depth: difference array, runs, window sums, scan workspace, tile index
     hpn::Scratch d_sw, d_win_sw;                                  // the sweep's state (frontier, chain) and the window sums of what it has swept
-    hpn::Scratch w_off, w_bins, w_len, w_gc, w_misc;      // bam_sliding_count accumulators
+    hpn::Scratch w_off, w_bins, w_len, w_gc, w_misc, w_todo;      // bam_sliding_count accumulators; passes left for k_window_rest
     hipEvent_t ev_beg[hpn::kFamCount] = {};
     hipEvent_t ev_end[hpn::kFamCount] = {};
     bool ev_valid[hpn::kFamCount] = {};
@@ -78,6 +78,8 @@ struct hpn_ctx {
     hpn::Scratch g_crc;   // hpn_crc32_dev: block table + block CRCs
     hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds;  // gzip: symbols, per-stretch results, histories, member ends
     std::vector<hpn_gz_member> gz_members;              // members that ended inside the last hpn_gz_inflate_dev call
+    bool gz_pending = false;                            // between hpn_gz_inflate_begin_dev and _finish_dev
+    uint32_t gz_n_chunks = 0, gz_sym_cap = 0;
     uint64_t r_n = 0;
     bool r_fields = false;  // the SoA view of the current index has been gathered
     // RCCL

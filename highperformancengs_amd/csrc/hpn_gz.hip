@@ -26,16 +26,49 @@ uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 
 using namespace hpn;
 
+namespace {
+constexpr uint32_t kGzBounds = 65536;   // members that may end inside one call (beyond: status 23, the caller takes another route)
+}
+
 extern "C" {
 
-int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks, uint32_t sym_cap,
-                       const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap, uint8_t *d_window_out, hpn_gz_info *info)
+// The symbolic decode of a call's stretches needs nothing of the text in front of them; resolving the histories does (the 32 KiB
+// window in front of the first stretch).  hpn_gz_inflate_begin_dev starts the first on the context's stream and returns at once;
+// hpn_gz_inflate_finish_dev takes the window, resolves, translates and reports.  Between the two the caller may wait for whoever
+// inflates the stretches in front of these -- on another device (host/gz_gpu.hpp: batches of one file over several contexts).
+int hpn_gz_inflate_begin_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks, uint32_t sym_cap)
 {
-    if (!c || !info || (n_chunks && (!d_comp || !d_chunks))) return HPN_E_ARG;
-    memset(info, 0, sizeof *info);
+    if (!c || (n_chunks && (!d_comp || !d_chunks))) return HPN_E_ARG;
     if (n_chunks > 65535u || (sym_cap & 7u) || (n_chunks && !sym_cap)) return fail(c, HPN_E_ARG, "hpn_gz_inflate_dev: n_chunks <= 65535, sym_cap a multiple of 8");
     HPN_HIP(c, hipSetDevice(c->device));
+    c->gz_pending = false;
+    c->gz_members.clear();
+    c->gz_n_chunks = n_chunks, c->gz_sym_cap = sym_cap;
+    if (n_chunks) {
+        int rc;
+        if ((rc = scratch_reserve(c, c->g_sym, (size_t)n_chunks * sym_cap * sizeof(uint16_t) + 64)) != HPN_OK) return rc;
+        if ((rc = scratch_reserve(c, c->g_meta, (size_t)n_chunks * 32)) != HPN_OK) return rc;
+        if ((rc = scratch_reserve(c, c->g_windows, ((size_t)n_chunks + 1) * 32768)) != HPN_OK) return rc;
+        if ((rc = scratch_reserve(c, c->g_summary, 64)) != HPN_OK) return rc;
+        if ((rc = scratch_reserve(c, c->g_bounds, 16 + (size_t)kGzBounds * 16)) != HPN_OK) return rc;
+        HPN_HIP(c, hipEventRecord(c->ev_beg[kFamInflate], c->stream));
+        HPN_HIP(c, launch_gz_sym_inflate(d_comp, d_chunks, n_chunks, (uint16_t *)c->g_sym.p, sym_cap, c->g_meta.p, c->g_bounds.p, kGzBounds, c->n_cu, c->stream));
+        HPN_HIP(c, hipEventRecord(c->ev_end[kFamInflate], c->stream));
+        c->ev_valid[kFamInflate] = true;
+    }
+    c->gz_pending = true;
+    return HPN_OK;
+}
+
+int hpn_gz_inflate_finish_dev(hpn_ctx *c, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap, uint8_t *d_window_out, hpn_gz_info *info)
+{
+    if (!c || !info) return HPN_E_ARG;
+    memset(info, 0, sizeof *info);
+    if (!c->gz_pending) return fail(c, HPN_E_STATE, "hpn_gz_inflate_finish_dev without hpn_gz_inflate_begin_dev");
+    HPN_HIP(c, hipSetDevice(c->device));
+    const uint32_t n_chunks = c->gz_n_chunks, sym_cap = c->gz_sym_cap;
     if (n_chunks == 0) {
+        c->gz_pending = false;
         if (d_window_out && d_window_in) HPN_HIP(c, hipMemcpyAsync(d_window_out, d_window_in, 32768, hipMemcpyDeviceToDevice, c->stream));
         else if (d_window_out) HPN_HIP(c, hipMemsetAsync(d_window_out, 0, 32768, c->stream));
         HPN_HIP(c, hipStreamSynchronize(c->stream));
@@ -43,21 +76,8 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     }
     const bool dbg = getenv("HPN_GZ_DEBUG") != nullptr;
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
-    const double t0 = now();
-    int rc;
-    if ((rc = scratch_reserve(c, c->g_sym, (size_t)n_chunks * sym_cap * sizeof(uint16_t) + 64)) != HPN_OK) return rc;
-    if ((rc = scratch_reserve(c, c->g_meta, (size_t)n_chunks * 32)) != HPN_OK) return rc;
-    if ((rc = scratch_reserve(c, c->g_windows, ((size_t)n_chunks + 1) * 32768)) != HPN_OK) return rc;
-    if ((rc = scratch_reserve(c, c->g_summary, 64)) != HPN_OK) return rc;
-    constexpr uint32_t kBounds = 65536;   // members that may end inside one call (beyond: status 23, the caller takes another route)
-    if ((rc = scratch_reserve(c, c->g_bounds, 16 + (size_t)kBounds * 16)) != HPN_OK) return rc;
-    c->gz_members.clear();
-    uint16_t *sym = (uint16_t *)c->g_sym.p;
     const double t1 = now();
-    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamInflate], c->stream));
-    HPN_HIP(c, launch_gz_sym_inflate(d_comp, d_chunks, n_chunks, sym, sym_cap, c->g_meta.p, c->g_bounds.p, kBounds, c->n_cu, c->stream));
-    HPN_HIP(c, hipEventRecord(c->ev_end[kFamInflate], c->stream));
-    c->ev_valid[kFamInflate] = true;
+    uint16_t *sym = (uint16_t *)c->g_sym.p;
     HPN_HIP(c, launch_gz_windows(sym, sym_cap, c->g_meta.p, n_chunks, d_window_in, (uint8_t *)c->g_windows.p, d_window_out,
                                  (u64 *)c->g_summary.p, c->n_cu, c->stream));
     u64 summary[4] = {0, 0, 0, 0};
@@ -66,7 +86,7 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
     HPN_HIP(c, hipMemcpyAsync(&n_bounds, c->g_bounds.p, 4, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
     if (n_bounds && !summary[1]) {   // members that ended inside stretches: where in this call's text, and their ISIZE
-        if (n_bounds > kBounds) n_bounds = kBounds;
+        if (n_bounds > kGzBounds) n_bounds = kGzBounds;
         struct Meta { uint32_t n_out, status, final_block, reserved; uint64_t end_bit, text_off; };
         struct Bound { uint32_t chunk, n_out, isize, crc; };
         std::vector<Meta> metas(n_chunks);
@@ -89,18 +109,33 @@ int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_
         HPN_HIP(c, hipStreamSynchronize(c->stream));
         info->end_bit = m.end_bit;
     }
-    if (info->status) return HPN_OK;  // reported, not an API failure: the caller takes another route
+    // (the symbols stay: a call that reports HPN_E_CAPACITY may be finished again with a larger text buffer)
+    if (info->status) {
+        c->gz_pending = false;
+        return HPN_OK;  // reported, not an API failure: the caller takes another route
+    }
     if (info->n_bytes > text_cap) return fail(c, HPN_E_CAPACITY, "hpn_gz_inflate_dev: %llu bytes of text, capacity %llu", (unsigned long long)info->n_bytes, (unsigned long long)text_cap);
     if (info->n_bytes && !d_text) return HPN_E_ARG;
     HPN_HIP(c, launch_gz_translate(sym, sym_cap, c->g_meta.p, n_chunks, (const uint8_t *)c->g_windows.p, d_text, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
+    c->gz_pending = false;
     if (dbg) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, c->ev_beg[kFamInflate], c->ev_end[kFamInflate]);
-        fprintf(stderr, "[hpn_gz] %u stretches: scratch %.3f s, inflate + histories %.3f s (inflate kernel %.1f ms), translate %.3f s, %.1f MB of text\n",
-                n_chunks, t1 - t0, t2 - t1, ms, now() - t2, info->n_bytes / 1e6);
+        fprintf(stderr, "[hpn_gz] %u stretches: histories %.3f s (inflate kernel %.1f ms), translate %.3f s, %.1f MB of text\n",
+                n_chunks, t2 - t1, ms, now() - t2, info->n_bytes / 1e6);
     }
     return HPN_OK;
+}
+
+int hpn_gz_inflate_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks, uint32_t sym_cap,
+                       const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap, uint8_t *d_window_out, hpn_gz_info *info)
+{
+    if (!c || !info) return HPN_E_ARG;
+    memset(info, 0, sizeof *info);
+    const int rc = hpn_gz_inflate_begin_dev(c, d_comp, d_chunks, n_chunks, sym_cap);
+    if (rc != HPN_OK) return rc;
+    return hpn_gz_inflate_finish_dev(c, d_window_in, d_text, text_cap, d_window_out, info);
 }
 
 int hpn_gz_find_starts_dev(hpn_ctx *c, const uint8_t *d_comp, uint64_t comp_bytes, const hpn_span *slices, uint32_t n, uint64_t *found)

@@ -1294,6 +1294,66 @@ __device__ __forceinline__ void put_line(P p, int32_t start, int32_t end, int32_
     p[at] = '\n';
 }
 
+// ---- lines of ONE layout (round 4) ----------------------------------------------------------------------------------------------
+// What made the byte-wise line expensive was not the bytes but deciding, per character and lane, whether to store it (digits are
+// right-aligned: ~100 compare / mask / store groups per line).  In a wave of neighbouring runs the three numbers of a line nearly
+// always have the same digit counts in every lane (coordinates cross a power of ten a handful of times per chromosome; depths mostly
+// stay within 10..99), and then the line has ONE layout for the whole wave: every field sits at a wave-uniform offset, the
+// digits -- shifted to the front of their registers with wave-uniform shifts -- are stored without any predicate, and a lane's
+// address arithmetic is one add per field.  A start that equals the end of the line before (adjacent runs: the rule at 30x) takes
+// that line's digits.  Waves whose lines differ take put_line as before.
+struct Dig {
+    uint32_t a, b, c;        // characters 0..3, 4..7, 8..9 of the number, most significant first
+};
+// the nd (wave-uniform, 1..10) decimal digits of v, left-justified
+__device__ __forceinline__ Dig dec_left(uint32_t v, int nd)
+{
+    const uint32_t hi = v / 100000000u;                                   // 0 .. 42
+    const uint32_t r = v - (__umul24(hi, 390625u) << 8);                  // 10^8 = 390625 * 256
+    const uint32_t mid = (uint32_t)(((u64)((r >> 4) & 0x7fffffu) * 13743896ull) >> 33);   // r / 10000 (see put_dec)
+    const uint32_t lo = r - __umul24(mid, 10000u);
+    const uint32_t ht = __umul24(hi, 103u) >> 10;
+    const uint32_t s0 = (ht | (hi - __umul24(ht, 10u)) << 8) + 0x3030u, s1 = ascii4(mid), s2 = ascii4(lo);   // "hh", "mmmm", "llll"
+    // the ten characters as a stream x0 x1 x2 ("hhmm", "mmll", "ll"), then moved to the front by skip = 10 - nd characters
+    const uint32_t x0 = s0 | s1 << 16, x1 = __builtin_amdgcn_alignbyte(s2, s1, 2), x2 = s2 >> 16;
+    const int skip = 10 - nd, d = skip >> 2, b = skip & 3;                // wave-uniform: scalar selects
+    const uint32_t a0 = d == 0 ? x0 : d == 1 ? x1 : x2, a1 = d == 0 ? x1 : d == 1 ? x2 : 0u, a2 = d == 0 ? x2 : 0u;
+    return Dig{__builtin_amdgcn_alignbyte(a1, a0, (uint32_t)b), __builtin_amdgcn_alignbyte(a2, a1, (uint32_t)b), a2 >> (8 * b)};
+}
+// the first n (wave-uniform, <= 4) characters of w to p[0..n): byte stores, the odd bytes through one shift
+__device__ __forceinline__ void put_chars(uint8_t *p, uint32_t w, int n)
+{
+    const uint32_t o = w >> 8;
+    if (n > 0) p[0] = (uint8_t)w;
+    if (n > 1) p[1] = (uint8_t)o;
+    if (n > 2) p[2] = (uint8_t)(w >> 16);
+    if (n > 3) p[3] = (uint8_t)(o >> 16);
+}
+__device__ __forceinline__ void put_dig(uint8_t *p, const Dig g, int nd)
+{
+    put_chars(p, g.a, nd < 4 ? nd : 4);
+    if (nd > 4) put_chars(p + 4, g.b, nd - 4 < 4 ? nd - 4 : 4);
+    if (nd > 8) put_chars(p + 8, g.c, nd - 8);
+}
+// One line whose digit counts n1, n2, n3 (wave-uniform) and name (<= 8 characters, in n0 / n1w) are the same in every lane;
+// depth < 10000.  S: the digits of start (the caller's: converted, or the previous line's end).
+__device__ __forceinline__ void put_line_uniform(uint8_t *p, const Dig S, const Dig E, uint32_t depth, int n1, int n2, int n3, uint32_t n0, uint32_t n1w,
+                                                 int name_len)
+{
+    put_chars(p, n0, name_len < 4 ? name_len : 4);
+    if (name_len > 4) put_chars(p + 4, n1w, name_len - 4);
+    uint8_t *q = p + name_len;
+    q[0] = '\t';
+    put_dig(q + 1, S, n1);
+    q += n1 + 1;
+    q[0] = '\t';
+    put_dig(q + 1, E, n2);
+    q += n2 + 1;
+    q[0] = '\t';
+    put_chars(q + 1, ascii4(depth) >> (8 * (4 - n3)), n3);
+    q[n3 + 1] = '\n';
+}
+
 struct FmtName {
     uint32_t w[16];       // 64 characters
 };
@@ -1365,9 +1425,25 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
         // unaligned stores stall in LDS (SQ_LDS_UNALIGNED_STALL 394 M cycles: 1.15 ms against 1.03) and are worse still straight to
         // memory (2.27 ms): profiles/r03/bedgraph_text_variants.txt.  The byte-wise line stays.)
         if (name_len <= kFmtMaxName) {                        // staged: build in LDS, copy out in 16-byte pieces
+            Dig prevE{0, 0, 0};
+            bool have_prev = false;                           // prevE holds the digits of line k - 1's end (wave-uniform)
 #pragma unroll
             for (int k = 0; k < kFmtPer; ++k) {
-                if (len[sb][k]) put_line(s_text + at, rs[sb][k], re[sb][k], rd[sb][k], len[sb][k], n0, n1, nm, name_len);
+                // one layout for the whole wave?  (digit counts, a line in every lane, nothing negative, depth of at most four digits)
+                const uint32_t pk = len[sb][k] >> 16, pk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk);
+                const bool same = name_len <= 8 && pk0 != 0 &&
+                                  __ballot(pk != pk0 || (uint32_t)rd[sb][k] >= 10000u || (rs[sb][k] | re[sb][k]) < 0) == 0;
+                if (same) {
+                    const int n1d = (int)(pk0 & 15u), n2d = (int)((pk0 >> 4) & 15u), n3d = (int)((pk0 >> 8) & 15u);
+                    const Dig E = dec_left((uint32_t)re[sb][k], n2d);
+                    Dig S = prevE;                                                   // adjacent runs: the line before ended where this one starts
+                    if (!have_prev || __ballot(rs[sb][k] != re[sb][k > 0 ? k - 1 : 0])) S = dec_left((uint32_t)rs[sb][k], n1d);
+                    put_line_uniform(s_text + at, S, E, (uint32_t)rd[sb][k], n1d, n2d, n3d, n0, n1, name_len);
+                    prevE = E, have_prev = true;
+                } else {
+                    if (len[sb][k]) put_line(s_text + at, rs[sb][k], re[sb][k], rd[sb][k], len[sb][k], n0, n1, nm, name_len);
+                    have_prev = false;
+                }
                 at += (len[sb][k] & 0xffffu);
             }
             __syncthreads();

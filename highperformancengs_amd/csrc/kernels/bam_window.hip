@@ -189,26 +189,262 @@ constexpr int kWinSpan = 1024;                    // consecutive records per wav
 // masked wave sums (valid in every lane)
 __device__ __forceinline__ uint32_t wave_sum_if(bool in, uint32_t v) { return wave_sum(in ? v : 0u); }
 
+// A raw buffer descriptor over [base, base + bytes): loads through it take a 32-bit lane offset plus a scalar offset (no
+// 64-bit address arithmetic in the vector unit) and return zero for anything that does not lie inside whole.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t span_rsrc(const void *base, uint64_t bytes)
+{
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    const uint32_t nb = bytes > 0x7fffffffull ? 0x7fffffffu : (uint32_t)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b)),
+        0, (int)__builtin_amdgcn_readfirstlane(nb), 0x00020000);
+}
+
+// GC count of one 16-byte piece added to acc; nk[j] = ~(the nibbles of word j to count, as a subset of 0x44444444).
+// Four vector instructions and a count-and-add per word (gfx950 has a three-input bit operation): 3w has b1 ^ b2 at bit 2 of a
+// nibble whose bit 0 is clear (no carry reaches it); (w << 2) | nk puts "bit 0 set, or not to be counted" there and ones
+// everywhere else; w >> 1 puts bit 3 there; verdict = 3w & ~that & ~(w >> 1).
+__device__ __forceinline__ uint32_t gc_add_piece(const u32 q, const uint32_t *nk, uint32_t acc)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = q[j];
+        const uint32_t a = (w << 1) + w, b0n = (w << 2) | nk[j], b3 = w >> 1;
+        const uint32_t v = a & ~b0n & ~b3;
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(v));      // count-and-add in one instruction, as a chain (no partial sums kept)
+    }
+    return acc;
+}
+
+// Offsets that can never lie inside a fast pass's descriptor (at most kFastReach bytes), whatever is added to them:
+// kNoRecord marks a record that is skipped (flag & 4, tid < 0, beyond n), kNoLane a lane without a piece in a step.
+constexpr uint32_t kFastReach = 0x3fffffffu, kNoRecord = 0x40000000u, kNoLane = 0x80000000u;
+
+// The sequence loads and the count of a fast pass of STEPS steps: every lane fetches the offset of its record of each step from
+// the lane that holds the record (ds_bpermute, all of them first), adds its piece's offset, loads 16 bytes and counts.  A
+// skipped record hands out kNoRecord and a lane without a piece adds kNoLane: the hardware drops those loads and returns zeros,
+// which count as nothing -- no mask, no branch, and the bytes of skipped records are not even fetched.
+template <int STEPS>
+__device__ __forceinline__ uint32_t fast_pass_gc(__amdgpu_buffer_rsrc_t rsrc, uint32_t srel, uint32_t bp_addr, int rps, uint32_t off_mid,
+                                                 uint32_t off_last, const uint32_t *nk, uint32_t acc)
+{
+    uint32_t at[STEPS];
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) at[t] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bp_addr + (uint32_t)(4 * t * rps)), (int)srel);
+    __builtin_amdgcn_sched_barrier(0);        // (all the exchanges in flight together, then all the loads)
+    u32 q[STEPS];
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        const uint32_t a = at[t] + (t + 1 < STEPS ? off_mid : off_last);
+#ifdef DIAG_NOSEQ
+        q[t] = u32{a, a * 3u, a * 5u, a * 7u};
+#else
+        q[t] = __builtin_bit_cast(u32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, a, 0, 0));
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) acc = gc_add_piece(q[t], nk, acc);
+    return acc;
+}
+
 __global__ __launch_bounds__(kWinThreads) void k_window_add(
     const int32_t *__restrict__ rec_tid, const int32_t *__restrict__ rec_pos, const uint32_t *__restrict__ rec_flag,
     const int32_t *__restrict__ l_qseq, const uint64_t *__restrict__ seq_off, const uint8_t *__restrict__ seq4,
     uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets, const uint64_t *__restrict__ win_off,
     uint32_t *__restrict__ bins, u64 *__restrict__ gc, uint32_t *__restrict__ len, uint32_t *__restrict__ touched,
-    u64 *__restrict__ n_count, uint32_t *__restrict__ bad)
+    u64 *__restrict__ n_count, uint32_t *__restrict__ todo /* [0]: passes left for k_window_rest, their numbers from [1] */)
 {
-    // Waves work on their own: no LDS table, no barrier.  A wave takes spans of 1024 consecutive records, 64 per pass, and
-    // keeps the sums of the window it is in (a coordinate-sorted BAM stays in one window for thousands of records at WGS
-    // depth); they go to memory with three atomics when the window changes.  Passes with more than eight different
-    // windows (unsorted input) hand the rest to per-record atomics.
-    __shared__ uint32_t s_gc[kWinThreads / kWave][kWave];   // per wave: the GC sums of the 64 records of a pass
+    // Waves work on their own: no barrier.  A wave takes spans of 1024 consecutive records, 64 per pass, and keeps the sums of
+    // the window it is in (a coordinate-sorted BAM stays in one window for thousands of records at WGS depth); they go to
+    // memory with three atomics when the window changes.
+    //
+    // The pass the kernel is built around (round 4): 64 records of ONE target, ONE window and ONE read length, as in a
+    // coordinate-sorted BAM of fixed-length reads.  Whether a pass is one is decided with wave-uniform state -- the target, the
+    // window's position range [w_lo, w_lo + W) and the read length of the pass before sit in scalar registers, a lane only
+    // compares its record against them (no division, no window-table loads) -- and then nothing is attributed to records at
+    // all: a lane adds the GC of its pieces to a private register (pieces of records that are skipped, flag & 4 / tid < 0,
+    // masked by one bit test), bins and len grow by popcount(ok) and popcount(ok) x length in scalar registers, and the
+    // lanes' registers are summed once, when the window changes or the span ends.  The fields come through buffer
+    // descriptors of the span (address = descriptor + lane x 4 + pass x 256: no vector address arithmetic).
+    // Everything else -- mixed lengths, a window or target boundary inside the pass, unsorted input, reads over 256 bases, the
+    // last bytes of the sequence buffer -- is left to k_window_rest: the pass's number goes on a list (one atomic per such
+    // pass; ~2 % of the passes of a sorted WGS BAM at W = 20000).  Two kernels rather than two branches because the general
+    // pass needs three times the registers: inlined here it halved this kernel's occupancy.
     const int lane = lane_id();
     const uint64_t lim = seq_end ? seq_end : seq_off[n];   // first byte offset of seq4 that must not be read
     const uint64_t nspan = (n + kWinSpan - 1) / kWinSpan;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * (kWinThreads / kWave) + wave_id(), nwaves = (uint64_t)gridDim.x * (kWinThreads / kWave);
+    // (the wave's number through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in a wave's lanes, and
+    //  would run every loop and branch below under an execution mask)
+    const uint64_t wave0 = (uint64_t)blockIdx.x * (kWinThreads / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id()),
+                   nwaves = (uint64_t)gridDim.x * (kWinThreads / kWave);
+    uint32_t counted = 0;
+    GcLayout lay;
+    uint32_t off_mid = kNoLane, off_last = kNoLane;           // fast pass: 16 x piece number, or "no load" for a lane without a piece
+    uint32_t bp_addr = 0;                                     // fast pass: 4 x (record of step 0) for ds_bpermute
+    const uint32_t Wm = 0xffffffffu / W;                    // div_by()
+    const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u;
+    // what the pass before established (all wave-uniform)
+    int32_t c_tid = -1;            // target whose window table entry is cached
+    uint64_t c_lo = 0;             // win_off[c_tid]
+    uint32_t c_nwin = 0;           // windows of c_tid (clamped to 2^32 - 1)
+    uint32_t w_lo = 0;             // first position of the cached window
+    bool w_valid = false;          // [w_lo, w_lo + W) belongs to slot c_slot of target c_tid
+    uint64_t c_slot = 0;
+    for (uint64_t span = wave0; span < nspan; span += nwaves) {
+        u64 cur = ~0ull;                                   // window slot the sums belong to (same value in every lane)
+        uint32_t a_bins = 0, a_len = 0, cur_tid = 0;
+        u64 a_gc = 0;
+        uint32_t lane_gc = 0;                              // this lane's share of the window's GC sum (fast passes)
+        auto flush = [&]() {                               // wave-uniform control flow only: every lane takes part in the sum
+            const uint32_t tot = wave_sum(lane_gc);
+            lane_gc = 0;
+            if (cur != ~0ull && lane == 0) {
+                atomicAdd(&bins[cur], a_bins);
+                atomicAdd(&len[cur], a_len);
+                atomicAdd(&gc[cur], a_gc + tot);
+                touched[cur_tid] = 1u;
+            }
+        };
+        const uint64_t r0 = span * kWinSpan;
+        const uint32_t in_span = (uint32_t)(n - r0 < (uint64_t)kWinSpan ? n - r0 : (uint64_t)kWinSpan);
+        const __amdgpu_buffer_rsrc_t d_tid = span_rsrc(rec_tid + r0, (uint64_t)in_span * 4), d_pos = span_rsrc(rec_pos + r0, (uint64_t)in_span * 4),
+                                     d_flag = span_rsrc(rec_flag + r0, (uint64_t)in_span * 4), d_lq = span_rsrc(l_qseq + r0, (uint64_t)in_span * 4),
+                                     d_so = span_rsrc(seq_off + r0, (uint64_t)in_span * 8);
+        // the fields of a pass are loaded one pass ahead, beside the sequence loads of the pass before: one exposed round
+        // trip per pass instead of two (fields, then the sequences they point to)
+        struct Fields {
+            int32_t t = -1, p = 0, l = 0;
+            uint32_t f = 0;
+            uint64_t so = 0;
+        };
+        auto fields_of = [&](int pass) {
+            Fields x;
+            const int so4 = pass * (kWave * 4), so8 = pass * (kWave * 8);
+            x.t = __builtin_amdgcn_raw_buffer_load_b32(d_tid, lane4, so4, 0);
+            x.p = __builtin_amdgcn_raw_buffer_load_b32(d_pos, lane4, so4, 0);
+            x.f = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(d_flag, lane4, so4, 0);
+            x.l = __builtin_amdgcn_raw_buffer_load_b32(d_lq, lane4, so4, 0);
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(d_so, lane8, so8, 0));
+            x.so = ((uint64_t)v[1] << 32) | v[0];
+            return x;
+        };
+        Fields nxt = fields_of(0);
+        const int npass = (int)((in_span + kWave - 1) / kWave);
+        for (int pass = 0; pass < npass; ++pass) {
+            const Fields cf = nxt;
+            if (pass + 1 < npass) nxt = fields_of(pass + 1);
+            const uint32_t nvalid = in_span - (uint32_t)pass * kWave;           // >= 1; lanes at or beyond it hold no record
+            const bool valid = (uint32_t)lane < nvalid;
+            const bool okf = valid && cf.t >= 0 && !(cf.f & 4u);                // :96-97
+            const u64 okm = __ballot(okf);
+            // ---- is this a fast pass?  (every test below is one or two vector compares against scalar registers) ----
+            bool fast = false;
+            int lq0 = 0;
+            uint64_t s0 = 0;
+            uint32_t srel = 0, reach = 0;
+            if (okm) {
+                const int first = __builtin_ctzll(okm);
+                const int32_t t0 = __builtin_amdgcn_readlane(cf.t, first);
+                lq0 = __builtin_amdgcn_readlane(cf.l, 0);                           // (lane 0 is always valid)
+                if (t0 != c_tid && t0 < n_targets) {                                // a new target: its window table entry, once
+                    c_tid = t0;
+                    c_lo = win_off[t0];
+                    const uint64_t nw = win_off[t0 + 1] - c_lo;
+                    c_nwin = nw > 0xffffffffull ? 0xffffffffu : (uint32_t)nw;
+                    w_valid = false;
+                }
+                if (t0 == c_tid && lq0 > 0 && lq0 <= 256) {
+                    // one target, one length (skipped records too: their pieces are loaded, and dropped by a bit test)
+                    u64 odd = __ballot((okf && cf.t != t0) || (valid && cf.l != lq0) || (okf && cf.p < 0));
+                    if (!odd && !(w_valid && __ballot(okf && (uint32_t)cf.p - w_lo >= W) == 0)) {
+                        // not (known to be) inside the cached window: the window of the first record, by division
+                        const uint32_t wfull = div_by((uint32_t)cf.p, W, Wm);
+                        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wfull, first);
+                        odd = __ballot(okf && wfull != w0);
+                        const uint32_t w16 = w0 & 0xffffu;                          // (unsigned short)(c->pos / window) (:117)
+                        if (!odd && w16 < c_nwin) {
+                            w_valid = true, w_lo = w0 * W, c_slot = c_lo + w16;
+                        } else {
+                            odd = 1;                                                // several windows, or one the reference would write out of bounds
+                            w_valid = false;
+                        }
+                    }
+                    if (!odd) {
+                        // the sequences relative to the first record's, inside what may be read, 2 GiB at most
+                        s0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(cf.so >> 32), 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cf.so, 0);
+                        const uint64_t room = lim > s0 ? lim - s0 : 0;
+                        reach = room > kFastReach ? kFastReach : (uint32_t)room;
+                        const uint64_t rel = cf.so - s0;                              // (wraps for a record in front of the first: then it is huge)
+                        const uint32_t piece_bytes = 16u * (uint32_t)((((lq0 + 1) >> 1) + 15) >> 4);
+                        fast = __ballot(valid && rel + piece_bytes > reach) == 0;     // no piece of the pass straddles the end of what may be read
+                        srel = okf ? (uint32_t)rel : kNoRecord;                       // a skipped record's pieces are not loaded
+                    }
+                }
+            }
+            if (fast) {
+                if (lq0 != lay.lq) {               // a new read length: lane -> (record of the step, piece) and the byte masks
+                    const int nb = (lq0 + 1) >> 1, P = (nb + 15) >> 4;                // 1..8, the same in every lane
+                    lay.lq = lq0, lay.rps = kWave / P, lay.steps = (kWave + lay.rps - 1) / lay.rps;
+                    lay.pg = lane / P, lay.psub = lane - lay.pg * P;
+                    const int rem = nb - 16 * lay.psub;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int hi = min(max(rem - 4 * j, 0), 4);
+                        uint32_t m = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+                        if ((lq0 & 1) && hi > 0 && rem - 4 * j <= 4) m &= ~(0xfu << (8 * (hi - 1)));
+                        lay.m[j] = ~(m & 0x44444444u);             // NOT the nibbles of word j that are bases of the read (gc_add_piece)
+                    }
+                    const bool used = lay.pg < lay.rps;
+                    off_mid = used ? 16u * (uint32_t)lay.psub : kNoLane;
+                    off_last = used && (lay.steps - 1) * lay.rps + lay.pg < kWave ? off_mid : kNoLane;
+                    bp_addr = 4u * (uint32_t)lay.pg;
+                }
+                if (c_slot != cur) {
+                    flush();
+                    cur = c_slot, a_bins = 0, a_len = 0, a_gc = 0, cur_tid = (uint32_t)c_tid;
+                }
+                const uint32_t nok = (uint32_t)__builtin_popcountll(okm);
+                counted += nok, a_bins += nok, a_len += nok * (uint32_t)lq0;     // n_count (:104), bins, len (:119-121)
+                const __amdgpu_buffer_rsrc_t rsrc = span_rsrc(seq4 + s0, reach);
+#define HPN_FAST_STEPS(N) case N: lane_gc = fast_pass_gc<N>(rsrc, srel, bp_addr, lay.rps, off_mid, off_last, lay.m, lane_gc); break;
+                switch (lay.steps) {          // ceil(64 / floor(64 / pieces per record)): 1, 2, 3, 4, 6 (150 bases), 7 or 8
+                    HPN_FAST_STEPS(1) HPN_FAST_STEPS(2) HPN_FAST_STEPS(3) HPN_FAST_STEPS(4) HPN_FAST_STEPS(5) HPN_FAST_STEPS(6) HPN_FAST_STEPS(7)
+                    default: lane_gc = fast_pass_gc<8>(rsrc, srel, bp_addr, lay.rps, off_mid, off_last, lay.m, lane_gc); break;
+                }
+#undef HPN_FAST_STEPS
+                continue;
+            }
+            // ---- not a fast pass: k_window_rest takes it ----
+            if (okm && lane == 0) todo[1 + atomicAdd(&todo[0], 1u)] = (uint32_t)(r0 / kWave) + (uint32_t)pass;
+        }
+        flush();
+    }
+    if (lane == 0 && counted) atomicAdd(n_count, (u64)counted);
+}
+
+// The passes k_window_add left: 64 records each, any mixture.  Per-record GC through the wave's 64 LDS words
+// (gc_of_wave_records), up to eight windows per pass with wave sums, then per-record atomics.  A wave takes 16 list entries at a
+// time and keeps the sums of the window it is in across them (the list of an unsorted input is nearly in order).
+__global__ __launch_bounds__(kWinThreads) void k_window_rest(
+    const int32_t *__restrict__ rec_tid, const int32_t *__restrict__ rec_pos, const uint32_t *__restrict__ rec_flag,
+    const int32_t *__restrict__ l_qseq, const uint64_t *__restrict__ seq_off, const uint8_t *__restrict__ seq4,
+    uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets, const uint64_t *__restrict__ win_off,
+    uint32_t *__restrict__ bins, u64 *__restrict__ gc, uint32_t *__restrict__ len, uint32_t *__restrict__ touched,
+    u64 *__restrict__ n_count, uint32_t *__restrict__ bad, const uint32_t *__restrict__ todo)
+{
+    __shared__ uint32_t s_gc[kWinThreads / kWave][kWave];   // per wave: the GC sums of the 64 records of a pass
+    const uint32_t n_todo = todo[0];
+    if (n_todo == 0) return;
+    const int lane = lane_id();
+    const uint64_t lim = seq_end ? seq_end : seq_off[n];   // first byte offset of seq4 that must not be read
+    const uint32_t wave0 = blockIdx.x * (kWinThreads / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane(wave_id()), nwaves = gridDim.x * (kWinThreads / kWave);
     uint32_t counted = 0;
     GcLayout lay;
     const uint32_t Wm = 0xffffffffu / W;                    // div_by()
-    for (uint64_t span = wave0; span < nspan; span += nwaves) {
+    constexpr uint32_t kChunk = 16;
+    for (uint32_t e0 = wave0 * kChunk; e0 < n_todo; e0 += nwaves * kChunk) {
         u64 cur = ~0ull;                                   // window slot the sums belong to (same value in every lane)
         uint32_t a_bins = 0, a_len = 0, cur_tid = 0;
         u64 a_gc = 0;
@@ -220,32 +456,16 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                 touched[cur_tid] = 1u;
             }
         };
-        // the fields of a pass are loaded one pass ahead, beside the sequence loads of the pass before: one exposed round
-        // trip per pass instead of two (fields, then the sequences they point to)
-        struct Fields {
-            int32_t t = -1, p = 0, l = 0;
-            uint32_t f = 0;
-            uint64_t so = 0;
-        };
-        auto fields_of = [&](uint64_t r) {
-            Fields x;
-            if (r < n) x.t = rec_tid[r], x.p = rec_pos[r], x.l = l_qseq[r], x.f = rec_flag[r], x.so = seq_off[r];
-            return x;
-        };
-        Fields nxt = fields_of(span * kWinSpan + lane);
-        for (int pass = 0; pass < kWinSpan / kWave; ++pass) {
-            const uint64_t r = span * kWinSpan + (uint64_t)pass * kWave + lane;
-            if (__ballot(r < n) == 0) break;
-            const Fields cf = nxt;
-            if (pass + 1 < kWinSpan / kWave) nxt = fields_of(r + kWave);
+        for (uint32_t e = e0; e < e0 + kChunk && e < n_todo; ++e) {
+            const uint64_t r = (uint64_t)todo[1 + e] * kWave + lane;
             bool ok = false;
             uint64_t slot = 0, so = 0;
             uint32_t lq = 0, tt = 0;
             int32_t lqs = 0;
             if (r < n) {
-                const int32_t t = cf.t, p = cf.p, l = cf.l;
-                const uint32_t f = cf.f;
-                so = cf.so, lqs = l;                           // skipped records are read too: a wave of one length stays one
+                const int32_t t = rec_tid[r], p = rec_pos[r], l = l_qseq[r];
+                const uint32_t f = rec_flag[r];
+                so = seq_off[r], lqs = l;                      // skipped records are read too: a wave of one length stays one
                 if (t >= 0 && !(f & 4u)) {                     // :96-97
                     if (t >= n_targets) {
                         atomicOr(bad, 1u);
@@ -266,7 +486,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
 #ifdef DIAG_NOGC
             const uint32_t g = (uint32_t)so & 63u;
 #else
-            const uint32_t g = (uint32_t)(uint16_t)gc_of_wave_records(seq4, so, lqs, lim, s_gc[wave_id()], lay);   // unsigned short current_GC (:118)
+            const uint32_t g = (uint32_t)(uint16_t)gc_of_wave_records(seq4, so, lqs, lim, s_gc[__builtin_amdgcn_readfirstlane(wave_id())], lay);   // unsigned short current_GC (:118)
 #endif
             u64 rem = __ballot(ok);
             counted += (uint32_t)__builtin_popcountll(rem);   // n_count (:104); the same in every lane
@@ -281,12 +501,12 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                     break;
                 }
                 const int f = __builtin_ctzll(rem);
-                const u64 s0 = __shfl((u64)slot, f, kWave);
-                const bool in = ok && slot == s0;
+                const u64 sl0 = __shfl((u64)slot, f, kWave);
+                const bool in = ok && slot == sl0;
                 const u64 m = __ballot(in);
-                if (s0 != cur) {
+                if (sl0 != cur) {
                     flush();
-                    cur = s0, a_bins = 0, a_len = 0, a_gc = 0, cur_tid = __shfl(tt, f, kWave);
+                    cur = sl0, a_bins = 0, a_len = 0, a_gc = 0, cur_tid = __shfl(tt, f, kWave);
                 }
                 a_bins += (uint32_t)__builtin_popcountll(m);
                 a_len += wave_sum_if(in, lq);
@@ -299,16 +519,32 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
     if (lane == 0 && counted) atomicAdd(n_count, (u64)counted);
 }
 
+size_t window_todo_words(uint64_t n) { return (size_t)((n + kWave - 1) / kWave) + 1; }   // the list of passes left for k_window_rest
+
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
                              const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
-                             u64 *n_count, uint32_t *bad, int n_cu, hipStream_t st)
+                             u64 *n_count, uint32_t *bad, uint32_t *todo /* window_todo_words(n) */, int n_cu, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
+    if (n >= ((uint64_t)1 << 32) * kWave) return hipErrorInvalidValue;      // pass numbers are 32-bit
+    hipError_t e = hipMemsetAsync(todo, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     uint64_t want = ((n + kWinSpan - 1) / kWinSpan + kWinThreads / kWave - 1) / (kWinThreads / kWave);
-    const uint64_t cap = (uint64_t)n_cu * 8;
+    // exactly the workgroups the chip holds at once: the spans are dealt out round-robin, so a grid of 8 per CU on a kernel that
+    // fits 7 runs a second round at one eighth of the chip (1.06 ms where one round takes half of that)
+    static const int per_cu = [] {
+        int b = 0;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_window_add, kWinThreads, 0) == hipSuccess && b > 0 ? b : 4;
+    }();
+    const uint64_t cap = (uint64_t)n_cu * (uint64_t)per_cu;
     hipLaunchKernelGGL(k_window_add, dim3((unsigned)(want < cap ? want : cap)), dim3(kWinThreads), 0, st, tid_a, pos, flag,
-                       l_qseq, seq_off, seq4, n, seq_end, W, n_targets, win_off, bins, gc, len, touched, n_count, bad);
+                       l_qseq, seq_off, seq4, n, seq_end, W, n_targets, win_off, bins, gc, len, touched, n_count, todo);
+    // whatever the fast kernel left (nothing: its waves return at once)
+    want = ((n + kWave - 1) / kWave + 16 * (kWinThreads / kWave) - 1) / (16 * (kWinThreads / kWave));
+    const uint64_t cap2 = (uint64_t)n_cu * 4;
+    hipLaunchKernelGGL(k_window_rest, dim3((unsigned)(want < cap2 ? want : cap2)), dim3(kWinThreads), 0, st, tid_a, pos, flag,
+                       l_qseq, seq_off, seq4, n, seq_end, W, n_targets, win_off, bins, gc, len, touched, n_count, bad, todo);
     return hipGetLastError();
 }
 

@@ -87,6 +87,18 @@ def max_over_ranks(seconds: float, device="cpu") -> float:
     return float(t.item())
 
 
+def gather_floats(x: float, device="cpu") -> list:
+    """[x of rank 0, x of rank 1, ...] on every rank (bench.py: each rank's mean kernel time)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(x)]
+    mine = torch.tensor([x], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 class ShardedTally:
     """One rank's side of the sharded fastq_count: tally the resident block, sum the count vector over the ranks,
     fetch it.  The sum is ONE all-reduce of W_BAD+1 (or TALLY_WORDS) u64 words: on the context's stream through the

@@ -43,7 +43,9 @@ typedef enum hpn_status {
     HPN_E_NOMEM = -5,
     HPN_E_STATE = -6,    /* call sequence error (e.g. depth_add before depth_begin) */
     HPN_E_RCCL = -7,
-    HPN_E_CAPACITY = -8  /* caller-provided output buffer too small; required size reported */
+    HPN_E_CAPACITY = -8, /* caller-provided output buffer too small; required size reported */
+    HPN_E_PARTIAL = -9   /* a grouped collective failed after some ranks were enqueued: the vectors
+                            may or may not hold sums and must not be added again (abandon the input) */
 } hpn_status;
 
 typedef struct hpn_ctx hpn_ctx;
@@ -327,6 +329,17 @@ int hpn_gz_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_gz_chunk *
                        uint32_t sym_cap, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap,
                        uint8_t *d_window_out, hpn_gz_info *info);
 int hpn_gz_members(hpn_ctx *ctx, hpn_gz_member *out, uint32_t cap, uint32_t *n); /* HPN_E_CAPACITY: *n tells how many */
+/* The same call in two halves, for ONE file whose batches of stretches go to several contexts (one per GPU) in turn: the
+ * symbolic decode of a batch needs nothing of the text in front of it, only the resolution of the histories does (the 32 KiB
+ * window the batch before ends with).  _begin_dev starts the decode on the context's stream and returns; _finish_dev takes the
+ * window (d_window_in: on THIS context's device; NULL for the file's first batch), resolves, translates into d_text and
+ * reports like hpn_gz_inflate_dev; d_window_out receives this batch's last 32 KiB for the next one (the caller carries it
+ * to the next context's device).  HPN_E_CAPACITY from _finish_dev leaves the decoded symbols in place: call it again with
+ * the room info->n_bytes asks for.  hpn_gz_inflate_dev = _begin_dev + _finish_dev.  gzread behind the reference's gzgets
+ * (IO_stream.h:122-136, fastq_count.c:112-118) is what the pair stands in for. */
+int hpn_gz_inflate_begin_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_gz_chunk *d_chunks, uint32_t n_chunks, uint32_t sym_cap);
+int hpn_gz_inflate_finish_dev(hpn_ctx *ctx, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap, uint8_t *d_window_out,
+                              hpn_gz_info *info);
 
 /* CRC-32 (RFC 1952) of byte ranges of a device buffer: crc[k] of d_data[spans[k].off .. + spans[k].len).  gzread, which the
  * reference reads every input through (IO_stream.h:122-136), verifies each gzip member's CRC-32 and stops handing out bytes
@@ -459,11 +472,17 @@ int hpn_allreduce_u64(hpn_ctx *ctx, uint64_t *d_vec, size_t n);
  * on n distinct devices, else HPN_E_ARG and nothing is made -- callers then add the vectors on the
  * host), hpn_allreduce_u64_all sums d_vecs[i] (on ctxs[i]'s device) in place into every one of them in
  * one RCCL group, each on its context's stream; the call returns when all have finished.  This is where
- * reduceStats' element-wise sum goes (fastq_count_kthread.c:180-210).  hpn_comm_library: the path of
+ * reduceStats' element-wise sum goes (fastq_count_kthread.c:180-210).  A failure before anything was
+ * enqueued (HPN_E_RCCL / HPN_E_HIP) leaves the vectors as they were: the caller may add them on the
+ * host; HPN_E_PARTIAL does not.  No path returns with the RCCL group open.  hpn_comm_library: the path of
  * the RCCL library the binding resolved to ("" before the first use / when none could be loaded). */
 int hpn_comm_init_all(hpn_ctx **ctxs, int n);
 int hpn_allreduce_u64_all(hpn_ctx **ctxs, uint64_t **d_vecs, int n, size_t n_words);
 const char *hpn_comm_library(void);
+/* Ranks of the context's communicator as RCCL itself reports them (ncclCommCount): what bench.py
+ * prints beside n_gpus, so that a job that believes it has N ranks and a communicator of one cannot
+ * pass for an N-GPU run.  HPN_E_STATE without a communicator. */
+int hpn_comm_count(hpn_ctx *ctx, int *n_ranks);
 
 /* ---- synthetic inputs, generated in HBM -----------------------------------
  * Counter-based: byte k of record r depends only on (seed, r, k), so any shard

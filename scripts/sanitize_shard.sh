@@ -23,6 +23,8 @@ open(T + "/a.fq", "wb").write(text)
 open(T + "/a.fq.gz", "wb").write(b"".join(gzip.compress(text[i:i + 300000], 6) for i in range(0, len(text), 300000)))
 open(T + "/nonl.fq", "wb").write(text[:-1])
 open(T + "/trunc.fq", "wb").write(text[:len(text) // 2 + 17])
+big = b"@big\n" + b"A" * 100000 + b"\n+\n" + b"I" * 100000 + b"\n"
+open(T + "/big.fq", "wb").write(b"".join(recs[:3000]) + big + b"".join(recs[3000:]))
 lens = [len(r.split(b"\n")[1]) for r in recs]
 open(T + "/want.txt", "w").write("%d %d\n" % (len(recs), sum(lens)))
 S, E = 3, 90
@@ -48,6 +50,14 @@ for s in tsan asan; do
       c=$(grep -c "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $T/err.txt || true)
       ok=WRONG; cmp -s $T/got.trim $T/want.trim && [ "$out" = "0 0 $WR" ] && ok=ok
       echo "trim a.fq lanes=$lanes chunk=$chunk $s: $c sanitizer reports, result $ok ($out)"
+    done
+    # one record longer than a piece's tail in mid-file: its lane finds the piece irregular while the others wait for output slabs queued
+    # behind it -- the route must come back ("0 1 ...") and not hang, with the irregular lane slowed too
+    for slow in 0 300; do
+      out=$(HPN_STUB_IRREGULAR_SLEEP_MS=$slow HPN_TEXT_CHUNK=65536 timeout 120 $T/$s trim $T/big.fq $lanes 3 90 $T/got.trim 2> $T/err.txt || echo HUNG)
+      c=$(grep -c "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error" $T/err.txt || true)
+      ok=WRONG; [ "${out:0:3}" = "0 1" ] && ok=ok
+      echo "trim big.fq (must be abandoned, not hang) lanes=$lanes slow=$slow $s: $c sanitizer reports, result $ok ($out)"
     done
   done
 done

@@ -35,3 +35,16 @@ def expected(case, name="stdout"):
             return f.read()
     with open(path, "rb") as f:
         return f.read()
+
+
+@pytest.fixture(scope="session")
+def rccl_stub():
+    """Path of the test-only librccl stand-in (tests/stub/rccl_stub.cpp), built on first use: HPN_RCCL_LIB=<path> makes
+    csrc/hpn_comm.hip bind it instead of RCCL, so the grouped collective runs with n > 1 'ranks' on a one-GPU box."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "stub", "rccl_stub.cpp")
+    out = os.path.join(ROOT, "tests", "stub", "librccl_stub.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-I/opt/rocm/include", src, "-o", out,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    return out

@@ -193,8 +193,10 @@ def make_bam_inputs():
 CASES = []
 
 
-def run_case(name, tool, args, inputs, cwd_outputs=True):
-    """Run a reference tool in a scratch dir holding copies of `inputs`."""
+def run_case(name, tool, args, inputs, cwd_outputs=True, stdin=None, unordered=False):
+    """Run a reference tool in a scratch dir holding copies of `inputs`.
+    stdin: a file whose bytes are piped in (the tools read "-" from stdin, IO_stream.h:122-136);
+    unordered: stdout rows come in thread completion order (fastq_count.c:126 prints under a mutex): compare as a sorted set."""
     out_dir = os.path.join(EXP, name)
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir)
@@ -205,8 +207,9 @@ def run_case(name, tool, args, inputs, cwd_outputs=True):
                 shutil.copy(src + ".bai", td)
         before = set(os.listdir(td))
         p = subprocess.run([os.path.join(REF, tool)] + args, cwd=td, stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE)
-        w(os.path.join(out_dir, "stdout"), p.stdout)
+                           stderr=subprocess.PIPE, stdin=open(stdin, "rb") if stdin else subprocess.DEVNULL)
+        out = b"".join(sorted(p.stdout.splitlines(keepends=True))) if unordered else p.stdout
+        w(os.path.join(out_dir, "stdout"), out)
         # bam_sliding_count also plots <bam>_hits.png (draw_hits, libgd): not part of the scan path, not recorded
         files = sorted(f for f in set(os.listdir(td)) - before if not f.endswith("_hits.png"))
         for f in files:
@@ -217,7 +220,11 @@ def run_case(name, tool, args, inputs, cwd_outputs=True):
                 shutil.copy(os.path.join(td, f), os.path.join(out_dir, f))
     CASES.append({"name": name, "tool": tool, "args": args,
                   "inputs": [os.path.relpath(i, HERE) for i in inputs],
-                  "returncode": p.returncode, "files": files})
+                  "returncode": p.returncode, "files": files,
+                  **({"stdin": os.path.relpath(stdin, HERE)} if stdin else {}),
+                  **({"unordered": True} if unordered else {}),
+                  # usage / diagnostics go to stderr (its text carries timings and the program path: only its presence is recorded)
+                  "stderr_usage": b"Usage" in p.stderr or b"usage" in p.stderr})
     print(f"{name}: rc={p.returncode} stdout={len(p.stdout)}B files={files}")
 
 
@@ -291,6 +298,37 @@ def main():
     run_case("sliding_two_files_rev", "bam_sliding_count", ["-w", "5000", "-o", "two", "rand.bam", "e.bam"],
              [bm("rand.bam"), bm("e.bam")])
     run_case("sliding_wrap", "bam_sliding_count", ["-w", "3", "-o", "wr", "wrap.bam"], [bm("wrap.bam")])
+    # ---- the command-line surface: stdin, a missing input, -h, an unknown option, no arguments, -t over several files ----
+    run_case("count_stdin", "fastq_count", ["-H", "-L", "-"], [], stdin=fq("t.fq"))
+    run_case("count_stdin_gz", "fastq_count", ["-"], [], stdin=fq("syn_100.fq.gz"))            # gzdopen(0): gzip on stdin too
+    run_case("count_stdin_mixed", "fastq_count", ["-t", "1", "-H", "short.fq", "-"], [fq("short.fq")], stdin=fq("t.fq"))
+    run_case("kthread_stdin", "fastq_count_kthread", ["-L", "-o", "-", "-"], [], stdin=fq("short.fq"))   # per-file report "-.0.tsv"
+    run_case("trim_stdin", "fastq_trim", ["-i", "-", "-s", "2", "-e", "8"], [], stdin=fq("t.fq"))
+    run_case("trim_stdin_default_in", "fastq_trim", ["-s", "1", "-e", "9", "-o", "fromstdin"], [], stdin=fq("t.fq.gz"))   # -i defaults to "-"
+    # open(O_CREAT | O_RDONLY): a missing input is CREATED empty and counted as an empty file (IO_stream.h:127)
+    run_case("count_missing", "fastq_count", ["-H", "nothere.fq"], [])
+    run_case("kthread_missing", "fastq_count_kthread", ["-o", "-", "nothere.fq", "t.fq"], [fq("t.fq")])
+    run_case("trim_missing", "fastq_trim", ["-i", "nothere.fq", "-o", "o"], [])
+    # -h and an unknown option (getopt returns '?'): usage on stderr, exit(1), nothing on stdout, no file made
+    run_case("count_help", "fastq_count", ["-h"], [])
+    run_case("count_badopt", "fastq_count", ["-x", "t.fq"], [fq("t.fq")])
+    run_case("count_noargs", "fastq_count", [], [])                                             # no files: header-less nothing, exit 0
+    run_case("kthread_help", "fastq_count_kthread", ["-h"], [])
+    run_case("trim_help", "fastq_trim", ["-h"], [])
+    run_case("trim_noargs", "fastq_trim", [], [])
+    run_case("trim_badopt", "fastq_trim", ["-q", "3", "-i", "t.fq"], [fq("t.fq")])
+    run_case("trim_ignored_v_z", "fastq_trim", ["-v", "-z", "-i", "t.fq", "-s", "1", "-e", "5"], [fq("t.fq")])   # accepted and ignored (:133-138)
+    run_case("depth_help", "bam2depth", ["-h"], [])
+    run_case("depth_noargs", "bam2depth", [], [])
+    run_case("sliding_help", "bam_sliding_count", ["-h"], [])
+    run_case("wig_help", "bam2wig", ["-h"], [])
+    # five files on three threads: rows in completion order -> compared as a sorted set
+    five = ["t.fq", "short.fq", "syn_var_a.fq", "syn_100.fq.gz", "len0.fq"]
+    run_case("count_t3_five", "fastq_count", ["-t", "3", "-H", "-L"] + five, [fq(n) for n in five], unordered=True)
+    run_case("kthread_t3_five", "fastq_count_kthread", ["-t", "3", "-H", "-L", "-o", "m.tsv"] + five, [fq(n) for n in five])
+    # bam2depth -r lacks its break and runs into -s (atoi of the region); both are otherwise unused (bam2depth.c:281-285)
+    run_case("depth_r_falls_into_s", "bam2depth", ["-r", "c1:1-50", "-s", "1", "-w", "100", "-o", "d", "e.bam"], [bm("e.bam")])
+    run_case("depth_r_only", "bam2depth", ["-w", "100", "-r", "7", "-o", "d", "e.bam"], [bm("e.bam")])
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "reference_tools": "oracle/_ref (compiled from /root/reference by oracle/Makefile)",

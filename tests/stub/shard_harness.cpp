@@ -12,8 +12,10 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hpngs.h"
@@ -58,6 +60,12 @@ int hpn_fastq_text_piece_lines(hpn_ctx *c, const void *text, uint64_t nbytes, ui
     for (uint64_t k = 0; k + 1 < lim; ++k) out->n_lines += c->text[k] == '\n';
     return HPN_OK;
 }
+// HPN_STUB_IRREGULAR_SLEEP_MS: the lane that finds its piece irregular reports it that much later, so the lanes beside it are
+// already blocked behind its sequence number when the route stops (the hang the round-3 advisor reproduced in fastq_trim).
+static void slow_irregular()
+{
+    if (const char *e = getenv("HPN_STUB_IRREGULAR_SLEEP_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e)));
+}
 // records owned by the pending piece: (start, line ends e0..e3) by the rule of include/hpngs.h; false: a record does not end in the text
 static bool piece_records(hpn_ctx *c, uint64_t lines_before, std::vector<uint64_t> &starts, std::vector<uint64_t> &ends)
 {
@@ -84,6 +92,7 @@ int hpn_fastq_text_piece_count(hpn_ctx *c, uint64_t lines_before, uint32_t, hpn_
     c->pending = false;
     std::vector<uint64_t> st, en;
     if (!piece_records(c, lines_before, st, en)) {
+        slow_irregular();
         info->irregular = HPN_TEXT_PARTIAL;
         return HPN_OK;
     }
@@ -102,6 +111,7 @@ int hpn_fastq_text_piece_trim(hpn_ctx *c, uint64_t lines_before, int32_t S, int3
     c->pending = false;
     std::vector<uint64_t> st, en;
     if (!piece_records(c, lines_before, st, en)) {
+        slow_irregular();
         info->irregular = HPN_TEXT_PARTIAL;
         return HPN_OK;
     }

@@ -272,6 +272,23 @@ def test_window_reads_of_one_length(ctx, cigar, sort):
     _window_check(ctx, soa, 1000)
 
 
+@pytest.mark.parametrize("cigar,W", [("150M", 20000), ("151M", 1000), ("36M", 50), ("250M", 7)])
+def test_window_every_nibble_code_and_window_seams(ctx, cigar, W):
+    """The GC test is a bit formula on packed nibbles (C = 2, G = 4 of =ACMGRSVTWYHKDBN, bam.h:260): all sixteen codes in every
+    position, on the pass the kernel is built around (one target, one window, one length per 64 records) and on its seams -- small
+    windows put several windows under one pass, which the second kernel takes (bam_sliding_count.c:106-121)."""
+    refs = [("chrA", 1_500_000), ("chrB", 400_000)]
+    soa = make_soa(30_011, refs, 23, sort=True, cigars=[cigar])
+    rng = np.random.default_rng(5)
+    soa.seq4[:] = rng.integers(0, 256, soa.seq4.size, dtype=np.uint8)
+    _window_check(ctx, soa, W)
+    # flags that skip records (4) in runs and singly, and a stretch of unmapped records (tid -1) in the middle
+    soa.flag[1000:1200] = 4
+    soa.flag[5000:9000:7] |= 4
+    soa.tid[20_000:20_100] = -1
+    _window_check(ctx, soa, W)
+
+
 def test_window_index_wraps_like_unsigned_short(ctx):
     # target_len / W + 1 > 65536: (unsigned short)(pos / W) wraps (bam_sliding_count.c:117)
     refs = [("long", 10_000_000)]

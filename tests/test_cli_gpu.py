@@ -26,32 +26,55 @@ CASES = ["count_a1", "count_a1_gz", "count_empty", "count_nonl", "count_crlf", "
          "depth_a3", "depth_a3_wig", "depth_a3_stdout", "depth_rand", "depth_rand_w1000", "depth_two_files",
          "wig_a3", "wig_a3_w7", "wig_rand", "wig_rand_w1000", "wig_rand_w37",
          "sliding_a3", "sliding_rand", "sliding_rand_w700", "sliding_rand_w37", "sliding_region", "sliding_region_chr",
-         "sliding_two_files", "sliding_two_files_rev", "sliding_wrap"]
+         "sliding_two_files", "sliding_two_files_rev", "sliding_wrap",
+         # the command-line surface: stdin ("-", IO_stream.h:122-136), a missing input (O_CREAT makes it, :127), -h / unknown
+         # option / no arguments (usage on stderr, exit 1: fastq_count.c:135-156,194-196), -v -z ignored (fastq_trim.c:133-138), five files on
+         # three threads (rows in completion order: compared as a sorted set), bam2depth -r running into -s (bam2depth.c:281-285)
+         "count_stdin", "count_stdin_gz", "count_stdin_mixed", "kthread_stdin", "trim_stdin", "trim_stdin_default_in",
+         "count_missing", "kthread_missing", "trim_missing", "count_help", "count_badopt", "count_noargs", "kthread_help",
+         "trim_help", "trim_noargs", "trim_badopt", "trim_ignored_v_z", "depth_help", "depth_noargs", "sliding_help", "wig_help",
+         "count_t3_five", "kthread_t3_five", "depth_r_falls_into_s", "depth_r_only"]
 
 
-def _run(tool, args, inputs, cwd, env=None):
+# cases that end in the usage text before any route is chosen: run once (test_drop_in), not once per route
+NO_ROUTE = ("_help", "_noargs", "_badopt")
+FASTQ_ROUTE_CASES = [c for c in CASES if c.startswith(("count_", "kthread_", "trim_")) and not c.endswith(NO_ROUTE)]
+BAM_ROUTE_CASES = [c for c in CASES if c.startswith(("depth_", "wig_", "sliding_")) and not c.endswith(NO_ROUTE)]
+
+
+def _run(tool, args, inputs, cwd, env=None, stdin=None):
     for src in inputs:
         shutil.copy(src, cwd)
         if src.endswith(".bam"):
             shutil.copy(src + ".bai", cwd)
     before = set(os.listdir(cwd))
     p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       env={**os.environ, **(env or {})})
+                       env={**os.environ, **(env or {})}, stdin=open(stdin, "rb") if stdin else subprocess.DEVNULL)
     return p, sorted(set(os.listdir(cwd)) - before)
+
+
+def _check(manifest, case, tmp_path, env=None, force_t1=True):
+    """Run golden case `case` through the tool here and compare return code, stdout and every file with the reference's."""
+    c = manifest[case]
+    args = list(c["args"])
+    if force_t1 and c["tool"] == "fastq_count" and "-t" not in args and c["inputs"]:
+        args = ["-t", "1"] + args  # rows are printed in completion order; one at a time = input order
+    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, env,
+                    os.path.join(GOLDEN, c["stdin"]) if c.get("stdin") else None)
+    assert p.returncode == c["returncode"], p.stderr.decode()
+    got = b"".join(sorted(p.stdout.splitlines(keepends=True))) if c.get("unordered") else p.stdout
+    assert got == expected(case), p.stderr.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    if c.get("stderr_usage"):
+        assert b"sage" in p.stderr           # the usage text went to stderr (its wording is this build's own)
+    return p
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_drop_in(manifest, case, tmp_path):
-    c = manifest[case]
-    args = list(c["args"])
-    if c["tool"] == "fastq_count" and "-t" not in args:
-        args = ["-t", "1"] + args  # rows are printed in completion order; one at a time = input order
-    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path)
-    assert p.returncode == c["returncode"], p.stderr.decode()
-    assert p.stdout == expected(case), p.stderr.decode()
-    assert files == c["files"]
-    for f in files:
-        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    _check(manifest, case, tmp_path)
 
 
 # The FASTQ tools frame regular text on the GPU (hpn_fastq_text_*) and everything else with
@@ -60,18 +83,9 @@ def test_drop_in(manifest, case, tmp_path):
 @pytest.mark.parametrize("env", [{"HPN_TEXT": "0"}, {"HPN_TEXT_CHUNK": "100"}, {"HPN_TEXT_CHUNK": "4099"},
                                  {"HPN_PGZ_FORCE": "1", "HPN_PGZ_CHUNK": "1500", "HPN_GZ_THREADS": "3"}],
                          ids=["host-framer", "chunk100", "chunk4099", "two-pass-gzip"])
-@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("count_", "kthread_", "trim_"))])
+@pytest.mark.parametrize("case", FASTQ_ROUTE_CASES)
 def test_drop_in_fastq_routes(manifest, case, env, tmp_path):
-    c = manifest[case]
-    args = list(c["args"])
-    if c["tool"] == "fastq_count" and "-t" not in args:
-        args = ["-t", "1"] + args
-    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, env)
-    assert p.returncode == c["returncode"], p.stderr.decode()
-    assert p.stdout == expected(case), p.stderr.decode()
-    assert files == c["files"]
-    for f in files:
-        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    _check(manifest, case, tmp_path, env)
 
 
 # ONE FASTQ input over several GPUs (host/text_shard.hpp): the input's bytes go in pieces cut anywhere to one
@@ -85,26 +99,43 @@ SHARDED_REGULAR = {"count_a1", "count_a1_gz", "count_empty", "count_crlf", "coun
                    "trim_a1_file", "trim_syn_100"}
 
 
-@pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_TEXT_CHUNK": "8192"}, {"HPN_NGPU": "5", "HPN_TEXT_CHUNK": "20000"}],
-                         ids=["2lanes", "3lanes-8k", "5lanes-20k"])
-@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("count_", "kthread_", "trim_"))])
+@pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_TEXT_CHUNK": "8192"}, {"HPN_NGPU": "5", "HPN_TEXT_CHUNK": "20000"},
+                                 {"HPN_NGPU": "8", "HPN_TEXT_CHUNK": "8192"}],     # the 8-way shape of a full node: 8 contexts, 10 pinned buffers, 8 tickets on the board
+                         ids=["2lanes", "3lanes-8k", "5lanes-20k", "8lanes-8k"])
+@pytest.mark.parametrize("case", FASTQ_ROUTE_CASES)
 def test_drop_in_one_fastq_over_several_lanes(manifest, case, env, tmp_path):
     c = manifest[case]
-    args = list(c["args"])
-    if c["tool"] == "fastq_count" and "-t" not in args:
-        args = ["-t", "1"] + args
-    p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, {**env, "HPN_TIMING": "1"})
-    assert p.returncode == c["returncode"], p.stderr.decode()
-    assert p.stdout == expected(case), p.stderr.decode()
-    assert files == c["files"]
-    for f in files:
-        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    args = c["args"]
+    p = _check(manifest, case, tmp_path, {**env, "HPN_TIMING": "1"})
     took = p.stderr.count(f"one input over {env['HPN_NGPU']} lanes".encode())
     if case in SHARDED_REGULAR:
         assert took >= 1 and b"abandoned" not in p.stderr, p.stderr.decode()
         assert b"(lanes share a device)" in p.stderr       # and said how the sum was made
     if c["tool"] == "fastq_trim" and "-o" not in args:
         assert took == 0                                    # output to stdout cannot be rewound: one context
+
+
+# ONE gzip input over several GPUs (host/gz_shard.hpp): batches of deflate stretches go to the lanes in turn, every lane finds its
+# own block starts, inflates symbolically, and three chains carry the 32 KiB window, the member state (ISIZE / CRC-32 as gzread
+# checks them behind the reference's gzgets, IO_stream.h:122-136) and the line count from batch to batch.  Small stretches, batches
+# and text slices put many seams into the goldens' small files; the damaged files must leave the route and still give the
+# reference's bytes (what zlib hands out before it fails).
+GZ_SHARDED = ["count_a1_gz", "count_multi", "count_syn_var_b", "count_syn_100", "kthread_a1", "kthread_syn", "count_badcrc", "count_badcrc_mid",
+              "count_badisize", "kthread_badcrc", "count_stdin_gz", "count_t3_five"]
+
+
+@pytest.mark.parametrize("env", [{"HPN_NGPU": "2", "HPN_GZ_STRETCH": "8192", "HPN_GZ_BATCH": "7", "HPN_GZ_SLICE": "20000"},
+                                 {"HPN_NGPU": "3", "HPN_GZ_STRETCH": "4096", "HPN_GZ_BATCH": "5", "HPN_GZ_FIND": "device"},
+                                 {"HPN_NGPU": "8", "HPN_GZ_STRETCH": "16384", "HPN_GZ_BATCH": "4", "HPN_GZ_FIND": "host", "HPN_GZ_SLICE": "9000"}],
+                         ids=["2lanes", "3lanes-device-search", "8lanes"])
+@pytest.mark.parametrize("case", GZ_SHARDED)
+def test_drop_in_one_gzip_over_several_lanes(manifest, case, env, tmp_path):
+    p = _check(manifest, case, tmp_path, {**env, "HPN_GZ_GPU_FORCE": "1", "HPN_TIMING": "1"})
+    took = p.stderr.count(f"one gzip input over {env['HPN_NGPU']} lanes".encode())
+    if "bad" in case:
+        assert b"gzip over " in p.stderr and b"abandoned" in p.stderr, p.stderr.decode()      # the member checks saw the damage
+    elif case in ("count_multi", "count_syn_var_b", "count_syn_100", "kthread_syn", "count_t3_five"):
+        assert took >= 1, p.stderr.decode()
 
 
 def test_sharded_route_on_a_larger_file(tmp_path):
@@ -160,33 +191,46 @@ def test_trim_of_a_damaged_gzip(tmp_path):
 # chunks that cut blocks every 64 KiB, must give the reference's bytes.
 @pytest.mark.parametrize("env", [{"HPN_BAM_GPU": "0"}, {"HPN_BAM_CHUNK": "65600"}, {"HPN_BEDGRAPH_HOST": "1"}],
                          ids=["host-ingest", "chunk64k", "bedgraph-from-runs"])
-@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("depth_", "wig_", "sliding_"))])
+@pytest.mark.parametrize("case", BAM_ROUTE_CASES)
 def test_drop_in_bam_routes(manifest, case, env, tmp_path):
-    c = manifest[case]
-    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, env)
-    assert p.returncode == c["returncode"], p.stderr.decode()
-    assert p.stdout == expected(case), p.stderr.decode()
-    assert files == c["files"]
-    for f in files:
-        assert open(tmp_path / f, "rb").read() == expected(case, f), f
+    _check(manifest, case, tmp_path, env)
 
 
 # Several GPUs: bam2depth / bam2wig hand whole targets, largest first, to one worker per device and write the
 # results in target order; bam_sliding_count hands record batches to the devices in turn and adds their per-window
 # vectors before the float32 replay.  HPN_NGPU forces that many workers on whatever devices exist (worker % devices), so
 # the path runs on a one-GPU box: the bytes must be the reference's, and the route must really have been taken.
-@pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_BAM_CHUNK": "65600"}], ids=["2workers", "3workers-chunk64k"])
-@pytest.mark.parametrize("case", [c for c in CASES if c.startswith(("depth_", "wig_", "sliding_"))])
+@pytest.mark.parametrize("env", [{"HPN_NGPU": "2"}, {"HPN_NGPU": "3", "HPN_BAM_CHUNK": "65600"}, {"HPN_NGPU": "8", "HPN_BAM_CHUNK": "65600"}],
+                         ids=["2workers", "3workers-chunk64k", "8workers-chunk64k"])
+@pytest.mark.parametrize("case", BAM_ROUTE_CASES)
 def test_drop_in_bam_multi_gpu_route(manifest, case, env, tmp_path):
     c = manifest[case]
-    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, {**env, "HPN_TIMING": "1"})
+    p = _check(manifest, case, tmp_path, {**env, "HPN_TIMING": "1"})
+    if "-r" not in c["args"] and c["inputs"]:      # (a region goes through the index on the host reader)
+        # bam2depth / bam2wig give a worker to each target that holds records at most; bam_sliding_count uses all it is given
+        assert b"GPU ingest on " in p.stderr and b" workers" in p.stderr and b"abandoned" not in p.stderr, p.stderr.decode()
+        if env["HPN_NGPU"] != "8" or c["tool"] == "bam_sliding_count":
+            assert f"GPU ingest on {env['HPN_NGPU']} workers".encode() in p.stderr, p.stderr.decode()
+
+
+@pytest.mark.parametrize("case", ["depth_rand", "depth_two_files", "wig_rand"])
+def test_depth_look_ahead_budget_holds_workers_back(manifest, case, tmp_path):  # noqa: D401
+    """Finished targets wait in host memory until every earlier one is written; HPN_DEPTH_LOOKAHEAD bounds the estimated bytes of
+    what is claimed and not yet written.  With a budget of one byte only the target the writer waits for (or any, when nothing is
+    held) may be taken: the workers wait for the writer, and the bytes are still the reference's (round-3 advisor: the budget
+    could not bound anything -- the lowest unclaimed target was always admitted).  bam2depth.c:325-339 is the loop this orders."""
+    c = manifest[case]
+    p, files = _run(c["tool"], list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path,
+                    {"HPN_NGPU": "3", "HPN_DEPTH_LOOKAHEAD": "1", "HPN_TIMING": "1"})
     assert p.returncode == c["returncode"], p.stderr.decode()
-    assert p.stdout == expected(case), p.stderr.decode()
-    assert files == c["files"]
+    assert p.stdout == expected(case) and files == c["files"]
     for f in files:
         assert open(tmp_path / f, "rb").read() == expected(case, f), f
-    if "-r" not in c["args"]:      # (a region goes through the index on the host reader)
-        assert f"GPU ingest on {env['HPN_NGPU']} workers".encode() in p.stderr and b"abandoned" not in p.stderr, p.stderr.decode()
+    import re
+    m = re.findall(rb"look-ahead: at most ([0-9.]+) MB of estimated output claimed and not yet written \(budget ([0-9.]+) MB\), (\d+) waits", p.stderr)
+    assert m, p.stderr.decode()
+    for peak, budget, waits in m:
+        assert int(waits) > 0 and float(budget) < 1e-3       # workers were held back: one target at a time
 
 
 def test_bam_multi_gpu_route_falls_back(tmp_path):
@@ -289,12 +333,15 @@ def test_bgzipped_fastq_is_inflated_on_the_gpu(tmp_path):
             z.write(text[i:i + 40000])
         z.close()
     outs = []
-    for env in ({}, {"HPN_BAM_CHUNK": "70000"}, {"HPN_NO_BGZF": "1", "HPN_NO_MGZ": "1", "HPN_TEXT": "0"}):
+    # (HPN_BGZF_SLICE: one inflate launch can hold more text than one framing call takes -- 2 GiB -- so the text is cut into
+    #  slices anywhere; 5000-byte slices put many cuts into this small file)
+    for env in ({}, {"HPN_BAM_CHUNK": "70000"}, {"HPN_NO_BGZF": "1", "HPN_NO_MGZ": "1", "HPN_TEXT": "0"}, {"HPN_BGZF_SLICE": "5000"},
+                {"HPN_BGZF_SLICE": "65537", "HPN_BAM_CHUNK": "70000"}):
         p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "s.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, env={**os.environ, **env})
         assert p.returncode == 0, p.stderr.decode()
         outs.append(p.stdout)
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
     want = orc.fastq_count_report([str(tmp_path / "s.fq.gz")], names=["s.fq.gz"], header=True, length_detail=True)
     assert outs[0] == want
     # the same bytes with a damaged block in the middle: the GPU route gives up, zlib's verdict stands
@@ -358,14 +405,20 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
         for env in ({"HPN_GZ_GPU_FORCE": "1"}, {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000", "HPN_GZ_FIND": "host"},
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "7"},
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000", "HPN_GZ_FIND": "device"},
-                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "100000", "HPN_GZ_BATCH": "5", "HPN_GZ_FIND": "device"}):
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "100000", "HPN_GZ_BATCH": "5", "HPN_GZ_FIND": "device"},
+                    # the same file over several lanes (host/gz_shard.hpp): batches in turn, windows / member state / lines handed on
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_NGPU": "3", "HPN_GZ_STRETCH": "40000", "HPN_GZ_BATCH": "7", "HPN_GZ_SLICE": "300000"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_NGPU": "2", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "4", "HPN_GZ_FIND": "device"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_NGPU": "5", "HPN_GZ_STRETCH": "60000", "HPN_GZ_BATCH": "6"}):
             p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", name], cwd=tmp_path, stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, env={**os.environ, "HPN_TIMING": "1", **env})
             assert p.returncode == ref.returncode, p.stderr.decode()
             if name != "bad.fq.gz":   # (what survives a damaged stream depends on the reader)
                 assert p.stdout == ref.stdout, (name, env)
-            used = b"[hpn] gzip on the GPU" in p.stderr
+            used = b"[hpn] gzip on the GPU" in p.stderr or b"one gzip input over" in p.stderr
             assert used == (name in ("one.fq.gz", "lvl1.fq.gz", "two.fq.gz", "many.fq.gz", "tiny.fq.gz")), (name, env, p.stderr)
+            if "HPN_NGPU" in env and used:
+                assert f"one gzip input over {env['HPN_NGPU']} lanes".encode() in p.stderr, (name, env, p.stderr)
     # fastq_trim to a file takes the same route; whatever it has to hand back (here also: a read shorter than -s) starts over
     for name in ("one.fq.gz", "two.fq.gz", "many.fq.gz", "ragged.fq.gz", "tail.fq.gz"):
         outs = []
