@@ -11,6 +11,7 @@
 """
 import ctypes as C
 import filecmp
+import json
 import os
 import shutil
 import statistics
@@ -364,7 +365,38 @@ def _outputs(d, inputs):
     return sorted(f for f in os.listdir(d) if f not in inputs and not f.endswith("_hits.png"))
 
 
-def _steady_state_legs(ctx, cores, td, pair, L):
+def host_link(td):
+    """What feeds the plain-text legs on THIS box: pinned host -> device copies and pread out of the page cache into pinned memory
+    (scripts/micro/h2d_bw.hip, built and run here).  Every end-to-end leg is priced against it: input_GBps / link_GBps = link_frac.
+    None when the micro-benchmark cannot be built or run (the legs then carry no link_frac)."""
+    exe = os.path.join(td, "h2d_bw")
+    try:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "scripts", "micro", "h2d_bw.hip"), "-o", exe, "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        out = subprocess.run([exe, td], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout.decode()
+        j = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        j["h2d_best_GBps"] = max(v for k, v in j.items() if k.startswith("h2d_"))
+        j["pread_best_GBps"] = max(v for k, v in j.items() if k.startswith("pread_pagecache"))
+        j["pipelined_best_GBps"] = max(v for k, v in j.items() if k.endswith("pipelined_GBps"))
+        return j
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        if os.path.exists(exe):
+            os.unlink(exe)
+
+
+def _price(leg, in_bytes, link):
+    """input_GBps of our run and its share of the box's pipelined pread + H2D rate (a leg cannot beat that from the page cache)."""
+    if leg.get("hpngs") and in_bytes:
+        leg["input_bytes"] = int(in_bytes)
+        leg["input_GBps"] = round(in_bytes / leg["hpngs"]["seconds"] / 1e9, 2)
+        if link:
+            leg["link_frac"] = round(leg["input_GBps"] / link["pipelined_best_GBps"], 3)
+    return leg
+
+
+def _steady_state_legs(ctx, cores, td, pair, L, link=None):
     """Inputs large enough that start-up (HIP init + context + exit, measured on a one-record file and reported as
     startup_s) is a few per cent of the wall: what the tools sustain from the page cache over one PCIe link."""
     import torch
@@ -390,7 +422,7 @@ def _steady_state_legs(ctx, cores, td, pair, L):
     for nm in names8:
         os.symlink(os.path.join(td, "small.fq"), os.path.join(td, nm))
 
-    def ours_only(label, tool, args, inputs, unit_bases, env=None, compare_to=None):
+    def ours_only(label, tool, args, inputs, unit_bases, env=None, compare_to=None, keep_sizes=False):
         wd = tempfile.mkdtemp(prefix="ours_", dir=td)
         for i in inputs:
             os.symlink(os.path.join(td, i), os.path.join(wd, i))
@@ -400,7 +432,20 @@ def _steady_state_legs(ctx, cores, td, pair, L):
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
         res = {"leg": label, "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode},
                "reference": None, "startup_s": round(t_start, 3), "startup_share": round(t_start / dt, 3)}
-        out = {f: open(os.path.join(wd, f), "rb").read() for f in _outputs(wd, inputs)}
+        if keep_sizes:     # outputs of many GB: (size, CRC-32) instead of the bytes
+            out = {}
+            for f in _outputs(wd, inputs):
+                crc, size = 0, 0
+                with open(os.path.join(wd, f), "rb") as fh:
+                    while True:
+                        blk = fh.read(64 << 20)
+                        if not blk:
+                            break
+                        crc, size = zlib.crc32(blk, crc), size + len(blk)
+                out[f] = (size, crc)
+            res["output_bytes"] = sum(v[0] for v in out.values())
+        else:
+            out = {f: open(os.path.join(wd, f), "rb").read() for f in _outputs(wd, inputs)}
         if compare_to is not None:
             res["outputs_identical_to"] = compare_to[0]
             res["outputs_identical"] = bool(out == compare_to[1])
@@ -412,11 +457,11 @@ def _steady_state_legs(ctx, cores, td, pair, L):
     r = pair(f"fastq_count_kthread -t 8, 8 plain files x {n_small:.1e} x {L} bp ({8 * n_small * rec / 1e9:.1f} GB)", "fastq_count_kthread",
              lambda wd: ["-t", "8", "-o", "m.tsv"] + names8, names8, 8 * small_bases)
     r["startup_s"] = round(t_start, 3)
-    legs.append(r)
+    legs.append(_price(r, 8 * n_small * rec, link))
     r = pair(f"fastq_count, ONE plain file {n_big:.1e} x {L} bp ({n_big * rec / 1e9:.1f} GB; default route: two lanes on the one device)", "fastq_count",
              lambda wd: ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases)
     r["startup_s"] = round(t_start, 3)
-    legs.append(r)
+    legs.append(_price(r, n_big * rec, link))
     # the same file by record block over lanes (host/text_shard.hpp).  On this box the lanes share the one device and its one
     # PCIe link; the default above already uses TWO of them for a file of this size (one lane's copy runs beside the other's
     # kernels), HPN_NGPU=1 is the single-context route, HPN_NGPU=4 shows what more lanes on one link cost
@@ -424,8 +469,34 @@ def _steady_state_legs(ctx, cores, td, pair, L):
                                ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases, env={"HPN_NGPU": "1"})
     lanes, _ = ours_only("fastq_count, the same ONE file by record block over 4 lanes (HPN_NGPU=4, lanes share the device)", "fastq_count",
                          ["-o", "rep.txt", "big.fq"], ["big.fq"], big_bases, env={"HPN_NGPU": "4"}, compare_to=("one context", base_out))
-    legs.extend([base, lanes])
+    legs.extend([_price(base, n_big * rec, link), _price(lanes, n_big * rec, link)])
+    # ---- fastq_trim at steady state (BASELINE configs[2]'s tool): 16.3 GB in, ~15 GB of trimmed text out to a file ----
+    trim_args = ["-i", "big.fq", "-s", "5", "-e", "140", "-o", "t"]
+    t1, t1_out = ours_only(f"fastq_trim -s 5 -e 140, ONE plain file {n_big:.1e} x {L} bp ({n_big * rec / 1e9:.1f} GB) -> t.trim.fastq (default route)", "fastq_trim",
+                           trim_args, ["big.fq"], big_bases, keep_sizes=True)
+    legs.append(_price(t1, n_big * rec, link))
+    t4, _ = ours_only("fastq_trim, the same file by record block over 4 lanes (HPN_NGPU=4, lanes share the device), output compared by size + CRC", "fastq_trim",
+                      trim_args, ["big.fq"], big_bases, env={"HPN_NGPU": "4"}, compare_to=("the default route", t1_out), keep_sizes=True)
+    legs.append(_price(t4, n_big * rec, link))
     os.unlink(os.path.join(td, "big.fq"))
+    # the two mates of a paired run (configs[2]: 2 x 150 bp): two fastq_trim processes side by side on the one device
+    for nm in ("m1.fq", "m2.fq"):
+        os.symlink(os.path.join(td, "small.fq"), os.path.join(td, nm))
+    wd = tempfile.mkdtemp(prefix="mates_", dir=td)
+    for nm in ("m1.fq", "m2.fq"):
+        os.symlink(os.path.join(td, nm), os.path.join(wd, nm))
+    t0 = time.perf_counter()
+    ps = [subprocess.Popen([os.path.join(BIN, "fastq_trim"), "-i", nm, "-s", "5", "-e", "140", "-o", nm[:2]], cwd=wd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+          for nm in ("m1.fq", "m2.fq")]
+    rcs = [q.wait() for q in ps]
+    dt = time.perf_counter() - t0
+    same = filecmp.cmp(os.path.join(wd, "m1.trim.fastq"), os.path.join(wd, "m2.trim.fastq"), shallow=False) if rcs == [0, 0] else False
+    legs.append(_price({"leg": f"fastq_trim -s 5 -e 140 on the two mates at once: 2 processes x {n_small:.1e} x {L} bp ({2 * n_small * rec / 1e9:.1f} GB in), one device",
+                        "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(2 * small_bases / dt / 1e9, 3), "rc": max(rcs)}, "reference": None,
+                        "outputs_identical_to": "each other (the same reads)", "outputs_identical": bool(same), "startup_s": round(t_start, 3)}, 2 * n_small * rec, link))
+    shutil.rmtree(wd, ignore_errors=True)
+    for nm in ("m1.fq", "m2.fq"):
+        os.unlink(os.path.join(td, nm))
     # gzip, one member, 4.1 GB of text x 3 members' worth would take the reference minutes: ours only, checked against the
     # plain-text run of the same reads (which the pair above ties to the reference)
     raw = open(os.path.join(td, "small.fq"), "rb").read()
@@ -439,7 +510,8 @@ def _steady_state_legs(ctx, cores, td, pair, L):
                            "fastq_count", ["-o", "rep.txt", "gz3.fq.gz"], ["gz3.fq.gz"], 3 * small_bases)
     row = gz_out.get("rep.txt", b"").decode().split("\t")
     gz["counts_closed_form"] = bool(len(row) > 2 and int(row[1]) == 3 * n_small and float(row[2]) == 3 * small_bases)
-    legs.append(gz)
+    gz["text_GBps"] = round(3 * n_small * rec / gz["hpngs"]["seconds"] / 1e9, 2)
+    legs.append(_price(gz, gz_bytes, link))
     for nm in names8 + ["small.fq", "gz3.fq.gz", "one.fq"]:
         os.unlink(os.path.join(td, nm))
     return legs
@@ -449,6 +521,8 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
     legs = []
     td = tempfile.mkdtemp(prefix="hpn_e2e_")
     try:
+        link = host_link(td)
+        legs.append({"leg": "host link of this box (scripts/micro/h2d_bw.hip): pinned H2D, pread from the page cache, both pipelined", "host_link": link})
         text = _fastq_text(ctx, reads, L, 31)
         raw = text.tobytes()
         del text
@@ -498,7 +572,7 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
         for f in ("plain.fq", "members.fq.gz", "single.fq.gz"):
             os.unlink(os.path.join(td, f))
         try:
-            legs.extend(_steady_state_legs(ctx, cores, td, pair, L))
+            legs.extend(_steady_state_legs(ctx, cores, td, pair, L, link))
         except Exception as e:  # noqa: BLE001  (disk or memory of the box: the short legs above stand)
             legs.append({"leg": "steady state", "failed": str(e)[:300]})
         # ---- BAM --------------------------------------------------------------------------------------------------

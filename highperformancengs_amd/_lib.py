@@ -114,6 +114,7 @@ SYMBOLS = [
     ("hpn_fastq_text_piece_trim", _int, [_vp, _u64, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_bgzf_inflate_dev", _int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("hpn_gz_inflate_dev", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
+    ("hpn_inflate_slots", _int, [_vp, C.POINTER(_u32)]),
     ("hpn_gz_inflate_begin_dev", _int, [_vp, _vp, _vp, _u32, _u32]),
     ("hpn_gz_inflate_finish_dev", _int, [_vp, _vp, _vp, _u64, _vp, C.POINTER(GzInfo)]),
     ("hpn_gz_members", _int, [_vp, _vp, _u32, C.POINTER(_u32)]),

@@ -47,7 +47,9 @@ public:
     }
     void bind(hpn_ctx *ctx) { ctx_ = ctx; }
     hpn_ctx *ctx() const { return ctx_; }
-    const uint8_t *d_raw() const { return (const uint8_t *)d_out_; }
+    const uint8_t *d_raw() const { return d_out_ ? (const uint8_t *)d_out_ + pad_front_ : nullptr; }
+    // writable room in front of and behind the inflated bytes (text batches framed as pieces: the byte before, the 4 KiB after)
+    void set_out_pad(size_t front, size_t back) { pad_front_ = front, pad_back_ = back; }
 
     // Bytes and table to the device, inflate, then (records) index or (text) check every block.
     // 1 = ok, -1 = not decodable here.  On return the pinned chunk `pb.body` points into is free again.
@@ -58,7 +60,7 @@ public:
         if (!nb) return 1;
         const size_t comp_bytes = pb.carry.size() + pb.body_len;
         if (!reserve<uint8_t>(d_comp_, cap_comp_, comp_bytes + 64) || !reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) ||
-            !reserve<uint8_t>(d_out_, cap_out_, pb.out_bytes + 64) || !reserve<uint32_t>(d_status_, cap_status_, nb))
+            !reserve<uint8_t>(d_out_, cap_out_, pb.out_bytes + 64 + pad_front_ + pad_back_) || !reserve<uint32_t>(d_status_, cap_status_, nb))
             return -1;
         if (nb > h_blocks_cap_) {
             if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
@@ -72,7 +74,7 @@ public:
         }
         if (pb.body_len && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + pb.carry.size(), pb.body, pb.body_len) != HPN_OK) return -1;
         if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
-        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
+        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_ + pad_front_,
                                  (uint32_t *)d_status_) != HPN_OK)
             return -1;
         if (text_mode) {  // no records: wait, check every block's status
@@ -84,7 +86,7 @@ public:
             return 1;
         }
         // the sync inside the index call also covers the copies out of the pinned chunk
-        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, pb.first_off,
+        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_ + pad_front_, (const hpn_bgzf_block *)d_blocks_, nb, pb.first_off,
                                   (const uint32_t *)d_status_, info) != HPN_OK)
             return -1;
         return info->flags ? -1 : 1;
@@ -121,7 +123,7 @@ public:
         memset(info, 0, sizeof *info);
         const size_t nb = pieces_.size();
         if (!nb) return 1;
-        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) || !reserve<uint8_t>(d_out_, cap_out_, at_out_ + 64) ||
+        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) || !reserve<uint8_t>(d_out_, cap_out_, at_out_ + 64 + pad_front_ + pad_back_) ||
             !reserve<uint32_t>(d_status_, cap_status_, nb))
             return -1;
         if (nb > h_blocks_cap_) {
@@ -131,7 +133,7 @@ public:
         }
         memcpy(h_blocks_, pieces_.data(), nb * sizeof(hpn_bgzf_block));
         if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
-        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_,
+        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_ + pad_front_,
                                  (uint32_t *)d_status_) != HPN_OK)
             return -1;
         if (text_mode) {  // no records: wait, check every block's status
@@ -142,7 +144,7 @@ public:
             info->n_records = at_out_;
             return 1;
         }
-        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
+        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_ + pad_front_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
                                   (const uint32_t *)d_status_, info) != HPN_OK)
             return -1;
         return info->flags ? -1 : 1;
@@ -166,6 +168,7 @@ private:
         return true;
     }
     hpn_ctx *ctx_;
+    size_t pad_front_ = 0, pad_back_ = 0;
     std::vector<uint32_t> status_;
     void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr;
     size_t cap_comp_ = 0, cap_blocks_ = 0, cap_out_ = 0, cap_status_ = 0, h_blocks_cap_ = 0;
@@ -219,7 +222,7 @@ public:
         }
         fclose(f);
         if (!ok) return false;
-        chunk_ = (size_t)88 << 20;  // ~4,500 blocks: about one round of the inflate kernel's 5,120 wave slots
+        chunk_ = (size_t)88 << 20;  // ~4,500 blocks: most of one round of the inflate kernel's 6,144 wave slots
         if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
         pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         if (!pump_->ok()) return false;
@@ -229,14 +232,14 @@ public:
 
     // bgzip-compressed text (a .fastq.gz written by bgzip): batches of inflated bytes on the device,
     // no records to index.  next() then fills only info->n_records with the batch's byte count.
-    bool open_text(hpn_ctx *ctx, const char *path)
+    bool open_text(hpn_ctx *ctx, const char *path, int nbuf = 3)
     {
         ctx_ = ctx;
         dev_.bind(ctx);
         text_mode_ = true;
         chunk_ = (size_t)88 << 20;
         if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
-        pump_.reset(new TextPump(ctx, path, chunk_, 3, true));
+        pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         return pump_->ok();
     }
     bool at_eof() const { return eof_ && carry_.empty(); }
@@ -391,6 +394,7 @@ private:
     BgzfDevice dev_;
 
     friend class BgzfFanout;
+    friend class BgzfTextFanout;
 };
 
 inline bool bam_gpu_enabled()

@@ -23,6 +23,7 @@
 // added and the caller reads the file another way.
 #pragma once
 #include "gz_gpu.hpp"
+#include "text_relay.hpp"
 #include "text_shard.hpp"
 
 namespace hpn {
@@ -94,10 +95,8 @@ public:
     int run(uint32_t tally_flags, bool *unusable)
     {
         *unusable = false;
-        flags_ = tally_flags;
+        relay_.reset(new TextRelay(tally_flags));
         const int L = g_.lanes();
-        pub_.assign((size_t)n_batches_, Pub());
-        board_.assign((size_t)n_batches_ + 1, 0);
         window_.assign(32768, 0);
         lanes_.clear();
         for (int l = 0; l < L; ++l) lanes_.emplace_back(new Lane());
@@ -130,15 +129,8 @@ private:
         void *d_text = nullptr, *d_win_in = nullptr, *d_win_out = nullptr, *h_win = nullptr, *h_edge = nullptr;
         size_t cap_text = 0;
     };
-    struct Pub {    // what a batch tells its neighbours once its text exists
-        bool ready = false;
-        uint64_t n_bytes = 0;
-        uint32_t head_n = 0;
-        uint8_t last_byte = 0;
-        bool ends_stream = false;      // no text follows this batch's
-        std::vector<uint8_t> head;     // its first min(4096, n_bytes) bytes
-    };
-    static constexpr size_t kFront = 64;   // room in front of a batch's text for the byte before it
+    static constexpr uint64_t kLookAhead = 16;
+    static constexpr size_t kFront = TextRelay::kFront;   // room in front of a batch's text for the byte before it
 
     bool give_up(const char *why)
     {
@@ -149,9 +141,14 @@ private:
     {
         {
             std::lock_guard<std::mutex> lk(m_);
-            if (!abort_) abort_ = true, why_ = why, rc_ = rc;
+            if (!abort_) {
+                abort_ = true, rc_ = rc;
+                snprintf(why_store_, sizeof why_store_, "%s", why);
+                why_ = why_store_;
+            }
         }
         cv_.notify_all();
+        if (relay_) relay_->abort(why, rc);
     }
     bool stopped()
     {
@@ -236,7 +233,9 @@ private:
     bool prepare(Lane &ln, Slot &sl, uint64_t b)
     {
         const uint64_t k0 = b * S_, k1 = (b + 1) * S_ < n_slices_ ? (b + 1) * S_ : n_slices_;
-        const uint64_t look = k1 + 2 < n_slices_ ? k1 + 2 : n_slices_;         // two slices behind the batch tell where its last stretch ends
+        // the slices behind the batch tell where its last stretch ends: the first block start in them (looked for one slice after the
+        // other; a deflate block of well-compressed text can be longer than a small slice)
+        const uint64_t look = k1 + kLookAhead < n_slices_ ? k1 + kLookAhead : n_slices_;
         const uint64_t base_byte = body_byte_ + k0 * stretch_;
         uint64_t up_end = body_byte_ + look * stretch_ + 8192;
         if (up_end > size_ || look == n_slices_) up_end = size_;
@@ -244,10 +243,11 @@ private:
         std::vector<uint64_t> found((size_t)(look - k0), kGzNone);
         auto host_search = [&](int nthreads) {
             std::atomic<uint64_t> take{0};
+            const uint64_t own = k1 - k0;                 // the batch's own slices side by side, then the slices behind it until one has a start
             auto work = [&] {
                 for (;;) {
                     const uint64_t i = take.fetch_add(1);
-                    if (i >= found.size()) return;
+                    if (i >= own) return;
                     if (found[(size_t)i] != kGzNone) continue;
                     if (k0 + i == 0) {
                         found[0] = body_byte_ * 8;        // the member's first block
@@ -261,6 +261,14 @@ private:
             std::vector<std::thread> pool;
             for (int t = 0; t < nthreads; ++t) pool.emplace_back(work);
             for (auto &t : pool) t.join();
+            for (uint64_t i = own; i < found.size(); ++i) {
+                if (found[(size_t)i] == kGzNone) {
+                    uint64_t lo, hi;
+                    slice_bits(k0 + i, lo, hi);
+                    found[(size_t)i] = find_start(lo, hi);
+                }
+                if (found[(size_t)i] != kGzNone) break;
+            }
         };
         const int share = threads_ / g_.lanes() < 1 ? 1 : threads_ / g_.lanes();
         if (search_on_device_) {
@@ -366,7 +374,7 @@ private:
         hpn_ctx *ctx = g_.ctx(l);
         void *p = nullptr;
         if (hpn_dev_malloc(ctx, 32768, &ln.d_win_in) != HPN_OK || hpn_dev_malloc(ctx, 32768, &ln.d_win_out) != HPN_OK || hpn_host_malloc(ctx, 32768, &ln.h_win) != HPN_OK ||
-            hpn_host_malloc(ctx, HPN_TEXT_PIECE_TAIL + 64, &p) != HPN_OK)
+            hpn_host_malloc(ctx, TextRelay::kEdgeBytes, &p) != HPN_OK)
             return stop("memory for the hand-overs");
         ln.h_edge = p;
         uint32_t turn = 0;
@@ -425,26 +433,14 @@ private:
         const uint64_t nb = info.n_bytes;
         const bool ends_stream = sl.final_data || (n == 0 && after_final_.load());
         if (sl.final_data) after_final_ = true;
-        if (!ends_stream && nb < HPN_TEXT_PIECE_TAIL) return fail("a batch with hardly any text");
-        // what the neighbours need of this text: its first bytes (the tail of the batch before), its last byte (the head of the next)
-        uint8_t *edge = (uint8_t *)ln.h_edge;
-        const uint32_t head_n = (uint32_t)(nb < HPN_TEXT_PIECE_TAIL ? nb : HPN_TEXT_PIECE_TAIL);
-        if (nb) {
-            if (hpn_memcpy_d2h(ctx, edge, (uint8_t *)ln.d_text + kFront, head_n) != HPN_OK || hpn_memcpy_d2h(ctx, edge + HPN_TEXT_PIECE_TAIL, (uint8_t *)ln.d_text + kFront + nb - 1, 1) != HPN_OK ||
-                hpn_ctx_sync(ctx) != HPN_OK)
-                return fail_ctx(ctx);
-        }
         {
             std::lock_guard<std::mutex> lk(m_);
             memcpy(window_.data(), ln.h_win, 32768);
             w_next_ = b + 1;
-            Pub &pb = pub_[(size_t)b];
-            pb.n_bytes = nb, pb.head_n = head_n, pb.ends_stream = ends_stream;
-            pb.head.assign(edge, edge + head_n);
-            pb.last_byte = nb ? edge[HPN_TEXT_PIECE_TAIL] : 0;
-            pb.ready = true;
         }
         cv_.notify_all();
+        // what the neighbours need of this text: its first bytes (the tail of the batch before), its last byte (the head of the next)
+        if (!relay_->publish(ctx, b, (const uint8_t *)ln.d_text + kFront, nb, ends_stream, ln.h_edge)) return fail(relay_->why());
         // ---- M: gzread's checks of every member that ended in this batch ----
         {
             uint32_t nm = 0;
@@ -495,96 +491,9 @@ private:
             sl.state = 0;
         }
         cv_.notify_all();
-        return frame(ln, b, nb, ends_stream);
-    }
-    // ---- L: the batch's text in slices through the piece calls; the lines in front of it come down the chain ----
-    bool frame(Lane &ln, uint64_t b, uint64_t nb, bool ends_stream)
-    {
-        hpn_ctx *ctx = ln.ctx;
-        uint8_t *text = (uint8_t *)ln.d_text + kFront;
-        uint64_t lines_here = 0;
-        bool have_board = false;
-        uint64_t before = 0;
-        auto board = [&]() -> bool {       // lines in front of this batch (all earlier batches have indexed all their text)
-            if (have_board) return true;
-            std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return l_next_ >= b || abort_; });
-            if (abort_) return false;
-            before = board_[(size_t)b], have_board = true;
-            return true;
-        };
-        if (nb) {
-            uint32_t head = 0;
-            if (b) {    // the byte in front of this batch: the last byte of the nearest batch with text before it
-                uint8_t prev = 0;
-                bool any = false;
-                {
-                    std::unique_lock<std::mutex> lk(m_);
-                    for (uint64_t i = b; i-- > 0 && !any;) {
-                        cv_.wait(lk, [&] { return pub_[(size_t)i].ready || abort_; });
-                        if (abort_) return false;
-                        if (pub_[(size_t)i].n_bytes) prev = pub_[(size_t)i].last_byte, any = true;
-                    }
-                }
-                if (any) {
-                    *(uint8_t *)ln.h_edge = prev;
-                    if (hpn_memcpy_h2d(ctx, text - 1, ln.h_edge, 1) != HPN_OK || hpn_ctx_sync(ctx) != HPN_OK) return fail_ctx(ctx);
-                    head = 1;
-                }
-            }
-            const uint64_t slice = slice_bytes();
-            for (uint64_t at = 0; at < nb;) {
-                const uint64_t own = nb - at < slice ? nb - at : slice;
-                const bool last_slice = at + own == nb;
-                uint64_t tail = last_slice ? 0 : (nb - at - own < HPN_TEXT_PIECE_TAIL ? nb - at - own : HPN_TEXT_PIECE_TAIL);
-                bool last_piece = false;
-                if (last_slice && ends_stream) last_piece = true;
-                if (last_slice && !ends_stream) {     // the tail lies in the next batch's text
-                    std::unique_lock<std::mutex> lk(m_);
-                    cv_.wait(lk, [&] { return pub_[(size_t)b + 1].ready || abort_; });
-                    if (abort_) return false;
-                    const Pub &nx = pub_[(size_t)b + 1];
-                    tail = nx.head_n;
-                    if (tail) memcpy(ln.h_edge, nx.head.data(), tail);
-                    if (tail < HPN_TEXT_PIECE_TAIL && !nx.ends_stream) return fail("a batch with hardly any text");
-                    last_piece = tail == 0;
-                    lk.unlock();
-                    if (tail && (hpn_memcpy_h2d(ctx, text + nb, ln.h_edge, tail) != HPN_OK || hpn_ctx_sync(ctx) != HPN_OK)) return fail_ctx(ctx);
-                }
-                const uint32_t h = at ? 1u : head;
-                hpn_text_piece pl;
-                int rc = hpn_fastq_text_piece_lines(ctx, text + at - h, h + own + tail, h, own, last_piece ? 1 : 0, &pl);
-                if (rc != HPN_OK) return fail_ctx(ctx);
-                if (pl.irregular) return fail("irregular text");
-                if (!board()) return false;
-                if (last_slice) {     // this batch's lines are all counted: the next batch may frame
-                    std::lock_guard<std::mutex> lk(m_);
-                    board_[(size_t)b + 1] = before + lines_here + pl.n_lines;
-                    l_next_ = b + 1;
-                }
-                if (last_slice) cv_.notify_all();
-                hpn_text_info info;
-                rc = hpn_fastq_text_piece_count(ctx, before + lines_here, flags_, &info);
-                if (rc != HPN_OK) return fail_ctx(ctx);
-                if (info.irregular) return fail("irregular text");
-                lines_here += pl.n_lines;
-                at += own;
-            }
-        } else {
-            if (!board()) return false;
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                board_[(size_t)b + 1] = before;
-                l_next_ = b + 1;
-            }
-            cv_.notify_all();
-        }
+        // ---- L: the batch's text in slices through the piece calls; the lines in front of it come down the relay ----
+        if (!relay_->frame(ctx, b, (uint8_t *)ln.d_text + kFront, nb, ends_stream, ln.h_edge)) return fail(relay_->why());
         return true;
-    }
-    static uint64_t slice_bytes()   // HPN_GZ_SLICE: tests cut small texts into several pieces
-    {
-        const char *e = getenv("HPN_GZ_SLICE");
-        return e && atoll(e) >= 2 * (long long)HPN_TEXT_PIECE_TAIL ? (uint64_t)atoll(e) : (uint64_t)256 << 20;
     }
     bool fail_ctx(hpn_ctx *ctx)
     {
@@ -613,7 +522,7 @@ private:
     uint64_t size_ = 0, body_byte_ = 0, n_slices_ = 0, n_batches_ = 0;
     size_t stretch_ = 0;
     double ratio_ = 4.0;
-    uint32_t sym_cap_ = 0, flags_ = 0;
+    uint32_t sym_cap_ = 0;
     bool search_on_device_ = false;
     const bool check_crc_ = !(getenv("HPN_GZ_CRC") && getenv("HPN_GZ_CRC")[0] == '0');
     std::vector<std::unique_ptr<Lane>> lanes_;
@@ -624,10 +533,10 @@ private:
     int rc_ = HPN_OK;
     const char *why_ = "";
     char why_buf_[160];
-    uint64_t w_next_ = 0, m_next_ = 0, l_next_ = 0;
+    uint64_t w_next_ = 0, m_next_ = 0;
     std::vector<uint8_t> window_;
-    std::vector<Pub> pub_;
-    std::vector<uint64_t> board_;
+    std::unique_ptr<TextRelay> relay_;
+    char why_store_[200];
     uint64_t total_text_ = 0, member_start_ = 0, n_members_ = 0;
     uint32_t member_crc_ = 0;
     std::atomic<bool> after_final_{false};
@@ -644,7 +553,9 @@ inline int tally_gz_sharded(LaneGroup &g, const char *path, hpn_tally *acc, bool
         return HPN_OK;
     }
     const long cpus = usable_cpus() / text_workers_in_flight();
-    uint32_t per_call = (uint32_t)(5120 / text_workers_in_flight());
+    uint32_t slots = 5120;
+    (void)hpn_inflate_slots(g.ctx(0), &slots);                        // stretches a chip decodes at once
+    uint32_t per_call = (uint32_t)(slots / (uint32_t)text_workers_in_flight());
     if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
     GzSharded gs(g, path, (int)(cpus < 1 ? 1 : cpus > 32 ? 32 : cpus), per_call < 1 ? 1 : per_call);
     if (!gs.open()) {

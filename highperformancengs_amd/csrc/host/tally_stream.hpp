@@ -11,6 +11,7 @@
 #include "../host/text_stream.hpp"
 #include "../host/text_shard.hpp"
 #include "../host/gz_shard.hpp"
+#include "../host/bgzf_shard.hpp"
 #include "hpngs.h"
 
 namespace hpn {
@@ -194,7 +195,9 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
     *unusable = false;
     GzGpuStream gs;
     const long cpus = usable_cpus() / text_workers_in_flight();
-    uint32_t per_call = (uint32_t)(5120 / text_workers_in_flight());  // the chip runs 5,120 stretches at a time (20 decoder waves per CU)
+    uint32_t slots = 5120;
+    (void)hpn_inflate_slots(ctx, &slots);                             // stretches the chip decodes at once (24 decoder waves per CU: 6,144)
+    uint32_t per_call = (uint32_t)(slots / (uint32_t)text_workers_in_flight());
     if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);  // (tests: several device calls per file)
     const double t0 = wall_s();
     if (!gs.open(ctx, path, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call)) {
@@ -250,6 +253,11 @@ inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_
 {
     const bool is_stdin = strncmp(path, "-", 1) == 0 || !strcmp(path, "");
     if (text_path_enabled() && !is_stdin && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(path)) {
+        if (group && group->lanes() > 1) {      // chunks of whole blocks over one context per device (host/bgzf_shard.hpp)
+            bool unusable = false;
+            const int rc = tally_bgzf_sharded(*group, path, acc, &unusable);
+            if (!unusable) return rc;
+        }
         bool unusable = false;
         const int rc = tally_bgzf_on_gpu(ctx, path, acc, &unusable);
         if (!unusable) return rc;

@@ -19,6 +19,7 @@ hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const vo
 hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const void *d_slices, uint32_t n, uint64_t *d_found, int n_cu,
                                  hipStream_t st);
 uint32_t crc_block_bytes();
+uint32_t inflate_waves_per_cu();
 hipError_t launch_crc32_blocks(const uint8_t *d_data, const void *d_blocks, uint32_t n_blocks, uint32_t *d_out, hipStream_t st);
 uint32_t crc_fold_blocks(const uint32_t *crcs, uint64_t n_blocks, uint64_t total_len);
 uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
@@ -193,6 +194,13 @@ int hpn_crc32_dev(hpn_ctx *c, const uint8_t *d_data, const hpn_span *spans, uint
         crc[k] = crc_fold_blocks(out.data() + at, nb, spans[k].len);
         at += nb;
     }
+    return HPN_OK;
+}
+
+int hpn_inflate_slots(hpn_ctx *c, uint32_t *n_slots)
+{
+    if (!c || !n_slots) return HPN_E_ARG;
+    *n_slots = (uint32_t)c->n_cu * inflate_waves_per_cu();
     return HPN_OK;
 }
 

@@ -201,16 +201,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t span_rsrc(const void *base, ui
 }
 
 // GC count of one 16-byte piece added to acc; nk[j] = ~(the nibbles of word j to count, as a subset of 0x44444444).
-// Four vector instructions and a count-and-add per word (gfx950 has a three-input bit operation): 3w has b1 ^ b2 at bit 2 of a
-// nibble whose bit 0 is clear (no carry reaches it); (w << 2) | nk puts "bit 0 set, or not to be counted" there and ones
-// everywhere else; w >> 1 puts bit 3 there; verdict = 3w & ~that & ~(w >> 1).
+// Per word: w ^ (w << 1) has b1 ^ b2 at bit 2 of every nibble, (w << 2) | nk puts "bit 0 set, or not to be counted" there (and
+// ones everywhere else), w >> 1 puts bit 3 there; verdict = that xor, and not the other two (gfx950's three-input bit operation
+// folds the logic into two instructions), then one count-and-add.  (3 w instead of the xor would save an instruction and is
+// wrong: the sum carries from one nibble into the next.)
 __device__ __forceinline__ uint32_t gc_add_piece(const u32 q, const uint32_t *nk, uint32_t acc)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t w = q[j];
-        const uint32_t a = (w << 1) + w, b0n = (w << 2) | nk[j], b3 = w >> 1;
-        const uint32_t v = a & ~b0n & ~b3;
+        const uint32_t one = (w << 1) ^ w, b0n = (w << 2) | nk[j], b3 = w >> 1;
+        const uint32_t v = one & ~b0n & ~b3;
         asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(v));      // count-and-add in one instruction, as a chain (no partial sums kept)
     }
     return acc;
@@ -219,6 +220,19 @@ __device__ __forceinline__ uint32_t gc_add_piece(const u32 q, const uint32_t *nk
 // Offsets that can never lie inside a fast pass's descriptor (at most kFastReach bytes), whatever is added to them:
 // kNoRecord marks a record that is skipped (flag & 4, tid < 0, beyond n), kNoLane a lane without a piece in a step.
 constexpr uint32_t kFastReach = 0x3fffffffu, kNoRecord = 0x40000000u, kNoLane = 0x80000000u;
+#ifndef HPN_K5_NT
+#define HPN_K5_NT 2
+#endif
+#ifndef HPN_K5_CHUNK
+#define HPN_K5_CHUNK 16
+#endif
+#ifndef HPN_K5_SPAN
+#define HPN_K5_SPAN 1
+#endif
+#ifndef HPN_K5_EU
+#define HPN_K5_EU 5
+#endif
+constexpr int kNt = HPN_K5_NT;     // cache policy of a buffer load: 2 = non-temporal (the bytes are read once)
 
 // The sequence loads and the count of a fast pass of STEPS steps: every lane fetches the offset of its record of each step from
 // the lane that holds the record (ds_bpermute, all of them first), adds its piece's offset, loads 16 bytes and counts.  A
@@ -248,7 +262,48 @@ __device__ __forceinline__ uint32_t fast_pass_gc(__amdgpu_buffer_rsrc_t rsrc, ui
     return acc;
 }
 
-__global__ __launch_bounds__(kWinThreads) void k_window_add(
+// bytes k .. 3 of a word (k <= 0: all, k >= 4: none)
+__device__ __forceinline__ uint32_t bytes_from(int k) { return k <= 0 ? 0xffffffffu : k >= 4 ? 0u : 0xffffffffu << (8 * k); }
+
+// A pass whose sequences lie back to back (a batch handed over as arrays: seq_off[r + 1] = seq_off[r] + bytes) and have an even
+// number of bases: the pass's bytes are ONE span, read as aligned 16-byte pieces in lane order -- a wave instruction is 1 KiB of
+// whole cache lines, a quarter of the requests the record-wise pieces put to the vector cache (whose request rate, not HBM and
+// not instruction issue, bounded the kernel: 1.04 ms whether a pass cost 485 or 200 vector instructions).  Every nibble of the span
+// is a base; only the first and the last piece need a mask (the bytes before the span in its first 16, after it in its last).
+// total = bytes from the aligned start to the span's end, head = bytes of the first piece in front of the span.
+template <int STEPS>
+__device__ __forceinline__ uint32_t span_pass_gc(__amdgpu_buffer_rsrc_t rsrc, uint32_t head, uint32_t total, uint32_t acc)
+{
+    const uint32_t c0 = 16u * (uint32_t)lane_id();
+    u32 q[STEPS];
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        const uint32_t c = c0 + 1024u * (uint32_t)t;
+        const uint32_t off = t + 1 < STEPS || c < total ? c0 : kNoLane;     // (only the last step has lanes beyond the span)
+#ifdef DIAG_NOSEQ
+        q[t] = u32{off, off * 3u, off * 5u, off * 7u};
+#else
+        q[t] = __builtin_bit_cast(u32, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 1024 * t, kNt));   // read once: non-temporal
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t all[4] = {~0x44444444u, ~0x44444444u, ~0x44444444u, ~0x44444444u};
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        if (t == 0 || t == STEPS - 1) {
+            const int c = (int)c0 + 1024 * t, lo = (int)head - c, hi = (int)total - c;     // the piece's bytes [lo, hi) belong to the span
+            uint32_t nk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nk[j] = ~(bytes_from(lo - 4 * j) & ~bytes_from(hi - 4 * j) & 0x44444444u);
+            acc = gc_add_piece(q[t], nk, acc);
+        } else {
+            acc = gc_add_piece(q[t], all, acc);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(HPN_K5_EU, 8))) void k_window_add(
     const int32_t *__restrict__ rec_tid, const int32_t *__restrict__ rec_pos, const uint32_t *__restrict__ rec_flag,
     const int32_t *__restrict__ l_qseq, const uint64_t *__restrict__ seq_off, const uint8_t *__restrict__ seq4,
     uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets, const uint64_t *__restrict__ win_off,
@@ -321,12 +376,12 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
         auto fields_of = [&](int pass) {
             Fields x;
             const int so4 = pass * (kWave * 4), so8 = pass * (kWave * 8);
-            x.t = __builtin_amdgcn_raw_buffer_load_b32(d_tid, lane4, so4, 0);
-            x.p = __builtin_amdgcn_raw_buffer_load_b32(d_pos, lane4, so4, 0);
-            x.f = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(d_flag, lane4, so4, 0);
-            x.l = __builtin_amdgcn_raw_buffer_load_b32(d_lq, lane4, so4, 0);
+            x.t = __builtin_amdgcn_raw_buffer_load_b32(d_tid, lane4, so4, kNt);
+            x.p = __builtin_amdgcn_raw_buffer_load_b32(d_pos, lane4, so4, kNt);
+            x.f = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(d_flag, lane4, so4, kNt);
+            x.l = __builtin_amdgcn_raw_buffer_load_b32(d_lq, lane4, so4, kNt);
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(d_so, lane8, so8, 0));
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(d_so, lane8, so8, kNt));
             x.so = ((uint64_t)v[1] << 32) | v[0];
             return x;
         };
@@ -343,7 +398,10 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
             bool fast = false;
             int lq0 = 0;
             uint64_t s0 = 0;
-            uint32_t srel = 0, reach = 0;
+            uint32_t srel = 0, srel_all = 0, srel_skip = 0, reach = 0, second_lo = 0;
+            uint64_t second_slot = 0;
+            u64 m_second = 0;                 // ok records of the pass that belong to the window after the cached one
+            bool span = false;
             if (okm) {
                 const int first = __builtin_ctzll(okm);
                 const int32_t t0 = __builtin_amdgcn_readlane(cf.t, first);
@@ -366,6 +424,13 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                         const uint32_t w16 = w0 & 0xffffu;                          // (unsigned short)(c->pos / window) (:117)
                         if (!odd && w16 < c_nwin) {
                             w_valid = true, w_lo = w0 * W, c_slot = c_lo + w16;
+                        } else if (w16 < c_nwin && ((w0 + 1u) & 0xffffu) < c_nwin && __ballot(okf && wfull - w0 > 1u) == 0) {
+                            // the pass crosses ONE window seam (the ~2 % of a sorted BAM's passes that are not of one window): the
+                            // records of the first window now, those of the next as a second round of this pass
+                            odd = 0;
+                            m_second = __ballot(okf && wfull != w0);
+                            w_valid = true, w_lo = w0 * W, c_slot = c_lo + w16;
+                            second_lo = (w0 + 1u) * W, second_slot = c_lo + ((w0 + 1u) & 0xffffu);
                         } else {
                             odd = 1;                                                // several windows, or one the reference would write out of bounds
                             w_valid = false;
@@ -380,6 +445,11 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                         const uint32_t piece_bytes = 16u * (uint32_t)((((lq0 + 1) >> 1) + 15) >> 4);
                         fast = __ballot(valid && rel + piece_bytes > reach) == 0;     // no piece of the pass straddles the end of what may be read
                         srel = okf ? (uint32_t)rel : kNoRecord;                       // a skipped record's pieces are not loaded
+                        srel_all = (uint32_t)rel;
+                        // back to back, an even number of bases, at least a piece per record: the pass is one span (span_pass_gc)
+                        const uint32_t nbytes = (uint32_t)lq0 >> 1;
+                        span = HPN_K5_SPAN && !m_second && fast && !(lq0 & 1) && lq0 >= 32 && __ballot(valid && rel != (uint64_t)((uint32_t)lane * nbytes)) == 0;
+                        srel_skip = valid && !okf ? (uint32_t)rel : kNoRecord;        // ... from which the skipped records are taken off again
                     }
                 }
             }
@@ -401,19 +471,63 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
                     off_last = used && (lay.steps - 1) * lay.rps + lay.pg < kWave ? off_mid : kNoLane;
                     bp_addr = 4u * (uint32_t)lay.pg;
                 }
+                const __amdgpu_buffer_rsrc_t rsrc = span_rsrc(seq4 + s0, reach);
+                if (m_second) {
+                    // two windows under the pass: each round takes its records' pieces (the others hand out kNoRecord)
+                    for (int round = 0; round < 2; ++round) {
+                        const u64 m = round ? m_second : okm & ~m_second;
+                        if (round) w_lo = second_lo, c_slot = second_slot;
+                        if (c_slot != cur) {
+                            flush();
+                            cur = c_slot, a_bins = 0, a_len = 0, a_gc = 0, cur_tid = (uint32_t)c_tid;
+                        }
+                        const uint32_t nm = (uint32_t)__builtin_popcountll(m);
+                        counted += nm, a_bins += nm, a_len += nm * (uint32_t)lq0;
+                        const uint32_t sr = (m >> lane) & 1ull ? srel_all : kNoRecord;
+#define HPN_FAST_STEPS(N) case N: lane_gc = fast_pass_gc<N>(rsrc, sr, bp_addr, lay.rps, off_mid, off_last, lay.m, lane_gc); break;
+                        switch (lay.steps) {
+                            HPN_FAST_STEPS(1) HPN_FAST_STEPS(2) HPN_FAST_STEPS(3) HPN_FAST_STEPS(4) HPN_FAST_STEPS(5) HPN_FAST_STEPS(6) HPN_FAST_STEPS(7)
+                            default: lane_gc = fast_pass_gc<8>(rsrc, sr, bp_addr, lay.rps, off_mid, off_last, lay.m, lane_gc); break;
+                        }
+#undef HPN_FAST_STEPS
+                    }
+                    continue;
+                }
                 if (c_slot != cur) {
                     flush();
                     cur = c_slot, a_bins = 0, a_len = 0, a_gc = 0, cur_tid = (uint32_t)c_tid;
                 }
                 const uint32_t nok = (uint32_t)__builtin_popcountll(okm);
                 counted += nok, a_bins += nok, a_len += nok * (uint32_t)lq0;     // n_count (:104), bins, len (:119-121)
-                const __amdgpu_buffer_rsrc_t rsrc = span_rsrc(seq4 + s0, reach);
-#define HPN_FAST_STEPS(N) case N: lane_gc = fast_pass_gc<N>(rsrc, srel, bp_addr, lay.rps, off_mid, off_last, lay.m, lane_gc); break;
-                switch (lay.steps) {          // ceil(64 / floor(64 / pieces per record)): 1, 2, 3, 4, 6 (150 bases), 7 or 8
-                    HPN_FAST_STEPS(1) HPN_FAST_STEPS(2) HPN_FAST_STEPS(3) HPN_FAST_STEPS(4) HPN_FAST_STEPS(5) HPN_FAST_STEPS(6) HPN_FAST_STEPS(7)
-                    default: lane_gc = fast_pass_gc<8>(rsrc, srel, bp_addr, lay.rps, off_mid, off_last, lay.m, lane_gc); break;
+                const u64 validm = __ballot(valid);
+                uint32_t head = 0, total = 0;
+                if (span) {
+                    head = (uint32_t)(((uint64_t)(uintptr_t)seq4 + s0) & 15u);
+                    total = head + nvalid * ((uint32_t)lq0 >> 1);
+                    span = total <= 8192u && (uint64_t)total - head + 16u <= (uint64_t)reach + 0u;    // eight steps at most; the last piece inside what may be read
+                }
+                uint32_t sub = 0;          // GC of the pieces fetched record-wise: the pass's (no span), or its skipped records' (span)
+#define HPN_FAST_STEPS(N) case N: sub = fast_pass_gc<N>(rsrc, span ? srel_skip : srel, bp_addr, lay.rps, off_mid, off_last, lay.m, 0u); break;
+                if (!span || okm != validm) {
+                    switch (lay.steps) {          // ceil(64 / floor(64 / pieces per record)): 1, 2, 3, 4, 6 (150 bases), 7 or 8
+                        HPN_FAST_STEPS(1) HPN_FAST_STEPS(2) HPN_FAST_STEPS(3) HPN_FAST_STEPS(4) HPN_FAST_STEPS(5) HPN_FAST_STEPS(6) HPN_FAST_STEPS(7)
+                        default: sub = fast_pass_gc<8>(rsrc, span ? srel_skip : srel, bp_addr, lay.rps, off_mid, off_last, lay.m, 0u); break;
+                    }
                 }
 #undef HPN_FAST_STEPS
+                if (!span) {
+                    lane_gc += sub;
+                } else {
+                    // the whole span, then the skipped records' share off again (lane sums modulo 2^32: the wave's sum is what counts)
+                    const __amdgpu_buffer_rsrc_t rs2 = span_rsrc(seq4 + s0 - head, (uint64_t)reach + head);
+#define HPN_SPAN_STEPS(N) case N: lane_gc = span_pass_gc<N>(rs2, head, total, lane_gc); break;
+                    switch ((total + 1023u) >> 10) {
+                        HPN_SPAN_STEPS(1) HPN_SPAN_STEPS(2) HPN_SPAN_STEPS(3) HPN_SPAN_STEPS(4) HPN_SPAN_STEPS(5) HPN_SPAN_STEPS(6) HPN_SPAN_STEPS(7)
+                        default: lane_gc = span_pass_gc<8>(rs2, head, total, lane_gc); break;
+                    }
+#undef HPN_SPAN_STEPS
+                    lane_gc -= sub;
+                }
                 continue;
             }
             // ---- not a fast pass: k_window_rest takes it ----
@@ -425,7 +539,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_add(
 }
 
 // The passes k_window_add left: 64 records each, any mixture.  Per-record GC through the wave's 64 LDS words
-// (gc_of_wave_records), up to eight windows per pass with wave sums, then per-record atomics.  A wave takes 16 list entries at a
+// (gc_of_wave_records), up to eight windows per pass with wave sums, then per-record atomics.  A wave takes four list entries at a
 // time and keeps the sums of the window it is in across them (the list of an unsorted input is nearly in order).
 __global__ __launch_bounds__(kWinThreads) void k_window_rest(
     const int32_t *__restrict__ rec_tid, const int32_t *__restrict__ rec_pos, const uint32_t *__restrict__ rec_flag,
@@ -443,7 +557,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_rest(
     uint32_t counted = 0;
     GcLayout lay;
     const uint32_t Wm = 0xffffffffu / W;                    // div_by()
-    constexpr uint32_t kChunk = 16;
+    constexpr uint32_t kChunk = HPN_K5_CHUNK;      // (list entries per wave and turn: a sorted BAM leaves ~2 % of its passes, spread thin)
     for (uint32_t e0 = wave0 * kChunk; e0 < n_todo; e0 += nwaves * kChunk) {
         u64 cur = ~0ull;                                   // window slot the sums belong to (same value in every lane)
         uint32_t a_bins = 0, a_len = 0, cur_tid = 0;
@@ -541,7 +655,7 @@ hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uin
     hipLaunchKernelGGL(k_window_add, dim3((unsigned)(want < cap ? want : cap)), dim3(kWinThreads), 0, st, tid_a, pos, flag,
                        l_qseq, seq_off, seq4, n, seq_end, W, n_targets, win_off, bins, gc, len, touched, n_count, todo);
     // whatever the fast kernel left (nothing: its waves return at once)
-    want = ((n + kWave - 1) / kWave + 16 * (kWinThreads / kWave) - 1) / (16 * (kWinThreads / kWave));
+    want = ((n + kWave - 1) / kWave + HPN_K5_CHUNK * (kWinThreads / kWave) - 1) / (HPN_K5_CHUNK * (kWinThreads / kWave));
     const uint64_t cap2 = (uint64_t)n_cu * 4;
     hipLaunchKernelGGL(k_window_rest, dim3((unsigned)(want < cap2 ? want : cap2)), dim3(kWinThreads), 0, st, tid_a, pos, flag,
                        l_qseq, seq_off, seq4, n, seq_end, W, n_targets, win_off, bins, gc, len, touched, n_count, bad, todo);

@@ -94,7 +94,7 @@ struct ByteSink {
     }
 };
 
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
                                                         uint32_t n_blocks, uint8_t *__restrict__ outbuf,
                                                         uint32_t *__restrict__ status)
 {

@@ -102,7 +102,7 @@ struct SymSink {
     }
 };
 
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
                                                           uint32_t n_chunks, uint16_t *__restrict__ symbuf, uint32_t sym_cap,
                                                           GzMeta *__restrict__ meta, GzBound *__restrict__ bounds, uint32_t bounds_cap,
                                                           uint32_t *__restrict__ n_bounds)
@@ -311,7 +311,7 @@ __device__ __forceinline__ bool gz_trial(InfLds &s, const uint8_t *__restrict__ 
     return !some.bad;
 }
 
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_gz_find_starts(const uint8_t *__restrict__ comp, uint64_t comp_len, const GzSlice *__restrict__ slices,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_gz_find_starts(const uint8_t *__restrict__ comp, uint64_t comp_len, const GzSlice *__restrict__ slices,
                                                           uint32_t n, uint64_t *__restrict__ found)
 {
     __shared__ InfLds s;
@@ -586,5 +586,7 @@ hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const vo
                        d_text);
     return hipGetLastError();
 }
+
+uint32_t inflate_waves_per_cu() { return kInflateWavesPerCu; }
 
 }  // namespace hpn

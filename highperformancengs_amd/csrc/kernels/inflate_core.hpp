@@ -6,15 +6,31 @@
 
 namespace hpn {
 
-constexpr uint32_t kRing = 1024;             // compressed-input ring (bytes), refilled by halves
+// The decoder's LDS footprint and register budget decide how many single-wave decoders a CU holds (scripts/micro/lds_occupancy.hip:
+// LDS comes in granules of 1,280 bytes): same-session A/B builds set these from the command line (scripts/ab_build.sh).
+#ifndef HPN_INF_RING
+#define HPN_INF_RING 512
+#endif
+#ifndef HPN_INF_LIT
+#define HPN_INF_LIT 852
+#endif
+#ifndef HPN_INF_WAVES
+#define HPN_INF_WAVES 24
+#endif
+#ifndef HPN_INF_EU
+#define HPN_INF_EU 6
+#endif
+constexpr uint32_t kRing = HPN_INF_RING;      // compressed-input ring (bytes), refilled by halves
 // Root bits and table sizes (root + sub-tables).  The sub-tables are sized like zlib's (inftrees.c: per root prefix, for the
 // longest code under it), so its bound holds: `enough 286 9 15` = 852 entries for the literal/length table; the distance table's
 // worst case is exactly 400 (30 symbols, 8-bit root: every length distribution enumerated).  A 9-bit literal root instead of
-// 10 bits: with 4 KiB instead of 5.5 for that table a decoder takes six of the CU's 1,280-byte LDS granules instead of seven
-// (scripts/micro/lds_occupancy.hip), 20 decoders per CU instead of 18 -- gz 44.0 -> 48.7, BGZF 39.5 -> 42.1 GB/s; codes longer
+// 10 bits (round 3: six LDS granules of 1,280 bytes instead of seven, 20 decoders per CU instead of 18); round 4: the literal
+// table cut to zlib's bound (852 entries, not 1,024) and the input ring to 512 bytes -- 6,000 bytes = five granules -- and the
+// kernels held to 80 registers: 24 decoders per CU, 6,144 on the chip (same-session A/B, scripts/ab_inflate.sh: gz 47.0 -> 49.8,
+// BGZF 43.4 -> 46.2 GB/s; 20 % more decoders buy 6 %: the bound is instruction issue, not latency).  Codes longer
 // than the root are looked up a second time by the lanes that hold them (window()).
 constexpr uint32_t kLitRoot = 9, kDistRoot = 8;
-constexpr uint32_t kLitSize = 512 + 512, kDistSize = 256 + 144;
+constexpr uint32_t kLitSize = HPN_INF_LIT, kDistSize = 256 + 144;
 
 // table entry: [31:16] value, [15:8] extra-bit count (or sub-table index bits), [7:4] kind, [3:0] code bits
 enum { kLit = 0, kLit2 = 1, kLen = 2, kEob = 3, kSub = 4, kDist = 5, kBad = 15 };  // literal kinds first: one compare
@@ -31,8 +47,8 @@ struct InfLds {
     uint16_t count[16], first[16], next[16];
 };
 
-static_assert(sizeof(InfLds) <= 6 * 1280, "six LDS granules per decoder: 20 of them per CU (5 waves per SIMD at <= 96 VGPRs)");
-constexpr uint32_t kInflateWavesPerCu = 20;
+constexpr uint32_t kInflateWavesPerCu = HPN_INF_WAVES;
+static_assert(((sizeof(InfLds) + 1279) / 1280) * 1280 * kInflateWavesPerCu <= 160 * 1024, "LDS granules of the decoders of one CU");
 
 struct Bits {  // wave-uniform bit reader over the LDS ring
     u64 bb = 0;

@@ -131,13 +131,15 @@ int main(int argc, char *argv[])
         GzGpuStream gs;
         const long cpus = usable_cpus();
         uint32_t per_call = 5120;
+        (void)hpn_inflate_slots(ctx, &per_call);                          // stretches the chip decodes at once
+        const uint32_t slots = per_call;
         if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
         // several device calls per file, so that the writer thread has text to write while the next part is inflated:
         // a quarter of the file per call, in stretches small enough to fill the chip each time
         size_t stretch = 0;
         struct stat sb;
         if (!getenv("HPN_GZ_STRETCH") && stat(infile, &sb) == 0) {
-            stretch = ((size_t)sb.st_size / 4 / 5120 + 65536) & ~(size_t)65535;
+            stretch = ((size_t)sb.st_size / 4 / slots + 65536) & ~(size_t)65535;
             stretch = stretch < ((size_t)256 << 10) ? (size_t)256 << 10 : stretch > ((size_t)1 << 20) ? (size_t)1 << 20 : stretch;
         }
         bool usable = gs.open(ctx, infile, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call, stretch);

@@ -329,6 +329,9 @@ int hpn_gz_inflate_dev(hpn_ctx *ctx, const uint8_t *d_comp, const hpn_gz_chunk *
                        uint32_t sym_cap, const uint8_t *d_window_in, uint8_t *d_text, uint64_t text_cap,
                        uint8_t *d_window_out, hpn_gz_info *info);
 int hpn_gz_members(hpn_ctx *ctx, hpn_gz_member *out, uint32_t cap, uint32_t *n); /* HPN_E_CAPACITY: *n tells how many */
+/* Decoder wavefronts the context's device runs at once (CUs x decoders per CU): one stretch (hpn_gz_inflate_dev) or one BGZF
+ * block (hpn_bgzf_inflate_dev) each -- the number of stretches that fills the chip exactly once.  Hosts size their batches by it. */
+int hpn_inflate_slots(hpn_ctx *ctx, uint32_t *n_slots);
 /* The same call in two halves, for ONE file whose batches of stretches go to several contexts (one per GPU) in turn: the
  * symbolic decode of a batch needs nothing of the text in front of it, only the resolution of the histories does (the 32 KiB
  * window the batch before ends with).  _begin_dev starts the decode on the context's stream and returns; _finish_dev takes the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_gz_sym_inflate / k_gz_windows / k_gz_translate at chip scale: 5,120 stretches of a deflate stream in one call (one per decoder wave of the chip).
+"""k_gz_sym_inflate / k_gz_windows / k_gz_translate at chip scale: 6,144 stretches of a deflate stream in one call (one per decoder wave of the chip).
 
 The stretches are cut at Z_SYNC_FLUSH points (byte-aligned block starts, later stretches refer back into earlier ones, so
 the symbolic output does hold history placeholders); the table repeats the stream's ~50 stretches round-robin to fill the
@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import highperformancengs_amd as hp  # noqa: E402
 
-n_stretch = int(sys.argv[1]) if len(sys.argv) > 1 else 5120
+n_stretch = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
 rng = np.random.default_rng(1)
 n, L = 300_000, 100
 seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n, L))
