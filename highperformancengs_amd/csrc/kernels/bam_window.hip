@@ -230,7 +230,7 @@ constexpr uint32_t kFastReach = 0x3fffffffu, kNoRecord = 0x40000000u, kNoLane = 
 #define HPN_K5_SPAN 1
 #endif
 #ifndef HPN_K5_EU
-#define HPN_K5_EU 5
+#define HPN_K5_EU 4
 #endif
 constexpr int kNt = HPN_K5_NT;     // cache policy of a buffer load: 2 = non-temporal (the bytes are read once)
 

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t 
 struct InfLds {
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
-    uint32_t ring[kRing / 4];
+    uint32_t ring[kRing / 4 + 1];   // (+ a copy of word 0 behind the last: a window reads two neighbouring words with one instruction)
     uint8_t lens[384];     // code lengths being assembled (19 code-length codes | 286 + 30 lengths from offset 32)
     uint16_t count[16], first[16], next[16];
 };
@@ -74,6 +74,7 @@ __device__ __forceinline__ void stage(InfLds &s, Bits &b, const uint8_t *__restr
         u32 v = {0, 0, 0, 0};
         if (at < in_len + 16u) __builtin_memcpy(&v, in + at, 16);  // the buffer is padded by the host
         *(u32 *)((uint8_t *)s.ring + (at & (kRing - 1))) = v;
+        if ((at & (kRing - 1)) == 0) s.ring[kRing / 4] = v[0];
     }
     b.filled += kRing / 2;
 }
@@ -247,8 +248,8 @@ __device__ __forceinline__ Win window(const InfLds &s, Pos p)
 {
     const uint32_t q = p.bit + (uint32_t)lane_id();
     const uint32_t byte = p.byte + (q >> 3);
-    const uint32_t i0 = (byte >> 2) & (kRing / 4 - 1), i1 = (i0 + 1u) & (kRing / 4 - 1);
-    const uint32_t v = (uint32_t)((((u64)s.ring[i1] << 32) | s.ring[i0]) >> (8u * (byte & 3u)));   // 32 bits from `byte` on
+    const uint32_t i0 = (byte >> 2) & (kRing / 4 - 1);
+    const uint32_t v = (uint32_t)((((u64)s.ring[i0 + 1u] << 32) | s.ring[i0]) >> (8u * (byte & 3u)));   // 32 bits from `byte` on (ring[kRing / 4] = ring[0])
     Win w;
     w.raw = v >> (q & 7u);
     w.el = s.lit[w.raw & ((1u << kLitRoot) - 1u)];
@@ -256,11 +257,10 @@ __device__ __forceinline__ Win window(const InfLds &s, Pos p)
     // codes longer than a root table: the lanes that hold one take the second-level entry themselves and count the root's bits
     // into it -- the walk sees a plain entry of up to 15 bits (left to the serial reader, each such code on the chain is a
     // detour of a thousand clocks: rare length codes and the 256-symbol alphabets of BAM blocks have them)
-    if (__ballot(((w.el >> 4) & 15u) == kSub)) {
-        if (((w.el >> 4) & 15u) == kSub) w.el = s.lit[(w.el >> 16) + ((w.raw >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
-    }
-    if (__ballot(((w.ed >> 4) & 15u) == kSub)) {
-        if (((w.ed >> 4) & 15u) == kSub) w.ed = s.dist[(w.ed >> 16) + ((w.raw >> kDistRoot) & ((1u << ((w.ed >> 8) & 15u)) - 1u))] + kDistRoot;
+    const bool sub_l = (w.el & 0xf0u) == (kSub << 4), sub_d = (w.ed & 0xf0u) == (kSub << 4);
+    if (__ballot(sub_l || sub_d)) {      // (one test for both tables: most windows hold no long code)
+        if (sub_l) w.el = s.lit[(w.el >> 16) + ((w.raw >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
+        if (sub_d) w.ed = s.dist[(w.ed >> 16) + ((w.raw >> kDistRoot) & ((1u << ((w.ed >> 8) & 15u)) - 1u))] + kDistRoot;
     }
     return w;
 }
@@ -393,8 +393,20 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, ui
     }
     const u64 taken = on & __ballot(emits);
     const bool mine = (taken >> lane) & 1u;
-    const uint32_t units = mine ? (is_lit ? kind + 1u : len) : 0u;
-    const uint32_t upto = wave_prefix(units), at = sink.op + upto - units, total = lane_of(upto, kWave - 1);
+    uint32_t at, total;
+    if ((taken & len_lanes) == 0) {
+        // literals only (one or two per symbol): a lane's place is the number of taken lanes below it plus those of them that hold
+        // a pair -- four count instructions on the two masks instead of a six-step prefix sum
+        const u64 pairs = taken & __ballot(kind == kLit2);
+        uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
+        below = __builtin_amdgcn_mbcnt_hi((uint32_t)(pairs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pairs, below));
+        at = sink.op + below;
+        total = (uint32_t)__builtin_popcountll(taken) + (uint32_t)__builtin_popcountll(pairs);
+    } else {
+        const uint32_t units = mine ? (is_lit ? kind + 1u : len) : 0u;
+        const uint32_t upto = wave_prefix(units);
+        at = sink.op + upto - units, total = lane_of(upto, kWave - 1);
+    }
     if (sink.op + total > sink.out_len) {
         err = 12;
         return kWinError;
