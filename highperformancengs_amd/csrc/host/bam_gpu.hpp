@@ -14,7 +14,10 @@
 #pragma once
 #include <zlib.h>
 
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "bam_reader.hpp"
 #include "text_stream.hpp"
@@ -30,6 +33,19 @@ struct BgzfParsed {
     size_t body_len = 0;
     uint64_t out_bytes = 0;      // inflated size of the batch
     uint32_t first_off = 0;      // offset of the first record inside block 0
+};
+
+// The compressed side of ONE inflate launch, prepared ahead of time: the bytes of up to `rounds` chunks on the device (copied
+// through a context of their own, so the copies run beside the kernels of the launch before) and the launch's block table.
+struct BgzfStage {
+    void *d_comp = nullptr;
+    size_t cap = 0, at_comp = 0;
+    std::vector<hpn_bgzf_block> pieces;
+    uint64_t at_out = 0;
+    uint32_t first_off = 0;
+    bool have_first = false, eof = false;
+    int result = 1;          // 1 = blocks (or an empty batch), 0 = the file's end, -1 = not decodable here
+    int state = 0;           // 0 free (the producer may fill it), 1 ready (next() may take it)
 };
 
 // One context's side of the ingest: device buffers, copies, inflate, record index.  Several of these can take the
@@ -150,6 +166,39 @@ public:
         return info->flags ? -1 : 1;
     }
 
+    // The launch a BgzfStage holds: block table to the device, inflate, then (records) index or (text) check every block.
+    int finish_stage(const BgzfStage &st, bool text_mode, hpn_raw_info *info)
+    {
+        memset(info, 0, sizeof *info);
+        const size_t nb = st.pieces.size();
+        if (!nb) return 1;
+        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) || !reserve<uint8_t>(d_out_, cap_out_, st.at_out + 64 + pad_front_ + pad_back_) ||
+            !reserve<uint32_t>(d_status_, cap_status_, nb))
+            return -1;
+        if (nb > h_blocks_cap_) {
+            if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
+            h_blocks_cap_ = nb + nb / 2 + 1024;
+            if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
+        }
+        memcpy(h_blocks_, st.pieces.data(), nb * sizeof(hpn_bgzf_block));
+        if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
+        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)st.d_comp, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_ + pad_front_,
+                                 (uint32_t *)d_status_) != HPN_OK)
+            return -1;
+        if (text_mode) {  // no records: wait, check every block's status
+            status_.resize(nb);
+            if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
+            for (uint32_t s2 : status_)
+                if (s2) return -1;
+            info->n_records = st.at_out;
+            return 1;
+        }
+        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_ + pad_front_, (const hpn_bgzf_block *)d_blocks_, nb, st.first_off,
+                                  (const uint32_t *)d_status_, info) != HPN_OK)
+            return -1;
+        return info->flags ? -1 : 1;
+    }
+
 private:
     std::vector<hpn_bgzf_block> pieces_;
     size_t at_comp_ = 0;
@@ -176,7 +225,14 @@ private:
 
 class BgzfGpuStream {
 public:
-    ~BgzfGpuStream() { pump_.reset(); }
+    ~BgzfGpuStream()
+    {
+        halt_producer();
+        pump_.reset();
+        for (BgzfStage &st : stage_)
+            if (st.d_comp && up_ctx_) hpn_dev_free(up_ctx_, st.d_comp);
+        if (up_ctx_) hpn_ctx_destroy(up_ctx_);
+    }
 
     // Parses the BAM header (host, zlib) and positions the stream at the first record.
     // nbuf: pinned chunks of read-ahead (one more than the contexts that take batches)
@@ -242,12 +298,13 @@ public:
         pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         return pump_->ok();
     }
-    bool at_eof() const { return eof_ && carry_.empty(); }
+    bool at_eof() const { return ahead_ ? last_eof_ : eof_ && carry_.empty(); }   // the batch next() returned last ends the file
 
     // Continue at a BGZF virtual offset (compressed block offset << 16 | offset inside the inflated block), as the
     // .bai gives it for the first record of a target: the same buffers, a fresh read-ahead.
     bool seek(uint64_t voffset)
     {
+        halt_producer();
         if (!pump_ || !pump_->restart(voffset >> 16)) return false;
         first_off_ = (uint32_t)(voffset & 0xffff), skip_ = 0, eof_ = false;
         carry_.clear();
@@ -259,11 +316,53 @@ public:
 
     // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
     // be empty), 0 = end of file, -1 = not decodable here (the caller switches to the host path).
+    // The compressed bytes of the batch AFTER this one are read, parsed and copied to the device by a producer thread through a
+    // context of its own while this batch is inflated and used (round 4: the copies were a fifth of the ingest's device time,
+    // in line with the kernels on one stream).  HPN_BAM_AHEAD=0: everything on the caller's thread and context, as before.
     int next(hpn_raw_info *info)
     {
         memset(info, 0, sizeof *info);
-        if (!dev_.begin((size_t)rounds_ * (chunk_ + 65536 + 64))) return -1;
-        for (int taken = 0; taken < rounds_;) {       // several chunks under one inflate launch (BgzfDevice::add)
+        if (!ahead_enabled()) {
+            ahead_ = false;
+            if (!dev_.begin((size_t)rounds_ * (chunk_ + 65536 + 64))) return -1;
+            BgzfStage none;
+            const int r = gather(nullptr, none);
+            if (r != 1) return r;
+            if (!dev_.blocks_added()) return eof_ ? 0 : 1;       // (a batch may be empty)
+            return dev_.finish(text_mode_, info);
+        }
+        if (ended_) return final_;                       // (the end, or a failure, has been handed out: it stays)
+        if (!producer_.joinable() && !start_producer()) return -1;
+        ahead_ = true;
+        BgzfStage &st = stage_[turn_ & 1];
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return st.state == 1; });
+        }
+        int r = st.result;
+        last_eof_ = st.eof;
+        if (r == 1 && !st.pieces.empty()) r = dev_.finish_stage(st, text_mode_, info);
+        {   // the launch has read the stage's bytes (finish_stage waits for its kernels): the producer may fill it again
+            std::lock_guard<std::mutex> lk(mu_);
+            st.state = 0;
+        }
+        cv_.notify_all();
+        ++turn_;
+        if (r != 1) ended_ = true, final_ = r;
+        return r;
+    }
+
+private:
+    static bool ahead_enabled()
+    {
+        const char *e = getenv("HPN_BAM_AHEAD");
+        return !(e && e[0] == '0');
+    }
+    // Up to rounds_ chunks of the file: parsed, their bytes on the device.  st == nullptr: into dev_ through the caller's context
+    // (BgzfDevice::add); else into the stage through up_ctx_.  1 = ok, -1 = not decodable / truncated.
+    int gather(BgzfStage *st, BgzfStage &)
+    {
+        for (int taken = 0; taken < rounds_;) {       // several chunks under one inflate launch
             TextPump::Chunk c;
             if (eof_ || !pump_->next(c)) {
                 if (!carry_.empty()) return -1;              // a partial block at the end: truncated file
@@ -282,14 +381,85 @@ public:
             }
             BgzfParsed pb;
             int r = parse(c, at, pb);
-            if (r == 1 && !dev_.add(pb)) r = -1;
+            if (r == 1 && !(st ? stage_add(*st, pb) : dev_.add(pb))) r = -1;
             pump_->recycle(c);
             if (r != 1) return r;
             ++taken;
         }
-        if (!dev_.blocks_added()) return eof_ ? 0 : 1;       // (a batch may be empty)
-        return dev_.finish(text_mode_, info);
+        return 1;
     }
+    bool stage_add(BgzfStage &st, const BgzfParsed &pb)
+    {
+        const size_t comp_bytes = pb.carry.size() + pb.body_len;
+        if (!pb.blocks.empty() && !st.have_first) st.first_off = pb.first_off, st.have_first = true;
+        if (st.at_comp + comp_bytes + 64 > st.cap) return false;
+        if (!pb.carry.empty() && hpn_memcpy_h2d(up_ctx_, (uint8_t *)st.d_comp + st.at_comp, pb.carry.data(), pb.carry.size()) != HPN_OK) return false;
+        if (pb.body_len && hpn_memcpy_h2d(up_ctx_, (uint8_t *)st.d_comp + st.at_comp + pb.carry.size(), pb.body, pb.body_len) != HPN_OK) return false;
+        for (hpn_bgzf_block b : pb.blocks) {
+            b.in_off += st.at_comp, b.out_off += st.at_out;
+            st.pieces.push_back(b);
+        }
+        st.at_comp += comp_bytes, st.at_out += pb.out_bytes;
+        return hpn_ctx_sync(up_ctx_) == HPN_OK;        // (pageable carry, and the pinned chunk goes back to the reader)
+    }
+    bool start_producer()
+    {
+        if (!up_ctx_) {
+            int device = 0;
+            if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) return false;
+        }
+        stop_ = false, turn_ = 0;
+        for (BgzfStage &st : stage_) st.state = 0;
+        producer_ = std::thread([this] {
+            for (uint32_t k = 0;; ++k) {
+                BgzfStage &st = stage_[k & 1];
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return st.state == 0 || stop_; });
+                    if (stop_) return;
+                }
+                const size_t room = (size_t)rounds_ * (chunk_ + 65536 + 64) + 64;
+                st.pieces.clear(), st.at_comp = 0, st.at_out = 0, st.first_off = 0, st.have_first = false;
+                int r = 1;
+                if (room > st.cap) {
+                    if (st.d_comp) hpn_dev_free(up_ctx_, st.d_comp);
+                    st.d_comp = nullptr, st.cap = 0;
+                    if (hpn_dev_malloc(up_ctx_, room + room / 8, &st.d_comp) == HPN_OK) st.cap = room + room / 8;
+                    else r = -1;
+                }
+                if (r == 1) r = gather(&st, st);
+                if (r == 1 && st.pieces.empty() && eof_) r = 0;
+                st.result = r, st.eof = eof_ && carry_.empty();
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    st.state = 1;
+                }
+                cv_.notify_all();
+                if (r != 1) return;          // the end (or a failure) has been handed over
+            }
+        });
+        return true;
+    }
+    void halt_producer()
+    {
+        if (!producer_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        producer_.join();
+        for (BgzfStage &st : stage_) st.state = 0;
+        stop_ = false, ended_ = false;
+    }
+    hpn_ctx *up_ctx_ = nullptr;
+    BgzfStage stage_[2];
+    std::thread producer_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false, ahead_ = false, last_eof_ = false, ended_ = false;
+    int final_ = 0;
+    uint32_t turn_ = 0;
 
 private:
     // 0 = need more bytes, 1 = complete (*need = header length), -1 = not BAM

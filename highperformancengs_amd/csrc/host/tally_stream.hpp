@@ -213,6 +213,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
         *unusable = true;
         return HPN_OK;
     }
+    const double t_open = wall_s() - t0;
     const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
     int rc = hpn_fastq_text_begin(ctx);
     const uint64_t slice = (uint64_t)256 << 20;
@@ -242,8 +243,8 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
         return rc;
     }
     if (getenv("HPN_TIMING"))
-        fprintf(stderr, "[hpn] gzip on the GPU: inflate + frame + tally %.3f s (block starts %.3f s, upload %.3f s, device inflate %.3f s)\n",
-                wall_s() - t0, gs.seconds_find(), gs.seconds_upload(), gs.seconds_device());
+        fprintf(stderr, "[hpn] gzip on the GPU: inflate + frame + tally %.3f s (open %.3f s, block starts %.3f s, upload %.3f s, device inflate %.3f s)\n",
+                wall_s() - t0, t_open, gs.seconds_find(), gs.seconds_upload(), gs.seconds_device());
     return hpn_fastq_tally_fetch(ctx, acc);
 }
 

@@ -517,7 +517,7 @@ private:
                 todo_.erase(it);
                 ++next_;
             }
-            if (j.n) fwrite(buf_[(size_t)j.idx], 1, j.n, out_);
+            if (j.n) write_slab(out_, buf_[(size_t)j.idx], j.n);
             give_back(j.lane, j.idx);
         }
     }

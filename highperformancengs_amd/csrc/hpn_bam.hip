@@ -31,6 +31,7 @@ hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uin
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
                              u64 *n_count, uint32_t *bad, uint32_t *todo, int n_cu, hipStream_t st);
 size_t window_todo_words(uint64_t n);
+uint32_t depth_tile_size();
 hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
                             uint32_t *counts, u64 *bases, int32_t *info, hipStream_t st);
 hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *counts,
@@ -108,7 +109,7 @@ int hpn_depth_progress(hpn_ctx *c, uint64_t *swept_positions)
     uint32_t frontier = 0;
     HPN_HIP(c, hipMemcpyAsync(&frontier, c->d_sw.p, sizeof frontier, hipMemcpyDeviceToHost, c->stream));   // ctl[kSwFrontier]
     HPN_HIP(c, hipStreamSynchronize(c->stream));
-    *swept_positions = (uint64_t)frontier * 16384u;   // kTile
+    *swept_positions = (uint64_t)frontier * depth_tile_size();
     return HPN_OK;
 }
 
@@ -188,7 +189,7 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
         if (getenv("HPN_SWEEP_DIAG") && sw_ctl[0]) {   // (DIAG_SWEEP_STAMPS builds leave eight words per swept tile in its stretch of d_diff)
             const uint32_t nt = sw_ctl[0];
             std::vector<uint32_t> st((size_t)nt * 8);
-            if (hipMemcpy2D(st.data(), 32, c->d_diff.p, 16384 * 4, 32, nt, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (hipMemcpy2D(st.data(), 32, c->d_diff.p, (size_t)depth_tile_size() * 4, 32, nt, hipMemcpyDeviceToHost) == hipSuccess) {
                 double sum[8] = {0}, mx[8] = {0};
                 uint32_t n = 0, late = 0;
                 for (uint32_t t = 0; t < nt; ++t) {

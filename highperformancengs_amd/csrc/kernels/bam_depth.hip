@@ -41,7 +41,10 @@ namespace hpn {
 
 // Tile shapes were swept in one session (profiles/r02/k3_k4_sweeps.txt): K3 runs at 0.59-0.62 ms per 5e7 records for
 // tiles of 4096 .. 16384 positions and any unroll (it moves 2.2 GB at 4.7 TB/s, reads and writes mixed).
-constexpr int kTile = 16384;                // positions per K3 tile = granularity of the `written` words
+#ifndef HPN_TILE
+#define HPN_TILE 16384
+#endif
+constexpr int kTile = HPN_TILE;             // positions per K3 tile = granularity of the `written` words (A/B builds: 8192)
 constexpr int kTileThreads = kTile / 16;    // 16 positions per lane in the flush
 constexpr uint32_t kReach = 2048;           // breakpoints up to this far behind pos are gathered by the owner tile
 constexpr int kTileUnroll = 4;              // records per lane in flight in k_depth_tiles
@@ -920,7 +923,9 @@ constexpr int kSwThreads = kTile / kDsPer;
 constexpr int kSwLbWaves = HPN_SW_LB_WAVES;                  // waves of a tile's workgroup that look back side by side
 constexpr uint32_t kSwStageRuns = (kTile - 8) / 3 - 1;       // runs of one tile the image's LDS can stage (5457; a tile at 30x holds ~4400)
 static_assert(kSwThreads == kTileThreads && 3 * (kSwStageRuns + 1) + 8 <= (uint32_t)kTile, "the tile image doubles as the runs' staging area");
-__device__ __forceinline__ uint32_t sw_word(uint32_t p) { return (((((p >> 2) & 3u) << 10) + (p >> 4)) << 2) | (p & 3u); }
+constexpr int kSwLog = kTile == 16384 ? 10 : kTile == 8192 ? 9 : kTile == 4096 ? 8 : -1;   // log2(lanes of a tile's workgroup)
+static_assert(kSwLog > 0 && (1 << kSwLog) == kTile / kDsPer, "tile sizes the sweep's LDS image is laid out for");
+__device__ __forceinline__ uint32_t sw_word(uint32_t p) { return (((((p >> 2) & 3u) << kSwLog) + (p >> 4)) << 2) | (p & 3u); }
 
 template <typename Recs>
 __global__ __launch_bounds__(kSwThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -1616,5 +1621,7 @@ hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char
                        name_len, d_long_name, out, (u64 *)ws + 2, (u64 *)ws + 1, ticket, ticket + 1);
     return hipGetLastError();
 }
+
+uint32_t depth_tile_size() { return (uint32_t)kTile; }
 
 }  // namespace hpn

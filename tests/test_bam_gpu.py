@@ -289,6 +289,17 @@ def test_window_every_nibble_code_and_window_seams(ctx, cigar, W):
     _window_check(ctx, soa, W)
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 70, 109, 110, 128, 1024 + 68, 5 * 1024 + 100, 7 * 1024 + 1023])
+def test_window_every_tail_of_a_span(ctx, n):
+    """A wave takes 1,024 records in passes of 64; the last span of a batch is ragged.  A pass's record count must never exceed 64
+    (round 4 counted the GC of the records behind a pass twice when 65..109 records were left: found by the hg38-shaped file test
+    on the host route, whose batch ended 68 records into a span)."""
+    refs = [("chrA", 900_000)]
+    soa = make_soa(n, refs, 41 + n, sort=True, cigars=["150M"])
+    _window_check(ctx, soa, 20000)
+    _window_check(ctx, soa, 1000)
+
+
 def test_window_index_wraps_like_unsigned_short(ctx):
     # target_len / W + 1 > 65536: (unsigned short)(pos / W) wraps (bam_sliding_count.c:117)
     refs = [("long", 10_000_000)]
