@@ -294,12 +294,6 @@ private:
         uint64_t slices = (left + calls - 1) / calls;  // even shares: no call is left with a sliver
         bool last_batch = calls <= 1;
         if (last_batch) slices = left;
-        // the file's first batch is a short one: nothing can run beside its search and upload, so the device starts on a quarter
-        // of a chip-fill while the first full batch is prepared (7.2 GB file: the device waited 0.1-0.2 s of 0.6 for batch 0)
-        if (next_start_ == first_bit_ && !getenv("HPN_GZ_BATCH") && slices >= 2048) {
-            slices = (slices + 3) / 4;
-            last_batch = false;
-        }
         const double t0 = wall_s();
         std::vector<uint64_t> found((size_t)slices + 1, kGzNone);
         found[0] = next_start_;

@@ -30,7 +30,7 @@ def run(tool, args, env, reps=2, cwd=td):
         dt = time.perf_counter() - t0
         if dt < best:
             best, err, out = dt, p.stderr.decode(), p.stdout
-    lines = [l for l in err.splitlines() if l.startswith("[hpn]") and "context" not in l]
+    lines = [l for l in err.splitlines() if (l.startswith("[hpn]") or l.startswith("Finished")) and "context 0.0" not in l]
     print(f"--- {tool} {' '.join(args)}  {env}: {best:.3f} s")
     for l in lines[-6:]:
         print("    " + l[:260])
