@@ -55,7 +55,7 @@ RQC_MAXLEN = 300
 
 class RawInfo(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("tid_min", C.c_int32), ("tid_max", C.c_int32), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("tail_bytes", C.c_uint32)]
 
 
 class GzInfo(C.Structure):
@@ -93,6 +93,7 @@ SYMBOLS = [
     ("hpn_host_free", _int, [_vp, _vp]),
     ("hpn_memcpy_h2d", _int, [_vp, _vp, _vp, _sz]),
     ("hpn_memcpy_d2h", _int, [_vp, _vp, _vp, _sz]),
+    ("hpn_memcpy_d2d", _int, [_vp, _vp, _vp, _sz]),
     ("hpn_fastq_tally", _int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(Tally)]),
     ("hpn_fastq_tally_dev", _int, [_vp, _vp, _vp, _vp, _u64, _u32]),
     ("hpn_fastq_tally_fetch", _int, [_vp, C.POINTER(Tally)]),

@@ -225,24 +225,87 @@ def write_bam(path: str, refs: Sequence[Tuple[str, int]], records: Iterable[BamR
             commit(pending[0], pending[1], end)
         z.close()
     if index:
-        with open(path + ".bai", "wb") as fh:
-            fh.write(b"BAI\1" + struct.pack("<i", n_ref))
-            for t in range(n_ref):
-                fh.write(struct.pack("<i", len(bins[t])))
-                for b in sorted(bins[t]):
-                    ch = bins[t][b]
-                    fh.write(struct.pack("<Ii", b, len(ch)))
-                    for beg, end in ch:
-                        fh.write(struct.pack("<QQ", beg, end))
-                n_intv = (max(lidx[t]) + 1) if lidx[t] else 0
-                fh.write(struct.pack("<i", n_intv))
-                last = 0
-                for w in range(n_intv):  # fill_missing: carry the previous offset forward
-                    v = lidx[t].get(w, 0)
-                    if v == 0:
-                        v = last
-                    last = v
-                    fh.write(struct.pack("<Q", v))
+        _write_bai(path + ".bai", n_ref, bins, lidx)
+    return n
+
+
+def _write_bai(path: str, n_ref: int, bins, lidx) -> None:
+    """bins[t]: bin -> [[beg, end], ...] chunks of virtual offsets; lidx[t]: 16 kb window -> smallest voffset (bam_index.c)."""
+    with open(path, "wb") as fh:
+        fh.write(b"BAI\1" + struct.pack("<i", n_ref))
+        for t in range(n_ref):
+            fh.write(struct.pack("<i", len(bins[t])))
+            for b in sorted(bins[t]):
+                ch = bins[t][b]
+                fh.write(struct.pack("<Ii", b, len(ch)))
+                for beg, end in ch:
+                    fh.write(struct.pack("<QQ", beg, end))
+            n_intv = (max(lidx[t]) + 1) if lidx[t] else 0
+            fh.write(struct.pack("<i", n_intv))
+            last = 0
+            for w in range(n_intv):  # fill_missing: carry the previous offset forward
+                v = lidx[t].get(w, 0)
+                if v == 0:
+                    v = last
+                last = v
+                fh.write(struct.pack("<Q", v))
+
+
+def repack_bam(src: str, dst: str, block: int = 20000, level: int = 6, index: bool = True) -> int:
+    """The records of `src`, byte for byte, written the way htsjdk (Picard, GATK) writes a BAM: the uncompressed stream --
+    header and records -- cut into BGZF blocks of `block` bytes wherever that falls, so records run across block ends
+    (samtools never lets them, bam.c:238 bgzf_flush_try).  + `dst`.bai with the virtual offsets of the new blocks.
+    Returns the number of records.  Input tooling for the tests of the straddling-record decode (kernels/bam_raw.hip)."""
+    assert 0 < block <= 65536
+    with gzip.open(src, "rb") as fh:
+        data = fh.read()
+    addr = []                                            # compressed offset of every new block
+    with open(dst, "wb") as fh:
+        at = 0
+        for i in range(0, len(data), block):
+            piece = data[i:i + block]
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = co.compress(piece) + co.flush()
+            bsize = len(comp) + 26
+            addr.append(at)
+            fh.write(struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, bsize - 1) + comp +
+                     struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+            at += bsize
+        addr.append(at)
+        fh.write(_BGZF_EOF)
+
+    def voff(u: int) -> int:                             # what bgzf_tell reports with u bytes of the stream consumed (bgzf.c:342)
+        return (addr[u // block] << 16) | (u % block)
+
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    o = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, o)
+    o += 4
+    for _ in range(n_ref):
+        o += 8 + struct.unpack_from("<i", data, o)[0]
+    bins = [dict() for _ in range(n_ref)]
+    lidx = [dict() for _ in range(n_ref)]
+    n = 0
+    while o < len(data):
+        (bs,) = struct.unpack_from("<i", data, o)
+        tid, pos, l_name, _mq, _bin, n_cig = struct.unpack_from("<iiBBHH", data, o + 4)
+        if tid >= 0:
+            cig = struct.unpack_from("<%dI" % n_cig, data, o + 36 + l_name)
+            rl = cigar_ref_len(cig)
+            rend = pos + (rl if rl > 0 else 1)
+            beg, end = voff(o), voff(o + 4 + bs)
+            ch = bins[tid].setdefault(reg2bin(pos, rend), [])
+            if ch and ch[-1][1] == beg:
+                ch[-1][1] = end
+            else:
+                ch.append([beg, end])
+            for w in range(pos >> 14, ((rend - 1) >> 14) + 1):
+                if w not in lidx[tid] or beg < lidx[tid][w]:
+                    lidx[tid][w] = beg
+        o += 4 + bs
+        n += 1
+    if index:
+        _write_bai(dst + ".bai", n_ref, bins, lidx)
     return n
 
 

@@ -58,6 +58,7 @@ public:
     {
         if (ctx_) {
             hpn_dev_free(ctx_, d_comp_), hpn_dev_free(ctx_, d_blocks_), hpn_dev_free(ctx_, d_out_), hpn_dev_free(ctx_, d_status_);
+            if (d_carry_) hpn_dev_free(ctx_, d_carry_);
             hpn_host_free(ctx_, h_blocks_);
         }
     }
@@ -66,6 +67,15 @@ public:
     const uint8_t *d_raw() const { return d_out_ ? (const uint8_t *)d_out_ + pad_front_ : nullptr; }
     // writable room in front of and behind the inflated bytes (text batches framed as pieces: the byte before, the 4 KiB after)
     void set_out_pad(size_t front, size_t back) { pad_front_ = front, pad_back_ = back; }
+    // Records may run across block ends (htsjdk-written BAMs; bgzf_read hides the blocks from bam_read1, bgzf.c:342) and so
+    // across the END of a launch: the bytes of the unfinished record (hpn_raw_info.tail_bytes) are kept and laid in front of
+    // the next launch's stream, whose blocks move up by as much -- the stream starts at a record again (kernels/bam_raw.hip).
+    // Switched on by the stream that owns this device side and feeds it IN FILE ORDER; batches dealt to several devices
+    // (BgzfFanout) cannot carry and give such a file back to the one-stream route.
+    void allow_carry(bool on) { carry_ok_ = on, carry_n_ = 0; }
+    void drop_carry() { carry_n_ = 0; }                  // (behind a seek: the next launch starts at a record of its own)
+    size_t carried() const { return carry_n_; }          // != 0 at the end of the file: it ends inside a record
+    static constexpr size_t kMaxCarry = (size_t)4 << 20; // the longest unfinished record kept from launch to launch
 
     // Bytes and table to the device, inflate, then (records) index or (text) check every block.
     // 1 = ok, -1 = not decodable here.  On return the pinned chunk `pb.body` points into is free again.
@@ -75,37 +85,14 @@ public:
         const size_t nb = pb.blocks.size();
         if (!nb) return 1;
         const size_t comp_bytes = pb.carry.size() + pb.body_len;
-        if (!reserve<uint8_t>(d_comp_, cap_comp_, comp_bytes + 64) || !reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) ||
-            !reserve<uint8_t>(d_out_, cap_out_, pb.out_bytes + 64 + pad_front_ + pad_back_) || !reserve<uint32_t>(d_status_, cap_status_, nb))
-            return -1;
-        if (nb > h_blocks_cap_) {
-            if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
-            h_blocks_cap_ = nb + nb / 2 + 1024;
-            if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
-        }
-        memcpy(h_blocks_, pb.blocks.data(), nb * sizeof(hpn_bgzf_block));
+        if (!reserve<uint8_t>(d_comp_, cap_comp_, comp_bytes + 64)) return -1;
         if (!pb.carry.empty()) {
             if (hpn_memcpy_h2d(ctx_, d_comp_, pb.carry.data(), pb.carry.size()) != HPN_OK) return -1;
             if (hpn_ctx_sync(ctx_) != HPN_OK) return -1;  // pageable source
         }
         if (pb.body_len && hpn_memcpy_h2d(ctx_, (uint8_t *)d_comp_ + pb.carry.size(), pb.body, pb.body_len) != HPN_OK) return -1;
-        if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
-        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_ + pad_front_,
-                                 (uint32_t *)d_status_) != HPN_OK)
-            return -1;
-        if (text_mode) {  // no records: wait, check every block's status
-            status_.resize(nb);
-            if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
-            for (uint32_t st : status_)
-                if (st) return -1;
-            info->n_records = pb.out_bytes;
-            return 1;
-        }
-        // the sync inside the index call also covers the copies out of the pinned chunk
-        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_ + pad_front_, (const hpn_bgzf_block *)d_blocks_, nb, pb.first_off,
-                                  (const uint32_t *)d_status_, info) != HPN_OK)
-            return -1;
-        return info->flags ? -1 : 1;
+        // (the sync inside the index call / the status read-back also covers the copies out of the pinned chunk)
+        return launch(d_comp_, pb.blocks.data(), nb, pb.out_bytes, pb.first_off, text_mode, false, info);
     }
 
     // The same in pieces: several chunks of the file under ONE inflate launch.  A launch of one round of the chip's ~5,000
@@ -136,70 +123,62 @@ public:
     size_t blocks_added() const { return pieces_.size(); }
     int finish(bool text_mode, hpn_raw_info *info)
     {
+        return launch(d_comp_, pieces_.data(), pieces_.size(), at_out_, first_off_, text_mode, carry_ok_, info);
+    }
+
+    // The launch a BgzfStage holds: block table to the device, inflate, then (records) index or (text) check every block.
+    int finish_stage(const BgzfStage &st, bool text_mode, hpn_raw_info *info)
+    {
+        return launch(st.d_comp, st.pieces.data(), st.pieces.size(), st.at_out, st.first_off, text_mode, carry_ok_, info);
+    }
+
+private:
+    // Table to the device, inflate behind the carried bytes, index (records) or check (text); then keep the new tail.
+    int launch(const void *d_comp, const hpn_bgzf_block *table, size_t nb, uint64_t out_bytes, uint32_t first_off, bool text_mode,
+               bool may_carry, hpn_raw_info *info)
+    {
         memset(info, 0, sizeof *info);
-        const size_t nb = pieces_.size();
         if (!nb) return 1;
-        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) || !reserve<uint8_t>(d_out_, cap_out_, at_out_ + 64 + pad_front_ + pad_back_) ||
-            !reserve<uint32_t>(d_status_, cap_status_, nb))
+        const size_t h = may_carry && !text_mode ? carry_n_ : 0;      // bytes of the record the launch before ended in
+        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) ||
+            !reserve<uint8_t>(d_out_, cap_out_, h + out_bytes + 64 + pad_front_ + pad_back_) || !reserve<uint32_t>(d_status_, cap_status_, nb))
             return -1;
         if (nb > h_blocks_cap_) {
             if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
             h_blocks_cap_ = nb + nb / 2 + 1024;
             if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
         }
-        memcpy(h_blocks_, pieces_.data(), nb * sizeof(hpn_bgzf_block));
+        hpn_bgzf_block *hb = (hpn_bgzf_block *)h_blocks_;
+        memcpy(hb, table, nb * sizeof(hpn_bgzf_block));
+        if (h)
+            for (size_t i = 0; i < nb; ++i) hb[i].out_off += h;
+        uint8_t *stream = (uint8_t *)d_out_ + pad_front_;
         if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
-        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_ + pad_front_,
-                                 (uint32_t *)d_status_) != HPN_OK)
+        if (h && hpn_memcpy_d2d(ctx_, stream, d_carry_, h) != HPN_OK) return -1;
+        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)d_comp, (const hpn_bgzf_block *)d_blocks_, nb, stream, (uint32_t *)d_status_) != HPN_OK)
             return -1;
         if (text_mode) {  // no records: wait, check every block's status
             status_.resize(nb);
             if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
             for (uint32_t st : status_)
                 if (st) return -1;
-            info->n_records = at_out_;
+            info->n_records = out_bytes;
             return 1;
         }
-        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_ + pad_front_, (const hpn_bgzf_block *)d_blocks_, nb, first_off_,
-                                  (const uint32_t *)d_status_, info) != HPN_OK)
+        if (hpn_bam_raw_index_dev(ctx_, stream, (const hpn_bgzf_block *)d_blocks_, nb, h ? 0u : first_off, (const uint32_t *)d_status_,
+                                  info) != HPN_OK)
             return -1;
-        return info->flags ? -1 : 1;
-    }
-
-    // The launch a BgzfStage holds: block table to the device, inflate, then (records) index or (text) check every block.
-    int finish_stage(const BgzfStage &st, bool text_mode, hpn_raw_info *info)
-    {
-        memset(info, 0, sizeof *info);
-        const size_t nb = st.pieces.size();
-        if (!nb) return 1;
-        if (!reserve<hpn_bgzf_block>(d_blocks_, cap_blocks_, nb) || !reserve<uint8_t>(d_out_, cap_out_, st.at_out + 64 + pad_front_ + pad_back_) ||
-            !reserve<uint32_t>(d_status_, cap_status_, nb))
-            return -1;
-        if (nb > h_blocks_cap_) {
-            if (h_blocks_) hpn_host_free(ctx_, h_blocks_);
-            h_blocks_cap_ = nb + nb / 2 + 1024;
-            if (hpn_host_malloc(ctx_, h_blocks_cap_ * sizeof(hpn_bgzf_block), &h_blocks_) != HPN_OK) return -1;
+        if (info->flags & 3u) return -1;
+        carry_n_ = 0;
+        if (info->tail_bytes) {
+            if (!may_carry || info->tail_bytes > kMaxCarry) return -1;
+            if (!d_carry_ && hpn_dev_malloc(ctx_, kMaxCarry, &d_carry_) != HPN_OK) return -1;
+            // (in stream order: before the next launch's inflate writes over the stream, after this launch's index)
+            if (hpn_memcpy_d2d(ctx_, d_carry_, stream + h + out_bytes - info->tail_bytes, info->tail_bytes) != HPN_OK) return -1;
+            carry_n_ = info->tail_bytes;
         }
-        memcpy(h_blocks_, st.pieces.data(), nb * sizeof(hpn_bgzf_block));
-        if (hpn_memcpy_h2d(ctx_, d_blocks_, h_blocks_, nb * sizeof(hpn_bgzf_block)) != HPN_OK) return -1;
-        if (hpn_bgzf_inflate_dev(ctx_, (const uint8_t *)st.d_comp, (const hpn_bgzf_block *)d_blocks_, nb, (uint8_t *)d_out_ + pad_front_,
-                                 (uint32_t *)d_status_) != HPN_OK)
-            return -1;
-        if (text_mode) {  // no records: wait, check every block's status
-            status_.resize(nb);
-            if (hpn_memcpy_d2h(ctx_, status_.data(), d_status_, nb * sizeof(uint32_t)) != HPN_OK || hpn_ctx_sync(ctx_) != HPN_OK) return -1;
-            for (uint32_t s2 : status_)
-                if (s2) return -1;
-            info->n_records = st.at_out;
-            return 1;
-        }
-        if (hpn_bam_raw_index_dev(ctx_, (const uint8_t *)d_out_ + pad_front_, (const hpn_bgzf_block *)d_blocks_, nb, st.first_off,
-                                  (const uint32_t *)d_status_, info) != HPN_OK)
-            return -1;
-        return info->flags ? -1 : 1;
+        return 1;
     }
-
-private:
     std::vector<hpn_bgzf_block> pieces_;
     size_t at_comp_ = 0;
     uint64_t at_out_ = 0;
@@ -219,7 +198,9 @@ private:
     hpn_ctx *ctx_;
     size_t pad_front_ = 0, pad_back_ = 0;
     std::vector<uint32_t> status_;
-    void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr;
+    void *d_comp_ = nullptr, *d_blocks_ = nullptr, *d_out_ = nullptr, *d_status_ = nullptr, *h_blocks_ = nullptr, *d_carry_ = nullptr;
+    size_t carry_n_ = 0;
+    bool carry_ok_ = false;
     size_t cap_comp_ = 0, cap_blocks_ = 0, cap_out_ = 0, cap_status_ = 0, h_blocks_cap_ = 0;
 };
 
@@ -283,6 +264,7 @@ public:
         pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         if (!pump_->ok()) return false;
         skip_ = start_;
+        dev_.allow_carry(true);                 // one stream, batches in file order: records may run from one launch into the next
         return true;
     }
 
@@ -308,6 +290,7 @@ public:
         if (!pump_ || !pump_->restart(voffset >> 16)) return false;
         first_off_ = (uint32_t)(voffset & 0xffff), skip_ = 0, eof_ = false;
         carry_.clear();
+        dev_.drop_carry();
         if (!rounds_env()) rounds_ = 1;
         return true;
     }
@@ -328,7 +311,7 @@ public:
             BgzfStage none;
             const int r = gather(nullptr, none);
             if (r != 1) return r;
-            if (!dev_.blocks_added()) return eof_ ? 0 : 1;       // (a batch may be empty)
+            if (!dev_.blocks_added()) return eof_ ? (dev_.carried() ? -1 : 0) : 1;   // (a batch may be empty; a file may not end inside a record)
             return dev_.finish(text_mode_, info);
         }
         if (ended_) return final_;                       // (the end, or a failure, has been handed out: it stays)
@@ -342,6 +325,7 @@ public:
         int r = st.result;
         last_eof_ = st.eof;
         if (r == 1 && !st.pieces.empty()) r = dev_.finish_stage(st, text_mode_, info);
+        if (r == 0 && dev_.carried()) r = -1;            // the file ends inside a record: the host route reports it as the reference does
         {   // the launch has read the stage's bytes (finish_stage waits for its kernels): the producer may fill it again
             std::lock_guard<std::mutex> lk(mu_);
             st.state = 0;

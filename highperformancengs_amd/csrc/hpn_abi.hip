@@ -202,6 +202,13 @@ int hpn_memcpy_d2h(hpn_ctx *c, void *dst, const void *src, size_t bytes)
     return HPN_OK;
 }
 
+int hpn_memcpy_d2d(hpn_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return HPN_E_ARG;
+    if (bytes) HPN_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return HPN_OK;
+}
+
 // ---- fastq tally -----------------------------------------------------------------
 
 }  // extern "C"

@@ -32,10 +32,10 @@ hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uin
                              u64 *n_count, uint32_t *bad, uint32_t *todo, int n_cu, hipStream_t st);
 size_t window_todo_words(uint64_t n);
 uint32_t depth_tile_size();
-hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
-                            uint32_t *counts, u64 *bases, int32_t *info, hipStream_t st);
-hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *counts,
-                            const u64 *bases, uint64_t *rec_off, hipStream_t st);
+hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *status,
+                            uint32_t *starts, uint32_t *counts, u64 *exits, int32_t *lo, int32_t *hi, u64 *bases, int32_t *info, hipStream_t st);
+hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *starts,
+                            const uint32_t *counts, const u64 *bases, uint64_t *rec_off, hipStream_t st);
 hipError_t launch_raw_fields(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t *tid, int32_t *pos, uint32_t *flag,
                              int32_t *l_qseq, uint64_t *seq_off, int n_cu, hipStream_t st);
 }  // namespace hpn
@@ -294,24 +294,37 @@ int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block
     c->r_n = 0, c->r_fields = false;
     if (n_blocks == 0) return HPN_OK;
     int rc;
-    if ((rc = scratch_reserve(c, c->r_counts, n_blocks * sizeof(uint32_t))) != HPN_OK) return rc;
+    // per block: (u64) where its chain leaves it | records counted | guessed start | smallest, largest refID
+    if ((rc = scratch_reserve(c, c->r_counts, n_blocks * (sizeof(u64) + 4 * sizeof(uint32_t)) + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->r_bases, (n_blocks + 1) * sizeof(u64))) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->r_info, 64)) != HPN_OK) return rc;
-    const int32_t init[4] = {0, INT32_MAX, INT32_MIN, 0};
+    u64 *d_exits = (u64 *)c->r_counts.p;
+    uint32_t *d_counts = (uint32_t *)(d_exits + n_blocks), *d_starts = d_counts + n_blocks;
+    int32_t *d_lo = (int32_t *)(d_starts + n_blocks), *d_hi = d_lo + n_blocks;
+    const int32_t init[6] = {0, INT32_MAX, INT32_MIN, 0, -1, -1};      // [4..5]: u64 ~0 = no unfinished record at the call's end
     HPN_HIP(c, hipMemcpyAsync(c->r_info.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    HPN_HIP(c, launch_raw_count(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_status, (uint32_t *)c->r_counts.p, (u64 *)c->r_bases.p,
-                                (int32_t *)c->r_info.p, c->stream));
-    int32_t h[4];
+    HPN_HIP(c, launch_raw_count(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_status, d_starts, d_counts, d_exits, d_lo, d_hi,
+                                (u64 *)c->r_bases.p, (int32_t *)c->r_info.p, c->stream));
+    int32_t h[6];
     u64 total = 0;
+    hpn_bgzf_block last;
     HPN_HIP(c, hipMemcpyAsync(h, c->r_info.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipMemcpyAsync(&total, (const u64 *)c->r_bases.p + n_blocks, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HPN_HIP(c, hipMemcpyAsync(&last, d_blocks + (n_blocks - 1), sizeof last, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
+    u64 tail;
+    memcpy(&tail, h + 4, 8);
+    const u64 stream_len = last.out_off + last.out_len;
     info->flags = (uint32_t)h[0];
     info->n_records = total;
     info->tid_min = total ? h[1] : 0, info->tid_max = total ? h[2] : -1;
-    if (info->flags || total == 0) return HPN_OK;  // nothing indexed: the caller decodes this file on the host
+    if (tail != ~0ull && !(info->flags & 3u)) {
+        if (stream_len - tail > 0xffffffffull) info->flags |= 1u;
+        else info->tail_bytes = (uint32_t)(stream_len - tail);
+    }
+    if ((info->flags & 3u) || total == 0) return HPN_OK;  // nothing indexed: the caller decodes this file on the host (flags), or waits for more bytes
     if ((rc = scratch_reserve(c, c->r_off, total * sizeof(uint64_t))) != HPN_OK) return rc;
-    HPN_HIP(c, launch_raw_index(d_raw, d_blocks, (uint32_t)n_blocks, first_off, (const uint32_t *)c->r_counts.p, (const u64 *)c->r_bases.p,
+    HPN_HIP(c, launch_raw_index(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_starts, d_counts, (const u64 *)c->r_bases.p,
                                 (uint64_t *)c->r_off.p, c->stream));
     c->r_n = total;
     return HPN_OK;

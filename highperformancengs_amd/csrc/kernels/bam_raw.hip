@@ -2,16 +2,23 @@
 //
 // The reference walks a BAM with bam_read1 (samtools-0.1.19 bam.c:191): block_size, 32 bytes of
 // core fields, name, CIGAR, packed sequence, qualities -- one record after the other on the
-// host.  With the blocks inflated on the GPU (bgzf_inflate.hip) the record chain is walked
-// there too.  A chain is serial, but samtools never lets a record straddle a BGZF block
-// (bam_write1 calls bgzf_flush_try(4 + block_len), bam.c:238; the header is followed by a
-// flush), so every block starts at a record boundary and the blocks can be walked
-// independently: one lane per block hops through its ~200 records.  Files written otherwise
-// (records packed across blocks) are detected -- a walk that does not end exactly at its
-// block's end -- and the tools then decode the file on the host.
+// host, through bgzf_read, which does not care where blocks end (bgzf.c:342).  With the blocks inflated on the GPU
+// (bgzf_inflate.hip) the record chain is walked there too.  A chain is serial; what makes it parallel is knowing where the
+// first record of every block starts:
+//   * samtools never lets a record straddle a BGZF block (bam_write1 calls bgzf_flush_try(4 + block_len), bam.c:238; the
+//     header is followed by a flush): every block starts at a record, offset 0;
+//   * htsjdk (Picard, GATK -- most production BAMs) packs records across blocks.  Round 4: the start is GUESSED per block
+//     (k_raw_starts: the lowest offset at which a plausible chain of records begins -- sizes that fit, a name that ends in NUL,
+//     reference ids and positions in range) and then PROVEN for the whole call (k_raw_scan): the chain, followed block by block
+//     from the call's first record -- whose place is known --, must arrive exactly at each block's guess; where it does not,
+//     the block is walked again from where the chain does arrive.  The guesses make the walk parallel, never the result.
+// The inflated bytes of a batch are one contiguous stream, so a record that runs into the next block is whole in memory; the
+// record that runs past the batch's END is not: its bytes are reported (hpn_raw_info.tail_bytes) and the host copies them in
+// front of the next batch's stream (host/bam_gpu.hpp), which therefore starts at a record again.
 //
-//   k_raw_count    per block: number of records, smallest / largest refID, chain check
-//   k_raw_scan     exclusive scan of the per-block counts (one workgroup; a batch has ~10^4 blocks)
+//   k_raw_starts   per block: where its first record starts (wave per block; block 0: given)
+//   k_raw_count    per block: number of records that START in it, smallest / largest refID, where its chain leaves it
+//   k_raw_scan     exclusive scan of the per-block counts + the proof (one workgroup; a batch has ~10^4 blocks)
 //   k_raw_index    per block: byte offset of every record -> rec_off[]
 //   k_raw_fields   per record: refID, pos, flag, l_seq, offset of the packed sequence
 //                  (the SoA view k_window_add takes; the sequence stays where it is)
@@ -36,58 +43,194 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p)
 }
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
 
-// info words: [0] flags (1 = chain does not end at the block end, 2 = block failed to inflate),
-// [1] min refID, [2] max refID (as int32), [3] unused; total record count goes to bases[n_blocks]
+constexpr uint32_t kNoStart = 0xffffffffu;
+
+// Could a record start at p?  `room` = bytes of the batch's stream from p on.  0 = no; 1 = yes, *step = bytes to the next record;
+// 2 = cannot tell (the stream ends inside its fixed part or its name: the batch's tail).
+// bam_read1 trusts the fields (bam.c:191); the later kernels read name, CIGAR and sequence in place, so a record that lies about
+// them must not get past here.
+__device__ __forceinline__ int record_at(const uint8_t *p, uint64_t room, uint32_t *step)
+{
+    if (room < 36u) return 2;
+    const uint32_t bs = ld32(p);
+    if (bs < 32u || bs > (1u << 28)) return 0;
+    const int32_t tid = (int32_t)ld32(p + 4), pos = (int32_t)ld32(p + 8), mtid = (int32_t)ld32(p + 24), mpos = (int32_t)ld32(p + 28);
+    const uint32_t l_name = p[12], n_cigar = ld16(p + 16), l_seq = ld32(p + 20);
+    if (tid < -1 || pos < -1 || mtid < -1 || mpos < -1 || l_name == 0u || l_seq > 0x7fffffffu) return 0;
+    if (32ull + l_name + 4ull * n_cigar + (((uint64_t)l_seq + 1u) >> 1) + (uint64_t)l_seq > (uint64_t)bs) return 0;
+    if (room < 36u + l_name) return 2;
+    if (p[35u + l_name] != 0u) return 0;                   // read_name is NUL-terminated
+    *step = 4u + bs;
+    return 1;
+}
+
+// Where does the first record of block b start?  One wave per block (b >= 1; block 0's start is given): lane k tries offset
+// base + k and follows the chain four records (one well-formed header is no rarity in BAM bytes -- small integers everywhere;
+// four in a row are); the lowest offset whose chain holds is taken.  A chain that reaches the END of the call's stream before
+// its fourth record holds as far as it can be followed -- weaker, and where most wrong guesses come from (a plausible header
+// with a large block_size leaves the stream in one hop).  Guesses all: k_raw_scan proves each one or walks the block itself.
+__global__ __launch_bounds__(kWave) void k_raw_starts(const uint8_t *__restrict__ raw, const RawBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                      const uint32_t *__restrict__ status, uint32_t *__restrict__ starts)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const RawBlock blk = blocks[b], last = blocks[n_blocks - 1];
+    const uint64_t stream_len = last.out_off + last.out_len;
+    const int lane = lane_id();
+    if (b == 0 || status[b] || blk.out_len == 0) {           // (block 0 is walked from first_abs)
+        if (lane == 0) starts[b] = kNoStart;
+        return;
+    }
+    uint32_t found = kNoStart;
+    for (uint32_t base = 0; base < blk.out_len && found == kNoStart; base += kWave) {
+        const uint32_t s0 = base + (uint32_t)lane;
+        bool ok = s0 < blk.out_len;
+        uint64_t at = blk.out_off + s0;
+        for (int hop = 0; ok && hop < 4; ++hop) {      // four records in a row, into the blocks behind if need be (one stream)
+            if (at >= stream_len) break;                  // the chain has left the stream (its last record is the unfinished one)
+            uint32_t step = 0;
+            const int r = record_at(raw + at, stream_len - at, &step);
+            if (r == 0 || (r == 2 && hop == 0)) ok = false;      // (a start of which not even the fixed part is there: k_raw_scan's)
+            if (r != 1) break;
+            at += step;
+        }
+        const u64 m = __ballot(ok);
+        if (m) found = base + (uint32_t)__builtin_ctzll(m);
+    }
+    if (lane == 0) starts[b] = found;
+}
+
+constexpr uint32_t kBroken = 0x80000000u;      // counts[b]: the block's walk met an impossible record
+constexpr u64 kTailBit = 1ull << 63;           // exits[b]: the walk ended at an unfinished record, which starts at exits[b] & ~kTailBit
+
+// One block's records from `at` on: how many start in it, their smallest / largest refID, where the chain leaves the block.
+struct RawWalk {
+    uint32_t n;        // | kBroken
+    int32_t lo, hi;
+    u64 exit;          // | kTailBit
+};
+__device__ __forceinline__ RawWalk walk_block(const uint8_t *__restrict__ raw, uint64_t at, uint64_t end, uint64_t stream_len)
+{
+    RawWalk w = {0u, INT32_MAX, INT32_MIN, 0ull};
+    while (at < end) {
+        uint32_t step = 0;
+        const int r = record_at(raw + at, stream_len - at, &step);
+        if (r == 0) {
+            w.n |= kBroken;
+            break;
+        }
+        if (r == 2 || at + step > stream_len) {          // the record is not whole in this call: it starts the next one
+            at |= kTailBit;
+            break;
+        }
+        const int32_t tid = (int32_t)ld32(raw + at + 4u);
+        w.lo = tid < w.lo ? tid : w.lo, w.hi = tid > w.hi ? tid : w.hi;
+        at += step;
+        ++w.n;
+    }
+    w.exit = at;
+    return w;
+}
+
+// info words: [0] flags (1 = an impossible record on the chain, 2 = a block failed to inflate, 4 = records run across block ends
+// (packed BAM)), [1] min refID, [2] max refID (as int32), [3] unused; u64 at info + 4: stream offset of the call's unfinished
+// last record (~0: the stream ends on a record).  k_raw_count only sets flag 2; the rest is k_raw_scan's, from the proven chain.
 __global__ __launch_bounds__(kRawThreads) void k_raw_count(const uint8_t *__restrict__ raw, const RawBlock *__restrict__ blocks,
-                                                           uint32_t n_blocks, uint32_t first_off,
-                                                           const uint32_t *__restrict__ status, uint32_t *__restrict__ counts,
-                                                           int32_t *__restrict__ info)
+                                                           uint32_t n_blocks, uint64_t first_abs,
+                                                           const uint32_t *__restrict__ status, const uint32_t *__restrict__ starts,
+                                                           uint32_t *__restrict__ counts, u64 *__restrict__ exits, int32_t *__restrict__ lo,
+                                                           int32_t *__restrict__ hi, int32_t *__restrict__ info)
 {
     const uint32_t b = blockIdx.x * kRawThreads + threadIdx.x;
     if (b >= n_blocks) return;
+    const RawBlock blk = blocks[b], last = blocks[n_blocks - 1];
+    const uint64_t stream_len = last.out_off + last.out_len, end = blk.out_off + blk.out_len;
     if (status[b]) {
         atomicOr((uint32_t *)&info[0], 2u);
-        counts[b] = 0;
+        counts[b] = kBroken, exits[b] = end, lo[b] = INT32_MAX, hi[b] = INT32_MIN;
         return;
     }
-    const RawBlock blk = blocks[b];
-    const uint8_t *p = raw + blk.out_off;
-    uint32_t at = b == 0 ? first_off : 0u, n = 0;
-    int32_t lo = INT32_MAX, hi = INT32_MIN;
-    bool broken = at > blk.out_len;
-    while (!broken && at + 4u <= blk.out_len) {
-        const uint32_t bs = ld32(p + at);
-        if (bs < 32u || bs > blk.out_len - at - 4u) {  // a record never ends beyond its block here
-            broken = true;
-            break;
-        }
-        // the variable-length fields must fit the record (bam_read1 trusts them, bam.c:191; the later kernels
-        // read name, CIGAR and sequence in place, so a record that lies about them is caught here)
-        const uint32_t l_name = p[at + 12u], n_cigar = ld16(p + at + 16u), l_seq = ld32(p + at + 20u);
-        if (l_seq > 0x7fffffffu ||
-            32ull + l_name + 4ull * n_cigar + (((uint64_t)l_seq + 1u) >> 1) + (uint64_t)l_seq > (uint64_t)bs) {
-            broken = true;
-            break;
-        }
-        const int32_t tid = (int32_t)ld32(p + at + 4u);
-        lo = tid < lo ? tid : lo, hi = tid > hi ? tid : hi;
-        at += 4u + bs;
-        ++n;
-    }
-    if (broken || at != blk.out_len) atomicOr((uint32_t *)&info[0], 1u);
-    counts[b] = n;
-    if (n) atomicMin(&info[1], lo), atomicMax(&info[2], hi);
+    // a block without a start (its predecessor's record runs over it whole, or it lies behind the call's last whole record)
+    // counts nothing; whether that is right is k_raw_scan's to say
+    const uint64_t at = b == 0 ? first_abs : starts[b] == kNoStart ? end : blk.out_off + starts[b];
+    const RawWalk w = walk_block(raw, at, end, stream_len);
+    counts[b] = w.n, exits[b] = w.exit, lo[b] = w.lo, hi[b] = w.hi;
 }
 
-__global__ __launch_bounds__(1024) void k_raw_scan(const uint32_t *__restrict__ counts, uint32_t n_blocks, u64 *__restrict__ bases)
+// The proof, the exclusive scan of the per-block counts, the refID range.  One workgroup; a call has ~2 x 10^4 blocks at most.
+// The proof: walking the blocks in order, the chain enters block i at `from`.  Either it has already run past the block (a long
+// record, or the call's unfinished tail): then no record starts in the block, whatever its guess found; or the block's guessed
+// start IS `from` and the chain goes on where the block's own walk left it; or the guess was wrong (or there was none) and this
+// lane walks the block from `from` itself.  By induction from first_abs every counted record is a true one, and the unfinished
+// tail is the chain's, not a guess's.  In chunks of 1,024 blocks through LDS, one lane walking; samtools' blocks and all but a
+// few of htsjdk's (near the stream's end, where chains are short) are taken on their guess.
+__global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ raw, uint32_t *__restrict__ counts, uint32_t n_blocks,
+                                                   u64 *__restrict__ bases, const RawBlock *__restrict__ blocks, uint64_t first_abs,
+                                                   uint32_t *__restrict__ starts, const u64 *__restrict__ exits,
+                                                   const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int32_t *__restrict__ info)
 {
     __shared__ u64 s_wave[16];
-    __shared__ u64 s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
+    __shared__ u64 s_carry, s_from, s_tail;
+    __shared__ uint32_t s_flags;
+    __shared__ u64 s_off[1024], s_end[1024], s_exit[1024];
+    __shared__ uint32_t s_cnt[1024], s_start[1024];
+    __shared__ int32_t s_lo[1024], s_hi[1024];
+    const RawBlock last = blocks[n_blocks - 1];
+    const u64 stream_len = last.out_off + last.out_len;
+    if (threadIdx.x == 0) s_carry = 0, s_from = first_abs, s_tail = ~0ull, s_flags = 0;
+    int32_t my_lo = INT32_MAX, my_hi = INT32_MIN;
     for (uint32_t i0 = 0; i0 < n_blocks; i0 += 1024u) {
         const uint32_t i = i0 + threadIdx.x;
-        const u64 v = i < n_blocks ? counts[i] : 0;
+        __syncthreads();
+        if (i < n_blocks) {
+            const RawBlock blk = blocks[i];
+            s_off[threadIdx.x] = blk.out_off, s_end[threadIdx.x] = blk.out_off + blk.out_len;
+            s_exit[threadIdx.x] = exits[i], s_cnt[threadIdx.x] = counts[i], s_start[threadIdx.x] = starts[i];
+            s_lo[threadIdx.x] = lo[i], s_hi[threadIdx.x] = hi[i];
+        } else {
+            s_cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        // the common chunk needs no walk: every block's chain ends inside the next block, exactly at that block's guess
+        bool plain = true, crosses = false;
+        if (i < n_blocks) {
+            const u64 arrives = threadIdx.x == 0 ? s_from : s_exit[threadIdx.x - 1];     // (an exit with kTailBit equals no guess)
+            const u64 own = i == 0 ? first_abs : s_start[threadIdx.x] == kNoStart ? ~0ull : s_off[threadIdx.x] + s_start[threadIdx.x];
+            plain = own == arrives && arrives < s_end[threadIdx.x] && !(s_cnt[threadIdx.x] & kBroken) && !(s_exit[threadIdx.x] & kTailBit);
+            crosses = s_exit[threadIdx.x] > s_end[threadIdx.x] && i + 1 < n_blocks;
+        }
+        const bool all_plain = __syncthreads_and(plain), any_cross = __syncthreads_or(crosses);
+        if (all_plain) {
+            if (i == (n_blocks - i0 < 1024u ? n_blocks - 1 : i0 + 1023u)) {
+                s_from = s_exit[threadIdx.x];
+                if (any_cross) s_flags |= 4u;
+            }
+        } else if (threadIdx.x == 0) {
+            u64 from = s_from, tail = s_tail;
+            uint32_t flags = s_flags;
+            const uint32_t m = n_blocks - i0 < 1024u ? n_blocks - i0 : 1024u;
+            for (uint32_t k = 0; k < m; ++k) {
+                const u64 end = s_end[k];
+                if (from >= end) {                                  // the chain never sets foot in this block
+                    s_cnt[k] = 0, s_start[k] = kNoStart;
+                    continue;
+                }
+                const u64 own = i0 + k == 0 ? first_abs : s_start[k] == kNoStart ? ~0ull : s_off[k] + s_start[k];
+                if (own != from) {                                  // no guess, or not where the chain arrives: walked here
+                    const RawWalk w = walk_block(raw, from, end, stream_len);
+                    s_cnt[k] = w.n, s_exit[k] = w.exit, s_lo[k] = w.lo, s_hi[k] = w.hi;
+                    s_start[k] = (uint32_t)(from - s_off[k]);
+                }
+                if (s_cnt[k] & kBroken) flags |= 1u, s_cnt[k] &= ~kBroken;
+                if (s_exit[k] & kTailBit) tail = s_exit[k] & ~kTailBit, from = stream_len;
+                else from = s_exit[k];
+                if (flags & 1u) from = stream_len;              // (nothing behind an impossible record is looked at)
+                if (from > end && i0 + k + 1 < n_blocks) flags |= 4u;
+            }
+            s_from = from, s_tail = tail, s_flags = flags;
+        }
+        __syncthreads();
+        const u64 v = s_cnt[threadIdx.x];
         u64 inc = v;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
@@ -98,27 +241,37 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint32_t *__restrict__ 
         __syncthreads();
         u64 before = s_carry;
         for (int w = 0; w < wave_id(); ++w) before += s_wave[w];
-        if (i < n_blocks) bases[i] = before + inc - v;
+        if (i < n_blocks) {
+            bases[i] = before + inc - v, counts[i] = (uint32_t)v, starts[i] = s_start[threadIdx.x];
+            if (v) my_lo = s_lo[threadIdx.x] < my_lo ? s_lo[threadIdx.x] : my_lo, my_hi = s_hi[threadIdx.x] > my_hi ? s_hi[threadIdx.x] : my_hi;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = before + inc;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) bases[n_blocks] = s_carry;
+    __syncthreads();
+    if (my_lo <= my_hi) atomicMin(&info[1], my_lo), atomicMax(&info[2], my_hi);
+    if (threadIdx.x == 0) {
+        bases[n_blocks] = s_carry;
+        uint32_t flags = s_flags;
+        if (s_from != stream_len) flags |= 1u;
+        if (flags) atomicOr((uint32_t *)&info[0], flags);
+        *(u64 *)(info + 4) = s_tail;
+    }
 }
 
 __global__ __launch_bounds__(kRawThreads) void k_raw_index(const uint8_t *__restrict__ raw, const RawBlock *__restrict__ blocks,
-                                                           uint32_t n_blocks, uint32_t first_off, const uint32_t *__restrict__ counts,
-                                                           const u64 *__restrict__ bases, uint64_t *__restrict__ rec_off)
+                                                           uint32_t n_blocks, uint64_t first_abs, const uint32_t *__restrict__ starts,
+                                                           const uint32_t *__restrict__ counts, const u64 *__restrict__ bases,
+                                                           uint64_t *__restrict__ rec_off)
 {
     const uint32_t b = blockIdx.x * kRawThreads + threadIdx.x;
     if (b >= n_blocks) return;
     const RawBlock blk = blocks[b];
-    const uint8_t *p = raw + blk.out_off;
-    uint32_t at = b == 0 ? first_off : 0u;
+    uint64_t at = b == 0 ? first_abs : blk.out_off + starts[b];
     u64 r = bases[b];
     for (uint32_t k = 0, n = counts[b]; k < n; ++k) {
-        rec_off[r++] = blk.out_off + at;
-        at += 4u + ld32(p + at);
+        rec_off[r++] = at;
+        at += 4u + ld32(raw + at);
     }
 }
 
@@ -140,22 +293,24 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_fields(const uint8_t *__res
     }
 }
 
-hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *status,
-                            uint32_t *counts, u64 *bases, int32_t *info, hipStream_t st)
+hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *status,
+                            uint32_t *starts, uint32_t *counts, u64 *exits, int32_t *lo, int32_t *hi, u64 *bases, int32_t *info, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_raw_starts, dim3(n_blocks), dim3(kWave), 0, st, raw, (const RawBlock *)blocks, n_blocks, status, starts);
     hipLaunchKernelGGL(k_raw_count, dim3((n_blocks + kRawThreads - 1) / kRawThreads), dim3(kRawThreads), 0, st, raw,
-                       (const RawBlock *)blocks, n_blocks, first_off, status, counts, info);
-    hipLaunchKernelGGL(k_raw_scan, dim3(1), dim3(1024), 0, st, counts, n_blocks, bases);
+                       (const RawBlock *)blocks, n_blocks, first_abs, status, starts, counts, exits, lo, hi, info);
+    hipLaunchKernelGGL(k_raw_scan, dim3(1), dim3(1024), 0, st, raw, counts, n_blocks, bases, (const RawBlock *)blocks, first_abs, starts,
+                       exits, lo, hi, info);
     return hipGetLastError();
 }
 
-hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint32_t first_off, const uint32_t *counts,
-                            const u64 *bases, uint64_t *rec_off, hipStream_t st)
+hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *starts,
+                            const uint32_t *counts, const u64 *bases, uint64_t *rec_off, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_raw_index, dim3((n_blocks + kRawThreads - 1) / kRawThreads), dim3(kRawThreads), 0, st, raw,
-                       (const RawBlock *)blocks, n_blocks, first_off, counts, bases, rec_off);
+                       (const RawBlock *)blocks, n_blocks, first_abs, starts, counts, bases, rec_off);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ int main(int argc, char *argv[])
       const int workers = multi_gpu_workers_for(infiles[i], true);   // > 1: targets are spread over the GPUs (host/bam_multi.hpp)
       bool try_multi = workers > 1 && bam_gpu_enabled();
       // first with the BGZF inflate and the record walk on the GPU; a file that cannot be decoded
-      // there (records straddling blocks, damaged block) is done again with the host reader
+      // there (a damaged block, an impossible record, a file that ends inside a record) is done again with the host reader
       for (int pass = bam_gpu_enabled() ? 0 : 1; pass < 2; ++pass) {
         DepthFeeder bam;
         BamHeader hdr;

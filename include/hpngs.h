@@ -77,6 +77,7 @@ int hpn_host_malloc(hpn_ctx *ctx, size_t bytes, void **hptr); /* pinned */
 int hpn_host_free(hpn_ctx *ctx, void *hptr);
 int hpn_memcpy_h2d(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream */
 int hpn_memcpy_d2h(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream */
+int hpn_memcpy_d2d(hpn_ctx *ctx, void *dst, const void *src, size_t bytes); /* async on ctx stream; same device */
 int hpn_dev_mem_info(hpn_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes); /* of the context's device, now */
 
 /* ---- fastq_count: replaces count_read's scan loop ------------------------------
@@ -440,20 +441,27 @@ int hpn_window_finish(hpn_ctx *ctx, uint32_t *bins, uint64_t *gc, uint32_t *len,
 
 /* ---- BAM records in place in inflated BGZF blocks -----------------------------------------
  * bam_read1 (samtools-0.1.19 bam.c:191) on the device: after hpn_bgzf_inflate_dev the records
- * are indexed where they lie.  samtools never lets a record straddle a BGZF block (bam.c:238
- * bgzf_flush_try; the header ends with a flush), so every block starts at a record boundary and
- * is walked independently; `first_off` is the offset of the first record inside block 0 (the
- * block the BAM header ends in).  info->flags: 1 = some block's record chain does not end at
- * the block's end (a file written otherwise), 2 = a block failed to inflate -- in both cases
- * nothing is indexed and the caller decodes the file on the host.  Synchronous (returns the
- * record count and the refID range of the batch).  The two add calls then run the depth /
- * window kernels over the indexed records, like hpn_depth_add_dev / hpn_window_add_dev.
+ * are indexed where they lie.  The inflated blocks of a call are ONE stream d_raw[0, out_off + out_len
+ * of the last block): `first_off` is the stream offset of its first record (inside block 0: the block
+ * the BAM header ends in; 0 when the caller has put the unfinished record of the call before in front,
+ * see tail_bytes).  Where every block's first record starts is found on the device and proven for the
+ * whole call (every block's chain must arrive exactly at the next block's found start: by induction
+ * from first_off all starts are true), so both writers' files decode: samtools never lets a record
+ * straddle a block (bam.c:238 bgzf_flush_try), htsjdk packs records across blocks -- which bgzf_read
+ * (bgzf.c:342) hides from the reference.  info->flags: 1 = the proof failed or a record is impossible
+ * (a damaged file, or records longer than a block), 2 = a block failed to inflate -- in both cases
+ * nothing is indexed and the caller decodes the file on the host; 4 (informational) = records do run
+ * across block ends.  info->tail_bytes: the call's stream ends inside a record of which that many bytes
+ * are there (not indexed): the caller copies d_raw[stream end - tail_bytes, stream end) in front of the
+ * next call's stream (out_off of its blocks moved up by as much) and passes first_off = 0.
+ * Synchronous (returns the record count and the refID range of the batch).  The two add calls then run
+ * the depth / window kernels over the indexed records, like hpn_depth_add_dev / hpn_window_add_dev.
  * d_raw must be readable 16 bytes past the end of the inflated stream (the window kernel
  * reads packed sequences in unaligned 16-byte pieces). */
 typedef struct hpn_raw_info {
     uint64_t n_records;
     int32_t tid_min, tid_max;
-    uint32_t flags, reserved;
+    uint32_t flags, tail_bytes;
 } hpn_raw_info;
 int hpn_bam_raw_index_dev(hpn_ctx *ctx, const uint8_t *d_raw, const hpn_bgzf_block *d_blocks, uint64_t n_blocks,
                           uint32_t first_off, const uint32_t *d_status, hpn_raw_info *info);

@@ -205,6 +205,8 @@ int main(int argc, char **argv)
         if (argc > 5) threads = atoi(argv[5]);
         per_block = argc <= 6;       // a 7th argument: pack records across blocks instead
     }
+    if (const char *e = getenv("BAM_SYNTH_PACKED"))      // records packed across BGZF blocks (batches of 2^20 records still end with a block)
+        if (e[0] == '1') per_block = false;
     const int contigs = (int)tname.size();
     FILE *f = fopen(argv[1], "wb");
     if (!f) return perror(argv[1]), 1;
@@ -338,7 +340,29 @@ int main(int argc, char **argv)
                 fwrite(q.seq4.data(), 1, q.seq4.size(), soa_f[4]);
             }
         const std::vector<BlockAt> at = write_compressed(f, B.z);
-        if (per_block) {                                   // index the batch: every record lies inside one block
+        if (!per_block) {                                  // packed (htsjdk's way): a record starts in block b and may end blocks later
+            const uint64_t after = (uint64_t)ftello(f);
+            auto voff = [&](size_t p, size_t &b) {         // bgzf_tell with p bytes of the batch consumed (b: cursor, moves forward)
+                while (b < at.size() && p >= at[b].raw_end) ++b;
+                return b < at.size() ? (at[b].file_off << 16 | (uint64_t)(p - at[b].raw_beg)) : after << 16;
+            };
+            size_t b0 = 0, b1 = 0;
+            for (size_t p = 0; p < raw.size();) {
+                uint32_t bs, pos, flag_nc;
+                memcpy(&bs, raw.data() + p, 4), memcpy(&pos, raw.data() + p + 8, 4), memcpy(&flag_nc, raw.data() + p + 16, 4);
+                const uint8_t *cg = raw.data() + p + 36 + raw[p + 12];
+                uint32_t rl = 0;
+                for (uint32_t q = 0; q < (flag_nc & 0xffffu); ++q) {
+                    uint32_t w;
+                    memcpy(&w, cg + 4 * q, 4);
+                    if ((w & 15) == 0 || (w & 15) == 2 || (w & 15) == 3 || (w & 15) == 7 || (w & 15) == 8) rl += w >> 4;
+                }
+                const size_t e = p + 4 + bs;
+                const uint64_t vbeg = voff(p, b0), vend = voff(e, b1);
+                idx.add(c, pos, pos + (rl ? rl : 1), vbeg, vend);
+                p = e;
+            }
+        } else {                                           // index the batch: every record lies inside one block
             const uint64_t after = (uint64_t)ftello(f);
             for (size_t b = 0; b < at.size(); ++b) {
                 const uint64_t next = b + 1 < at.size() ? at[b + 1].file_off : after;
@@ -366,7 +390,6 @@ int main(int argc, char **argv)
     fclose(f);
     for (FILE *q : soa_f)
         if (q) fclose(q);
-    if (per_block) idx.write(std::string(argv[1]) + ".bai");
-    else fclose(fopen((std::string(argv[1]) + ".bai").c_str(), "wb"));   // packed records: our tools only (they need the file to exist)
+    idx.write(std::string(argv[1]) + ".bai");
     return 0;
 }

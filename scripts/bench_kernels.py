@@ -109,8 +109,12 @@ if not only or only & {"k3", "k4", "k5"}:
             if r:
                 ts3.append(t3), ts4.append(t4)
         slots = TL + 1 + (1 << 21)
-        emit("K3 k_depth_scatter", statistics.median(ts3), n * 16 + 4 * n_ops + 8 * n_m, records=n, cigar_ops=n_ops)
-        emit("K4 k_depth_scan (scan+RLE+window sums)", statistics.median(ts4), slots * 4 + 12 * len(runs) + 8 * len(win),
+        # sorted records take the swept route (bam_depth.hip): add = k_depth_index + k_depth_sweep (difference array, prefix sum and
+        # runs in one pass, nothing through HBM), finish = k_depth_scan over the last tiles only -- so the two are ONE leg; the
+        # two-pass route's K3 and K4 by themselves are timed by scripts/bench_depth_legs.py
+        alg = n * 16 + 4 * n_ops + 8 * n_m + slots * 4 + 12 * len(runs) + 8 * len(win)
+        emit("K3+K4 swept route: k_depth_index + k_depth_sweep (+ k_depth_scan over the last tiles)", statistics.median(ts3) + statistics.median(ts4),
+             alg, add_ms=round(statistics.median(ts3), 4), finish_ms=round(statistics.median(ts4), 4), records=n, cigar_ops=n_ops,
              positions=slots, runs=len(runs))
         mean_cov = float(win.sum()) / TL
         assert 20 < mean_cov < 31, mean_cov

@@ -49,8 +49,14 @@ def _to_device(ctx, raw, skip_header=True):
     """-> (d_raw, info, keepalive) with the blocks from the one holding the first record on"""
     import torch
     blks = _blocks(raw)
-    text = b"".join(zlib.decompress(raw[a:a + n], -15) for a, n, _ in blks[:4])
-    hl = _header_len(text)
+    text, hl = b"", None
+    for a, n, _ in blks:                                    # as many blocks as the header takes (tiny blocks: several)
+        text += zlib.decompress(raw[a:a + n], -15)
+        try:
+            hl = _header_len(text)
+            break
+        except struct.error:
+            continue
     first, acc = 0, 0
     while acc + blks[first][2] <= hl and first < len(blks) - 1:  # the block the header ends in (or the next one)
         acc += blks[first][2]
@@ -92,17 +98,102 @@ def test_index_depth_and_window_on_raw_records(ctx, bam):
         assert got[4] == want[6]
 
 
-def test_records_straddling_blocks_are_flagged(ctx):
-    raw = open(golden_path("bam", "rand.bam"), "rb").read()
+def _packed(raw, block):
+    """the same uncompressed stream cut into BGZF blocks of `block` bytes: records now run across block ends (htsjdk's way)"""
     data = b"".join(zlib.decompress(raw[a:a + n], -15) for a, n, _ in _blocks(raw))
     packed = b""
-    for i in range(0, len(data), 20000):  # fixed-size blocks: records now cross block boundaries
-        piece = data[i:i + 20000]
+    for i in range(0, len(data), block):
+        piece = data[i:i + block]
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
         comp = co.compress(piece) + co.flush()
         packed += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
                    (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
-    _, info, _ = _to_device(ctx, packed)
+    return packed, data
+
+
+@pytest.mark.parametrize("block", [97, 1000, 20000, 65536])
+def test_records_straddling_blocks_are_decoded(ctx, block):
+    """htsjdk-style BAM (records packed across BGZF blocks; block = 97: every record covers several blocks, most blocks hold
+    no record start): every block's first record is found and the chain proven on the device (k_raw_starts / k_raw_scan), the
+    depth and window kernels then see the same records as with samtools' record-aligned blocks."""
+    raw = open(golden_path("bam", "rand.bam"), "rb").read()
+    soa = bamio.read_bam_records(golden_path("bam", "rand.bam"))
+    packed, _ = _packed(raw, block)
+    d_raw, info, keep = _to_device(ctx, packed)
+    assert info.flags & 3 == 0 and info.flags & 4 and info.tail_bytes == 0
+    assert info.n_records == len(soa.tid) and info.tid_min == int(soa.tid.min()) and info.tid_max == int(soa.tid.max())
+    W = 100
+    for tid, (name, tlen) in enumerate(soa.refs):
+        runs, win = ctx.depth_target_raw(d_raw, tid, tlen, W, 0x704)
+        rc, wruns, wbins = orc.depth_target(soa, tid, W, 0x704)
+        assert rc == 0 and np.array_equal(runs, wruns) and np.array_equal(win.astype(np.float64), wbins), name
+    got = ctx.window_counts_raw(d_raw, orc.window_offsets(soa.refs, W), W)
+    want = orc.window_counts(soa, W)
+    for g, w in zip(got[:4], want[2:6]):
+        assert np.array_equal(np.asarray(g), np.asarray(w))
+    assert got[4] == want[6]
+
+
+@pytest.mark.parametrize("block,cut", [(20000, 2), (1000, 37), (97, 400), (97, 401), (97, 402), (97, 403)])
+def test_unfinished_record_at_the_end_of_a_call_is_reported_and_carried(ctx, block, cut):
+    """A call that ends inside a record indexes the whole records and reports the bytes of the unfinished one
+    (hpn_raw_info.tail_bytes); with those bytes in front of the next call's stream (blocks moved up, first_off = 0) the two
+    calls together index every record of the file -- what host/bam_gpu.hpp does from launch to launch."""
+    import torch
+    raw = open(golden_path("bam", "rand.bam"), "rb").read()
+    soa = bamio.read_bam_records(golden_path("bam", "rand.bam"))
+    packed, data = _packed(raw, block)
+    blks = _blocks(packed)
+    hl = _header_len(data)
+    first = hl // block                                     # the block the first record starts in
+    rec_at = [hl]
+    while rec_at[-1] < len(data):
+        rec_at.append(rec_at[-1] + 4 + struct.unpack_from("<i", data, rec_at[-1])[0])
+    d_comp = torch.from_numpy(np.frombuffer(packed + bytes(64), np.uint8).copy()).cuda()
+
+    def call(lo, hi, front, first_off):
+        """blocks [lo, hi) behind `front` carried bytes -> (info, inflated stream as bytes)"""
+        table = np.zeros((hi - lo, 3), np.uint64)
+        outo = len(front)
+        for i, (a, n, isz) in enumerate(blks[lo:hi]):
+            table[i] = (a, n | (isz << 32), outo)
+            outo += isz
+        d_blocks = torch.from_numpy(table.view(np.int64)).cuda()
+        d_out = torch.zeros(outo + 64, dtype=torch.uint8, device="cuda")
+        if front:
+            d_out[:len(front)] = torch.from_numpy(np.frombuffer(front, np.uint8).copy()).cuda()
+        d_status = torch.zeros(hi - lo, dtype=torch.int32, device="cuda")
+        ctx.bgzf_inflate_dev(d_comp, d_blocks, hi - lo, d_out, d_status)
+        info = ctx.bam_raw_index_dev(d_out, d_blocks, hi - lo, first_off, d_status)
+        return info, bytes(d_out[:outo].cpu().numpy())
+
+    mid = first + cut
+    end_a = min(mid * block, len(data))
+    n_a = sum(1 for k in range(len(rec_at) - 1) if rec_at[k + 1] <= end_a)          # records whole in the first call
+    tail = end_a - rec_at[n_a]
+    info, stream = call(first, mid, b"", hl - first * block)
+    assert info.flags & 3 == 0 and info.n_records == n_a and info.tail_bytes == tail, (info.flags, info.n_records, info.tail_bytes, tail)
+    front = stream[len(stream) - tail:] if tail else b""
+    info2, _ = call(mid, len(blks), front, 0)
+    assert info2.flags & 3 == 0 and info2.tail_bytes == 0 and info2.n_records == len(soa.tid) - n_a
+    assert min(info.tid_min, info2.tid_min) == int(soa.tid.min()) and max(info.tid_max, info2.tid_max) == int(soa.tid.max())
+
+
+def test_a_start_that_is_not_one_is_refuted(ctx):
+    """The found starts are guesses until the chain proves them: a block whose bytes hold a well-formed chain of records at
+    the WRONG place (here: a block of the file pasted in the middle of a long record's qualities would do the same) must
+    flag the call, not shift the records.  Built by dropping one block of a packed file: the chain of the block before no
+    longer arrives at the next found start."""
+    raw = open(golden_path("bam", "rand.bam"), "rb").read()
+    packed, _ = _packed(raw, 1000)
+    blks, o, cut = _blocks(packed), 0, []
+    for k in range(len(blks)):
+        bsize = struct.unpack_from("<H", packed, o + 16)[0] + 1
+        cut.append((o, bsize))
+        o += bsize
+    k = len(blks) // 2
+    dropped = packed[:cut[k][0]] + packed[cut[k][0] + cut[k][1]:]
+    _, info, _ = _to_device(ctx, dropped)
     assert info.flags & 1 and info.flags & 2 == 0
 
 

@@ -74,6 +74,41 @@ def test_small_instance_every_route(tmp_path):
         assert open(d / "s.txt", "rb").read() == want_txt, env
 
 
+def test_small_instance_packed_across_blocks(tmp_path):
+    """The same four targets written htsjdk's way (records packed across BGZF blocks, bamio.repack_bam; a .bai whose virtual
+    offsets point into blocks): ~2,000 blocks, records run across most block ends and -- with small launches -- from one launch
+    into the next; one context, per-target workers (HPN_NGPU), batches in turn (bam_sliding_count gives those back to one stream)."""
+    from highperformancengs_amd import bamio
+    tg = [("chr1", 3_000_000, 400_000), ("chrM", 16569, 3300), ("chrEmpty", 70_000, 0), ("chr9", 1_200_000, 100_000)]
+    bam, prefix = c4.synth(str(tmp_path), "s.bam", tg, 4)
+    soa = c4.Soa(prefix, len(tg))
+    W = 20000
+    cache = {}
+
+    def oracle(t):
+        if t not in cache:
+            runs, bins = c4.oracle_depth_target(soa, tg, t, W)
+            cache[t] = c4.oracle_target_text(tg[t][0], tg[t][1], W, runs, bins)
+        return cache[t]
+    want_txt = c4.oracle_window_report(soa, tg, W)
+    packed = str(tmp_path / "packed.bam")
+    assert bamio.repack_bam(bam, packed, 65280, level=1) == soa.n
+    for env in ({"HPN_NGPU": "1"}, {"HPN_NGPU": "3"}, {"HPN_NGPU": "1", "HPN_BAM_CHUNK": "200000", "HPN_BAM_ROUNDS": "1"},
+                {"HPN_NGPU": "2", "HPN_BAM_CHUNK": "150000", "HPN_BAM_ROUNDS": "3"}, {"HPN_NGPU": "1", "HPN_BAM_AHEAD": "0", "HPN_BAM_CHUNK": "300000"}):
+        d = tmp_path / ("prun" + "".join(env.values()))
+        d.mkdir()
+        os.symlink(packed, d / "s.bam"), os.symlink(packed + ".bai", d / "s.bam.bai")
+        e = {**os.environ, **env, "HPN_TIMING": "1"}
+        p = subprocess.run([os.path.join(BIN, "bam2depth"), "-w", str(W), "-o", "d", "s.bam"], cwd=d, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"GPU ingest" in p.stderr and b"abandoned" not in p.stderr and b"host ingest" not in p.stderr, p.stderr.decode()
+        _check_depth_outputs(d, "s.bam", "d", soa, tg, W, oracle)
+        p = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", str(W), "-o", "s", "s.bam"], cwd=d, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"GPU ingest" in p.stderr and b"host ingest" not in p.stderr, p.stderr.decode()
+        assert open(d / "s.txt", "rb").read() == want_txt, env
+
+
 def test_hg38_shaped_bam_through_the_tools(tmp_path):
     tg = c4.targets(lambda n, l: 30.0 if n in ("chr21", "chrM") else 3.0)
     n_reads = sum(r for _, _, r in tg)

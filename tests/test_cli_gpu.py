@@ -233,34 +233,30 @@ def test_depth_look_ahead_budget_holds_workers_back(manifest, case, tmp_path):  
         assert int(waits) > 0 and float(budget) < 1e-3       # workers were held back: one target at a time
 
 
-def test_bam_multi_gpu_route_falls_back(tmp_path):
-    """A file the GPU ingest cannot take (records packed across blocks) abandons the several-worker route too and still
-    gives the reference's bytes through the host reader."""
-    import zlib
+def test_packed_bam_on_several_workers(tmp_path):
+    """Records packed across BGZF blocks (htsjdk's way; bamio.repack_bam writes the matching .bai): bam2depth's workers each read
+    their targets from the index offset -- which now points INTO a block -- and carry unfinished records from launch to launch;
+    bam_sliding_count's batches-in-turn route cannot carry, gives the file back and the one-stream route decodes it on the GPU."""
     src = golden_path("bam", "rand.bam")
-    raw, o, data = open(src, "rb").read(), 0, b""
-    while o < len(raw):
-        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
-        xlen = int.from_bytes(raw[o + 10:o + 12], "little")
-        data += zlib.decompress(raw[o + 12 + xlen:o + bsize - 8], -15)
-        o += bsize
-    with open(tmp_path / "rand.bam", "wb") as fh:
-        for i in range(0, len(data), 20000):
-            piece = data[i:i + 20000]
-            co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            comp = co.compress(piece) + co.flush()
-            fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
-                     (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
-        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
-    shutil.copy(src + ".bai", tmp_path / "rand.bam.bai")
-    for tool, args, case, outs in (("bam2depth", ["-o", "r", "rand.bam"], "depth_rand", ["rand.bam.1.bedGraph", "r.1.depth"]),
-                                   ("bam_sliding_count", ["rand.bam"], "sliding_rand", ["out.txt"])):
-        p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           env={**os.environ, "HPN_TIMING": "1", "HPN_NGPU": "2"})
-        assert p.returncode == 0, p.stderr.decode()
-        assert b"workers  (abandoned)" in p.stderr
-        for f in outs:
-            assert open(tmp_path / f, "rb").read() == expected(case, f), (tool, f)
+    for block in (20000, 777):
+        d = tmp_path / str(block)
+        d.mkdir()
+        bamio.repack_bam(src, str(d / "rand.bam"), block, level=0)         # (level 0: ~410 KB, several 65 KB chunks)
+        for tool, args, case, outs in (("bam2depth", ["-o", "r", "rand.bam"], "depth_rand", ["rand.bam.1.bedGraph", "r.1.depth"]),
+                                       ("bam_sliding_count", ["rand.bam"], "sliding_rand", ["out.txt"])):
+            for env in ({}, {"HPN_BAM_CHUNK": "65600", "HPN_BAM_ROUNDS": "1"}):
+                p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   env={**os.environ, "HPN_TIMING": "1", "HPN_NGPU": "2", **env})
+                assert p.returncode == 0, p.stderr.decode()
+                assert b"host ingest" not in p.stderr, p.stderr.decode()
+                if tool == "bam2depth":
+                    assert b"GPU ingest on 2 workers" in p.stderr and b"abandoned" not in p.stderr, p.stderr.decode()
+                elif env:         # batches of one chunk in turn: records run from a batch into the next worker's
+                    assert b"workers  (abandoned)" in p.stderr and b"[hpn] GPU ingest\n" in p.stderr, p.stderr.decode()
+                else:             # the whole file is one batch: nothing to carry
+                    assert b"[hpn] GPU ingest on 2 workers\n" in p.stderr, p.stderr.decode()
+                for f in outs:
+                    assert open(d / f, "rb").read() == expected(case, f), (tool, f, block, env)
 
 
 def test_region_reads_from_the_index_offset(tmp_path):
@@ -289,37 +285,48 @@ def test_region_reads_from_the_index_offset(tmp_path):
         os.unlink(tmp_path / "rand.bam"), os.unlink(tmp_path / "rand.bam.bai")
 
 
-def test_bam_gpu_ingest_is_used_and_falls_back(tmp_path):
-    """HPN_TIMING names the ingest: golden BAMs (record-aligned blocks) decode on the GPU; the same
-    records packed across block boundaries are detected and decoded by the host reader."""
-    import zlib
+def test_bam_gpu_ingest_takes_both_writers_files_and_falls_back_on_damage(tmp_path):
+    """HPN_TIMING names the ingest: golden BAMs (samtools: record-aligned blocks) decode on the GPU, and so do the same records
+    packed across block boundaries (htsjdk) -- with launches small enough that records also run from one launch into the next;
+    a file that ends inside a record is left to the host reader, which ends where bam_read1 does."""
     src = golden_path("bam", "rand.bam")
     p, _ = _run("bam2depth", ["-o", "d", "rand.bam"], [src], tmp_path, {"HPN_TIMING": "1"})
     assert p.returncode == 0 and b"[hpn] GPU ingest" in p.stderr and b"abandoned" not in p.stderr
     want = open(tmp_path / "rand.bam.1.bedGraph", "rb").read()
-    # re-block the same uncompressed stream in fixed 20000-byte pieces: records now straddle blocks
-    raw, o, data = open(src, "rb").read(), 0, b""
-    while o < len(raw):
-        bsize = int.from_bytes(raw[o + 16:o + 18], "little") + 1
-        xlen = int.from_bytes(raw[o + 10:o + 12], "little")
-        data += zlib.decompress(raw[o + 12 + xlen:o + bsize - 8], -15)
-        o += bsize
-    d2 = tmp_path / "packed"
-    d2.mkdir()
-    with open(d2 / "rand.bam", "wb") as fh:
-        for i in range(0, len(data), 20000):
-            piece = data[i:i + 20000]
-            co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            comp = co.compress(piece) + co.flush()
-            fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
-                     (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
-        fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
-    shutil.copy(src + ".bai", d2 / "rand.bam.bai")
-    p = subprocess.run([os.path.join(BIN, "bam2depth"), "-o", "d", "rand.bam"], cwd=d2, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       env={**os.environ, "HPN_TIMING": "1"})
-    assert p.returncode == 0, p.stderr.decode()
-    assert b"abandoned" in p.stderr and b"[hpn] host ingest" in p.stderr
-    assert open(d2 / "rand.bam.1.bedGraph", "rb").read() == want
+    want_s = expected("sliding_rand", "out.txt")
+    for block, env in ((20000, {}), (20000, {"HPN_BAM_CHUNK": "65600", "HPN_BAM_ROUNDS": "1"}), (333, {"HPN_BAM_CHUNK": "65600", "HPN_BAM_ROUNDS": "1"}),
+                       (65000, {"HPN_BAM_AHEAD": "0", "HPN_BAM_CHUNK": "65600", "HPN_BAM_ROUNDS": "1"}), (97, {})):
+        d2 = tmp_path / ("packed%d%s" % (block, "".join(env.values())))
+        d2.mkdir()
+        bamio.repack_bam(src, str(d2 / "rand.bam"), block, level=0 if env else 6)      # (level 0: the file spans several chunks)
+        p = subprocess.run([os.path.join(BIN, "bam2depth"), "-o", "d", "rand.bam"], cwd=d2, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env={**os.environ, "HPN_TIMING": "1", "HPN_NGPU": "1", **env})
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"[hpn] GPU ingest" in p.stderr and b"abandoned" not in p.stderr and b"host ingest" not in p.stderr, p.stderr.decode()
+        assert open(d2 / "rand.bam.1.bedGraph", "rb").read() == want, (block, env)
+        p = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "rand.bam"], cwd=d2, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env={**os.environ, "HPN_TIMING": "1", "HPN_NGPU": "1", **env})
+        assert p.returncode == 0, p.stderr.decode()
+        assert b"[hpn] GPU ingest" in p.stderr and b"abandoned" not in p.stderr, p.stderr.decode()
+        assert open(d2 / "out.txt", "rb").read() == want_s, (block, env)
+    # the file cut inside its last record (a BGZF EOF block behind it, so the container is whole): the GPU ingest gives it up
+    import gzip
+    data = gzip.open(src, "rb").read()
+    d3 = tmp_path / "cut"
+    d3.mkdir()
+    with open(d3 / "whole.bam", "wb") as fh:
+        z = bamio._Bgzf(fh)
+        z.write(data[:60000]), z._flush(), z.write(data[60000:len(data) - 20])
+        z.close()
+    bamio.repack_bam(str(d3 / "whole.bam"), str(d3 / "rand.bam"), 20000, index=False)
+    shutil.copy(src + ".bai", d3 / "rand.bam.bai")
+    p = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "rand.bam"], cwd=d3, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "HPN_TIMING": "1", "HPN_NGPU": "1"})
+    h = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-o", "host", "rand.bam"], cwd=d3, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "HPN_BAM_GPU": "0"})
+    assert p.returncode == h.returncode and b"[hpn] host ingest" in p.stderr, p.stderr.decode()
+    if p.returncode == 0:
+        assert open(d3 / "out.txt", "rb").read() == open(d3 / "host.txt", "rb").read()
 
 
 def test_bgzipped_fastq_is_inflated_on_the_gpu(tmp_path):
