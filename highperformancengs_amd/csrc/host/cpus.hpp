@@ -17,6 +17,20 @@ inline double wall_s()  // monotonic seconds, for the HPN_TIMING diagnostics
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+// HPN_TIMING=2: where the wall time of a run goes, as stamps since the process began (/proc/self/stat's start time is in clock
+// ticks, too coarse: the first stamp -- the first line of main -- stands for "loaded and linked")
+inline void stamp(const char *what, double arg = -1)
+{
+    static const bool on = [] {
+        const char *e = getenv("HPN_TIMING");
+        return e && e[0] == '2';
+    }();
+    if (!on) return;
+    static const double t0 = wall_s();
+    if (arg >= 0) fprintf(stderr, "[hpn t=%.3f] %s %.3f\n", wall_s() - t0, what, arg);
+    else fprintf(stderr, "[hpn t=%.3f] %s\n", wall_s() - t0, what);
+}
+
 inline int usable_cpus()
 {
     static const int n = [] {

@@ -81,6 +81,12 @@ public:
             search_on_device_ = e ? !strcmp(e, "device") : threads_ < 6;
         }
         max_stretches_ = max_stretches < 1 ? 1 : max_stretches > 65535u ? 65535u : max_stretches;
+        // A file that fills the chip twice or more with stretches of 256 KiB is taken in several batches, and then the DEVICE looks
+        // for the block starts whatever the core count (four times the stretches are four times the cores' search: 0.65 s for
+        // 24 K stretches on 15 cores).  One batch of 6,144 stretches of 1.2 MB holds 38 GB of symbol scratch + 12 GB of text at once:
+        // measured on a 7.2 GB file 0.34 s of device time on a fresh box and 1.8 - 2.4 s on a box whose memory had been in use
+        // (profiles/r04/e2e_tools_b.txt); four batches of a quarter of that run 0.10 s each on both.
+        if (!getenv("HPN_GZ_FIND") && size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10)) >= 2) search_on_device_ = true;
         // symbols of scratch per stretch: from the expansion of the member's first megabytes (FASTQ is homogeneous; a
         // stretch that needs more is decoded again with twice the room)
         {
@@ -129,6 +135,7 @@ public:
         // the compressed bytes reach the device through pinned chunks read in parallel (the page cache is not pinned)
         int device = 0;
         if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) return give_up("no context for the uploads");
+        stamp("gzip: probed, second context");
         pump_.reset(new TextPump(up_ctx_, path, (size_t)32 << 20, 3, true));
         if (!pump_->ok()) return give_up("reader not available");
         if (hpn_dev_malloc(ctx_, 32768, &d_win_[0]) != HPN_OK || hpn_dev_malloc(ctx_, 32768, &d_win_[1]) != HPN_OK) return give_up("device memory");
@@ -157,6 +164,7 @@ public:
             cv_.wait(g, [&] { return sl.state != 0; });
         }
         if (sl.state < 0) return give_up(sl.why) - 1;
+        stamp("batch prepared (block starts, compressed bytes on the device), stretches:", (double)sl.n);
         const uint32_t n = sl.n;
         const uint64_t comp_bytes = sl.comp_bytes, end_bit = sl.end_bit;
         const bool last_batch = sl.last;
@@ -178,6 +186,7 @@ public:
             break;
         }
         t_device_ += wall_s() - t2;
+        stamp("inflate returned");
         if ((info.status == 12 || info.status == 14 || info.status == 1) && !grown_) {  // out of room: once more with twice as much
             grown_ = true;
             sym_cap_ = cap_for(ratio_ * 3.0);

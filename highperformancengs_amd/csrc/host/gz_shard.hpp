@@ -74,7 +74,14 @@ public:
         uint64_t max_stretch = (uint64_t)((double)((uint64_t)3 << 19) * (ratio_ > 2.0 ? 2.0 / ratio_ : 1.0));
         if (max_stretch < ((uint64_t)512 << 10)) max_stretch = (uint64_t)512 << 10;
         const uint64_t calls = (size_ + S_ * max_stretch - 1) / (S_ * max_stretch);
-        const uint64_t want_calls = calls < (uint64_t)g_.lanes() ? (uint64_t)g_.lanes() : calls;   // at least one batch per lane
+        uint64_t want_calls = calls < (uint64_t)g_.lanes() ? (uint64_t)g_.lanes() : calls;   // at least one batch per lane
+        {   // as in GzGpuStream::open: a file that fills every lane's chip twice or more goes in up to four batches per lane, the
+            // block starts found by the device (bounded symbol scratch per batch; the next batch's upload beside this one's kernels)
+            const uint64_t fills = size_ / (S_ * (uint64_t)g_.lanes() * ((uint64_t)256 << 10));
+            if (!getenv("HPN_GZ_FIND") && fills >= 2) search_on_device_ = true;
+            const uint64_t per_lane = fills < 4 ? fills : 4;
+            if (search_on_device_ && fills >= 2 && want_calls < per_lane * (uint64_t)g_.lanes()) want_calls = per_lane * (uint64_t)g_.lanes();
+        }
         stretch_ = e ? (size_t)atoll(e) : (size_t)((size_ / (want_calls * S_) + 4096) & ~(uint64_t)4095);
         if (!e && stretch_ < ((size_t)256 << 10)) stretch_ = (size_t)256 << 10;
         if (!e && stretch_ > max_stretch) stretch_ = (size_t)max_stretch;
@@ -556,6 +563,7 @@ inline int tally_gz_sharded(LaneGroup &g, const char *path, hpn_tally *acc, bool
     uint32_t slots = 5120;
     (void)hpn_inflate_slots(g.ctx(0), &slots);                        // stretches a chip decodes at once
     uint32_t per_call = (uint32_t)(slots / (uint32_t)text_workers_in_flight());
+    if (!g.distinct()) per_call /= (uint32_t)g.lanes();              // lanes on ONE device (HPN_NGPU on a one-GPU box) share its decoder slots and its memory
     if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
     GzSharded gs(g, path, (int)(cpus < 1 ? 1 : cpus > 32 ? 32 : cpus), per_call < 1 ? 1 : per_call);
     if (!gs.open()) {

@@ -214,6 +214,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
         return HPN_OK;
     }
     const double t_open = wall_s() - t0;
+    stamp("gzip route open");
     const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
     int rc = hpn_fastq_text_begin(ctx);
     const uint64_t slice = (uint64_t)256 << 20;
@@ -224,6 +225,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
             *unusable = true;
             break;
         }
+        stamp("batch inflated, GB of text:", (double)n / 1e9);
         const bool fin = r == 0 || gs.at_end();
         for (uint64_t at = 0; rc == HPN_OK && !*unusable && (at < n || (fin && n == 0));) {
             const uint64_t k = n - at < slice ? n - at : slice;
@@ -233,6 +235,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
             at += k;
             if (n == 0) break;
         }
+        stamp("batch framed and tallied");
         if (fin) break;
     }
     if (*unusable || rc != HPN_OK) {

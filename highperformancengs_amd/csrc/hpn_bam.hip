@@ -317,6 +317,12 @@ int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block
     const u64 stream_len = last.out_off + last.out_len;
     info->flags = (uint32_t)h[0];
     info->n_records = total;
+    {
+        static const bool diag = [] { const char *e = getenv("HPN_TIMING"); return e && e[0] == '2'; }();
+        if (diag)
+            fprintf(stderr, "[hpn] record index: %llu blocks, %llu records, %u chunks of 1024 blocks walked by one lane, %u blocks walked again, flags %u\n",
+                    (unsigned long long)n_blocks, (unsigned long long)total, (uint32_t)h[3] >> 20, (uint32_t)h[3] & 0xfffffu, info->flags);
+    }
     info->tid_min = total ? h[1] : 0, info->tid_max = total ? h[2] : -1;
     if (tail != ~0ull && !(info->flags & 3u)) {
         if (stream_len - tail > 0xffffffffull) info->flags |= 1u;

@@ -1206,8 +1206,12 @@ constexpr int kFmtSubs = 8, kFmtTile = kFmtSub * kFmtSubs;   // ... and a workgr
 // bytes of text a piece may stage (512 lines of up to 78 bytes).  With the kernel's other ~600 bytes this stays within 32 of the
 // CU's LDS granules of 1,280 bytes (scripts/micro/lds_occupancy.hip): four workgroups per CU; 40,960 bytes of text were 33 granules
 // and three.
-constexpr int kFmtLds = 39936;
-constexpr int kFmtMaxName = kFmtLds / kFmtSub - 34;   // longest target name the staged path takes (44)
+#ifndef HPN_BG_LDS
+#define HPN_BG_LDS 39936
+#endif
+constexpr int kFmtLds = HPN_BG_LDS;                   // (A/B builds: smaller -> more workgroups per CU; a piece that does not fit goes straight to memory)
+constexpr int kFmtMaxName = 44;                       // longest target name the staged path takes
+constexpr int kFmtWaveLds = (kFmtLds / (kFmtThreads / kWave)) & ~15;   // every wave's own part (128 lines)
 
 __device__ __forceinline__ int dec_digits(uint32_t v)
 {
@@ -1363,9 +1367,139 @@ __device__ __forceinline__ void put_line_uniform(uint8_t *p, const Dig S, const 
     q[n3 + 1] = '\n';
 }
 
+// ---- lines of one layout, stored as aligned words (round 4) --------------------------------------------------------------------
+// The byte-wise store of a line is ~27 ds_write_b8 and as many address adds.  With the layout known at COMPILE time (name length and
+// the digit counts of start and end: ten instantiations cover chr1 .. chr22 / X / Y / M from position 10^4 to 10^9; the depth's
+// 1 .. 4 digits close the line and stay a run-time value) the line is put together in registers with constant shifts, moved to its
+// place inside the words it covers by one v_perm per word (selector from the lane's byte offset & 3), and stored as whole aligned
+// words.  A word that two lines share is completed before the store: by the lane itself between its two lines, from the lane
+// below (DPP wave shift) between lanes; only the wave's first and last line have an edge left, which goes byte by byte.
+constexpr int kLineWords = 9;      // a line of up to 8 + 1 + 9 + 1 + 9 + 1 + 4 + 1 = 34 characters
+// ORs the first NB characters of the left-justified field w0 w1 w2 (zero behind its last character) into the line at character POS
+template <int POS, int NB>
+__device__ __forceinline__ void line_or(uint32_t (&L)[kLineWords], uint32_t w0, uint32_t w1, uint32_t w2)
+{
+    const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (4 * j < NB) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int at = POS + 4 * j, i = at >> 2, sh = at & 3;
+            L[i] |= w[j] << (8 * sh);
+            if (sh && i + 1 < kLineWords) L[i + 1] |= w[j] >> (8 * (4 - sh));
+        }
+    }
+}
+// name (NAME characters in n0 n1w) \t S (N1 digits) \t E (N2 digits) \t depth (n3 digits, < 10000) \n   -> L; the line's length
+template <int NAME, int N1, int N2>
+__device__ __forceinline__ int line_words(uint32_t (&L)[kLineWords], uint32_t n0, uint32_t n1w, const Dig S, const Dig E, uint32_t depth, int n3)
+{
+    constexpr int P1 = NAME, P2 = P1 + 1 + N1, P3 = P2 + 1 + N2;     // where the three tabs stand
+#pragma unroll
+    for (int i = 0; i < kLineWords; ++i) L[i] = 0;
+    L[P1 >> 2] |= 9u << (8 * (P1 & 3)), L[P2 >> 2] |= 9u << (8 * (P2 & 3)), L[P3 >> 2] |= 9u << (8 * (P3 & 3));
+    constexpr uint32_t m0 = NAME >= 4 ? 0xffffffffu : (1u << (8 * NAME)) - 1u, m1 = NAME >= 8 ? 0xffffffffu : NAME > 4 ? (1u << (8 * (NAME - 4))) - 1u : 0u;
+    line_or<0, NAME>(L, n0 & m0, n1w & m1, 0u);
+    line_or<P1 + 1, N1>(L, S.a, S.b, S.c);
+    line_or<P2 + 1, N2>(L, E.a, E.b, E.c);
+    // the depth's digits, left-justified, and the newline behind them: five characters at the most
+    const uint32_t d = ascii4(depth) >> (8 * (4 - n3));
+    line_or<P3 + 1, 5>(L, n3 < 4 ? d | 10u << (8 * n3) : d, n3 < 4 ? 0u : 10u, 0u);
+    return P3 + 2 + n3;
+}
+// One line's words at byte offset `at` of the staging buffer: T[i] = word i of ([at & 3 zero bytes] + line), c = the words it
+// covers, the last of them incomplete when (at + len) & 3 != 0.
+struct LinePlace {
+    uint32_t T[kLineWords + 1];
+    uint32_t a, tb;        // bytes of the first word that belong to the line before; bytes of the last word that are this line's (0: all)
+    uint32_t tail;         // the last word when it is incomplete, else 0
+};
+__device__ __forceinline__ void line_place(LinePlace &pl, const uint32_t (&L)[kLineWords], uint32_t at, int len)
+{
+    pl.a = at & 3u, pl.tb = (at + (uint32_t)len) & 3u;
+    const uint32_t sel = 0x03020100u + 0x01010101u * (4u - pl.a);       // bytes 4 - a .. 7 - a of {L[i], L[i - 1]}
+    pl.T[0] = __builtin_amdgcn_perm(L[0], 0u, sel);
+#pragma unroll
+    for (int i = 1; i < kLineWords; ++i) pl.T[i] = __builtin_amdgcn_perm(L[i], L[i - 1], sel);
+    pl.T[kLineWords] = __builtin_amdgcn_perm(0u, L[kLineWords - 1], sel);
+}
+// word `idx` of T for idx in [LO, LO + 2] (wave-uniform base, lane-varying idx): selects, no indexed registers
+template <int LO>
+__device__ __forceinline__ uint32_t line_pick(const uint32_t (&T)[kLineWords + 1], uint32_t idx)
+{
+    const uint32_t x0 = T[LO < kLineWords + 1 ? LO : kLineWords], x1 = T[LO + 1 < kLineWords + 1 ? LO + 1 : kLineWords],
+                   x2 = T[LO + 2 < kLineWords + 1 ? LO + 2 : kLineWords];
+    return idx == (uint32_t)LO ? x0 : idx == (uint32_t)LO + 1u ? x1 : x2;
+}
+// The two lines of a lane (line 0 at `at`, line 1 right behind it), both of the layout <NAME, N1, N2> in every lane of the wave.
+template <int NAME, int N1, int N2>
+__device__ __forceinline__ void put_pair_words(uint8_t *s_text, uint32_t at, uint32_t n0, uint32_t n1w, const Dig S0, const Dig E0, uint32_t d0, int n30,
+                                               const Dig S1, const Dig E1, uint32_t d1, int n31)
+{
+    constexpr int kMin = NAME + 3 + N1 + N2 + 2;                     // shortest line of the layout (one depth digit)
+    constexpr int kLo = (kMin + 3) / 4 - 1;                          // index of the last word: >= kLo (a = 0, one digit), <= kLo + 2
+    uint32_t L[kLineWords];
+    LinePlace p0, p1;
+    const int len0 = line_words<NAME, N1, N2>(L, n0, n1w, S0, E0, d0, n30);
+    line_place(p0, L, at, len0);
+    const int len1 = line_words<NAME, N1, N2>(L, n0, n1w, S1, E1, d1, n31);
+    line_place(p1, L, at + (uint32_t)len0, len1);
+    const uint32_t c0 = (p0.a + (uint32_t)len0 + 3u) >> 2, c1 = (p1.a + (uint32_t)len1 + 3u) >> 2;     // words the lines cover
+    const uint32_t t0 = p0.tb ? line_pick<kLo>(p0.T, c0 - 1u) : 0u, t1 = p1.tb ? line_pick<kLo>(p1.T, c1 - 1u) : 0u;
+    // the word a line shares with the one before it: completed here
+    const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0: 0)
+    const int lane = lane_id();
+    uint32_t *w0 = reinterpret_cast<uint32_t *>(s_text + (at & ~3u)), *w1 = reinterpret_cast<uint32_t *>(s_text + ((at + (uint32_t)len0) & ~3u));
+    const uint32_t n_w0 = c0 - (p0.tb ? 1u : 0u), n_w1 = c1 - (p1.tb ? 1u : 0u);                     // whole words each line stores
+    // line 0: word 0 with the tail of the lane below (lane 0 of the wave: its own bytes, one by one), the rest as they are
+    if (lane != 0 || p0.a == 0u) {
+        if (n_w0 > 0u) w0[0] = p0.T[0] | below;
+    } else {
+        uint8_t *b = s_text + at;
+        const uint32_t v = p0.T[0] >> (8u * p0.a), k = 4u - p0.a < (uint32_t)len0 ? 4u - p0.a : (uint32_t)len0;
+        if (k > 0u) b[0] = (uint8_t)v;
+        if (k > 1u) b[1] = (uint8_t)(v >> 8);
+        if (k > 2u) b[2] = (uint8_t)(v >> 16);
+    }
+#pragma unroll
+    for (int i = 1; i < kLineWords + 1; ++i) {
+        if (i < kLo) w0[i] = p0.T[i];                                // (every lane's line reaches this far)
+        else if ((uint32_t)i < n_w0 && i <= kLo + 2) w0[i] = p0.T[i];
+    }
+    // line 1: word 0 with line 0's tail
+    if (n_w1 > 0u) w1[0] = p1.T[0] | t0;
+#pragma unroll
+    for (int i = 1; i < kLineWords + 1; ++i) {
+        if (i < kLo) w1[i] = p1.T[i];
+        else if ((uint32_t)i < n_w1 && i <= kLo + 2) w1[i] = p1.T[i];
+    }
+    // the wave's last line: nobody above to complete its last word
+    if (lane == kWave - 1 && p1.tb) {
+        uint8_t *b = s_text + ((at + (uint32_t)len0 + (uint32_t)len1) & ~3u);
+        if (p1.tb > 0u) b[0] = (uint8_t)t1;
+        if (p1.tb > 1u) b[1] = (uint8_t)(t1 >> 8);
+        if (p1.tb > 2u) b[2] = (uint8_t)(t1 >> 16);
+    }
+}
+
 struct FmtName {
     uint32_t w[16];       // 64 characters
 };
+
+// inclusive prefix sum over the lanes of a wave (DPP: shifts inside rows of 16, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v)
+{
+#define HPN_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
+    HPN_DPP_ADD(0x111, 0xf);
+    HPN_DPP_ADD(0x112, 0xf);
+    HPN_DPP_ADD(0x114, 0xf);
+    HPN_DPP_ADD(0x118, 0xf);
+    HPN_DPP_ADD(0x142, 0xa);
+    HPN_DPP_ADD(0x143, 0xc);
+#undef HPN_DPP_ADD
+    return v;
+}
 
 __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__restrict__ runs, uint64_t n_runs, FmtName name, int name_len,
                                                                const uint8_t *__restrict__ long_name, uint8_t *__restrict__ out,
@@ -1386,27 +1520,35 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
     const uint64_t tile = s_tile;
     const uint32_t n0 = name.w[0], n1 = name.w[1];
     const uint8_t *nm = name_len <= 64 ? reinterpret_cast<const uint8_t *>(s_name) : long_name;
-    // sizes of all the tile's lines first (piece by piece: lane l holds lines 2l, 2l+1 of every piece)
+    // sizes of all the tile's lines first (piece by piece: lane l holds lines 2l, 2l+1 of every piece).  The runs are read twice --
+    // here for the sizes, again piece by piece when the lines are written (from the cache), sizes and places worked out again --:
+    // sixteen runs, their sizes and places held per lane across the chain wait were 72 of the kernel's 123 registers.
     typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
-    int32_t rs[kFmtSubs][kFmtPer], re[kFmtSubs][kFmtPer], rd[kFmtSubs][kFmtPer];
-    uint32_t len[kFmtSubs][kFmtPer], wex[kFmtSubs];
-#pragma unroll
-    for (int sb = 0; sb < kFmtSubs; ++sb) {
+    auto load_pair = [&](int sb, i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer]) {
         const uint64_t r0 = tile * kFmtTile + (uint64_t)sb * kFmtSub + (uint64_t)tid * kFmtPer;
+#pragma unroll
+        for (int k = 0; k < kFmtPer; ++k) {
+            v[k] = i32x3{0, 0, 0};
+            ln[k] = r0 + k < n_runs ? 1u : 0u;                 // (a line at all; its size when the values are there: size_pair)
+            if (ln[k]) v[k] = *reinterpret_cast<const i32x3 *>(&runs[r0 + k]);
+        }
+    };
+    auto size_pair = [&](const i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer]) {
         uint32_t mine = 0;
 #pragma unroll
         for (int k = 0; k < kFmtPer; ++k) {
-            len[sb][k] = 0, rs[sb][k] = 0, re[sb][k] = 0, rd[sb][k] = 0;
-            if (r0 + k < n_runs) {
-                const i32x3 v = *reinterpret_cast<const i32x3 *>(&runs[r0 + k]);
-                rs[sb][k] = v[0], re[sb][k] = v[1], rd[sb][k] = v[2];
-                len[sb][k] = line_info(v[0], v[1], v[2], name_len, s_dig);
-            }
-            mine += (len[sb][k] & 0xffffu);
+            if (ln[k]) ln[k] = line_info(v[k][0], v[k][1], v[k][2], name_len, s_dig);
+            mine += (ln[k] & 0xffffu);
         }
-        u64 wtot;
-        wex[sb] = (uint32_t)wave_excl_scan((u64)mine, wtot);
-        if (lane_id() == kWave - 1) s_w[sb][wave_id()] = wtot;
+        return mine;
+    };
+#pragma unroll
+    for (int sb = 0; sb < kFmtSubs; ++sb) {
+        i32x3 v[kFmtPer];
+        uint32_t ln[kFmtPer];
+        load_pair(sb, v, ln);
+        const uint32_t mine = size_pair(v, ln), upto = wave_incl_u32(mine);
+        if (lane_id() == kWave - 1) s_w[sb][wave_id()] = upto;
     }
     __syncthreads();
     u64 agg = 0;                                              // bytes of the whole tile
@@ -1422,63 +1564,114 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
 #endif
         if (lane_id() == 0) s_x = ex;
     }
+    i32x3 cur[kFmtPer], nxt[kFmtPer];
+    uint32_t cur_ln[kFmtPer], nxt_ln[kFmtPer];
+    load_pair(0, cur, cur_ln);                                // (on their way during the chain wait)
     __syncthreads();
     u64 piece_base = s_x & kScanValueMask;                    // byte offset of the piece being written
-#pragma unroll
+#pragma unroll 1
     for (int sb = 0; sb < kFmtSubs; ++sb) {
+        if (sb + 1 < kFmtSubs) load_pair(sb + 1, nxt, nxt_ln);   // the next piece's runs are on their way while this one is written
+        int32_t rs[kFmtPer], re[kFmtPer], rd[kFmtPer];
+        uint32_t len[kFmtPer];
+#pragma unroll
+        for (int k = 0; k < kFmtPer; ++k) rs[k] = cur[k][0], re[k] = cur[k][1], rd[k] = cur[k][2], len[k] = cur_ln[k];
+        const uint32_t mine = size_pair(cur, len), wex = wave_incl_u32(mine) - mine;
         u64 before = 0, piece = 0;
 #pragma unroll
         for (int w = 0; w < kFmtThreads / kWave; ++w) {
             if (w < wave_id()) before += s_w[sb][w];
             piece += s_w[sb][w];
         }
-        uint32_t at = (uint32_t)before + wex[sb];             // this lane's first line inside the piece
+        // Every wave stages ITS 128 lines in its own part of the buffer and copies them out itself: no workgroup barrier in this
+        // loop (round 4; two per piece before), the waves drift apart and one's copy runs beside another's formatting.
+        const uint32_t wave_bytes = (uint32_t)s_w[sb][wave_id()];
+        uint8_t *const my = s_text + (uint32_t)wave_id() * (uint32_t)kFmtWaveLds;
+        uint32_t at = wex;                                    // this lane's first line inside the wave's part
         // (Round 3 tried lines built in registers -- digits shifted to the front with v_alignbyte, fields written with two overlapping
         // exact-length 8- / 4- / 2-byte stores at their own byte offsets: 270 M instead of 313 M vector instructions per chr1, but the
         // unaligned stores stall in LDS (SQ_LDS_UNALIGNED_STALL 394 M cycles: 1.15 ms against 1.03) and are worse still straight to
-        // memory (2.27 ms): profiles/r03/bedgraph_text_variants.txt.  The byte-wise line stays.)
-        if (name_len <= kFmtMaxName) {                        // staged: build in LDS, copy out in 16-byte pieces
+        // memory (2.27 ms): profiles/r03/bedgraph_text_variants.txt.  Round 4: whole ALIGNED words, put_pair_words.)
+        if (name_len <= kFmtMaxName && wave_bytes <= (uint32_t)kFmtWaveLds) {   // staged: build in LDS, copy out in 16-byte pieces
             Dig prevE{0, 0, 0};
             bool have_prev = false;                           // prevE holds the digits of line k - 1's end (wave-uniform)
-#pragma unroll
-            for (int k = 0; k < kFmtPer; ++k) {
-                // one layout for the whole wave?  (digit counts, a line in every lane, nothing negative, depth of at most four digits)
-                const uint32_t pk = len[sb][k] >> 16, pk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk);
-                const bool same = name_len <= 8 && pk0 != 0 &&
-                                  __ballot(pk != pk0 || (uint32_t)rd[sb][k] >= 10000u || (rs[sb][k] | re[sb][k]) < 0) == 0;
-                if (same) {
-                    const int n1d = (int)(pk0 & 15u), n2d = (int)((pk0 >> 4) & 15u), n3d = (int)((pk0 >> 8) & 15u);
-                    const Dig E = dec_left((uint32_t)re[sb][k], n2d);
-                    Dig S = prevE;                                                   // adjacent runs: the line before ended where this one starts
-                    if (!have_prev || __ballot(rs[sb][k] != re[sb][k > 0 ? k - 1 : 0])) S = dec_left((uint32_t)rs[sb][k], n1d);
-                    put_line_uniform(s_text + at, S, E, (uint32_t)rd[sb][k], n1d, n2d, n3d, n0, n1, name_len);
-                    prevE = E, have_prev = true;
-                } else {
-                    if (len[sb][k]) put_line(s_text + at, rs[sb][k], re[sb][k], rd[sb][k], len[sb][k], n0, n1, nm, name_len);
-                    have_prev = false;
+            // both lines of every lane of ONE layout the word path is compiled for?  (chr1 .. chrM names, 5 .. 9 digits)
+            bool by_words = false;
+#ifdef DIAG_BG_NOFMT
+            by_words = true;                                  // (timing only: nothing is formatted)
+#elif !defined(HPN_BG_BYTES)
+            {
+                static_assert(kFmtPer == 2, "put_pair_words takes a lane's two lines");
+                const uint32_t pk = len[0] >> 16, pk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk);
+                const int n1d = (int)(pk0 & 15u), n2d = (int)((pk0 >> 4) & 15u);
+                const bool fits = (name_len == 4 || name_len == 5) && n1d == n2d && n1d >= 5 && n1d <= 9 && pk0 != 0;
+                if (fits && __ballot((len[0] >> 16 & 0xffu) != (pk0 & 0xffu) || (len[1] >> 16 & 0xffu) != (pk0 & 0xffu) ||
+                                     (uint32_t)rd[0] >= 10000u || (uint32_t)rd[1] >= 10000u || (rs[0] | re[0] | rs[1] | re[1]) < 0) == 0) {
+                    by_words = true;
+                    const int n30 = (int)(len[0] >> 24) & 15, n31 = (int)(len[1] >> 24) & 15;   // (lane-varying: the depth's digits)
+                    const Dig S0 = dec_left((uint32_t)rs[0], n1d), E0 = dec_left((uint32_t)re[0], n1d), E1 = dec_left((uint32_t)re[1], n1d);
+                    Dig S1 = E0;                               // adjacent runs: line 1 starts where line 0 ends
+                    if (__ballot(rs[1] != re[0])) S1 = dec_left((uint32_t)rs[1], n1d);
+#define HPN_BG_CASE(NM, ND) \
+    case NM * 16 + ND: put_pair_words<NM, ND, ND>(my, at, n0, n1, S0, E0, (uint32_t)rd[0], n30, S1, E1, (uint32_t)rd[1], n31); break;
+                    switch (name_len * 16 + n1d) {
+                        HPN_BG_CASE(4, 5) HPN_BG_CASE(4, 6) HPN_BG_CASE(4, 7) HPN_BG_CASE(4, 8) HPN_BG_CASE(4, 9)
+                        HPN_BG_CASE(5, 5) HPN_BG_CASE(5, 6) HPN_BG_CASE(5, 7) HPN_BG_CASE(5, 8) HPN_BG_CASE(5, 9)
+                    }
+#undef HPN_BG_CASE
                 }
-                at += (len[sb][k] & 0xffffu);
             }
-            __syncthreads();
-            const uint32_t nbytes = (uint32_t)piece;
-            uint8_t *dst = out + piece_base;
-            for (uint32_t o = (uint32_t)tid * 16u; o < nbytes; o += kFmtThreads * 16u) {
-                if (o + 16u <= nbytes) {
-                    const u32 v = *reinterpret_cast<const u32 *>(s_text + o);
+#endif
+            if (!by_words) {
+#pragma unroll
+                for (int k = 0; k < kFmtPer; ++k) {
+                    // one layout for the whole wave?  (digit counts, a line in every lane, nothing negative, depth of at most four digits)
+                    const uint32_t pk = len[k] >> 16, pk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk);
+                    const bool same = name_len <= 8 && pk0 != 0 &&
+                                      __ballot(pk != pk0 || (uint32_t)rd[k] >= 10000u || (rs[k] | re[k]) < 0) == 0;
+                    if (same) {
+                        const int n1d = (int)(pk0 & 15u), n2d = (int)((pk0 >> 4) & 15u), n3d = (int)((pk0 >> 8) & 15u);
+                        const Dig E = dec_left((uint32_t)re[k], n2d);
+                        Dig S = prevE;                                               // adjacent runs: the line before ended where this one starts
+                        if (!have_prev || __ballot(rs[k] != re[k > 0 ? k - 1 : 0])) S = dec_left((uint32_t)rs[k], n1d);
+                        put_line_uniform(my + at, S, E, (uint32_t)rd[k], n1d, n2d, n3d, n0, n1, name_len);
+                        prevE = E, have_prev = true;
+                    } else {
+                        if (len[k]) put_line(my + at, rs[k], re[k], rd[k], len[k], n0, n1, nm, name_len);
+                        have_prev = false;
+                    }
+                    at += (len[k] & 0xffffu);
+                }
+            }
+            // (what a lane copies out is what OTHER lanes of the wave wrote: the wave's LDS operations run in order, the fence keeps
+            // the compiler from moving them)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint8_t *dst = out + piece_base + before;
+#ifdef DIAG_BG_NOCOPY
+            if (wave_bytes == 0xffffffffu)                    // (timing only: nothing is copied out)
+#endif
+            for (uint32_t o = (uint32_t)lane_id() * 16u; o < wave_bytes; o += (uint32_t)kWave * 16u) {
+                if (o + 16u <= wave_bytes) {
+                    const u32 v = *reinterpret_cast<const u32 *>(my + o);
                     __builtin_memcpy(dst + o, &v, 16);
                 } else {
-                    for (uint32_t b = o; b < nbytes; ++b) dst[b] = s_text[b];
+                    for (uint32_t b2 = o; b2 < wave_bytes; ++b2) dst[b2] = my[b2];
                 }
             }
-            __syncthreads();                                  // the buffer is rewritten by the next piece
-        } else {                                              // a very long target name: straight to memory
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the part is rewritten by the wave's next piece
+            __builtin_amdgcn_wave_barrier();
+        } else {                                              // a very long target name (or numbers): straight to memory
+            at += (uint32_t)before;
 #pragma unroll
             for (int k = 0; k < kFmtPer; ++k) {
-                if (len[sb][k]) put_line(out + piece_base + at, rs[sb][k], re[sb][k], rd[sb][k], len[sb][k], n0, n1, nm, name_len);
-                at += (len[sb][k] & 0xffffu);
+                if (len[k]) put_line(out + piece_base + at, rs[k], re[k], rd[k], len[k], n0, n1, nm, name_len);
+                at += (len[k] & 0xffffu);
             }
         }
         piece_base += piece;
+#pragma unroll
+        for (int k = 0; k < kFmtPer; ++k) cur[k] = nxt[k], cur_ln[k] = nxt_ln[k];
     }
     if (tile == (n_runs - 1) / kFmtTile && tid == kFmtThreads - 1) *total = piece_base;
 }

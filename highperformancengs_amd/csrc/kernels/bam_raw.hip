@@ -64,11 +64,29 @@ __device__ __forceinline__ int record_at(const uint8_t *p, uint64_t room, uint32
     return 1;
 }
 
+// record_at for a GUESS: also what real records look like beyond what makes them safe to read -- a read name of printable
+// characters (the SAM specification's [!-?A-~]{1,254}) and a block_size below 16 MB.  Without these a run of qualities read as a
+// header is plausible once per ~100 offsets, and where its block_size (33 .. 268 million) lands on a true record start of a
+// 700 MB stream, four records in a row follow: 2 in 1,000 blocks of a packed file guessed wrong, each walked again by one
+// lane, 7 ms per launch (scripts/diag_packed.py, HPN_TIMING=2).  A true record that fails here merely gets no guess.
+__device__ __forceinline__ int likely_record_at(const uint8_t *p, uint64_t room, uint32_t *step)
+{
+    const int r = record_at(p, room, step);
+    if (r != 1) return r;
+    if (*step > (1u << 24)) return 0;
+    const uint32_t l_name = p[12];
+    for (uint32_t k = 0; k + 1u < l_name; ++k)
+        if ((uint32_t)p[36u + k] - 33u > 93u) return 0;       // 33 .. 126
+    return 1;
+}
+
 // Where does the first record of block b start?  One wave per block (b >= 1; block 0's start is given): lane k tries offset
-// base + k and follows the chain four records (one well-formed header is no rarity in BAM bytes -- small integers everywhere;
-// four in a row are); the lowest offset whose chain holds is taken.  A chain that reaches the END of the call's stream before
-// its fourth record holds as far as it can be followed -- weaker, and where most wrong guesses come from (a plausible header
-// with a large block_size leaves the stream in one hop).  Guesses all: k_raw_scan proves each one or walks the block itself.
+// base + k and follows the chain four records (one well-formed header is no rarity in BAM bytes -- small integers everywhere,
+// and a run of qualities read as block_size is a plausible 10^8; four in a row are).  The lowest offset with four records
+// IN the stream is taken.  Only a block that has none (the last few records of a call) falls back on the lowest offset whose
+// chain holds as far as the stream goes: such a chain proves little -- a plausible header with a large block_size leaves a
+// 350 MB stream in one hop, and on a packed file that is what most blocks would find first (measured: nearly every guess wrong,
+// 10 s of serial re-walks for a 10 GB file).  Guesses all: k_raw_scan proves each one or walks the block itself.
 __global__ __launch_bounds__(kWave) void k_raw_starts(const uint8_t *__restrict__ raw, const RawBlock *__restrict__ blocks, uint32_t n_blocks,
                                                       const uint32_t *__restrict__ status, uint32_t *__restrict__ starts)
 {
@@ -81,23 +99,26 @@ __global__ __launch_bounds__(kWave) void k_raw_starts(const uint8_t *__restrict_
         if (lane == 0) starts[b] = kNoStart;
         return;
     }
-    uint32_t found = kNoStart;
+    uint32_t found = kNoStart, weak = kNoStart;
     for (uint32_t base = 0; base < blk.out_len && found == kNoStart; base += kWave) {
         const uint32_t s0 = base + (uint32_t)lane;
-        bool ok = s0 < blk.out_len;
+        bool ok = s0 < blk.out_len, whole = true;      // whole: all four records lie in the stream
         uint64_t at = blk.out_off + s0;
         for (int hop = 0; ok && hop < 4; ++hop) {      // four records in a row, into the blocks behind if need be (one stream)
-            if (at >= stream_len) break;                  // the chain has left the stream (its last record is the unfinished one)
             uint32_t step = 0;
-            const int r = record_at(raw + at, stream_len - at, &step);
+            const int r = at < stream_len ? likely_record_at(raw + at, stream_len - at, &step) : 2;
             if (r == 0 || (r == 2 && hop == 0)) ok = false;      // (a start of which not even the fixed part is there: k_raw_scan's)
-            if (r != 1) break;
+            if (r != 1) {
+                whole = false;                            // the chain has left the stream (its last record is the unfinished one)
+                break;
+            }
             at += step;
         }
-        const u64 m = __ballot(ok);
-        if (m) found = base + (uint32_t)__builtin_ctzll(m);
+        const u64 strong = __ballot(ok && whole), any = __ballot(ok);
+        if (strong) found = base + (uint32_t)__builtin_ctzll(strong);
+        else if (any && weak == kNoStart) weak = base + (uint32_t)__builtin_ctzll(any);
     }
-    if (lane == 0) starts[b] = found;
+    if (lane == 0) starts[b] = found != kNoStart ? found : weak;
 }
 
 constexpr uint32_t kBroken = 0x80000000u;      // counts[b]: the block's walk met an impossible record
@@ -177,7 +198,8 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
     __shared__ int32_t s_lo[1024], s_hi[1024];
     const RawBlock last = blocks[n_blocks - 1];
     const u64 stream_len = last.out_off + last.out_len;
-    if (threadIdx.x == 0) s_carry = 0, s_from = first_abs, s_tail = ~0ull, s_flags = 0;
+    __shared__ uint32_t s_walked, s_rewalked;                 // chunks the lane walked, blocks it walked again (info[3]: diagnostics)
+    if (threadIdx.x == 0) s_carry = 0, s_from = first_abs, s_tail = ~0ull, s_flags = 0, s_walked = 0, s_rewalked = 0;
     int32_t my_lo = INT32_MAX, my_hi = INT32_MIN;
     for (uint32_t i0 = 0; i0 < n_blocks; i0 += 1024u) {
         const uint32_t i = i0 + threadIdx.x;
@@ -206,6 +228,7 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
                 if (any_cross) s_flags |= 4u;
             }
         } else if (threadIdx.x == 0) {
+            ++s_walked;
             u64 from = s_from, tail = s_tail;
             uint32_t flags = s_flags;
             const uint32_t m = n_blocks - i0 < 1024u ? n_blocks - i0 : 1024u;
@@ -217,6 +240,7 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
                 }
                 const u64 own = i0 + k == 0 ? first_abs : s_start[k] == kNoStart ? ~0ull : s_off[k] + s_start[k];
                 if (own != from) {                                  // no guess, or not where the chain arrives: walked here
+                    ++s_rewalked;
                     const RawWalk w = walk_block(raw, from, end, stream_len);
                     s_cnt[k] = w.n, s_exit[k] = w.exit, s_lo[k] = w.lo, s_hi[k] = w.hi;
                     s_start[k] = (uint32_t)(from - s_off[k]);
@@ -256,6 +280,7 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
         if (s_from != stream_len) flags |= 1u;
         if (flags) atomicOr((uint32_t *)&info[0], flags);
         *(u64 *)(info + 4) = s_tail;
+        info[3] = (int32_t)(s_walked << 20 | (s_rewalked & 0xfffffu));
     }
 }
 

@@ -75,12 +75,14 @@ static void worker(int slot, int workers, FILE *out)
     const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
     if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] worker %d: context %.3f s\n", slot, wall_s() - t0);
+    stamp("context created");
     WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers), workers == 1);
     for (int i; (i = g_next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, g.infiles[i], out);
 }
 
 int main(int argc, char *argv[])
 {
+    stamp("main");
     g.outfile = "-";
     g.thread = (int)sysconf(_SC_NPROCESSORS_ONLN);
     int opt;
@@ -102,6 +104,7 @@ int main(int argc, char *argv[])
     if (const char *d = getenv("HPN_DEVICE")) g_dev0 = atoi(d), g_ndev = 1;
     else if (hpn_device_count(&g_ndev) != HPN_OK || g_ndev < 1) die_hpn(nullptr, HPN_E_NODEVICE, "fastq_count");
 
+    stamp("devices counted");
     const long long begin = usec();
     FILE *out = fopen_output_stream(g.outfile);
     if (g.header) print_count_header(out);
@@ -113,6 +116,7 @@ int main(int argc, char *argv[])
         for (auto &t : th) t.join();
     }
     fprintf(stderr, "Finished at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
+    stamp("finished");
     fclose(out);
     quick_exit_ok();
 }

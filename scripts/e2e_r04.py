@@ -30,9 +30,9 @@ def run(tool, args, env, reps=2, cwd=td):
         dt = time.perf_counter() - t0
         if dt < best:
             best, err, out = dt, p.stderr.decode(), p.stdout
-    lines = [l for l in err.splitlines() if (l.startswith("[hpn]") or l.startswith("Finished")) and "context 0.0" not in l]
+    lines = [l for l in err.splitlines() if (l.startswith("[hpn") or l.startswith("Finished")) and "context 0.0" not in l]
     print(f"--- {tool} {' '.join(args)}  {env}: {best:.3f} s")
-    for l in lines[-6:]:
+    for l in lines[-(60 if env.get("HPN_TIMING") == "2" else 6):]:
         print("    " + l[:260])
     sys.stdout.flush()
     return out
@@ -49,7 +49,7 @@ if what in ("gz", "all"):
             f.write(one)
     print(f"gz3.fq.gz: {3 * len(one) / 1e9:.2f} GB compressed, {3 * len(raw) / 1e9:.2f} GB of text, {3 * n} reads")
     del raw, one
-    outs = [run("fastq_count", ["gz3.fq.gz"], e) for e in ({}, {"HPN_NGPU": "2"}, {"HPN_NGPU": "3"}, {"HPN_GZ_FIND": "device"}, {"HPN_NGPU": "2", "HPN_GZ_FIND": "device"})]
+    outs = [run("fastq_count", ["gz3.fq.gz"], e) for e in ({}, {"HPN_TIMING": "2"}, {"HPN_NGPU": "2"}, {"HPN_NGPU": "3"}, {"HPN_GZ_FIND": "device"}, {"HPN_GZ_FIND": "device", "HPN_TIMING": "2"}, {"HPN_NGPU": "2", "HPN_GZ_FIND": "device"})]
     print("outputs identical:", all(o == outs[0] for o in outs), outs[0].decode().strip())
     os.unlink(os.path.join(td, "gz3.fq.gz"))
 
@@ -79,4 +79,11 @@ if what in ("bam", "all"):
                 print(f"{tool}: outputs identical to the record-aligned file's:", vals[0] == seen[tool])
             seen.setdefault(tool, vals[0])
         subprocess.run(["rm", "-rf", sub])
+if what == "rounds":      # chunks of 88 MB under one inflate launch (HPN_BAM_ROUNDS): 6,144 decoder waves take ~1.4 chunks at once
+    import c4
+    tg = c4.targets(lambda n, l: 30.0 if n in ("chr21", "chrM") else 3.0)
+    bam, prefix = c4.synth(td, "hg38.bam", tg, 15, soa=False)
+    for r in ("3", "4", "6", "8", "12"):
+        for tool, args in (("bam2depth", ["-w", "20000", "-o", "d", "hg38.bam"]), ("bam_sliding_count", ["-w", "20000", "-o", "s", "hg38.bam"])):
+            run(tool, args, {"HPN_BAM_ROUNDS": r, "HPN_NGPU": "1"}, reps=3)
 subprocess.run(["rm", "-rf", td])

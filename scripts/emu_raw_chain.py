@@ -17,6 +17,15 @@ def record_at(d, p, end):
     if d[p + 35 + l_name] != 0: return 0, 0
     return 1, 4 + bs
 
+def likely_record_at(d, p, end):
+    r, step = record_at(d, p, end)
+    if r != 1: return r, step
+    if step > (1 << 24): return 0, 0
+    l_name = d[p + 12]
+    for k in range(l_name - 1):
+        if not 33 <= d[p + 36 + k] <= 126: return 0, 0
+    return 1, step
+
 def index(d, blocks, first_abs):
     """d: stream bytes; blocks: list of (out_off, out_len); -> flags, n, tail_bytes, rec offsets"""
     L = blocks[-1][0] + blocks[-1][1]
@@ -25,18 +34,19 @@ def index(d, blocks, first_abs):
     for b, (o, n) in enumerate(blocks):
         if b == 0:
             starts[0] = 0; continue
+        weak = NONE
         for s0 in range(n):
-            at = o + s0; ok = True
+            at = o + s0; ok = True; whole = True
             for hop in range(4):
-                if at >= L: break
-                r, step = record_at(d, at, L)
-                if r == 0: ok = False
+                r, step = likely_record_at(d, at, L) if at < L else (2, 0)
+                if r == 0 or (r == 2 and hop == 0): ok = False
                 if r != 1:
-                    if hop == 0: ok = False
-                    break
+                    whole = False; break
                 at += step
-            if ok:
+            if ok and whole:
                 starts[b] = s0; break
+            if ok and weak == NONE: weak = s0
+        if starts[b] == NONE: starts[b] = weak
     flags = 0; tail = None
     counts = [0] * nb; exits = [0] * nb; recs = [[] for _ in range(nb)]; broken = [False] * nb; tails = [None] * nb
 
