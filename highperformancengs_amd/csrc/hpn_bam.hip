@@ -25,7 +25,7 @@ hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint6
 uint64_t bedgraph_text_bound(uint64_t n_runs, int name_len);
 size_t bedgraph_ws_bytes(uint64_t n_runs);
 hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char *name, int name_len, const uint8_t *d_long_name,
-                                uint8_t *out, void *ws, hipStream_t st);
+                                uint8_t *out, void *ws, int n_cu, hipStream_t st);
 hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uint32_t *flag, const int32_t *l_qseq,
                              const uint64_t *seq_off, const uint8_t *seq4, uint64_t n, uint64_t seq_end, uint32_t W, int32_t n_targets,
                              const uint64_t *win_off, uint32_t *bins, u64 *gc, uint32_t *len, uint32_t *touched,
@@ -259,7 +259,7 @@ int hpn_depth_bedgraph_format(hpn_ctx *c, const char *name, uint64_t *n_bytes)
     uint8_t *d_name = (uint8_t *)c->d_ws.p + bedgraph_ws_bytes(n) + 32;   // names beyond 64 characters ride behind the workspace
     if (name_len > 64) HPN_HIP(c, hipMemcpyAsync(d_name, name, name_len, hipMemcpyHostToDevice, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_beg[kFamDepth], c->stream));
-    HPN_HIP(c, launch_bedgraph_text((const hpn_run *)c->d_runs.p, n, name, (int)name_len, d_name, (uint8_t *)c->d_text.p, c->d_ws.p, c->stream));
+    HPN_HIP(c, launch_bedgraph_text((const hpn_run *)c->d_runs.p, n, name, (int)name_len, d_name, (uint8_t *)c->d_text.p, c->d_ws.p, c->n_cu, c->stream));
     HPN_HIP(c, hipEventRecord(c->ev_end[kFamDepth], c->stream));
     c->ev_valid[kFamDepth] = true;
     struct { uint32_t ticket, err; u64 total; } head;

@@ -1201,13 +1201,16 @@ __global__ __launch_bounds__(256) void k_win_from_runs(const hpn_run *__restrict
 // LDS and copies it out in 16-byte pieces.
 // ---------------------------------------------------------------------------
 constexpr int kFmtThreads = 256, kFmtPer = 2, kFmtSub = kFmtThreads * kFmtPer;   // 512 runs are staged at a time ...
-constexpr int kFmtSubs = 8, kFmtTile = kFmtSub * kFmtSubs;   // ... and a workgroup takes 8 such pieces in a row: one chain entry
+#ifndef HPN_BG_SUBS
+#define HPN_BG_SUBS 16
+#endif
+constexpr int kFmtSubs = HPN_BG_SUBS, kFmtTile = kFmtSub * kFmtSubs;   // ... and a workgroup takes 8 such pieces in a row: one chain entry
                                                              // per 4096 runs (one per 512 was 131 K entries x ~14 ns = 1.9 of 2.0 ms)
 // bytes of text a piece may stage (512 lines of up to 78 bytes).  With the kernel's other ~600 bytes this stays within 32 of the
 // CU's LDS granules of 1,280 bytes (scripts/micro/lds_occupancy.hip): four workgroups per CU; 40,960 bytes of text were 33 granules
 // and three.
 #ifndef HPN_BG_LDS
-#define HPN_BG_LDS 39936
+#define HPN_BG_LDS 24576
 #endif
 constexpr int kFmtLds = HPN_BG_LDS;                   // (A/B builds: smaller -> more workgroups per CU; a piece that does not fit goes straight to memory)
 constexpr int kFmtMaxName = 44;                       // longest target name the staged path takes
@@ -1399,7 +1402,8 @@ __device__ __forceinline__ int line_words(uint32_t (&L)[kLineWords], uint32_t n0
 #pragma unroll
     for (int i = 0; i < kLineWords; ++i) L[i] = 0;
     L[P1 >> 2] |= 9u << (8 * (P1 & 3)), L[P2 >> 2] |= 9u << (8 * (P2 & 3)), L[P3 >> 2] |= 9u << (8 * (P3 & 3));
-    constexpr uint32_t m0 = NAME >= 4 ? 0xffffffffu : (1u << (8 * NAME)) - 1u, m1 = NAME >= 8 ? 0xffffffffu : NAME > 4 ? (1u << (8 * (NAME - 4))) - 1u : 0u;
+    constexpr uint32_t m0 = NAME >= 4 ? 0xffffffffu : (1u << (8 * (NAME & 3))) - 1u;
+    constexpr uint32_t m1 = NAME >= 8 ? 0xffffffffu : NAME > 4 ? (1u << (8 * (NAME & 3))) - 1u : 0u;
     line_or<0, NAME>(L, n0 & m0, n1w & m1, 0u);
     line_or<P1 + 1, N1>(L, S.a, S.b, S.c);
     line_or<P2 + 1, N2>(L, E.a, E.b, E.c);
@@ -1432,54 +1436,50 @@ __device__ __forceinline__ uint32_t line_pick(const uint32_t (&T)[kLineWords + 1
                    x2 = T[LO + 2 < kLineWords + 1 ? LO + 2 : kLineWords];
     return idx == (uint32_t)LO ? x0 : idx == (uint32_t)LO + 1u ? x1 : x2;
 }
-// The two lines of a lane (line 0 at `at`, line 1 right behind it), both of the layout <NAME, N1, N2> in every lane of the wave.
+// The two lines of a lane (line 0 at `at`, line 1 right behind it), both of the layout <NAME, N1, N2> in every lane of the wave;
+// `part` is the wave's own staging area (its lane 0 starts at byte 0).  One line at a time, so that only one line's words are
+// live: line 0 stores its whole words at once and keeps its first word when that is shared with the lane below (h0) and its
+// last when that is incomplete (t0); line 1 completes t0 with its own first bytes, and its own incomplete last word with the
+// h0 of the lane above (DPP wave shift; the wave's last lane: with zeros -- behind the wave's text, never copied out).
 template <int NAME, int N1, int N2>
-__device__ __forceinline__ void put_pair_words(uint8_t *s_text, uint32_t at, uint32_t n0, uint32_t n1w, const Dig S0, const Dig E0, uint32_t d0, int n30,
+__device__ __forceinline__ void put_pair_words(uint8_t *part, uint32_t at, uint32_t n0, uint32_t n1w, const Dig S0, const Dig E0, uint32_t d0, int n30,
                                                const Dig S1, const Dig E1, uint32_t d1, int n31)
 {
     constexpr int kMin = NAME + 3 + N1 + N2 + 2;                     // shortest line of the layout (one depth digit)
-    constexpr int kLo = (kMin + 3) / 4 - 1;                          // index of the last word: >= kLo (a = 0, one digit), <= kLo + 2
+    constexpr int kLo = (kMin + 3) / 4 - 1;                          // index of a line's last word: >= kLo (a = 0, one digit), <= kLo + 2
     uint32_t L[kLineWords];
-    LinePlace p0, p1;
-    const int len0 = line_words<NAME, N1, N2>(L, n0, n1w, S0, E0, d0, n30);
-    line_place(p0, L, at, len0);
-    const int len1 = line_words<NAME, N1, N2>(L, n0, n1w, S1, E1, d1, n31);
-    line_place(p1, L, at + (uint32_t)len0, len1);
-    const uint32_t c0 = (p0.a + (uint32_t)len0 + 3u) >> 2, c1 = (p1.a + (uint32_t)len1 + 3u) >> 2;     // words the lines cover
-    const uint32_t t0 = p0.tb ? line_pick<kLo>(p0.T, c0 - 1u) : 0u, t1 = p1.tb ? line_pick<kLo>(p1.T, c1 - 1u) : 0u;
-    // the word a line shares with the one before it: completed here
-    const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0: 0)
-    const int lane = lane_id();
-    uint32_t *w0 = reinterpret_cast<uint32_t *>(s_text + (at & ~3u)), *w1 = reinterpret_cast<uint32_t *>(s_text + ((at + (uint32_t)len0) & ~3u));
-    const uint32_t n_w0 = c0 - (p0.tb ? 1u : 0u), n_w1 = c1 - (p1.tb ? 1u : 0u);                     // whole words each line stores
-    // line 0: word 0 with the tail of the lane below (lane 0 of the wave: its own bytes, one by one), the rest as they are
-    if (lane != 0 || p0.a == 0u) {
-        if (n_w0 > 0u) w0[0] = p0.T[0] | below;
-    } else {
-        uint8_t *b = s_text + at;
-        const uint32_t v = p0.T[0] >> (8u * p0.a), k = 4u - p0.a < (uint32_t)len0 ? 4u - p0.a : (uint32_t)len0;
-        if (k > 0u) b[0] = (uint8_t)v;
-        if (k > 1u) b[1] = (uint8_t)(v >> 8);
-        if (k > 2u) b[2] = (uint8_t)(v >> 16);
-    }
+    uint32_t h0, t0;
+    uint32_t at1;
+    {
+        LinePlace p0;
+        const int len0 = line_words<NAME, N1, N2>(L, n0, n1w, S0, E0, d0, n30);
+        line_place(p0, L, at, len0);
+        at1 = at + (uint32_t)len0;
+        const uint32_t c0 = (p0.a + (uint32_t)len0 + 3u) >> 2, n_w0 = c0 - (p0.tb ? 1u : 0u);      // words the line covers / stores whole
+        t0 = p0.tb ? line_pick<kLo>(p0.T, c0 - 1u) : 0u;
+        h0 = p0.a ? p0.T[0] : 0u;                                    // shared with the lane below: that lane stores it
+        uint32_t *w0 = reinterpret_cast<uint32_t *>(part + (at & ~3u));
+        if (p0.a == 0u) w0[0] = p0.T[0];
 #pragma unroll
-    for (int i = 1; i < kLineWords + 1; ++i) {
-        if (i < kLo) w0[i] = p0.T[i];                                // (every lane's line reaches this far)
-        else if ((uint32_t)i < n_w0 && i <= kLo + 2) w0[i] = p0.T[i];
+        for (int i = 1; i < kLineWords + 1; ++i) {
+            if (i < kLo) w0[i] = p0.T[i];                            // (every lane's line reaches this far)
+            else if ((uint32_t)i < n_w0 && i <= kLo + 2) w0[i] = p0.T[i];
+        }
     }
-    // line 1: word 0 with line 0's tail
-    if (n_w1 > 0u) w1[0] = p1.T[0] | t0;
+    {
+        LinePlace p1;
+        const int len1 = line_words<NAME, N1, N2>(L, n0, n1w, S1, E1, d1, n31);
+        line_place(p1, L, at1, len1);
+        const uint32_t c1 = (p1.a + (uint32_t)len1 + 3u) >> 2, n_w1 = c1 - (p1.tb ? 1u : 0u);
+        const uint32_t above = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x130, 0xf, 0xf, false);   // wave_shl:1: lane l + 1's h0 (lane 63: 0)
+        uint32_t *w1 = reinterpret_cast<uint32_t *>(part + (at1 & ~3u));
+        w1[0] = p1.T[0] | t0;
 #pragma unroll
-    for (int i = 1; i < kLineWords + 1; ++i) {
-        if (i < kLo) w1[i] = p1.T[i];
-        else if ((uint32_t)i < n_w1 && i <= kLo + 2) w1[i] = p1.T[i];
-    }
-    // the wave's last line: nobody above to complete its last word
-    if (lane == kWave - 1 && p1.tb) {
-        uint8_t *b = s_text + ((at + (uint32_t)len0 + (uint32_t)len1) & ~3u);
-        if (p1.tb > 0u) b[0] = (uint8_t)t1;
-        if (p1.tb > 1u) b[1] = (uint8_t)(t1 >> 8);
-        if (p1.tb > 2u) b[2] = (uint8_t)(t1 >> 16);
+        for (int i = 1; i < kLineWords + 1; ++i) {
+            if (i < kLo) w1[i] = p1.T[i];
+            else if ((uint32_t)i < n_w1 && i <= kLo + 2) w1[i] = p1.T[i];
+        }
+        if (p1.tb) w1[c1 - 1u] = line_pick<kLo>(p1.T, c1 - 1u) | above;
     }
 }
 
@@ -1501,74 +1501,119 @@ __device__ __forceinline__ uint32_t wave_incl_u32(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__restrict__ runs, uint64_t n_runs, FmtName name, int name_len,
+// Three kernels (round 4; one kernel with a look-back chain before): the lines' SIZES per (tile, piece, wave) and per tile, the
+// tiles' offsets (one workgroup), then the text -- every wave of the third kernel knows where its 128 lines go and needs no other
+// wave: no ticket, no chain, no workgroup barrier.  Measured on the one-kernel form (timing-only builds, profiles/r04/
+// bedgraph_breakdown.txt): sizes 0.30 + chain wait 0.12 + LDS traffic 0.10 + formatting 0.14 + stores 0.31 = the kernel's 0.97 ms
+// -- the parts ADD UP, a tile's phases wait for one another and four to six workgroups per CU do not hide that.
+typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void bg_load_pair(const hpn_run *__restrict__ runs, uint64_t n_runs, uint64_t r0, i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer])
+{
+#pragma unroll
+    for (int k = 0; k < kFmtPer; ++k) {
+        v[k] = i32x3{0, 0, 0};
+        ln[k] = r0 + k < n_runs ? 1u : 0u;                     // (a line at all; its size when the values are there: bg_size_pair)
+        if (ln[k]) v[k] = *reinterpret_cast<const i32x3 *>(&runs[r0 + k]);
+    }
+}
+__device__ __forceinline__ uint32_t bg_size_pair(const i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer], int name_len, const u64 *dig)
+{
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kFmtPer; ++k) {
+        if (ln[k]) ln[k] = line_info(v[k][0], v[k][1], v[k][2], name_len, dig);
+        mine += (ln[k] & 0xffffu);
+    }
+    return mine;
+}
+constexpr int kFmtWaves = kFmtThreads / kWave;
+static_assert(kFmtWaves == 4, "a piece's four wave totals travel as one 16-byte word");
+
+// wave_tot[(tile * kFmtSubs + piece) * 4 + wave] = bytes of that wave's 128 lines; tile_tot[tile] = bytes of the tile
+__global__ __launch_bounds__(kFmtThreads) void k_bedgraph_sizes(const hpn_run *__restrict__ runs, uint64_t n_runs, int name_len, uint64_t n_tiles,
+                                                                uint32_t *__restrict__ wave_tot, u64 *__restrict__ tile_tot)
+{
+    __shared__ u64 s_dig[33];
+    __shared__ uint32_t s_sum[kFmtWaves];
+    const int tid = threadIdx.x;
+    dec_digits_fill(s_dig, tid);
+    __syncthreads();
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int sb = 0; sb < kFmtSubs; ++sb) {
+            i32x3 v[kFmtPer];
+            uint32_t ln[kFmtPer];
+            bg_load_pair(runs, n_runs, tile * kFmtTile + (uint64_t)sb * kFmtSub + (uint64_t)tid * kFmtPer, v, ln);
+            const uint32_t upto = wave_incl_u32(bg_size_pair(v, ln, name_len, s_dig));
+            if (lane_id() == kWave - 1) wave_tot[(tile * kFmtSubs + (uint64_t)sb) * kFmtWaves + (uint64_t)wave_id()] = upto;
+            sum += upto;                                       // (lane 63's is the wave's)
+        }
+        if (lane_id() == kWave - 1) s_sum[wave_id()] = sum;
+        __syncthreads();
+        if (tid == 0) tile_tot[tile] = (u64)s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        __syncthreads();
+    }
+}
+
+// tile_base[t] = bytes in front of tile t (in place of tile_tot[t]); *total = all bytes.  One workgroup: a chromosome has ~10^4 tiles.
+__global__ __launch_bounds__(1024) void k_bedgraph_offsets(u64 *__restrict__ tile_tot, uint64_t n_tiles, u64 *__restrict__ total)
+{
+    __shared__ u64 s_wave[16];
+    __shared__ u64 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t i0 = 0; i0 < n_tiles; i0 += 1024u) {
+        const uint64_t i = i0 + threadIdx.x;
+        const u64 v = i < n_tiles ? tile_tot[i] : 0;
+        u64 inc = v;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const u64 t = __shfl_up(inc, o, kWave);
+            if (lane_id() >= o) inc += t;
+        }
+        if (lane_id() == kWave - 1) s_wave[wave_id()] = inc;
+        __syncthreads();
+        u64 before = s_carry;
+        for (int w = 0; w < wave_id(); ++w) before += s_wave[w];
+        if (i < n_tiles) tile_tot[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+#ifndef HPN_BG_EU
+#define HPN_BG_EU 6
+#endif
+#ifndef HPN_BG_VGPR
+#define HPN_BG_VGPR 80
+#endif
+__global__ __launch_bounds__(kFmtThreads) __attribute__((amdgpu_waves_per_eu(HPN_BG_EU, 8), amdgpu_num_vgpr(HPN_BG_VGPR)))
+void k_bedgraph_text(const hpn_run *__restrict__ runs, uint64_t n_runs, FmtName name, int name_len,
                                                                const uint8_t *__restrict__ long_name, uint8_t *__restrict__ out,
-                                                               u64 *__restrict__ status, u64 *__restrict__ total,
-                                                               uint32_t *__restrict__ ticket, uint32_t *__restrict__ err)
+                                                               const uint32_t *__restrict__ wave_tot, const u64 *__restrict__ tile_base)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_text[kFmtLds];
-    __shared__ u64 s_w[kFmtSubs][kFmtThreads / kWave];
-    __shared__ u64 s_x;
-    __shared__ uint32_t s_tile;
     __shared__ uint32_t s_name[16];
     __shared__ u64 s_dig[33];
     const int tid = threadIdx.x;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     if (tid < 16) s_name[tid] = name.w[tid];
     dec_digits_fill(s_dig, tid);
     __syncthreads();
-    const uint64_t tile = s_tile;
+    const uint64_t tile = blockIdx.x;
     const uint32_t n0 = name.w[0], n1 = name.w[1];
     const uint8_t *nm = name_len <= 64 ? reinterpret_cast<const uint8_t *>(s_name) : long_name;
-    // sizes of all the tile's lines first (piece by piece: lane l holds lines 2l, 2l+1 of every piece).  The runs are read twice --
-    // here for the sizes, again piece by piece when the lines are written (from the cache), sizes and places worked out again --:
-    // sixteen runs, their sizes and places held per lane across the chain wait were 72 of the kernel's 123 registers.
-    typedef int32_t i32x3 __attribute__((ext_vector_type(3)));
     auto load_pair = [&](int sb, i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer]) {
-        const uint64_t r0 = tile * kFmtTile + (uint64_t)sb * kFmtSub + (uint64_t)tid * kFmtPer;
-#pragma unroll
-        for (int k = 0; k < kFmtPer; ++k) {
-            v[k] = i32x3{0, 0, 0};
-            ln[k] = r0 + k < n_runs ? 1u : 0u;                 // (a line at all; its size when the values are there: size_pair)
-            if (ln[k]) v[k] = *reinterpret_cast<const i32x3 *>(&runs[r0 + k]);
-        }
+        bg_load_pair(runs, n_runs, tile * kFmtTile + (uint64_t)sb * kFmtSub + (uint64_t)tid * kFmtPer, v, ln);
     };
-    auto size_pair = [&](const i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer]) {
-        uint32_t mine = 0;
-#pragma unroll
-        for (int k = 0; k < kFmtPer; ++k) {
-            if (ln[k]) ln[k] = line_info(v[k][0], v[k][1], v[k][2], name_len, s_dig);
-            mine += (ln[k] & 0xffffu);
-        }
-        return mine;
-    };
-#pragma unroll
-    for (int sb = 0; sb < kFmtSubs; ++sb) {
-        i32x3 v[kFmtPer];
-        uint32_t ln[kFmtPer];
-        load_pair(sb, v, ln);
-        const uint32_t mine = size_pair(v, ln), upto = wave_incl_u32(mine);
-        if (lane_id() == kWave - 1) s_w[sb][wave_id()] = upto;
-    }
-    __syncthreads();
-    u64 agg = 0;                                              // bytes of the whole tile
-#pragma unroll
-    for (int sb = 0; sb < kFmtSubs; ++sb)
-#pragma unroll
-        for (int w = 0; w < kFmtThreads / kWave; ++w) agg += s_w[sb][w];
-    if (wave_id() == 0) {
-#ifdef DIAG_BG_NOCHAIN
-        const u64 ex = tile * (u64)(kFmtTile * 27);          // (timing only: WRONG offsets, no chain)
-#else
-        const u64 ex = scan_lookback(status, tile, agg, err);
-#endif
-        if (lane_id() == 0) s_x = ex;
-    }
+    auto size_pair = [&](const i32x3 (&v)[kFmtPer], uint32_t (&ln)[kFmtPer]) { return bg_size_pair(v, ln, name_len, s_dig); };
+    const u32 *const tots = reinterpret_cast<const u32 *>(wave_tot) + tile * kFmtSubs;   // (the four wave totals of a piece: one word)
     i32x3 cur[kFmtPer], nxt[kFmtPer];
     uint32_t cur_ln[kFmtPer], nxt_ln[kFmtPer];
-    load_pair(0, cur, cur_ln);                                // (on their way during the chain wait)
-    __syncthreads();
-    u64 piece_base = s_x & kScanValueMask;                    // byte offset of the piece being written
+    load_pair(0, cur, cur_ln);
+    u64 piece_base = tile_base[tile];                         // byte offset of the piece being written
 #pragma unroll 1
     for (int sb = 0; sb < kFmtSubs; ++sb) {
         if (sb + 1 < kFmtSubs) load_pair(sb + 1, nxt, nxt_ln);   // the next piece's runs are on their way while this one is written
@@ -1577,28 +1622,31 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
 #pragma unroll
         for (int k = 0; k < kFmtPer; ++k) rs[k] = cur[k][0], re[k] = cur[k][1], rd[k] = cur[k][2], len[k] = cur_ln[k];
         const uint32_t mine = size_pair(cur, len), wex = wave_incl_u32(mine) - mine;
+        const u32 wt = tots[sb];
         u64 before = 0, piece = 0;
 #pragma unroll
-        for (int w = 0; w < kFmtThreads / kWave; ++w) {
-            if (w < wave_id()) before += s_w[sb][w];
-            piece += s_w[sb][w];
+        for (int w = 0; w < kFmtWaves; ++w) {
+            if (w < wave_id()) before += wt[w];
+            piece += wt[w];
         }
         // Every wave stages ITS 128 lines in its own part of the buffer and copies them out itself: no workgroup barrier in this
         // loop (round 4; two per piece before), the waves drift apart and one's copy runs beside another's formatting.
-        const uint32_t wave_bytes = (uint32_t)s_w[sb][wave_id()];
+        const uint32_t wave_bytes = wave_id() == 0 ? wt[0] : wave_id() == 1 ? wt[1] : wave_id() == 2 ? wt[2] : wt[3];
         uint8_t *const my = s_text + (uint32_t)wave_id() * (uint32_t)kFmtWaveLds;
         uint32_t at = wex;                                    // this lane's first line inside the wave's part
         // (Round 3 tried lines built in registers -- digits shifted to the front with v_alignbyte, fields written with two overlapping
         // exact-length 8- / 4- / 2-byte stores at their own byte offsets: 270 M instead of 313 M vector instructions per chr1, but the
         // unaligned stores stall in LDS (SQ_LDS_UNALIGNED_STALL 394 M cycles: 1.15 ms against 1.03) and are worse still straight to
         // memory (2.27 ms): profiles/r03/bedgraph_text_variants.txt.  Round 4: whole ALIGNED words, put_pair_words.)
-        if (name_len <= kFmtMaxName && wave_bytes <= (uint32_t)kFmtWaveLds) {   // staged: build in LDS, copy out in 16-byte pieces
+        if (name_len <= kFmtMaxName && wave_bytes + 4u <= (uint32_t)kFmtWaveLds) {   // staged: build in LDS, copy out in 16-byte pieces
             Dig prevE{0, 0, 0};
             bool have_prev = false;                           // prevE holds the digits of line k - 1's end (wave-uniform)
             // both lines of every lane of ONE layout the word path is compiled for?  (chr1 .. chrM names, 5 .. 9 digits)
             bool by_words = false;
 #ifdef DIAG_BG_NOFMT
-            by_words = true;                                  // (timing only: nothing is formatted)
+            by_words = true;                                  // (timing only: nothing is formatted; the part is written so that the copy stays)
+            for (uint32_t o = (uint32_t)lane_id() * 16u; o < wave_bytes + 32u; o += (uint32_t)kWave * 16u)
+                *reinterpret_cast<u32 *>(my + o) = u32{(uint32_t)rs[0], (uint32_t)re[0], (uint32_t)rd[0], o};
 #elif !defined(HPN_BG_BYTES)
             {
                 static_assert(kFmtPer == 2, "put_pair_words takes a lane's two lines");
@@ -1647,9 +1695,19 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
             // the compiler from moving them)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // (16-byte stores at whatever byte the wave's text begins: placing the text in LDS as it lies in memory modulo 16, so that
+            // the stores are aligned, was measured and is slower -- 1.02 against 0.97 ms: the stores run at memory speed either way)
             uint8_t *dst = out + piece_base + before;
 #ifdef DIAG_BG_NOCOPY
-            if (wave_bytes == 0xffffffffu)                    // (timing only: nothing is copied out)
+            {                                                 // (timing only: the part is read, nothing is stored unless its words XOR to a magic value)
+                uint32_t x = 0;
+                for (uint32_t o = (uint32_t)lane_id() * 16u; o < wave_bytes; o += (uint32_t)kWave * 16u) {
+                    const u32 v = *reinterpret_cast<const u32 *>(my + o);
+                    x ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+                }
+                if (x == 0x12345678u) dst[lane_id()] = 1;
+            }
+            if (false)
 #endif
             for (uint32_t o = (uint32_t)lane_id() * 16u; o < wave_bytes; o += (uint32_t)kWave * 16u) {
                 if (o + 16u <= wave_bytes) {
@@ -1673,7 +1731,6 @@ __global__ __launch_bounds__(kFmtThreads) void k_bedgraph_text(const hpn_run *__
 #pragma unroll
         for (int k = 0; k < kFmtPer; ++k) cur[k] = nxt[k], cur_ln[k] = nxt_ln[k];
     }
-    if (tile == (n_runs - 1) / kFmtTile && tid == kFmtThreads - 1) *total = piece_base;
 }
 
 // ---------------------------------------------------------------------------
@@ -1807,19 +1864,29 @@ hipError_t launch_depth_scan(const int32_t *diff, const uint32_t *written, uint6
 // bedGraph text of `n_runs` runs into `out` (device; upper bound of the size: bedgraph_text_bound).
 // ws: [0] ticket, [1] err (uint32 each), then u64 total, then status[tiles]
 uint64_t bedgraph_text_bound(uint64_t n_runs, int name_len) { return n_runs * (uint64_t)(name_len + 34 + 3) + 64; }
-size_t bedgraph_ws_bytes(uint64_t n_runs) { return 16 + ((n_runs + kFmtTile - 1) / kFmtTile) * sizeof(u64); }
+static uint64_t bedgraph_tiles(uint64_t n_runs) { return (n_runs + kFmtTile - 1) / kFmtTile; }
+// ws: [0] unused, [1] err (uint32 each), then u64 total, then tile_base[tiles] (u64), then wave_tot[tiles * pieces * 4] (uint32)
+size_t bedgraph_ws_bytes(uint64_t n_runs)
+{
+    const uint64_t nt = bedgraph_tiles(n_runs);
+    return 16 + (nt + 1) * sizeof(u64) + nt * kFmtSubs * kFmtWaves * sizeof(uint32_t) + 16;
+}
 
 hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char *name, int name_len, const uint8_t *d_long_name,
-                                uint8_t *out, void *ws, hipStream_t st)
+                                uint8_t *out, void *ws, int n_cu, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(ws, 0, bedgraph_ws_bytes(n_runs), st);
+    hipError_t e = hipMemsetAsync(ws, 0, 16, st);
     if (e != hipSuccess || n_runs == 0) return e;
     FmtName nm;
     memset(&nm, 0, sizeof nm);
     memcpy(nm.w, name, (size_t)(name_len < 64 ? name_len : 64));   // (a longer name: its head here, all of it in d_long_name)
-    uint32_t *ticket = (uint32_t *)ws;
-    hipLaunchKernelGGL(k_bedgraph_text, dim3((unsigned)((n_runs + kFmtTile - 1) / kFmtTile)), dim3(kFmtThreads), 0, st, runs, n_runs, nm,
-                       name_len, d_long_name, out, (u64 *)ws + 2, (u64 *)ws + 1, ticket, ticket + 1);
+    const uint64_t nt = bedgraph_tiles(n_runs);
+    u64 *tile_base = (u64 *)ws + 2;
+    uint32_t *wave_tot = (uint32_t *)(tile_base + ((nt + 2) & ~(uint64_t)1));      // (16-byte aligned: read as whole words)
+    const uint64_t cap = (uint64_t)n_cu * 8;
+    hipLaunchKernelGGL(k_bedgraph_sizes, dim3((unsigned)(nt < cap ? nt : cap)), dim3(kFmtThreads), 0, st, runs, n_runs, name_len, nt, wave_tot, tile_base);
+    hipLaunchKernelGGL(k_bedgraph_offsets, dim3(1), dim3(1024), 0, st, tile_base, nt, (u64 *)ws + 1);
+    hipLaunchKernelGGL(k_bedgraph_text, dim3((unsigned)nt), dim3(kFmtThreads), 0, st, runs, n_runs, nm, name_len, d_long_name, out, wave_tot, tile_base);
     return hipGetLastError();
 }
 
