@@ -378,6 +378,21 @@ def host_link(td):
         j["h2d_best_GBps"] = max(v for k, v in j.items() if k.startswith("h2d_"))
         j["pread_best_GBps"] = max(v for k, v in j.items() if k.startswith("pread_pagecache"))
         j["pipelined_best_GBps"] = max(v for k, v in j.items() if k.endswith("pipelined_GBps"))
+        # ... and what ONE output file takes on this box (scripts/micro/write_bw.cpp: slabs of 128 MiB, pwrite on 1 / 4 threads; writes
+        # to one file are serialised by the file system, 10 GB/s on the round's boxes): the ceiling of fastq_trim's output
+        wexe = os.path.join(td, "write_bw")
+        try:
+            subprocess.check_call(["g++", "-O2", os.path.join(ROOT, "scripts", "micro", "write_bw.cpp"), "-o", wexe, "-lpthread"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            for t in (1, 4):
+                o = subprocess.run([wexe, os.path.join(td, "write_bw.out"), "4096", str(t), "0"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout.decode()
+                j[f"file_write_x{t}_GBps"] = float(o.split(":")[1].split()[0])
+            j["file_write_best_GBps"] = max(j["file_write_x1_GBps"], j["file_write_x4_GBps"])
+        except Exception:  # noqa: BLE001
+            pass
+        finally:
+            if os.path.exists(wexe):
+                os.unlink(wexe)
         return j
     except Exception:  # noqa: BLE001
         return None
@@ -393,6 +408,9 @@ def _price(leg, in_bytes, link):
         leg["input_GBps"] = round(in_bytes / leg["hpngs"]["seconds"] / 1e9, 2)
         if link:
             leg["link_frac"] = round(leg["input_GBps"] / link["pipelined_best_GBps"], 3)
+            if leg.get("output_bytes") and link.get("file_write_best_GBps"):      # fastq_trim: the output file is the slower side
+                leg["output_GBps"] = round(leg["output_bytes"] / leg["hpngs"]["seconds"] / 1e9, 2)
+                leg["file_write_frac"] = round(leg["output_GBps"] / link["file_write_best_GBps"], 3)
     return leg
 
 
@@ -620,17 +638,17 @@ def _c4_file_legs(cores, td):
             want[t] = c4.oracle_target_text(tg[t][0], tg[t][1], W, runs, bins) + (len(runs),)
         return want[t]
     shape = f"{n_reads:.2e} x 150 bp over the 25 hg38 contigs (30x chr21 + chrM, 3x the rest), BAM {os.path.getsize(bam) / 1e9:.1f} GB"
-    # (defaults on one device: bam2depth reads the file front to back on one worker, four chunks under an inflate launch;
-    # bam_sliding_count's three workers take one reader's record batches in turn)
+    # (defaults on one device: both tools read the file front to back on one worker, four / eight chunks under an inflate launch;
+    # HPN_NGPU=3: bam2depth's targets over three workers, bam_sliding_count's record batches to three workers in turn)
     for tool, args, env in (("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {}),
                             ("bam2depth", ["-w", str(W), "-o", "d", "hg38.bam"], {"HPN_NGPU": "3"}),
                             ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {}),
-                            ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "1"})):
+                            ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "3"})):
         wd = tempfile.mkdtemp(prefix="c4_", dir=td)
         os.symlink(bam, os.path.join(wd, "hg38.bam")), os.symlink(bam + ".bai", os.path.join(wd, "hg38.bam.bai"))
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
         how = {("bam2depth", ""): " (default: one worker)", ("bam2depth", "3"): " with the targets over three workers on the one device (HPN_NGPU=3)",
-               ("bam_sliding_count", ""): " (default: three workers on the one device)", ("bam_sliding_count", "1"): " on ONE worker (HPN_NGPU=1)"}[(tool, env.get("HPN_NGPU", ""))]
+               ("bam_sliding_count", ""): " (default: one worker)", ("bam_sliding_count", "3"): " with the record batches over three workers on the one device (HPN_NGPU=3)"}[(tool, env.get("HPN_NGPU", ""))]
         leg = {"leg": f"{tool} -w {W}{how}, {shape}",
                "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(n_reads * 150 / dt / 1e9, 3), "rc": p.returncode}, "reference": None}
         if tool == "bam2depth":

@@ -296,6 +296,10 @@ public:
     }
 
     const uint8_t *d_raw() const { return dev_.d_raw(); }
+    // chunks under one inflate launch for a caller that has nothing waiting on the first batch (bam_sliding_count: one report at the
+    // end): eight instead of four -- 6,144 decoder waves take ~1.4 chunks at once, and a launch ends with its slowest block
+    // (ingest of the 10.6 GB file 0.52 -> 0.48 s, the tool 0.95 -> 0.83 s: profiles/r04/e2e_rounds.txt).  HPN_BAM_ROUNDS overrides.
+    void prefer_rounds(int n) { if (!rounds_env() && n > 0) rounds_ = n; }
 
     // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
     // be empty), 0 = end of file, -1 = not decodable here (the caller switches to the host path).

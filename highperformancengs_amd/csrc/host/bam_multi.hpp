@@ -115,13 +115,15 @@ inline int multi_gpu_workers()
 // one inflate launch (BgzfGpuStream::next), which a per-target reader cannot (it would inflate its neighbours' blocks behind the
 // target's end) -- 10.6 GB BAM, bam2depth: one worker 1.42 s, three 1.56 s; bam_sliding_count's workers take record batches of
 // ONE reader in turn and stay at three (1.04 s against 1.19; scripts/e2e_bam_chunk.py).
-inline int multi_gpu_workers_for(const char *path, bool by_target = false)
+inline int multi_gpu_workers_for(const char *path, bool /*by_target*/ = false)
 {
     int n = multi_gpu_workers();
     if (!getenv("HPN_NGPU")) {
         struct stat sb;
         if (stat(path, &sb) == 0) {
-            if (n == 1 && !by_target && sb.st_size >= ((off_t)2 << 30)) n = 3;
+            // (round 3 gave a large file three workers on ONE device here: batches in turn hid the copies behind the kernels.  The
+            // one-stream route now reads ahead on a context of its own (host/bam_gpu.hpp) and is the faster one on one device:
+            // 0.83 - 0.91 s against 0.96 - 1.04 s on the 10.6 GB file, 2.5 against 3.5 s on the 47 GB one: profiles/r04)
             const long batches = (long)(sb.st_size / ((off_t)88 << 20)) + 1;
             if (batches < n) n = (int)batches;
         }

@@ -280,6 +280,8 @@ private:
 inline void write_slab(FILE *out, const void *p, size_t n)
 {
     if (!n) return;
+    static const bool kDrop = getenv("HPN_TRIM_NOWRITE") != nullptr;       // (timing only: what the output file costs -- scripts/e2e_trim.py)
+    if (kDrop) return;
     static const int kThreads = [] {
         const char *e = getenv("HPN_WRITE_THREADS");
         long t = e ? atol(e) : 4;

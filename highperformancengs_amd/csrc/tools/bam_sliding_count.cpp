@@ -171,6 +171,7 @@ int main(int argc, char *argv[])
             BgzfGpuStream gs;
             BamHeader h2;
             if (gs.open(ctx, infiles[i], h2)) {
+                gs.prefer_rounds(8);
                 hpn_raw_info info;
                 int r;
                 while ((r = gs.next(&info)) == 1)

@@ -162,7 +162,7 @@ def test_hg38_shaped_bam_through_the_tools(tmp_path):
     os.unlink(d1 / "hg38.bam.1.bedGraph")
     # ---- bam_sliding_count: out.txt on one context and on three workers --------------------------------------------------
     want = c4.oracle_window_report(soa, tg, W)
-    for d, env in ((d1, {"HPN_NGPU": "1"}), (d3, {"HPN_TIMING": "1"})):        # one context; the default (three workers for a file of this size)
+    for d, env in ((d1, {}), (d3, {"HPN_TIMING": "1", "HPN_NGPU": "3"})):        # the default on one device (one worker); batches to three workers in turn
         p = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", str(W), "-o", "s", "hg38.bam"], cwd=d, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, env={**os.environ, **env})
         assert p.returncode == 0, p.stderr.decode()
