@@ -296,9 +296,7 @@ public:
     }
 
     const uint8_t *d_raw() const { return dev_.d_raw(); }
-    // chunks under one inflate launch for a caller that has nothing waiting on the first batch (bam_sliding_count: one report at the
-    // end): eight instead of four -- 6,144 decoder waves take ~1.4 chunks at once, and a launch ends with its slowest block
-    // (ingest of the 10.6 GB file 0.52 -> 0.48 s, the tool 0.95 -> 0.83 s: profiles/r04/e2e_rounds.txt).  HPN_BAM_ROUNDS overrides.
+    // chunks under one inflate launch, for a caller that knows better than the default (HPN_BAM_ROUNDS overrides both)
     void prefer_rounds(int n) { if (!rounds_env() && n > 0) rounds_ = n; }
 
     // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
@@ -350,7 +348,11 @@ private:
     // (BgzfDevice::add); else into the stage through up_ctx_.  1 = ok, -1 = not decodable / truncated.
     int gather(BgzfStage *st, BgzfStage &)
     {
-        for (int taken = 0; taken < rounds_;) {       // several chunks under one inflate launch
+        // (the FIRST launch of a file read front to back is two chunks: what waits for the first records -- bam2depth's first
+        // target, the writer behind it -- starts that much earlier; the launches behind it take rounds_)
+        const int limit = launches_ == 0 && rounds_ > 2 && !rounds_env() ? 2 : rounds_;
+        ++launches_;
+        for (int taken = 0; taken < limit;) {         // several chunks under one inflate launch
             TextPump::Chunk c;
             if (eof_ || !pump_->next(c)) {
                 if (!carry_.empty()) return -1;              // a partial block at the end: truncated file
@@ -539,15 +541,18 @@ private:
     uint64_t start_ = 0, skip_ = 0;  // file offset of the block holding the first record
     uint32_t first_off_ = 0;         // ... and the record's offset inside it
     bool eof_ = false, text_mode_ = false;
-    // chunks per inflate launch: four when the file is read front to back; one behind a seek() -- a worker that reads ONE target
-    // (bam_multi.hpp) would inflate up to four chunks of its neighbours behind the target's last record (HPN_BAM_ROUNDS: both)
+    // chunks per inflate launch: eight when the file is read front to back (two in the first launch; round 3: four -- 6,144 decoder
+    // waves take ~1.4 chunks at once and a launch ends with its slowest block: ingest of the 10.6 GB file 0.52 -> 0.48 s,
+    // profiles/r04/e2e_rounds.txt); one behind a seek() -- a worker that reads ONE target (bam_multi.hpp) would inflate the chunks
+    // of its neighbours behind the target's last record (HPN_BAM_ROUNDS: both)
     static int rounds_env()
     {
         const char *e = getenv("HPN_BAM_ROUNDS");
         const int v = e ? atoi(e) : 0;
         return v < 0 ? 0 : v > 64 ? 64 : v;
     }
-    int rounds_ = rounds_env() ? rounds_env() : 4;
+    int rounds_ = rounds_env() ? rounds_env() : 8;
+    uint32_t launches_ = 0;
     std::vector<uint8_t> carry_;
     BgzfDevice dev_;
 
