@@ -385,24 +385,15 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, ui
     const uint32_t hop = emits && nxt < (uint32_t)kWave ? nxt : lane;
     u64 on = 1;
     uint32_t f = 0;
-#ifdef HPN_INF_HOP4
-    // (A/B: the chain's second, third and fourth successors worked out in the lanes first -- three ds_bpermute --, so that the four
-    // v_readlane of a round all select by the SAME scalar and only the first waits for it)
-    const uint32_t hop2 = from_lane(hop, hop), hop3 = from_lane(hop, hop2), hop4 = from_lane(hop2, hop2);
-    for (;;) {
-        const uint32_t a = lane_of(hop, f), b = lane_of(hop2, f), c = lane_of(hop3, f), d = lane_of(hop4, f);
-        asm("s_bitset1_b64 %0, %1\n\ts_bitset1_b64 %0, %2\n\ts_bitset1_b64 %0, %3\n\ts_bitset1_b64 %0, %4" : "+s"(on) : "s"(a), "s"(b), "s"(c), "s"(d));
-        f = d;
-        if (d == c) break;
-    }
-#else
+    // (measured and not kept, round 4: the chain's second, third and fourth successors worked out in the lanes first -- three
+    // ds_bpermute -- so that the four v_readlane of a round select by the same scalar and only the first waits for it: 50.6 / 47.0
+    // against 51.2 / 47.6 GB/s, profiles/r04/ab_inflate_hop4.txt)
     for (;;) {
         const uint32_t a = lane_of(hop, f), b = lane_of(hop, a), c = lane_of(hop, b), d = lane_of(hop, c);
         asm("s_bitset1_b64 %0, %1\n\ts_bitset1_b64 %0, %2\n\ts_bitset1_b64 %0, %3\n\ts_bitset1_b64 %0, %4" : "+s"(on) : "s"(a), "s"(b), "s"(c), "s"(d));
         f = d;
         if (d == c) break;
     }
-#endif
     const u64 taken = on & __ballot(emits);
     const bool mine = (taken >> lane) & 1u;
     uint32_t at, total;
