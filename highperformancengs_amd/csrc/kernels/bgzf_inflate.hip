@@ -96,11 +96,19 @@ struct ByteSink {
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
                                                         uint32_t n_blocks, uint8_t *__restrict__ outbuf,
-                                                        uint32_t *__restrict__ status)
+                                                        uint32_t *__restrict__ status, uint32_t *__restrict__ ticket)
 {
     __shared__ InfLds s;
     const int lane = lane_id();
+    // blocks are TAKEN, not dealt: a wave that is done with its block takes the next one nobody has (one atomic per block).  Dealt
+    // by stride, a launch ended with the wave whose blocks happened to be the slow ones (round 4: in the tools a launch is 3 - 6
+    // blocks per wave; same-session A/B in profiles/r04/ab_inflate_ticket.txt)
+#ifdef HPN_INF_STRIDE
     for (uint32_t bi = blockIdx.x; bi < n_blocks; bi += gridDim.x) {
+#else
+    for (uint32_t bi = blockIdx.x; bi < n_blocks;
+         bi = gridDim.x + uni(lane == 0 ? atomicAdd(ticket, 1u) : 0u)) {
+#endif
         const BgzfBlock blk = blocks[bi];
         const uint8_t *in = comp + blk.in_off;
         uint8_t *out = outbuf + blk.out_off;
@@ -166,12 +174,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_E
 }
 
 hipError_t launch_bgzf_inflate(const uint8_t *d_comp, const void *d_blocks, uint32_t n_blocks, uint8_t *d_out, uint32_t *d_status,
-                               int n_cu, hipStream_t st)
+                               uint32_t *d_ticket, int n_cu, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
-    const uint32_t cap = (uint32_t)n_cu * kInflateWavesPerCu;  // single-wave workgroups: 20 per CU (inflate_core.hpp)
+    const uint32_t cap = (uint32_t)n_cu * kInflateWavesPerCu;  // single-wave workgroups: 24 per CU (inflate_core.hpp)
+    hipError_t e = hipMemsetAsync(d_ticket, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < cap ? n_blocks : cap), dim3(kWave), 0, st, d_comp, (const BgzfBlock *)d_blocks,
-                       n_blocks, d_out, d_status);
+                       n_blocks, d_out, d_status, d_ticket);
     return hipGetLastError();
 }
 
