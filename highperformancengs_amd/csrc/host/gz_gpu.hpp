@@ -111,7 +111,14 @@ public:
             // ... and where the DEVICE looks for the block starts (cheap per stretch), a file that can fill the chip more than once
             // with stretches of 256 KiB is taken in up to four batches: the next batch's upload runs beside this one's device work
             const uint64_t fills = size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10));
-            if (search_on_device_ && calls < (fills < 4 ? fills : 4)) calls = fills < 4 ? fills : 4;
+            // ... as FEW batches as keep a batch's symbol scratch near 16 GB (2.8 bytes x the expansion per compressed byte in
+            // flight): every batch pays the histories' serial walk over its stretches once (23 ms per 6,000 stretches, whatever
+            // their size: profiles/r04/kernel_stats_gz_tool.csv) and ends with its longest stretch
+            uint64_t want = (uint64_t)((double)size_ * ratio_ * 2.8 / 16e9) + 1;
+            if (want < 2) want = 2;
+            if (want > 4) want = 4;
+            if (want > fills) want = fills;
+            if (search_on_device_ && calls < want) calls = want;
             // (rounded up to 4 KiB, not more: a stretch 12 % longer than the share leaves 12 % of the wave slots empty AND makes
             // the one launch 12 % longer -- 2.4 GB file, 4,608 slots: 4,097 stretches of 576 KiB where 4,590 of 516 fit)
             stretch_bytes = e ? (size_t)atoll(e) : (size_t)((size_ / (calls * max_stretches_) + 4096) & ~(uint64_t)4095);

@@ -284,9 +284,19 @@ __device__ __forceinline__ bool gz_trial(InfLds &s, const uint8_t *__restrict__ 
     if (take(b, 1) != 0 || take(b, 2) != 2u) return false;
     if (block_tables(s, b, in, in_len, 2) != 0) return false;
     uint32_t err = 0;
-    TextCheck all{1u << 20, 0u, 0u, 0u};
     Pos at = pos_of(b);
+#ifdef HPN_GZ_TRIAL_FULL
+    TextCheck all{1u << 20, 0u, 0u, 0u};
     if (!decode_symbols(s, b, at, in, in_len, all, err) || all.op == 0 || all.bad) return false;
+#else
+    // The block's first 4,096 symbols, not the block to its end (round 4): a header that parses, complete code tables and 4,096
+    // symbols of text are no accident, and the start is proven by the stretch before it arriving there anyway -- while a block of
+    // FASTQ text is ~10^5 symbols, ~15 ms of one wave: the search re-decoded a quarter of what the inflate kernel decodes
+    // (k_gz_find_starts 30.7 ms beside 76 ms of k_gz_sym_inflate per batch, profiles/r04/kernel_stats_gz_tool.csv).
+    TextCheck all{4096u, 0u, 0u, 0u};
+    if (!decode_symbols(s, b, at, in, in_len, all, err)) return err == 12u && !all.bad && all.op != 0;   // (12: the 4,096 symbols are through)
+    if (all.op == 0 || all.bad) return false;
+#endif
     // ... and the next block must at least begin like one (header parses, tables build, the first symbols decode to text):
     // decoding it to its end as well would double the cost for nothing -- whoever uses the start proves it anyway
     seek(s, b, at, in, in_len);
