@@ -47,6 +47,7 @@ public:
         }
         cv_.notify_all();
         if (producer_.joinable()) producer_.join();
+        if (ctx2_maker_.joinable()) ctx2_maker_.join();
         pump_.reset();
         if (ctx_) {
             for (Slot &s : slot_) {
@@ -56,6 +57,7 @@ public:
             hpn_dev_free(ctx_, d_text_), hpn_dev_free(ctx_, d_win_[0]), hpn_dev_free(ctx_, d_win_[1]);
         }
         if (up_ctx_) hpn_ctx_destroy(up_ctx_);
+        if (ctx2_) hpn_ctx_destroy(ctx2_);
         if (data_) munmap((void *)data_, size_);
         if (fd_ >= 0) close(fd_);
     }
@@ -111,10 +113,11 @@ public:
             // ... and where the DEVICE looks for the block starts (cheap per stretch), a file that can fill the chip more than once
             // with stretches of 256 KiB is taken in up to four batches: the next batch's upload runs beside this one's device work
             const uint64_t fills = size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10));
-            // ... as FEW batches as keep a batch's symbol scratch near 16 GB (2.8 bytes x the expansion per compressed byte in
+            // ... as FEW batches as keep a batch's symbol scratch near 10 GB (2.8 bytes x the expansion per compressed byte in
             // flight): every batch pays the histories' serial walk over its stretches once (23 ms per 6,000 stretches, whatever
-            // their size: profiles/r04/kernel_stats_gz_tool.csv) and ends with its longest stretch
-            uint64_t want = (uint64_t)((double)size_ * ratio_ * 2.8 / 16e9) + 1;
+            // their size: profiles/r04/kernel_stats_gz_tool.csv) and ends with its longest stretch -- but large allocations are
+            // what the runtime sometimes stalls in for seconds (see HPN_GZ_OVERLAP above), so the scratch stays modest
+            uint64_t want = (uint64_t)((double)size_ * ratio_ * 2.8 / 10e9) + 1;
             if (want < 2) want = 2;
             if (want > 4) want = 4;
             if (want > fills) want = fills;
@@ -147,6 +150,14 @@ public:
         if (!pump_->ok()) return give_up("reader not available");
         if (hpn_dev_malloc(ctx_, 32768, &d_win_[0]) != HPN_OK || hpn_dev_malloc(ctx_, 32768, &d_win_[1]) != HPN_OK) return give_up("device memory");
         producer_ = std::thread([this] { produce(); });
+        // HPN_GZ_OVERLAP=1: a second context, so that batch k + 1 decodes while batch k's histories are resolved (next()).  Off by
+        // default: measured -0.02 s of 0.57 on the 7.2 GB file (the one-workgroup history walk runs three times slower beside
+        // 6,144 decoder waves), for a second set of symbol scratch -- and allocations of this size are what sometimes takes the
+        // runtime seconds (profiles/r04/gz_stamps.txt: one run in six stalls 3.6 s in a 14 GB hipMalloc)
+        if (getenv("HPN_GZ_OVERLAP") && getenv("HPN_GZ_OVERLAP")[0] == '1')
+            ctx2_maker_ = std::thread([this, device] {            // (~30 ms, beside the first batch's upload)
+                if (hpn_ctx_create(device, &ctx2_) != HPN_OK) ctx2_ = nullptr;
+            });
         return true;
     }
     const uint8_t *d_text() const { return (const uint8_t *)d_text_; }
@@ -178,29 +189,50 @@ public:
         void *const d_comp_ = sl.d_comp, *const d_chunks_ = sl.d_chunks;
         const double t2 = wall_s();
         // ---- inflate, resolve, translate ----
+        // The batches alternate between two contexts (two streams): the symbolic decode of batch k + 1 is started BEFORE batch k's
+        // histories are resolved (one workgroup, a serial walk over the stretches: 23 ms per batch), its text translated, checked
+        // and tallied -- none of which needs the chip -- and its first waves take the decoder slots batch k's last stretches
+        // leave (round 4: all of that was in a row, 130 ms per batch of which 100 decode).
+        hpn_ctx *const cx = inflate_ctx(batch_);
+        auto begin = [&](hpn_ctx *c, Slot &b) {
+            const int rc = hpn_gz_inflate_begin_dev(c, (const uint8_t *)b.d_comp, (const hpn_gz_chunk *)b.d_chunks, b.n, sym_cap_);
+            b.begun = rc == HPN_OK, b.begun_cap = sym_cap_;
+            return rc;
+        };
+        if (!sl.begun) {
+            if (begin(cx, sl) != HPN_OK) return give_up(hpn_ctx_last_error(cx)) - 1;
+            stamp("symbolic decode started (the first: its scratch allocated)");
+        }
+        if (!last_batch && inflate_ctx(batch_ + 1) != cx) {
+            Slot &nx = slot_[(batch_ + 1) & 1];
+            {   // (prepared while this batch decodes: the wait is in that shadow)
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return nx.state != 0; });
+            }
+            if (nx.state > 0 && !nx.begun) (void)begin(inflate_ctx(batch_ + 1), nx);     // (a failure shows when the batch's turn comes)
+            stamp("the next batch's decode started");
+        }
         uint64_t want = (uint64_t)((double)comp_bytes * ratio_ * 1.25) + ((uint64_t)8 << 20);
         hpn_gz_info info;
         for (int attempt = 0;; ++attempt) {
             if (!reserve(ctx_, d_text_, cap_text_, want + 64)) return give_up("device memory (text)") - 1;
-            const int rc = hpn_gz_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
-                                              batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
-                                              (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
-            if (rc == HPN_E_CAPACITY && attempt == 0) {  // more text than guessed: once more with room for it
+            const int rc = hpn_gz_inflate_finish_dev(cx, batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
+                                                     (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
+            if (rc == HPN_E_CAPACITY && attempt == 0) {  // more text than guessed: once more with room for it (the symbols stay)
                 want = info.n_bytes;
                 continue;
             }
-            if (rc != HPN_OK) return give_up(hpn_ctx_last_error(ctx_)) - 1;
+            if (rc != HPN_OK) return give_up(hpn_ctx_last_error(cx)) - 1;
             break;
         }
         t_device_ += wall_s() - t2;
         stamp("inflate returned");
-        if ((info.status == 12 || info.status == 14 || info.status == 1) && !grown_) {  // out of room: once more with twice as much
-            grown_ = true;
-            sym_cap_ = cap_for(ratio_ * 3.0);
-            const int rc = hpn_gz_inflate_dev(ctx_, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
+        if ((info.status == 12 || info.status == 14 || info.status == 1) && (!grown_ || sl.begun_cap < sym_cap_)) {  // out of room: once more with twice as much
+            if (!grown_) grown_ = true, sym_cap_ = cap_for(ratio_ * 3.0);
+            const int rc = hpn_gz_inflate_dev(cx, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
                                               batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
                                               (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
-            if (rc != HPN_OK) return give_up(hpn_ctx_last_error(ctx_)) - 1;
+            if (rc != HPN_OK) return give_up(hpn_ctx_last_error(cx)) - 1;
         }
         if (info.status) {
             snprintf(why_buf_, sizeof why_buf_, "stretch %u of %u: decoder status %u", info.bad_chunk, n, info.status);
@@ -218,10 +250,10 @@ public:
             // fail: such a file is read again through zlib itself, tally_file).  The text of a member may span batches: the CRC
             // of each piece is taken while its text is on the device and folded into the member's (hpn_crc32_join).
             uint32_t nm = 0;
-            int rc = hpn_gz_members(ctx_, nullptr, 0, &nm);
+            int rc = hpn_gz_members(cx, nullptr, 0, &nm);
             if (rc == HPN_E_CAPACITY) {
                 members_.resize(nm);
-                rc = hpn_gz_members(ctx_, members_.data(), nm, &nm);
+                rc = hpn_gz_members(cx, members_.data(), nm, &nm);
             }
             if (rc != HPN_OK) return give_up("member list") - 1;
             spans_.clear();
@@ -273,6 +305,8 @@ private:
         uint32_t n = 0;
         uint64_t comp_bytes = 0, end_bit = kGzNone;
         bool last = false;
+        bool begun = false;          // its symbolic decode has been started (next(): beside the batch before)
+        uint32_t begun_cap = 0;      // ... with this much symbol scratch per stretch
         int state = 0;
         const char *why = "";
     };
@@ -427,7 +461,7 @@ private:
         }
         if (!reserve(up_ctx_, sl.d_chunks, sl.cap_chunks, (size_t)n * sizeof(hpn_gz_chunk))) return fail(sl, "device memory");
         if (hpn_memcpy_h2d(up_ctx_, sl.d_chunks, sl.h_chunks, (size_t)n * sizeof(hpn_gz_chunk)) != HPN_OK || hpn_ctx_sync(up_ctx_) != HPN_OK) return fail(sl, "copy failed");
-        sl.n = n, sl.comp_bytes = comp_bytes, sl.end_bit = end_bit, sl.last = last_batch;
+        sl.n = n, sl.comp_bytes = comp_bytes, sl.end_bit = end_bit, sl.last = last_batch, sl.begun = false;
         if (!last_batch) next_start_ = end_bit;
         return true;
     }
@@ -491,7 +525,14 @@ private:
         return hpn_ctx_sync(ctx_) == HPN_OK;
     }
 
-    hpn_ctx *ctx_ = nullptr, *up_ctx_ = nullptr;
+    hpn_ctx *ctx_ = nullptr, *up_ctx_ = nullptr, *ctx2_ = nullptr;
+    std::thread ctx2_maker_;
+    // the context batch b is decoded through: the caller's and a second one in turn (no second one: all through the caller's)
+    hpn_ctx *inflate_ctx(uint32_t b)
+    {
+        if (ctx2_maker_.joinable()) ctx2_maker_.join();
+        return (b & 1u) && ctx2_ ? ctx2_ : ctx_;
+    }
     // who looks for the block starts: the cores (0.4 ms per stretch and core, beside the upload and the batch before: with 16
     // cores that keeps up with the device), or the device (HPN_GZ_FIND=device; ~15 ms per batch, but behind the upload and not
     // beside an inflate kernel, which fills the CUs' LDS) -- the default where the process has few cores

@@ -76,12 +76,12 @@ public:
         const uint64_t calls = (size_ + S_ * max_stretch - 1) / (S_ * max_stretch);
         uint64_t want_calls = calls < (uint64_t)g_.lanes() ? (uint64_t)g_.lanes() : calls;   // at least one batch per lane
         {   // as in GzGpuStream::open: the DEVICE looks for the block starts of a file that fills the lanes' chips twice or more, and
-            // a device's share goes in as few batches as keep a batch's symbol scratch near 16 GB (lanes that share a device --
+            // a device's share goes in as few batches as keep a batch's symbol scratch near 10 GB (lanes that share a device --
             // HPN_NGPU on a one-GPU box -- share its memory: their batches are that much smaller)
             const uint64_t fills = size_ / (S_ * (uint64_t)g_.lanes() * ((uint64_t)256 << 10));
             if (!getenv("HPN_GZ_FIND") && fills >= 2) search_on_device_ = true;
             const double per_device = (double)size_ / (g_.distinct() ? (double)g_.lanes() : 1.0);
-            uint64_t want = (uint64_t)(per_device * ratio_ * 2.8 / 16e9) + 1;
+            uint64_t want = (uint64_t)(per_device * ratio_ * 2.8 / 10e9) + 1;
             // (per lane: the lanes of a device run side by side, so 1 / want of the device's share is in flight at a time)
             if (want > 4) want = 4;
             if (search_on_device_ && fills >= 2 && want_calls < want * (uint64_t)g_.lanes()) want_calls = want * (uint64_t)g_.lanes();

@@ -49,7 +49,7 @@ if what in ("gz", "all"):
             f.write(one)
     print(f"gz3.fq.gz: {3 * len(one) / 1e9:.2f} GB compressed, {3 * len(raw) / 1e9:.2f} GB of text, {3 * n} reads")
     del raw, one
-    outs = [run("fastq_count", ["gz3.fq.gz"], e) for e in ({}, {"HPN_TIMING": "2"}, {"HPN_NGPU": "2"}, {"HPN_NGPU": "3"}, {"HPN_GZ_FIND": "device"}, {"HPN_GZ_FIND": "device", "HPN_TIMING": "2"}, {"HPN_NGPU": "2", "HPN_GZ_FIND": "device"})]
+    outs = [run("fastq_count", ["gz3.fq.gz"], e) for e in ({}, {"HPN_GZ_OVERLAP": "1"}, {"HPN_TIMING": "2"}, {"HPN_NGPU": "2"}, {"HPN_NGPU": "3"}, {"HPN_GZ_FIND": "device"}, {"HPN_GZ_FIND": "device", "HPN_TIMING": "2"}, {"HPN_NGPU": "2", "HPN_GZ_FIND": "device"})]
     print("outputs identical:", all(o == outs[0] for o in outs), outs[0].decode().strip())
     os.unlink(os.path.join(td, "gz3.fq.gz"))
 
