@@ -179,6 +179,43 @@ def test_unfinished_record_at_the_end_of_a_call_is_reported_and_carried(ctx, blo
     assert min(info.tid_min, info2.tid_min) == int(soa.tid.min()) and max(info.tid_max, info2.tid_max) == int(soa.tid.max())
 
 
+def _bgzf_pack(data, block):
+    out = b""
+    for i in range(0, len(data), block):
+        piece = data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(piece) + co.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + (len(comp) + 25).to_bytes(2, "little") + comp +
+                (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
+    return out
+
+
+@pytest.mark.parametrize("block", [1000, 20000])
+def test_records_nobody_guesses_are_walked_by_the_proof(ctx, block):
+    """A guess asks for a printable read name (what makes four-in-a-row rare enough to trust); bam_read1 does not, and neither does
+    the proof: with every name made of control characters and bytes above 127 no block of a packed file gets a guess, the chain is
+    walked block by block from the call's first record, and the result is the same."""
+    raw = open(golden_path("bam", "rand.bam"), "rb").read()
+    soa = bamio.read_bam_records(golden_path("bam", "rand.bam"))
+    data = bytearray(b"".join(zlib.decompress(raw[a:a + n], -15) for a, n, _ in _blocks(raw)))
+    at = _header_len(bytes(data))
+    k = 0
+    while at < len(data):
+        bs = struct.unpack_from("<i", data, at)[0]
+        l_name = data[at + 12]
+        for j in range(l_name - 1):
+            data[at + 36 + j] = (1, 7, 0xe9, 0xff, 31, 127)[(k + j) % 6]
+        at += 4 + bs
+        k += 1
+    d_raw, info, keep = _to_device(ctx, _bgzf_pack(bytes(data), block))
+    assert info.flags & 3 == 0 and info.tail_bytes == 0 and info.n_records == len(soa.tid)
+    W = 100
+    for tid, (name, tlen) in enumerate(soa.refs):
+        runs, win = ctx.depth_target_raw(d_raw, tid, tlen, W, 0x704)
+        rc, wruns, wbins = orc.depth_target(soa, tid, W, 0x704)
+        assert rc == 0 and np.array_equal(runs, wruns) and np.array_equal(win.astype(np.float64), wbins), name
+
+
 def test_a_start_that_is_not_one_is_refuted(ctx):
     """The found starts are guesses until the chain proves them: a block whose bytes hold a well-formed chain of records at
     the WRONG place (here: a block of the file pasted in the middle of a long record's qualities would do the same) must
