@@ -77,7 +77,7 @@ struct hpn_ctx {
     hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info;
     hpn::Scratch g_crc;   // hpn_crc32_dev: block table + block CRCs
     hpn::Scratch b_ticket;   // hpn_bgzf_inflate_dev: the kernel's block counter
-    hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds;  // gzip: symbols, per-stretch results, histories, member ends
+    hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds, g_groups;  // gzip: symbols, per-stretch results, histories, member ends
     std::vector<hpn_gz_member> gz_members;              // members that ended inside the last hpn_gz_inflate_dev call
     bool gz_pending = false;                            // between hpn_gz_inflate_begin_dev and _finish_dev
     uint32_t gz_n_chunks = 0, gz_sym_cap = 0;

@@ -13,7 +13,8 @@ namespace hpn {
 hipError_t launch_gz_sym_inflate(const uint8_t *d_comp, const void *d_chunks, uint32_t n_chunks, uint16_t *d_sym, uint32_t sym_cap,
                                  void *d_meta, void *d_bounds, uint32_t bounds_cap, int n_cu, hipStream_t st);
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
-                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st);
+                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, void *d_groups, int n_cu, hipStream_t st);
+size_t gz_groups_bytes(uint32_t n_chunks);
 hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const void *d_meta, uint32_t n_chunks, const uint8_t *d_windows,
                                uint8_t *d_text, hipStream_t st);
 hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const void *d_slices, uint32_t n, uint64_t *d_found, int n_cu,
@@ -50,6 +51,7 @@ int hpn_gz_inflate_begin_dev(hpn_ctx *c, const uint8_t *d_comp, const hpn_gz_chu
         if ((rc = scratch_reserve(c, c->g_sym, (size_t)n_chunks * sym_cap * sizeof(uint16_t) + 64)) != HPN_OK) return rc;
         if ((rc = scratch_reserve(c, c->g_meta, (size_t)n_chunks * 32)) != HPN_OK) return rc;
         if ((rc = scratch_reserve(c, c->g_windows, ((size_t)n_chunks + 1) * 32768)) != HPN_OK) return rc;
+        if ((rc = scratch_reserve(c, c->g_groups, gz_groups_bytes(n_chunks))) != HPN_OK) return rc;     // the histories in three steps: group maps + histories
         if ((rc = scratch_reserve(c, c->g_summary, 64)) != HPN_OK) return rc;
         if ((rc = scratch_reserve(c, c->g_bounds, 16 + (size_t)kGzBounds * 16)) != HPN_OK) return rc;
         HPN_HIP(c, hipEventRecord(c->ev_beg[kFamInflate], c->stream));
@@ -80,7 +82,7 @@ int hpn_gz_inflate_finish_dev(hpn_ctx *c, const uint8_t *d_window_in, uint8_t *d
     const double t1 = now();
     uint16_t *sym = (uint16_t *)c->g_sym.p;
     HPN_HIP(c, launch_gz_windows(sym, sym_cap, c->g_meta.p, n_chunks, d_window_in, (uint8_t *)c->g_windows.p, d_window_out,
-                                 (u64 *)c->g_summary.p, c->n_cu, c->stream));
+                                 (u64 *)c->g_summary.p, c->g_groups.p, c->n_cu, c->stream));
     u64 summary[4] = {0, 0, 0, 0};
     uint32_t n_bounds = 0;
     HPN_HIP(c, hipMemcpyAsync(summary, c->g_summary.p, sizeof summary, hipMemcpyDeviceToHost, c->stream));

@@ -518,6 +518,198 @@ __global__ __launch_bounds__(1024) void k_gz_windows_lds(const uint16_t *__restr
     if (tid == 0) summary[0] = text, summary[1] = bad, summary[2] = bad_at, summary[3] = fin;
 }
 
+// ---- the histories in three steps (round 4) ------------------------------------------------------------------------------------
+// The walk above is a chain of n_chunks steps (3.3 - 3.8 us each: 23 ms per batch of 6,000 stretches, whatever their size -- a
+// fifth of a batch's device time in the tools).  But what a stretch does to the history is a MAP: every byte of the history
+// behind it is a literal or a position of the history in front of it -- and maps compose.  So:
+//   k_gz_win_maps    a workgroup per GROUP of kGzGroup consecutive stretches composes the group's map (32,768 entries of the
+//                    symbols' own encoding: < 256 a literal, else 256 + position in the history in front of the group), the
+//                    stretches one after the other in LDS -- the groups side by side;
+//   k_gz_win_chain   one workgroup walks the GROUPS (n / kGzGroup steps): the history in front of every group, the one behind
+//                    the batch; and the stretches' text offsets, the first bad stretch, the final one (what the walk above
+//                    gathered on its way);
+//   k_gz_win_apply   a workgroup per group again: the walk above, from the group's own history, writing windows[k].
+// Twice the look-ups, a chain of 2 x kGzGroup + n / kGzGroup steps instead of n.
+constexpr uint32_t kGzGroup = 64;
+
+// the four symbols of positions j .. j + 3 of the history behind stretch k, before the look-up (two to a register)
+typedef uint32_t gz_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gz_u32x2 gz_tail4(const uint16_t *__restrict__ symbuf, uint32_t sym_cap, const GzMeta *__restrict__ meta, uint32_t k, uint32_t j)
+{
+    const int32_t d = (int32_t)meta[k].n_out - (int32_t)kGzHist;   // symbol j of the history = symbol d + j of the stretch
+    const uint16_t *base = symbuf + (uint64_t)k * sym_cap + (int64_t)d;
+    gz_u32x2 r;
+    if ((int32_t)j + d >= 0) {
+        __builtin_memcpy(&r, base + j, 8);
+    } else {
+        uint32_t e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = (int32_t)(j + i) + d >= 0 ? (uint32_t)base[j + i] : 256u + (uint32_t)((int32_t)kGzHist + (int32_t)(j + i) + d);
+        r = gz_u32x2{e[0] | e[1] << 16, e[2] | e[3] << 16};
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_gz_win_maps(const uint16_t *__restrict__ symbuf, uint32_t sym_cap, const GzMeta *__restrict__ meta,
+                                                      uint32_t n_chunks, uint16_t *__restrict__ gmaps)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_map[2][kGzHist];       // 128 KB
+    constexpr int kGroups = (int)(kGzHist / (1024 * 4));           // 8 groups of four consecutive positions per thread
+    const uint32_t tid = threadIdx.x, k0 = blockIdx.x * kGzGroup, k1 = k0 + kGzGroup < n_chunks ? k0 + kGzGroup : n_chunks;
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+        *(gz_u32x2 *)(s_map[0] + j) = gz_u32x2{(256u + j) | (257u + j) << 16, (258u + j) | (259u + j) << 16};     // the identity
+    }
+    gz_u32x2 sv[kGroups], nx[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) sv[g] = gz_tail4(symbuf, sym_cap, meta, k0, ((uint32_t)g * 1024u + tid) * 4u);
+    __syncthreads();
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint16_t *cur = s_map[(k - k0) & 1];
+        uint16_t *nxt = s_map[(k - k0 + 1) & 1];
+        if (k + 1 < k1) {
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) nx[g] = gz_tail4(symbuf, sym_cap, meta, k + 1, ((uint32_t)g * 1024u + tid) * 4u);
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+            const uint32_t e0 = sv[g][0] & 0xffffu, e1 = sv[g][0] >> 16, e2 = sv[g][1] & 0xffffu, e3 = sv[g][1] >> 16;
+            const uint32_t m0 = e0 < 256u ? e0 : cur[e0 - 256u], m1 = e1 < 256u ? e1 : cur[e1 - 256u];
+            const uint32_t m2 = e2 < 256u ? e2 : cur[e2 - 256u], m3 = e3 < 256u ? e3 : cur[e3 - 256u];
+            *(gz_u32x2 *)(nxt + j) = gz_u32x2{m0 | m1 << 16, m2 | m3 << 16};
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) sv[g] = nx[g];
+        __syncthreads();
+    }
+    const uint16_t *fin = s_map[(k1 - k0) & 1];
+    uint16_t *out = gmaps + (uint64_t)blockIdx.x * kGzHist;
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+        *(gz_u32x2 *)(out + j) = *(const gz_u32x2 *)(fin + j);
+    }
+}
+
+// group_in + g * 32768 = the history in front of group g; windows_last = the one behind the batch (windows[n_chunks])
+__global__ __launch_bounds__(1024) void k_gz_win_chain(const uint16_t *__restrict__ gmaps, uint32_t n_groups, GzMeta *__restrict__ meta,
+                                                       uint32_t n_chunks, const uint8_t *__restrict__ window_in, uint8_t *__restrict__ group_in,
+                                                       uint8_t *__restrict__ windows_last, uint8_t *__restrict__ window_out, u64 *__restrict__ summary)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[2][kGzHist];
+    __shared__ u64 s_wave[16];
+    __shared__ u64 s_carry;
+    __shared__ uint32_t s_bad_at, s_fin;
+    constexpr int kGroups = (int)(kGzHist / (1024 * 4));
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_carry = 0, s_bad_at = 0xffffffffu, s_fin = 0;
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+        uint32_t v = 0;
+        if (window_in) __builtin_memcpy(&v, window_in + j, 4);
+        *(uint32_t *)(s_win[0] + j) = v;
+    }
+    __syncthreads();
+    // the stretches' text offsets (an exclusive scan of their sizes), the first stretch that failed, the final one
+    for (uint32_t i0 = 0; i0 < n_chunks; i0 += 1024u) {
+        const uint32_t i = i0 + tid;
+        const u64 v = i < n_chunks ? meta[i].n_out : 0;
+        if (i < n_chunks) {
+            if (meta[i].status) atomicMin(&s_bad_at, i);
+            if (meta[i].final_block) atomicMax(&s_fin, i + 1u);
+        }
+        u64 inc = v;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const u64 t = __shfl_up(inc, o, kWave);
+            if (lane_id() >= o) inc += t;
+        }
+        if (lane_id() == kWave - 1) s_wave[wave_id()] = inc;
+        __syncthreads();
+        u64 before = s_carry;
+        for (int w = 0; w < wave_id(); ++w) before += s_wave[w];
+        if (i < n_chunks) meta[i].text_off = before + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    gz_u32x2 mv[kGroups], nx[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) mv[g] = n_groups ? *(const gz_u32x2 *)(gmaps + ((uint32_t)g * 1024u + tid) * 4u) : gz_u32x2{0, 0};
+    for (uint32_t gi = 0; gi < n_groups; ++gi) {
+        const uint8_t *cur = s_win[gi & 1];
+        uint8_t *nxt = s_win[(gi + 1) & 1], *gout = group_in + (uint64_t)gi * kGzHist;
+        if (gi + 1 < n_groups) {
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) nx[g] = *(const gz_u32x2 *)(gmaps + (uint64_t)(gi + 1) * kGzHist + ((uint32_t)g * 1024u + tid) * 4u);
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+            *(uint32_t *)(gout + j) = *(const uint32_t *)(cur + j);                 // the history in front of this group
+            const uint32_t e0 = mv[g][0] & 0xffffu, e1 = mv[g][0] >> 16, e2 = mv[g][1] & 0xffffu, e3 = mv[g][1] >> 16;
+            const uint32_t b0 = e0 < 256u ? e0 : cur[e0 - 256u], b1 = e1 < 256u ? e1 : cur[e1 - 256u];
+            const uint32_t b2 = e2 < 256u ? e2 : cur[e2 - 256u], b3 = e3 < 256u ? e3 : cur[e3 - 256u];
+            *(uint32_t *)(nxt + j) = b0 | b1 << 8 | b2 << 16 | b3 << 24;
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) mv[g] = nx[g];
+        __syncthreads();
+    }
+    const uint8_t *last = s_win[n_groups & 1];
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+        const uint32_t v = *(const uint32_t *)(last + j);
+        *(uint32_t *)(windows_last + j) = v;
+        if (window_out) *(uint32_t *)(window_out + j) = v;
+    }
+    if (tid == 0) {
+        const uint32_t bad_at = s_bad_at;
+        summary[0] = s_carry, summary[1] = bad_at != 0xffffffffu ? meta[bad_at].status : 0u, summary[2] = bad_at != 0xffffffffu ? bad_at : 0u,
+        summary[3] = s_fin;
+    }
+}
+
+// windows + k * 32768 = the history in front of stretch k, for the stretches of group blockIdx.x
+__global__ __launch_bounds__(1024) void k_gz_win_apply(const uint16_t *__restrict__ symbuf, uint32_t sym_cap, const GzMeta *__restrict__ meta,
+                                                       uint32_t n_chunks, const uint8_t *__restrict__ group_in, uint8_t *__restrict__ windows)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[2][kGzHist];
+    constexpr int kGroups = (int)(kGzHist / (1024 * 4));
+    const uint32_t tid = threadIdx.x, k0 = blockIdx.x * kGzGroup, k1 = k0 + kGzGroup < n_chunks ? k0 + kGzGroup : n_chunks;
+    for (int g = 0; g < kGroups; ++g) {
+        const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+        const uint32_t v = *(const uint32_t *)(group_in + (uint64_t)blockIdx.x * kGzHist + j);
+        *(uint32_t *)(s_win[0] + j) = v;
+        *(uint32_t *)(windows + (uint64_t)k0 * kGzHist + j) = v;
+    }
+    gz_u32x2 sv[kGroups], nx[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) sv[g] = gz_tail4(symbuf, sym_cap, meta, k0, ((uint32_t)g * 1024u + tid) * 4u);
+    __syncthreads();
+    for (uint32_t k = k0; k + 1 < k1; ++k) {              // (the history behind the group's last stretch is the next group's: k_gz_win_chain)
+        const uint8_t *cur = s_win[(k - k0) & 1];
+        uint8_t *nxt = s_win[(k - k0 + 1) & 1], *gout = windows + (uint64_t)(k + 1) * kGzHist;
+        if (k + 2 < k1) {
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) nx[g] = gz_tail4(symbuf, sym_cap, meta, k + 1, ((uint32_t)g * 1024u + tid) * 4u);
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const uint32_t j = ((uint32_t)g * 1024u + tid) * 4u;
+            const uint32_t e0 = sv[g][0] & 0xffffu, e1 = sv[g][0] >> 16, e2 = sv[g][1] & 0xffffu, e3 = sv[g][1] >> 16;
+            const uint32_t b0 = e0 < 256u ? e0 : cur[e0 - 256u], b1 = e1 < 256u ? e1 : cur[e1 - 256u];
+            const uint32_t b2 = e2 < 256u ? e2 : cur[e2 - 256u], b3 = e3 < 256u ? e3 : cur[e3 - 256u];
+            const uint32_t v = b0 | b1 << 8 | b2 << 16 | b3 << 24;
+            *(uint32_t *)(nxt + j) = v;
+            *(uint32_t *)(gout + j) = v;
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) sv[g] = nx[g];
+        __syncthreads();
+    }
+}
+
 // symbols -> bytes: blockIdx.y = stretch, the x blocks stride over its symbols (8 per thread and step)
 constexpr int kGzTrThreads = 256;
 __global__ __launch_bounds__(kGzTrThreads) void k_gz_translate(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
@@ -571,12 +763,23 @@ hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const
     hipLaunchKernelGGL(k_gz_find_starts, dim3(n < cap ? n : cap), dim3(kWave), 0, st, d_comp, comp_len, (const GzSlice *)d_slices, n, d_found);
     return hipGetLastError();
 }
+size_t gz_groups_bytes(uint32_t n_chunks) { return (size_t)((n_chunks + kGzGroup - 1) / kGzGroup) * kGzHist * 3 + 64; }   // maps (u16) + histories (u8)
 hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_meta, uint32_t n_chunks, const uint8_t *d_window_in,
-                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, int n_cu, hipStream_t st)
+                             uint8_t *d_windows, uint8_t *d_window_out, u64 *d_summary, void *d_groups, int n_cu, hipStream_t st)
 {
     // (a call of more than half a chip-fill of stretches comes from a worker that has the device to itself: tally_gz_on_gpu
     // divides the chip's 5,120 slots among the workers in flight)
-    const char *how = getenv("HPN_GZ_WINDOWS");                  // lds / global: tests and A/B runs
+    const char *how = getenv("HPN_GZ_WINDOWS");                  // groups / lds / global: tests and A/B runs
+    if (d_groups && (how ? !strcmp(how, "groups") : n_chunks > (uint32_t)n_cu * 12u)) {
+        const uint32_t ng = (n_chunks + kGzGroup - 1) / kGzGroup;
+        uint16_t *gmaps = (uint16_t *)d_groups;
+        uint8_t *group_in = (uint8_t *)d_groups + (size_t)ng * kGzHist * sizeof(uint16_t);
+        hipLaunchKernelGGL(k_gz_win_maps, dim3(ng), dim3(1024), 0, st, d_sym, sym_cap, (const GzMeta *)d_meta, n_chunks, gmaps);
+        hipLaunchKernelGGL(k_gz_win_chain, dim3(1), dim3(1024), 0, st, gmaps, ng, (GzMeta *)d_meta, n_chunks, d_window_in, group_in,
+                           d_windows + (size_t)n_chunks * kGzHist, d_window_out, d_summary);
+        hipLaunchKernelGGL(k_gz_win_apply, dim3(ng), dim3(1024), 0, st, d_sym, sym_cap, (const GzMeta *)d_meta, n_chunks, group_in, d_windows);
+        return hipGetLastError();
+    }
     if (how ? !strcmp(how, "lds") : n_chunks > (uint32_t)n_cu * 12u)
         hipLaunchKernelGGL(k_gz_windows_lds, dim3(1), dim3(1024), 0, st, d_sym, sym_cap, (GzMeta *)d_meta, n_chunks, d_window_in, d_windows,
                            d_window_out, d_summary);
