@@ -6,6 +6,7 @@ the depth report is compared with the oracle run on the generator's own records,
 bam_sliding_count's report on three workers against one.  Peak host RSS of every run is reported (the 12 GB look-ahead budget).
 
     python scripts/c4_30x_big.py [workdir] [threads]      -> one JSON object on stdout; copy it to profiles/r04/c4_30x_big.json
+    C4_PACKED=1: the same records written htsjdk's way (packed across BGZF blocks)   -> profiles/r04/c4_30x_big_packed.json
 
 Checker use of oracle/ (tests/c4.py); the product runs are the built binaries."""
 import json
@@ -47,7 +48,8 @@ def main():
     tg = c4.targets(lambda n, l: 30.0 if n in BIG else 3.0)
     n_reads = sum(r for _, _, r in tg)
     t0 = time.perf_counter()
-    bam, prefix = c4.synth(td, "hg38_big.bam", tg, threads)
+    packed = os.environ.get("C4_PACKED") == "1"          # htsjdk's layout: records packed across BGZF blocks (bam_synth's BAM_SYNTH_PACKED)
+    bam, prefix = c4.synth(td, "hg38_big.bam", tg, threads, env={"BAM_SYNTH_PACKED": "1"} if packed else None)
     t_synth = time.perf_counter() - t0
     os.unlink(prefix + ".seq4")                      # 19 GB the depth check does not need
     open(prefix + ".seq4", "wb").close()
@@ -67,7 +69,8 @@ def main():
     for ext in (".tid", ".pos", ".flag", ".kind", ".seq4"):
         os.unlink(prefix + ext)
     W = 20000
-    out = {"input": f"{n_reads:.3e} x 150 bp over the 25 hg38 contigs: 30x on chr1-chr7, 3x elsewhere; BAM {os.path.getsize(bam) / 1e9:.1f} GB",
+    out = {"input": f"{n_reads:.3e} x 150 bp over the 25 hg38 contigs: 30x on chr1-chr7, 3x elsewhere; BAM {os.path.getsize(bam) / 1e9:.1f} GB"
+                    + (", records packed across BGZF blocks" if packed else ""),
            "input_made_in_s": round(t_synth, 1), "runs": []}
     per_target = []
     for label, env in (("bam2depth, one worker", {}), ("bam2depth, targets over three workers (HPN_NGPU=3)", {"HPN_NGPU": "3"})):
