@@ -209,7 +209,6 @@ public:
     ~BgzfGpuStream()
     {
         halt_producer();
-        if (up_maker_.joinable()) up_maker_.join();
         pump_.reset();
         for (BgzfStage &st : stage_)
             if (st.d_comp && up_ctx_) hpn_dev_free(up_ctx_, st.d_comp);
@@ -222,11 +221,6 @@ public:
     {
         ctx_ = ctx;
         dev_.bind(ctx);
-        if (ahead_enabled() && !up_ctx_ && !up_maker_.joinable())
-            up_maker_ = std::thread([this] {
-                int device = 0;
-                if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) up_ctx_ = nullptr;
-            });
         FILE *f = fopen(path, "rb");
         if (!f) return false;
         std::vector<uint8_t> text, raw;
@@ -400,8 +394,8 @@ private:
     }
     bool start_producer()
     {
-        if (up_maker_.joinable()) up_maker_.join();
-        if (!up_ctx_) {
+        if (!up_ctx_) {    // (made here, not on a thread beside open(): a tool that leaves through exit() while such a thread is inside the
+                           // runtime crashes in the runtime's own teardown -- bam2depth without an index did)
             int device = 0;
             if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) return false;
         }
@@ -450,7 +444,6 @@ private:
         stop_ = false, ended_ = false;
     }
     hpn_ctx *up_ctx_ = nullptr;
-    std::thread up_maker_;           // makes up_ctx_ beside open()'s header parse (~25 ms that the first next() used to pay)
     BgzfStage stage_[2];
     std::thread producer_;
     std::mutex mu_;

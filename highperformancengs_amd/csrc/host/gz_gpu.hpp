@@ -212,7 +212,7 @@ public:
         };
         if (!sl.begun) {
             if (begin(cx, sl) != HPN_OK) return give_up(hpn_ctx_last_error(cx)) - 1;
-            stamp("symbolic decode started (the first: its scratch allocated)");
+            stamp("symbolic decode started (a context's first: its scratch allocated)");
         }
         if (!last_batch && inflate_ctx(batch_ + 1) != cx) {
             Slot &nx = slot_[(batch_ + 1) & 1];
