@@ -133,6 +133,7 @@ SYMBOLS = [
     ("hpn_depth_finish", _int, [_vp, _u32, _vp, _u64, C.POINTER(_u64), _vp]),
     ("hpn_depth_bedgraph_format", _int, [_vp, C.c_char_p, C.POINTER(_u64)]),
     ("hpn_depth_bedgraph_read", _int, [_vp, _u64, _vp, _u64]),
+    ("hpn_depth_bedgraph_dev", _int, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     ("hpn_window_begin", _int, [_vp, _i32, _vp, _u32]),
     ("hpn_window_add", _int, [_vp, C.POINTER(BamBatch)]),
     ("hpn_window_add_dev", _int, [_vp, C.POINTER(BamBatch)]),

@@ -250,7 +250,7 @@ int hpn_depth_bedgraph_format(hpn_ctx *c, const char *name, uint64_t *n_bytes)
     const size_t name_len = strlen(name);
     if (name_len > 4096) return fail(c, HPN_E_ARG, "target name of %zu characters", name_len);
     const uint64_t n = c->depth_nruns;
-    c->depth_text_bytes = 0;
+    c->depth_text_bytes = 0, c->depth_text_formatted = 0;
     *n_bytes = 0;
     if (n == 0) return HPN_OK;
     int rc;
@@ -266,8 +266,15 @@ int hpn_depth_bedgraph_format(hpn_ctx *c, const char *name, uint64_t *n_bytes)
     HPN_HIP(c, hipMemcpyAsync(&head, c->d_ws.p, sizeof head, hipMemcpyDeviceToHost, c->stream));
     HPN_HIP(c, hipStreamSynchronize(c->stream));
     if (head.err) return fail(c, HPN_E_HIP, "prefix-scan hand-off timed out");
-    c->depth_text_bytes = head.total;
+    c->depth_text_bytes = head.total, c->depth_text_formatted = head.total;
     *n_bytes = head.total;
+    return HPN_OK;
+}
+
+int hpn_depth_bedgraph_dev(hpn_ctx *c, const uint8_t **d_text, uint64_t *n_bytes)
+{
+    if (!c || !d_text || !n_bytes) return HPN_E_ARG;
+    *d_text = (const uint8_t *)c->d_text.p, *n_bytes = c->depth_text_formatted;
     return HPN_OK;
 }
 

@@ -56,6 +56,7 @@ struct hpn_ctx {
     uint64_t depth_nruns = 0;
     uint64_t depth_runs_cap = 0;  // entries the device runs buffer holds
     uint64_t depth_text_bytes = 0;  // bedGraph text formatted on the device (hpn_depth_bedgraph_format)
+    uint64_t depth_text_formatted = 0;   // ... of the last hpn_depth_bedgraph_format (hpn_depth_bedgraph_dev: survives hpn_depth_begin)
     bool depth_sweeping = false;    // batches in coordinate order are swept as they come (k_depth_sweep)
     uint32_t depth_W = 0;           // window size the sweep takes its window sums for (0: none; hpn_depth_begin_w)
     // bam_sliding_count state

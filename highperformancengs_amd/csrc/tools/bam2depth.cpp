@@ -24,6 +24,95 @@ using namespace hpn;
 
 #define BAM_DEF_MASK (4 | 256 | 512 | 1024) /* bam.h:124 */
 
+// The bedGraph text of a finished target, from the device to the file, on the writer's thread: through a context (= a stream)
+// of its own, so that the copies run beside the kernels that already ingest the next target.  First a device-to-device copy
+// into the fetcher's own buffer (a millisecond per GB) -- after it the library's text buffer is free for the next target's
+// hpn_depth_bedgraph_format (taken() tells) --, then pinned slices of 64 MiB to the file, slice k written while k + 1 is copied.
+struct TextFetcher {
+    hpn_ctx *cx = nullptr;
+    void *pin[2] = {nullptr, nullptr}, *d_own = nullptr;
+    size_t own_cap = 0;
+    static constexpr size_t kSlice = (size_t)64 << 20;
+    bool tried = false;
+    std::mutex m;
+    std::condition_variable cv;
+    bool busy = false;               // a fetch has been handed the library's buffer and has not copied it yet
+    std::thread maker;
+    // The context and the pinned slices take ~40 ms to make: started on a thread when the first target begins (not earlier: a
+    // tool that leaves through exit() -- no index, a file that is no BAM -- while a thread is inside the runtime crashes in the
+    // runtime's teardown), joined when the first target's text is there.  false: not available, the caller reads the text in line.
+    void start(hpn_ctx *main_ctx)
+    {
+        if (tried) return;
+        tried = true;
+        maker = std::thread([this, main_ctx] {
+            int device = 0;
+            if (hpn_ctx_device(main_ctx, &device) != HPN_OK || hpn_ctx_create(device, &cx) != HPN_OK) {
+                cx = nullptr;
+                return;
+            }
+            if (hpn_host_malloc(cx, kSlice, &pin[0]) != HPN_OK || hpn_host_malloc(cx, kSlice, &pin[1]) != HPN_OK) release();
+        });
+    }
+    bool ready(hpn_ctx *main_ctx)
+    {
+        start(main_ctx);
+        if (maker.joinable()) maker.join();
+        return cx != nullptr;
+    }
+    void hand_over()                 // (main thread, before the writer thread is started with the buffer)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        busy = true;
+    }
+    void taken()                     // (main thread, before the library's buffer is written again)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !busy; });
+    }
+    bool fetch(const uint8_t *d_text, uint64_t n, FILE *out)
+    {
+        bool ok = true;
+        if (n > own_cap) {
+            if (d_own) hpn_dev_free(cx, d_own);
+            d_own = nullptr, own_cap = 0;
+            if (hpn_dev_malloc(cx, (size_t)n + (size_t)(n / 4) + 4096, &d_own) == HPN_OK) own_cap = (size_t)n + (size_t)(n / 4) + 4096;
+            else ok = false;
+        }
+        if (ok && n) ok = hpn_memcpy_d2d(cx, d_own, d_text, (size_t)n) == HPN_OK && hpn_ctx_sync(cx) == HPN_OK;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            busy = false;
+        }
+        cv.notify_all();
+        if (!ok) return false;
+        const uint8_t *src = (const uint8_t *)d_own;
+        uint64_t at = 0, prev = 0;
+        int k = 0;
+        if (n && hpn_memcpy_d2h(cx, pin[0], src, n < kSlice ? n : kSlice) != HPN_OK) return false;
+        while (at < n) {
+            const uint64_t len = n - at < kSlice ? n - at : kSlice;
+            if (hpn_ctx_sync(cx) != HPN_OK) return false;                  // slice k is here
+            prev = at, at += len;
+            if (at < n && hpn_memcpy_d2h(cx, pin[(k + 1) & 1], src + at, n - at < kSlice ? n - at : kSlice) != HPN_OK) return false;
+            fwrite(pin[k & 1], 1, (size_t)(at - prev), out);
+            ++k;
+        }
+        return true;
+    }
+    void release()
+    {
+        if (maker.joinable() && std::this_thread::get_id() != maker.get_id()) maker.join();
+        if (cx) {
+            if (pin[0]) hpn_host_free(cx, pin[0]);
+            if (pin[1]) hpn_host_free(cx, pin[1]);
+            if (d_own) hpn_dev_free(cx, d_own);
+            hpn_ctx_destroy(cx);
+        }
+        cx = nullptr, pin[0] = pin[1] = nullptr, d_own = nullptr, own_cap = 0;
+    }
+};
+
 static void usage(const char *prog)
 {
     fprintf(stderr,
@@ -148,6 +237,7 @@ int main(int argc, char *argv[])
         std::vector<char> text_buf[2];
         std::vector<uint64_t> win_buf[2];
         std::thread printer;
+        TextFetcher copy;
         double t_feed = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
         bool redo = false;
         for (int32_t j = 0; j < hdr.n_targets() && !redo; ++j) {
@@ -155,6 +245,7 @@ int main(int argc, char *argv[])
             const char *name = hdr.target_name[j].c_str();
             if ((rc = hpn_depth_begin_w(ctx, j, tlen, BAM_DEF_MASK, (uint32_t)window)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");   // sorted input: swept while it streams
             if (timing && j == 0) fprintf(stderr, "[hpn] first target begun at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
+            if (dev_text && j == 0) copy.start(ctx);
             t0 = wall_s();
             rc = bam.feed(j);
             t_feed += wall_s() - t0;
@@ -169,11 +260,21 @@ int main(int argc, char *argv[])
             win.assign((size_t)tlen / window + 1, 0);
             uint64_t n_runs = 0;
             std::vector<char> &text = text_buf[j & 1];
+            const uint8_t *d_text = nullptr;
+            uint64_t text_bytes = 0;
+            bool by_fetcher = false;
             if (dev_text) {
                 uint64_t nbytes = 0;
                 rc = hpn_depth_finish(ctx, window, nullptr, 0, &n_runs, win.data());
+                copy.taken();                                 // (the writer of the target before has the text it was handed)
                 if (rc == HPN_OK) rc = hpn_depth_bedgraph_format(ctx, name, &nbytes);
-                if (rc == HPN_OK) {
+                // (the text stays on the device: the writer thread copies it out through a context of its own, in pinned slices,
+                // while this thread already ingests the next target -- 3 GB of text per 10 GB of BAM were read back in line, into
+                // pageable memory, 0.10 of the tool's 0.87 s)
+                if (rc == HPN_OK && copy.ready(ctx)) {
+                    rc = hpn_depth_bedgraph_dev(ctx, &d_text, &text_bytes);
+                    by_fetcher = rc == HPN_OK;
+                } else if (rc == HPN_OK) {                    // (no second context: read in line, as before)
                     text.resize(nbytes);
                     rc = hpn_depth_bedgraph_read(ctx, 0, text.data(), nbytes);
                 }
@@ -188,9 +289,18 @@ int main(int argc, char *argv[])
             t_finish += wall_s() - t0;
             t0 = wall_s();
             if (printer.joinable()) printer.join();
-            printer = std::thread([=, &runs, &win, &text] {
-                if (dev_text) fwrite(text.data(), 1, text.size(), bedGraph);
-                else print_bedgraph(bedGraph, name, runs.data(), n_runs);
+            if (by_fetcher) copy.hand_over();
+            printer = std::thread([=, &runs, &win, &text, &copy] {
+                if (by_fetcher) {
+                    if (!copy.fetch(d_text, text_bytes, bedGraph)) {
+                        fprintf(stderr, "bam2depth: copying the bedGraph text of %s from the device failed\n", name);
+                        _exit(1);
+                    }
+                } else if (dev_text) {
+                    fwrite(text.data(), 1, text.size(), bedGraph);
+                } else {
+                    print_bedgraph(bedGraph, name, runs.data(), n_runs);
+                }
                 print_depth_bins(depth, name, tlen, window, win.data());
                 if (wig) {
                     print_wig_bins(WIG, name, tlen, window, win.data());
@@ -203,6 +313,7 @@ int main(int argc, char *argv[])
         t0 = wall_s();
         if (printer.joinable()) printer.join();
         t_print += wall_s() - t0;
+        copy.release();
         if (getenv("HPN_TIMING"))
             fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  waiting for the writer %.3f s%s\n",
                     bam.on_gpu() ? "GPU" : "host", t_feed, t_finish, t_print, redo ? "  (abandoned: not decodable on the GPU)" : "");

@@ -425,6 +425,10 @@ int hpn_depth_finish(hpn_ctx *ctx, uint32_t W, hpn_run *runs, uint64_t runs_cap,
  * text[offset, offset + nbytes) to `dst` (host; pinned memory makes the copy faster). */
 int hpn_depth_bedgraph_format(hpn_ctx *ctx, const char *target_name, uint64_t *n_bytes);
 int hpn_depth_bedgraph_read(hpn_ctx *ctx, uint64_t offset, void *dst, uint64_t nbytes);
+/* Where the text of the last hpn_depth_bedgraph_format lies on the device, for a caller that copies it out itself -- through
+ * another context's stream (hpn_memcpy_d2h), beside the kernels of the NEXT target: the bytes stay put until this context's
+ * next hpn_depth_bedgraph_format (hpn_depth_begin / _add / _finish do not touch them).  bam2depth's writer does this. */
+int hpn_depth_bedgraph_dev(hpn_ctx *ctx, const uint8_t **d_text, uint64_t *n_bytes);
 
 /* ---- bam_sliding_count: replaces fetch_func + cal_GC ----------------------------------
  * bam_sliding_count.c:84-124.  Slot of a record = win_off[tid] + (uint16)(pos/W)
