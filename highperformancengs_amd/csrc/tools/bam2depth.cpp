@@ -237,7 +237,12 @@ int main(int argc, char *argv[])
         std::vector<char> text_buf[2];
         std::vector<uint64_t> win_buf[2];
         std::thread printer;
-        TextFetcher copy;
+        // (one for the process, made for the first large input and never taken apart: the tool leaves through _exit, and taking a
+        // context apart costs as much as making it -- on a 600 MB BAM the fetcher's 40 + 30 ms were a quarter of the run, so
+        // files under 2 GiB read their text in line as before)
+        static TextFetcher &copy = *new TextFetcher;     // (never destroyed: no destructor runs on whatever path the tool leaves)
+        struct stat fsb;
+        const bool fetch_aside = stat(infiles[i], &fsb) == 0 && fsb.st_size >= ((off_t)2 << 30);
         double t_feed = 0, t_finish = 0, t_print = 0, t0;  // HPN_TIMING diagnostics
         bool redo = false;
         for (int32_t j = 0; j < hdr.n_targets() && !redo; ++j) {
@@ -245,7 +250,7 @@ int main(int argc, char *argv[])
             const char *name = hdr.target_name[j].c_str();
             if ((rc = hpn_depth_begin_w(ctx, j, tlen, BAM_DEF_MASK, (uint32_t)window)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");   // sorted input: swept while it streams
             if (timing && j == 0) fprintf(stderr, "[hpn] first target begun at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
-            if (dev_text && j == 0) copy.start(ctx);
+            if (dev_text && fetch_aside && j == 0) copy.start(ctx);
             t0 = wall_s();
             rc = bam.feed(j);
             t_feed += wall_s() - t0;
@@ -271,7 +276,7 @@ int main(int argc, char *argv[])
                 // (the text stays on the device: the writer thread copies it out through a context of its own, in pinned slices,
                 // while this thread already ingests the next target -- 3 GB of text per 10 GB of BAM were read back in line, into
                 // pageable memory, 0.10 of the tool's 0.87 s)
-                if (rc == HPN_OK && copy.ready(ctx)) {
+                if (rc == HPN_OK && fetch_aside && copy.ready(ctx)) {
                     rc = hpn_depth_bedgraph_dev(ctx, &d_text, &text_bytes);
                     by_fetcher = rc == HPN_OK;
                 } else if (rc == HPN_OK) {                    // (no second context: read in line, as before)
@@ -290,7 +295,7 @@ int main(int argc, char *argv[])
             t0 = wall_s();
             if (printer.joinable()) printer.join();
             if (by_fetcher) copy.hand_over();
-            printer = std::thread([=, &runs, &win, &text, &copy] {
+            printer = std::thread([=, &runs, &win, &text] {
                 if (by_fetcher) {
                     if (!copy.fetch(d_text, text_bytes, bedGraph)) {
                         fprintf(stderr, "bam2depth: copying the bedGraph text of %s from the device failed\n", name);
@@ -313,7 +318,7 @@ int main(int argc, char *argv[])
         t0 = wall_s();
         if (printer.joinable()) printer.join();
         t_print += wall_s() - t0;
-        copy.release();
+        if (copy.maker.joinable()) copy.maker.join();
         if (getenv("HPN_TIMING"))
             fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  waiting for the writer %.3f s%s\n",
                     bam.on_gpu() ? "GPU" : "host", t_feed, t_finish, t_print, redo ? "  (abandoned: not decodable on the GPU)" : "");
