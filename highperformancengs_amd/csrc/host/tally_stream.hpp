@@ -150,7 +150,7 @@ inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, boo
             break;
         }
         const bool last = r == 0 || gs.at_eof();
-        // One inflate launch covers up to four chunks of compressed bytes: at a ratio of 6 (binned qualities) that is past the
+        // One inflate launch covers up to eight chunks of compressed bytes: at a ratio of 6 (binned qualities) that is far past the
         // 2 GiB one hpn_fastq_text_count call frames.  The text is cut anywhere, as on the gzip route below.
         const uint64_t n = r == 0 ? 0 : bi.n_records, slice = bgzf_text_slice();
         for (uint64_t at = 0; rc == HPN_OK && !*unusable && (at < n || (last && n == 0));) {
