@@ -38,7 +38,8 @@ def test_gpus_n_starts_n_ranks_and_says_so(n):
     assert j["scaling"] == "weak" and j["config"]["reads_per_gpu"] == 3000
     assert j["config"]["backend"].startswith("stub")          # and nobody can mistake this line for a measurement
     # whole-job value: N ranks x reads x length x steps over the slowest rank's time
-    assert abs(j["value"] - n * 3000 * 60 * 2 / (j["ms_per_step"] * 2e-3) / 1e9) / j["value"] < 1e-2
+    # (value is printed with three decimals: on a loaded host it is small enough for that rounding to matter)
+    assert abs(j["value"] - n * 3000 * 60 * 2 / (j["ms_per_step"] * 2e-3) / 1e9) < 1e-2 * j["value"] + 6e-4
 
 
 def test_more_ranks_than_devices_fails_loudly():
