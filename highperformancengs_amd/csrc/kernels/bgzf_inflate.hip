@@ -72,26 +72,6 @@ struct ByteSink {
     {
         if (live) out[at] = (uint8_t)val;
     }
-    // (at + len <= out_len: checked by the caller)
-    __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t len, uint32_t dist)
-    {
-        if (dist > at) return 14;
-        const uint32_t start = at - dist, lane = (uint32_t)lane_id();
-        if (start + (len < dist ? len : dist) > safe) {
-            // the source reaches into bytes this wave stored a moment ago: wait for those stores
-            // (workgroup scope = this CU's vector cache: a counter wait, no cache invalidate)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            safe = at;
-        }
-        if (dist >= len) {  // the usual case: source and destination do not overlap
-            for (uint32_t i0 = 0; i0 < len; i0 += kWave)
-                if (i0 + lane < len) out[at + i0 + lane] = out[start + i0 + lane];
-        } else {  // overlapping match = periodic pattern: every source byte exists already
-            for (uint32_t i0 = 0; i0 < len; i0 += kWave)
-                if (i0 + lane < len) out[at + i0 + lane] = out[start + (i0 + lane) % dist];
-        }
-        return 0;
-    }
 };
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,

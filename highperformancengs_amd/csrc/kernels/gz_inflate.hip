@@ -81,25 +81,6 @@ struct SymSink {
     {
         if (live) *(uint16_t *)((uint8_t *)out + (at << 1)) = (uint16_t)val;
     }
-    // (at + len <= out_len: checked by the caller)
-    __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t len, uint32_t dist)
-    {
-        if (dist > at + kGzHist) return 14;
-        const int32_t start = (int32_t)at - (int32_t)dist;  // negative: in the history before this stretch
-        const uint32_t lane = (uint32_t)lane_id();
-        if (start + (int32_t)(len < dist ? len : dist) > (int32_t)safe) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            safe = at;
-        }
-        for (uint32_t i0 = 0; i0 < len; i0 += kWave) {
-            const uint32_t i = i0 + lane;
-            if (i < len) {
-                const int32_t idx = start + (int32_t)(dist >= len ? i : i % dist);
-                out[at + i] = idx < 0 ? (uint16_t)(256 + (int32_t)kGzHist + idx) : out[idx];
-            }
-        }
-        return 0;
-    }
 };
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_gz_sym_inflate(const uint8_t *__restrict__ comp, const GzChunk *__restrict__ chunks,
@@ -265,7 +246,6 @@ struct TextCheck {     // a sink that keeps nothing
         if (__ballot(mine && !(texty((e >> 16) & 255u) && (!two || texty(e >> 24))))) bad = 1;
     }
     __device__ __forceinline__ bool in_reach(uint32_t at, uint32_t dist) const { return dist <= at + kGzHist; }
-    __device__ __forceinline__ uint32_t match(uint32_t at, uint32_t, uint32_t dist) { return dist > at + kGzHist ? 14u : 0u; }
 };
 
 // does a dynamic block that decodes to text start at bit p, with something that begins like a block behind it?

@@ -39,12 +39,19 @@ __device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t 
     return value << 16 | extra << 8 | kind << 4 | nbits;
 }
 
+constexpr uint32_t kQueue = 128;               // decoded symbols waiting for their output positions (emit())
 struct InfLds {
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
-    uint32_t ring[kRing / 4 + 1];   // (+ a copy of word 0 behind the last: a window reads two neighbouring words with one instruction)
-    uint8_t lens[384];     // code lengths being assembled (19 code-length codes | 286 + 30 lengths from offset 32)
-    uint16_t count[16], first[16], next[16];
+    uint32_t ring[kRing / 4 + 2];   // (+ copies of words 0 and 1 behind the last: a window reads three neighbouring words)
+    union {
+        struct {                    // while a block's code tables are built
+            uint8_t lens[384];      // code lengths being assembled (19 code-length codes | 286 + 30 lengths from offset 32)
+            uint16_t count[16], first[16], next[16];
+        };
+        uint32_t queue[kQueue];     // while its symbols are decoded (empty between blocks)
+    };
+    uint32_t spot[kWave];           // assemble(): which symbol starts at which output position of a chunk
 };
 
 constexpr uint32_t kInflateWavesPerCu = HPN_INF_WAVES;
@@ -74,7 +81,7 @@ __device__ __forceinline__ void stage(InfLds &s, Bits &b, const uint8_t *__restr
         u32 v = {0, 0, 0, 0};
         if (at < in_len + 16u) __builtin_memcpy(&v, in + at, 16);  // the buffer is padded by the host
         *(u32 *)((uint8_t *)s.ring + (at & (kRing - 1))) = v;
-        if ((at & (kRing - 1)) == 0) s.ring[kRing / 4] = v[0];
+        if ((at & (kRing - 1)) == 0) s.ring[kRing / 4] = v[0], s.ring[kRing / 4 + 1] = v[1];
     }
     b.filled += kRing / 2;
 }
@@ -216,15 +223,16 @@ __device__ __forceinline__ uint32_t lookup(const uint32_t *tab, uint32_t root, B
 // arithmetic between the vector and the scalar unit, nor dropping the per-literal store, nor taking the LDS round trip off
 // the chain changed the kernel's time (round 3 A/B runs, profiles/r03/inflate_ab.txt).  So the work per symbol is moved to
 // the lanes, which were idle:
-//   * lane k looks up the code that WOULD start at bit k of the next 64 bits of the stream (one ring read and one table
-//     read per lane, for the literal/length table and for the distance table), and works out what that symbol would be:
-//     its literal(s), or its length, the distance code behind it (ds_bpermute from the lane where it starts) and the
-//     distance, and the offset of the code after it;
+//   * lane k holds the 64 bits of the stream from bit k of the window on (three ring words, two funnel shifts) and works out
+//     the symbol that WOULD start there, all by itself: literal(s), or length + distance (both codes, both runs of extra bits:
+//     at most 15 + 5 + 15 + 13 = 48 bits), and where the code after it starts;
 //   * the wave follows the true chain of symbol starts through those offsets -- v_readlane + s_bitset1 per symbol, nothing else;
-//   * the lanes on the chain then take their places in the output with one prefix sum; a window of literals goes out in one
-//     (two) store instruction(s), a window with matches is assembled by the lanes, one output position each (assemble()).
-// A symbol that does not fit the rest of the window starts the next window (it fits any window it starts: 15 + 5 + 15 +
-// 13 bits); a code longer than its root table (second-level look-up) is decoded by the serial reader, then windows resume.
+//   * the lanes on the chain append their symbols to a queue in LDS (one word each: units of output | literals or distance).
+// A window ends with the first symbol that STARTS at or behind bit 64 (round 5; until then a match had to lie inside the 64
+// lanes with both its codes, because the distance code was fetched from the lane where it starts: windows took ~55 bits).
+// Output positions are NOT worked out per window: when 64 symbols are queued they leave together (emit()): one prefix sum over
+// 64 symbols, and assemble() -- whose cost is per 64 output positions -- runs on full chunks instead of one window's ~14 bytes
+// (round 4: a window with a match paid for a whole chunk; that was 80 of its ~250 instructions).
 struct Pos {             // consumed position in the chunk: `bit` (0..7) bits into byte `byte`
     uint32_t byte, bit;
 };
@@ -240,27 +248,25 @@ __device__ __forceinline__ void seek(InfLds &s, Bits &b, Pos p, const uint8_t *_
     drop(b, p.bit);
 }
 struct Win {
-    uint32_t raw;        // >= 25 bits of the stream from bit (p + lane) on
-    uint32_t el, ed;     // root entries of the literal/length and of the distance table for them
+    uint32_t lo, hi;     // the 64 bits of the stream from bit (p + lane) on
+    uint32_t el;         // the literal/length entry for them (a code longer than the root table already resolved)
 };
-// (the ring holds the bytes the window reads, up to byte p.byte + 16: decode_symbols stages ahead of it)
-__device__ __forceinline__ Win window(const InfLds &s, Pos p)
+// bitpos: the window's first bit, counted from the chunk's first byte (only its low 12 bits matter).  The ring holds the bytes
+// the window reads, up to byte p.byte + 20: decode_symbols stages ahead of it.
+__device__ __forceinline__ Win window(const InfLds &s, uint32_t bitpos)
 {
-    const uint32_t q = p.bit + (uint32_t)lane_id();
-    const uint32_t byte = p.byte + (q >> 3);
-    const uint32_t i0 = (byte >> 2) & (kRing / 4 - 1);
-    const uint32_t v = (uint32_t)((((u64)s.ring[i0 + 1u] << 32) | s.ring[i0]) >> (8u * (byte & 3u)));   // 32 bits from `byte` on (ring[kRing / 4] = ring[0])
+    const uint32_t q = bitpos + (uint32_t)lane_id();
+    const uint32_t i0 = (q >> 5) & (kRing / 4 - 1);
+    const uint32_t w0 = s.ring[i0], w1 = s.ring[i0 + 1u], w2 = s.ring[i0 + 2u];   // (ring[kRing / 4 + k] = ring[k])
     Win w;
-    w.raw = v >> (q & 7u);
-    w.el = s.lit[w.raw & ((1u << kLitRoot) - 1u)];
-    w.ed = s.dist[w.raw & ((1u << kDistRoot) - 1u)];
-    // codes longer than a root table: the lanes that hold one take the second-level entry themselves and count the root's bits
-    // into it -- the walk sees a plain entry of up to 15 bits (left to the serial reader, each such code on the chain is a
-    // detour of a thousand clocks: rare length codes and the 256-symbol alphabets of BAM blocks have them)
-    const bool sub_l = (w.el & 0xf0u) == (kSub << 4), sub_d = (w.ed & 0xf0u) == (kSub << 4);
-    if (__ballot(sub_l || sub_d)) {      // (one test for both tables: most windows hold no long code)
-        if (sub_l) w.el = s.lit[(w.el >> 16) + ((w.raw >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
-        if (sub_d) w.ed = s.dist[(w.ed >> 16) + ((w.raw >> kDistRoot) & ((1u << ((w.ed >> 8) & 15u)) - 1u))] + kDistRoot;
+    w.lo = __builtin_amdgcn_alignbit(w1, w0, q);      // (the shift is q & 31)
+    w.hi = __builtin_amdgcn_alignbit(w2, w1, q);
+    w.el = s.lit[w.lo & ((1u << kLitRoot) - 1u)];
+    // a code longer than the root table: the lane that holds one takes the second-level entry itself and counts the root's
+    // bits into it -- the walk sees a plain entry of up to 15 bits (rare length codes and the 256-symbol alphabets of BAM blocks)
+    const bool sub_l = (w.el & 0xf0u) == (kSub << 4);
+    if (__ballot(sub_l)) {
+        if (sub_l) w.el = s.lit[(w.el >> 16) + ((w.lo >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
     }
     return w;
 }
@@ -298,9 +304,9 @@ __device__ __forceinline__ uint32_t wave_prefix_max(uint32_t v)
     return v;
 }
 
-// The output of a window that holds matches, 64 positions at a time, one position per lane.  The symbols on the chain sit
-// in their lanes (`mine`): rel = where the symbol's output starts (from sink.op), el = its table entry (the literals), dist =
-// its distance, 0 for literals.  Every output position finds its symbol (the symbols' lane numbers written to their start
+// The output of a batch of symbols, 64 positions at a time, one position per lane.  The symbols sit in their lanes (`mine`):
+// rel = where the symbol's output starts (from sink.op), el = its word (the literals in [31:16]), dist = its distance, 0 for
+// literals.  Every output position finds its symbol (the symbols' lane numbers written to their start
 // positions in 64 words of LDS, then a prefix maximum), takes the symbol's words from its lane (ds_bpermute) and is a
 // literal byte, or a copy of position - dist: of memory (sink.fetch: waits for this wave's stores first where they are
 // in the way; in front of a gzip stretch: a history placeholder), or of a lane of this very chunk -- those are followed by
@@ -312,7 +318,7 @@ template <typename Sink>
 __device__ __forceinline__ void assemble(InfLds &s, Sink &sink, bool mine, uint32_t rel, uint32_t el, uint32_t dist, uint32_t total)
 {
     const uint32_t lane = (uint32_t)lane_id();
-    uint32_t *spot = reinterpret_cast<uint32_t *>(s.lens);          // (the code lengths are not needed while symbols are decoded)
+    uint32_t *spot = s.spot;
     const uint32_t words = rel | dist << 16;                        // rel < 64 * 258, dist <= 32768
     uint32_t carry = 0;                                             // the symbol the chunk before ended in
     for (uint32_t c0 = 0; c0 < total; c0 += (uint32_t)kWave) {
@@ -328,7 +334,7 @@ __device__ __forceinline__ void assemble(InfLds &s, Sink &sink, bool mine, uint3
         const uint32_t w = from_lane(words, own - 1u), e = from_lane(el, own - 1u);
         const uint32_t p = c0 + lane, i = p - (w & 0xffffu), d = w >> 16;
         const bool live = p < total, copy = live && d != 0;
-        uint32_t val = (e >> (16u + 8u * (i & 1u))) & 255u;         // a literal: byte i of its entry
+        uint32_t val = (e >> (16u + 8u * (i & 1u))) & 255u;         // a literal: byte i of its word
         const int32_t from = (int32_t)(sink.op + p) - (int32_t)d;   // a copy: of this position (may lie in front of a gzip stretch)
         const bool near = copy && from >= (int32_t)(sink.op + c0);
 #ifndef DIAG_NOFETCH
@@ -352,35 +358,68 @@ __device__ __forceinline__ void assemble(InfLds &s, Sink &sink, bool mine, uint3
     }
 }
 
-// One window.  -> how it ended; o = bits consumed (the symbol at o is still to be decoded, except behind an end-of-block code).
-// The sink: op / out_len -- symbols written / allowed; lits(mine, two, at, e) -- the lanes for which `mine` holds store the one
-// (two) literal(s) of THEIR entry e at symbol `at`; in_reach(at, dist) -- a match at `at` may refer `dist` back; fetch / put:
-// see assemble(); match(at, len, dist) -> 0 or an error code (wave-uniform arguments: the serial reader's matches).
-enum { kWinNext = 0, kWinEob = 1, kWinSerial = 2, kWinError = 3 };
+// The symbols decoded and not yet written: words in s.queue[(head + i) % kQueue], i < n.  A word: [8:0] the units of output
+// (1 or 2: literals, [23:16] and [31:24]; 3..258: a match, its distance in [31:16]).
+struct Queue {
+    uint32_t head, n;
+};
+
+// The first `take` (<= 64) queued symbols leave.  -> 0 or the decoder's error code.
+// The sink: op / out_len -- units written / allowed; lits(mine, two, at, w) -- the lanes for which `mine` holds store the one
+// (two) literal(s) of THEIR word at `at`; in_reach(at, dist) -- a match at `at` may refer `dist` back; fetch / put: see assemble().
 template <typename Sink>
-__device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, uint32_t &o, uint32_t &err)
+__device__ __forceinline__ uint32_t emit(InfLds &s, Sink &sink, Queue &q, uint32_t take)
+{
+    const uint32_t lane = (uint32_t)lane_id();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the words were written by other lanes)
+    __builtin_amdgcn_wave_barrier();
+    const bool mine = lane < take;
+    const uint32_t w = mine ? s.queue[(q.head + lane) & (kQueue - 1u)] : 0u;
+    const uint32_t units = w & 0x1ffu;
+    const bool is_match = units >= 3u;
+    const uint32_t upto = wave_prefix(units), total = lane_of(upto, kWave - 1), rel = upto - units;
+    const uint32_t dist = is_match ? w >> 16 : 0u;
+    q.head = (q.head + take) & (kQueue - 1u), q.n -= take;
+    const u64 matches = __ballot(is_match);
+    if constexpr (Sink::kDry) sink.lits(mine && !is_match, units == 2u, 0u, w);   // nothing is stored: the sink only looks at the literals
+    if (__ballot(is_match && !sink.in_reach(sink.op + rel, dist))) return 14;
+    if (sink.op + total > sink.out_len) return 12;
+    if constexpr (!Sink::kDry) {
+        if (matches == 0) sink.lits(mine, units == 2u, sink.op + rel, w);
+#ifndef DIAG_NOASSEMBLE
+        else assemble(s, sink, mine, rel, w, dist, total);
+#endif
+    }
+    sink.op += total;
+    return 0;
+}
+
+// One window.  -> how it ended; o = bits consumed (the symbol at o is still to be decoded, except behind an end-of-block code).
+enum { kWinNext = 0, kWinEob = 1, kWinError = 3 };
+__device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint32_t &o, uint32_t &err)
 {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t kind = (w.el >> 4) & 15u, bits = w.el & 15u;
-    const bool is_lit = kind <= kLit2;
     // what the symbol starting here would be, and where the one behind it starts
-    uint32_t nxt = lane + bits, len = 0, dist = 0, why = kWinError;
-    bool is_match = false;
-    const u64 len_lanes = __ballot(kind == kLen);
-    if (len_lanes) {                                  // (same in every lane: windows of literals skip the three exchanges)
-        const uint32_t xb = (w.el >> 8) & 15u, o2 = lane + bits + xb;              // o2: where the distance code starts
-        len = (w.el >> 16) + ((w.raw >> bits) & ((1u << xb) - 1u));
-        const uint32_t d = from_lane(w.ed, o2), dk = (d >> 4) & 15u, dxb = (d >> 8) & 15u, o3 = o2 + (d & 15u);   // o3: its extra bits
-        dist = (d >> 16) + (from_lane(w.raw, o3) & ((1u << dxb) - 1u));
+    uint32_t nxt = lane + bits, word = (w.el & 0xffff0000u) | (kind + 1u);
+    bool emits = kind <= kLit2;
+    if (__ballot(kind == kLen)) {                     // (same in every lane: windows of literals skip this)
+        const uint32_t xb = (w.el >> 8) & 15u, o2 = bits + xb;                     // o2: where the distance code starts
+        const uint32_t len = (w.el >> 16) + ((w.lo >> bits) & ((1u << xb) - 1u));
+        const uint32_t d32 = __builtin_amdgcn_alignbit(w.hi, w.lo, o2);            // 32 bits from there on (o2 <= 20)
+        uint32_t ed = s.dist[d32 & ((1u << kDistRoot) - 1u)];
+        const bool sub_d = (ed & 0xf0u) == (kSub << 4);
+        if (__ballot(sub_d)) {
+            if (sub_d) ed = s.dist[(ed >> 16) + ((d32 >> kDistRoot) & ((1u << ((ed >> 8) & 15u)) - 1u))] + kDistRoot;
+        }
+        const uint32_t db = ed & 15u, dxb = (ed >> 8) & 15u;
+        const uint32_t dist = (ed >> 16) + ((d32 >> db) & ((1u << dxb) - 1u));     // db + dxb <= 28
         if (kind == kLen) {
-            nxt = o3 + dxb;
-            is_match = o2 < (uint32_t)kWave && dk == kDist && o3 < (uint32_t)kWave;
-            // a length whose distance is not in reach: beyond the window -> the next window starts with this symbol; a
-            // distance code longer than the root table -> the serial reader; anything else is not a distance code
-            why = o2 >= (uint32_t)kWave ? kWinNext : dk == kSub ? kWinSerial : dk != kDist ? kWinError : kWinNext;
+            nxt = lane + o2 + db + dxb;
+            emits = (ed & 0xf0u) == (kDist << 4);     // anything else is not a distance code: the chain stops here with an error
+            word = len | dist << 16;
         }
     }
-    const bool emits = is_lit || is_match;
     // the chain's fixed point: a lane whose symbol this window does not take, or whose symbol ends the window
     const uint32_t hop = emits && nxt < (uint32_t)kWave ? nxt : lane;
     u64 on = 1;
@@ -395,43 +434,10 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, ui
         if (d == c) break;
     }
     const u64 taken = on & __ballot(emits);
-    const bool mine = (taken >> lane) & 1u;
-    uint32_t at, total;
-    if ((taken & len_lanes) == 0) {
-        // literals only (one or two per symbol): a lane's place is the number of taken lanes below it plus those of them that hold
-        // a pair -- four count instructions on the two masks instead of a six-step prefix sum
-        const u64 pairs = taken & __ballot(kind == kLit2);
-        uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
-        below = __builtin_amdgcn_mbcnt_hi((uint32_t)(pairs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pairs, below));
-        at = sink.op + below;
-        total = (uint32_t)__builtin_popcountll(taken) + (uint32_t)__builtin_popcountll(pairs);
-    } else {
-        const uint32_t units = mine ? (is_lit ? kind + 1u : len) : 0u;
-        const uint32_t upto = wave_prefix(units);
-        at = sink.op + upto - units, total = lane_of(upto, kWave - 1);
-    }
-    if (sink.op + total > sink.out_len) {
-        err = 12;
-        return kWinError;
-    }
-    if constexpr (Sink::kDry) {                       // nothing is stored: the sink only looks at the literals
-        sink.lits(mine && is_lit, kind != 0, at, w.el);
-        if (__ballot(mine && !is_lit && !sink.in_reach(at, dist))) {
-            err = 14;
-            return kWinError;
-        }
-    } else if ((taken & len_lanes) == 0) {
-        sink.lits(mine, kind != 0, at, w.el);
-    } else {
-        if (__ballot(mine && !is_lit && !sink.in_reach(at, dist))) {
-            err = 14;
-            return kWinError;
-        }
-#ifndef DIAG_NOASSEMBLE
-        assemble(s, sink, mine, at - sink.op, w.el, is_lit ? 0u : dist, total);
-#endif
-    }
-    sink.op += total;
+    // the taken lanes' words, in stream order, behind what is queued
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
+    if ((taken >> lane) & 1u) s.queue[(q.head + q.n + below) & (kQueue - 1u)] = word;
+    q.n += (uint32_t)__builtin_popcountll(taken);
     if ((taken >> f) & 1u) {                          // the last symbol ends in or behind the window's last bit
         o = lane_of(nxt, f);
         return kWinNext;
@@ -442,13 +448,7 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Sink &sink, ui
         o += fe & 15u;
         return kWinEob;
     }
-    if (fk == kSub) return kWinSerial;
-    if (fk == kLen) {
-        const uint32_t how = lane_of(why, f);
-        if (how == kWinError) err = 13;
-        return how;
-    }
-    err = 15;
+    err = fk == kLen ? 13 : 15;                       // a length without a distance code behind it / not a code at all
     return kWinError;
 }
 
@@ -462,58 +462,38 @@ __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const
     auto due = [&]() { return b.filled < in_len + 8u ? b.filled - (8u + kRing / 4) : 0xffffffffu; };
     b.filled = uni(b.filled);
     uint32_t ahead = due();
+    Queue q{0u, 0u};
     for (;;) {
-        p.byte = uni(p.byte), p.bit = uni(p.bit), ahead = uni(ahead), sink.pin_state();
+        p.byte = uni(p.byte), p.bit = uni(p.bit), ahead = uni(ahead), q.head = uni(q.head), q.n = uni(q.n), sink.pin_state();
         if (p.byte > ahead) {
             stage(s, b, in, in_len);
             b.filled = uni(b.filled), ahead = due();
         }
-        const Win w = window(s, p);
+        const Win w = window(s, p.byte * 8u + p.bit);
         uint32_t o;
-        const uint32_t how = walk(s, w, sink, o, err);
+        const uint32_t how = walk(s, w, q, o, err);
         if (how == kWinError) return false;
-        if constexpr (Sink::kDry) {
-            if (sink.bad) {                          // (a trial decode of something that is not text: no need to go on)
-                err = 16;
-                return false;
+        if (q.n >= (uint32_t)kWave) {                 // (a window adds at most 64: the queue holds 128)
+            if ((err = emit(s, sink, q, kWave)) != 0) return false;
+            if constexpr (Sink::kDry) {
+                if (sink.bad) {                          // (a trial decode of something that is not text: no need to go on)
+                    err = 16;
+                    return false;
+                }
             }
         }
         p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
-        if (how == kWinEob) return true;
-        if (how == kWinSerial) {            // one symbol with a code longer than a root table, by the serial reader
-            seek(s, b, p, in, in_len);
-            const uint32_t e = lookup(s.lit, kLitRoot, b), kind = (e >> 4) & 15u;
-            if (kind <= kLit2) {
-                if (sink.op + kind + 1u > sink.out_len) {
-                    err = 12;
-                    return false;
-                }
-                sink.lits(lane_id() == 0, kind != 0, sink.op, e);
-                sink.op += kind + 1u;
-            } else if (kind == kLen) {
-                const uint32_t len = (e >> 16) + take(b, (e >> 8) & 255u);
-                refill(s, b, in, in_len);
-                const uint32_t d = lookup(s.dist, kDistRoot, b);
-                if (((d >> 4) & 15u) != kDist) {
-                    err = 13;
-                    return false;
-                }
-                const uint32_t dist = (d >> 16) + take(b, (d >> 8) & 255u);
-                if (sink.op + len > sink.out_len) {
-                    err = 14;
-                    return false;
-                }
-                if ((err = sink.match(sink.op, len, dist)) != 0) return false;
-                sink.op += len;
-            } else if (kind == kEob) {
-                p = pos_of(b);
-                return true;
-            } else {
-                err = 15;
-                return false;
+        if (how == kWinEob) {
+            while (q.n) {
+                if ((err = emit(s, sink, q, q.n < (uint32_t)kWave ? q.n : (uint32_t)kWave)) != 0) return false;
             }
-            p = pos_of(b);
-            b.filled = uni(b.filled), ahead = due();
+            if constexpr (Sink::kDry) {
+                if (sink.bad) {
+                    err = 16;
+                    return false;
+                }
+            }
+            return true;
         }
     }
 }
