@@ -264,10 +264,7 @@ __device__ __forceinline__ Win window(const InfLds &s, uint32_t bitpos)
     w.el = s.lit[w.lo & ((1u << kLitRoot) - 1u)];
     // a code longer than the root table: the lane that holds one takes the second-level entry itself and counts the root's
     // bits into it -- the walk sees a plain entry of up to 15 bits (rare length codes and the 256-symbol alphabets of BAM blocks)
-    const bool sub_l = (w.el & 0xf0u) == (kSub << 4);
-    if (__ballot(sub_l)) {
-        if (sub_l) w.el = s.lit[(w.el >> 16) + ((w.lo >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
-    }
+    if ((w.el & 0xf0u) == (kSub << 4)) w.el = s.lit[(w.el >> 16) + ((w.lo >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
     return w;
 }
 __device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -408,10 +405,7 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
         const uint32_t len = (w.el >> 16) + ((w.lo >> bits) & ((1u << xb) - 1u));
         const uint32_t d32 = __builtin_amdgcn_alignbit(w.hi, w.lo, o2);            // 32 bits from there on (o2 <= 20)
         uint32_t ed = s.dist[d32 & ((1u << kDistRoot) - 1u)];
-        const bool sub_d = (ed & 0xf0u) == (kSub << 4);
-        if (__ballot(sub_d)) {
-            if (sub_d) ed = s.dist[(ed >> 16) + ((d32 >> kDistRoot) & ((1u << ((ed >> 8) & 15u)) - 1u))] + kDistRoot;
-        }
+        if ((ed & 0xf0u) == (kSub << 4)) ed = s.dist[(ed >> 16) + ((d32 >> kDistRoot) & ((1u << ((ed >> 8) & 15u)) - 1u))] + kDistRoot;
         const uint32_t db = ed & 15u, dxb = (ed >> 8) & 15u;
         const uint32_t dist = (ed >> 16) + ((d32 >> db) & ((1u << dxb) - 1u));     // db + dxb <= 28
         if (kind == kLen) {
@@ -438,18 +432,13 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
     if ((taken >> lane) & 1u) s.queue[(q.head + q.n + below) & (kQueue - 1u)] = word;
     q.n += (uint32_t)__builtin_popcountll(taken);
-    if ((taken >> f) & 1u) {                          // the last symbol ends in or behind the window's last bit
-        o = lane_of(nxt, f);
-        return kWinNext;
-    }
-    const uint32_t fe = lane_of(w.el, f), fk = (fe >> 4) & 15u;
-    o = f;
-    if (fk == kEob) {
-        o += fe & 15u;
-        return kWinEob;
-    }
-    err = fk == kLen ? 13 : 15;                       // a length without a distance code behind it / not a code at all
-    return kWinError;
+    // the chain's last lane: its symbol was taken and ends in or behind the window's last bit, or it is the end-of-block code,
+    // or an error (a length without a distance code behind it: 13; not a code at all: 15)
+    const uint32_t fe = lane_of(w.el, f), fn = lane_of(nxt, f), fk = (fe >> 4) & 15u;
+    const bool last_taken = (taken >> f) & 1u;
+    o = last_taken || fk == kEob ? fn : f;           // (an end-of-block code's nxt = lane + bits, too)
+    if (!last_taken && fk != kEob) err = fk == kLen ? 13 : 15;
+    return last_taken ? kWinNext : fk == kEob ? kWinEob : kWinError;
 }
 
 // Decodes symbols from p on until the block's end-of-block code (-> true: p is behind it) or an error (-> false, err set).
@@ -464,37 +453,36 @@ __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const
     uint32_t ahead = due();
     Queue q{0u, 0u};
     for (;;) {
-        p.byte = uni(p.byte), p.bit = uni(p.bit), ahead = uni(ahead), q.head = uni(q.head), q.n = uni(q.n), sink.pin_state();
-        if (p.byte > ahead) {
-            stage(s, b, in, in_len);
-            b.filled = uni(b.filled), ahead = due();
-        }
-        const Win w = window(s, p.byte * 8u + p.bit);
-        uint32_t o;
-        const uint32_t how = walk(s, w, q, o, err);
+        // windows, until 64 symbols are queued or the block ends (the loop the decoder lives in: one exit test)
+        uint32_t how;
+        do {
+            p.byte = uni(p.byte), p.bit = uni(p.bit), ahead = uni(ahead), q.head = uni(q.head), q.n = uni(q.n);
+            if (p.byte > ahead) {
+                stage(s, b, in, in_len);
+                b.filled = uni(b.filled), ahead = due();
+            }
+            const Win w = window(s, p.byte * 8u + p.bit);
+            uint32_t o;
+            how = walk(s, w, q, o, err);
+            p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
+        } while (how == kWinNext && q.n < (uint32_t)kWave);
         if (how == kWinError) return false;
+        sink.pin_state();
         if (q.n >= (uint32_t)kWave) {                 // (a window adds at most 64: the queue holds 128)
             if ((err = emit(s, sink, q, kWave)) != 0) return false;
-            if constexpr (Sink::kDry) {
-                if (sink.bad) {                          // (a trial decode of something that is not text: no need to go on)
-                    err = 16;
-                    return false;
-                }
-            }
         }
-        p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
         if (how == kWinEob) {
             while (q.n) {
                 if ((err = emit(s, sink, q, q.n < (uint32_t)kWave ? q.n : (uint32_t)kWave)) != 0) return false;
             }
-            if constexpr (Sink::kDry) {
-                if (sink.bad) {
-                    err = 16;
-                    return false;
-                }
-            }
-            return true;
         }
+        if constexpr (Sink::kDry) {
+            if (sink.bad) {                              // (a trial decode of something that is not text: no need to go on)
+                err = 16;
+                return false;
+            }
+        }
+        if (how == kWinEob) return true;
     }
 }
 
