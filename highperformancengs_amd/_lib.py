@@ -84,6 +84,7 @@ SYMBOLS = [
     ("hpn_ctx_set_stream", _int, [_vp, _vp]),
     ("hpn_ctx_sync", _int, [_vp]),
     ("hpn_ctx_device", _int, [_vp, C.POINTER(C.c_int)]),
+    ("hpn_ctx_pci_address", _int, [_vp, C.c_char_p, _int]),
     ("hpn_ctx_last_error", C.c_char_p, [_vp]),
     ("hpn_ctx_last_kernel_ms", _int, [_vp, _int, C.POINTER(C.c_float)]),
     ("hpn_dev_malloc", _int, [_vp, _sz, C.POINTER(_vp)]),

@@ -217,7 +217,8 @@ public:
 
     // Parses the BAM header (host, zlib) and positions the stream at the first record.
     // nbuf: pinned chunks of read-ahead (one more than the contexts that take batches)
-    bool open(hpn_ctx *ctx, const char *path, BamHeader &hdr, int nbuf = 3)
+    // chunk: bytes per pinned chunk (0: default_chunk())
+    bool open(hpn_ctx *ctx, const char *path, BamHeader &hdr, int nbuf = 3, size_t chunk = 0)
     {
         ctx_ = ctx;
         dev_.bind(ctx);
@@ -259,8 +260,7 @@ public:
         }
         fclose(f);
         if (!ok) return false;
-        chunk_ = (size_t)88 << 20;  // ~4,500 blocks: most of one round of the inflate kernel's 6,144 wave slots
-        if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
+        chunk_ = default_chunk(chunk);
         pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         if (!pump_->ok()) return false;
         skip_ = start_;
@@ -270,13 +270,12 @@ public:
 
     // bgzip-compressed text (a .fastq.gz written by bgzip): batches of inflated bytes on the device,
     // no records to index.  next() then fills only info->n_records with the batch's byte count.
-    bool open_text(hpn_ctx *ctx, const char *path, int nbuf = 3)
+    bool open_text(hpn_ctx *ctx, const char *path, int nbuf = 3, size_t chunk = 0)
     {
         ctx_ = ctx;
         dev_.bind(ctx);
         text_mode_ = true;
-        chunk_ = (size_t)88 << 20;
-        if (const char *e = getenv("HPN_BAM_CHUNK")) chunk_ = (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
+        chunk_ = default_chunk(chunk);
         pump_.reset(new TextPump(ctx, path, chunk_, nbuf, true));
         return pump_->ok();
     }
@@ -295,9 +294,17 @@ public:
         return true;
     }
 
+    // Read ahead from now on (optional; next() does it otherwise): the upload context, the first chunks and their copies run
+    // beside whatever the caller does between open() and its first next() -- output files, hpn_depth_begin's buffers (round 5:
+    // bam2depth spent 76 ms there with the file untouched).  Not for a stream that will seek() first.
+    void start()
+    {
+        if (ahead_enabled() && !producer_.joinable() && !ended_) (void)start_producer();
+    }
+
     const uint8_t *d_raw() const { return dev_.d_raw(); }
     // chunks under one inflate launch, for a caller that knows better than the default (HPN_BAM_ROUNDS overrides both)
-    void prefer_rounds(int n) { if (!rounds_env() && n > 0) rounds_ = n; }
+    void prefer_rounds(int n) { if (!rounds_env() && n > 0 && !producer_.joinable()) rounds_ = n; }   // (before start())
 
     // Next batch of records, inflated and indexed on the device: 1 = ok (info filled in; a batch may
     // be empty), 0 = end of file, -1 = not decodable here (the caller switches to the host path).
@@ -327,6 +334,7 @@ public:
         int r = st.result;
         last_eof_ = st.eof;
         if (r == 1 && !st.pieces.empty()) r = dev_.finish_stage(st, text_mode_, info);
+        stamp("BGZF: launch inflated and indexed");
         if (r == 0 && dev_.carried()) r = -1;            // the file ends inside a record: the host route reports it as the reference does
         {   // the launch has read the stage's bytes (finish_stage waits for its kernels): the producer may fill it again
             std::lock_guard<std::mutex> lk(mu_);
@@ -348,13 +356,16 @@ private:
     // (BgzfDevice::add); else into the stage through up_ctx_.  1 = ok, -1 = not decodable / truncated.
     int gather(BgzfStage *st, BgzfStage &)
     {
-        // (the FIRST launch of a file read front to back is two chunks: what waits for the first records -- bam2depth's first
+        // (the FIRST launch of a file read front to back is six chunks: what waits for the first records -- bam2depth's first
         // target, the writer behind it -- starts that much earlier; the launches behind it take rounds_)
-        const int limit = launches_ == 0 && rounds_ > 2 && !rounds_env() ? 2 : rounds_;
+        const int limit = launches_ == 0 && rounds_ > 6 && !rounds_env() ? 6 : rounds_;
         ++launches_;
         for (int taken = 0; taken < limit;) {         // several chunks under one inflate launch
             TextPump::Chunk c;
-            if (eof_ || !pump_->next(c)) {
+            const double t_r = wall_s();
+            const bool got = !eof_ && pump_->next(c);
+            t_read_ += wall_s() - t_r;
+            if (!got) {
                 if (!carry_.empty()) return -1;              // a partial block at the end: truncated file
                 break;
             }
@@ -371,7 +382,9 @@ private:
             }
             BgzfParsed pb;
             int r = parse(c, at, pb);
+            const double t_c = wall_s();
             if (r == 1 && !(st ? stage_add(*st, pb) : dev_.add(pb))) r = -1;
+            t_copy_ += wall_s() - t_c;
             pump_->recycle(c);
             if (r != 1) return r;
             ++taken;
@@ -394,19 +407,33 @@ private:
     }
     bool start_producer()
     {
-        if (!up_ctx_) {    // (made here, not on a thread beside open(): a tool that leaves through exit() while such a thread is inside the
-                           // runtime crashes in the runtime's own teardown -- bam2depth without an index did)
-            int device = 0;
-            if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) return false;
-        }
         stop_ = false, turn_ = 0;
         for (BgzfStage &st : stage_) st.state = 0;
         producer_ = std::thread([this] {
+            bind_thread_near(ctx_);
+            if (!up_ctx_) {    // (on this thread: ~40 ms of queue creation beside the caller.  The tools leave through _exit (report.hpp:
+                               // leave) -- the runtime's own exit handlers crash under a thread that is inside the runtime)
+                int device = 0;
+                if (hpn_ctx_device(ctx_, &device) != HPN_OK || hpn_ctx_create(device, &up_ctx_) != HPN_OK) {
+                    up_ctx_ = nullptr;
+                    BgzfStage &st = stage_[0];
+                    st.result = -1;
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        st.state = 1;
+                    }
+                    cv_.notify_all();
+                    return;
+                }
+                stamp("BGZF: context for the uploads made");
+            }
             for (uint32_t k = 0;; ++k) {
                 BgzfStage &st = stage_[k & 1];
                 {
+                    const double t_w = wall_s();
                     std::unique_lock<std::mutex> lk(mu_);
                     cv_.wait(lk, [&] { return st.state == 0 || stop_; });
+                    t_stage_ += wall_s() - t_w;
                     if (stop_) return;
                 }
                 const size_t room = (size_t)rounds_ * (chunk_ + 65536 + 64) + 64;
@@ -421,12 +448,18 @@ private:
                 if (r == 1) r = gather(&st, st);
                 if (r == 1 && st.pieces.empty() && eof_) r = 0;
                 st.result = r, st.eof = eof_ && carry_.empty();
+                stamp("BGZF: launch prepared (compressed bytes on the device), blocks:", (double)st.pieces.size());
                 {
                     std::lock_guard<std::mutex> lk(mu_);
                     st.state = 1;
                 }
                 cv_.notify_all();
-                if (r != 1) return;          // the end (or a failure) has been handed over
+                if (r != 1) {                // the end (or a failure) has been handed over
+                    if (getenv("HPN_TIMING"))
+                        fprintf(stderr, "[hpn] BGZF read-ahead: waited %.3f s for the file reader, %.3f s in copies to the device, %.3f s for a free stage\n",
+                                t_read_, t_copy_, t_stage_);
+                    return;
+                }
             }
         });
         return true;
@@ -444,6 +477,7 @@ private:
         stop_ = false, ended_ = false;
     }
     hpn_ctx *up_ctx_ = nullptr;
+    double t_read_ = 0, t_copy_ = 0, t_stage_ = 0;   // HPN_TIMING: where the read-ahead thread waits
     BgzfStage stage_[2];
     std::thread producer_;
     std::mutex mu_;
@@ -542,17 +576,28 @@ private:
     uint64_t start_ = 0, skip_ = 0;  // file offset of the block holding the first record
     uint32_t first_off_ = 0;         // ... and the record's offset inside it
     bool eof_ = false, text_mode_ = false;
-    // chunks per inflate launch: eight when the file is read front to back (two in the first launch; round 3: four -- 6,144 decoder
-    // waves take ~1.4 chunks at once and a launch ends with its slowest block: ingest of the 10.6 GB file 0.52 -> 0.48 s,
-    // profiles/r04/e2e_rounds.txt); one behind a seek() -- a worker that reads ONE target (bam_multi.hpp) would inflate the chunks
-    // of its neighbours behind the target's last record (HPN_BAM_ROUNDS: both)
+    // Pinned chunks of 32 MiB (round 4: 88 MiB -- three of them cost 50 ms to pin in front of the file's first byte and as much
+    // again when the process ends), 22 of them = ~700 MiB of compressed bytes under one inflate launch when the file is read
+    // front to back (six in the first launch; 6,144 decoder waves hold ~130 MiB at once and a launch ends with its slowest
+    // block: profiles/r04/e2e_rounds.txt); one behind a seek() -- a worker that reads ONE target (bam_multi.hpp) would inflate
+    // the chunks of its neighbours behind the target's last record (HPN_BAM_CHUNK, HPN_BAM_ROUNDS: both)
+    // Streams whose every chunk is a launch of its own (one target behind a seek, batches dealt to several devices) ask for
+    // kLaunchChunk: ~4,500 blocks, most of one round of the chip's 6,144 decoder waves.
+    static size_t default_chunk(size_t asked = 0)
+    {
+        if (const char *e = getenv("HPN_BAM_CHUNK")) return (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
+        return asked ? asked : (size_t)32 << 20;
+    }
+public:
+    static constexpr size_t kLaunchChunk = (size_t)88 << 20;
+private:
     static int rounds_env()
     {
         const char *e = getenv("HPN_BAM_ROUNDS");
         const int v = e ? atoi(e) : 0;
         return v < 0 ? 0 : v > 64 ? 64 : v;
     }
-    int rounds_ = rounds_env() ? rounds_env() : 8;
+    int rounds_ = rounds_env() ? rounds_env() : 22;
     uint32_t launches_ = 0;
     std::vector<uint8_t> carry_;
     BgzfDevice dev_;
@@ -576,13 +621,22 @@ public:
         ctx_ = ctx;
         if (try_gpu) {
             gpu_.reset(new BgzfGpuStream());
-            if (gpu_->open(ctx, path, hdr)) return true;
+            if (gpu_->open(ctx, path, hdr)) {
+                gpu_->start();
+                return true;
+            }
             gpu_.reset();
             hdr = BamHeader();
         }
         return host_.open(path, hdr);
     }
     bool on_gpu() const { return (bool)gpu_; }
+    // The tool's last input is done: nothing is taken apart (pinned chunks, the upload context and its buffers: ~0.1 s of
+    // unpinning and queue destruction in front of an _exit that hands all of it back anyway).
+    void abandon()
+    {
+        (void)gpu_.release();
+    }
 
     // HPN_OK, an hpn_status, or 1 = the GPU ingest gave up (re-run the file with try_gpu = false)
     int feed(int32_t j)

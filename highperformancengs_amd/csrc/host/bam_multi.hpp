@@ -190,7 +190,7 @@ bool depth_targets_multi(const char *path, const BamHeader &hdr, uint32_t mask, 
         bool ok = ctx != nullptr;
         BgzfGpuStream gs;
         BamHeader h2;
-        ok = ok && gs.open(ctx, path, h2) && h2.n_targets() == nt;
+        ok = ok && gs.open(ctx, path, h2, 3, BgzfGpuStream::kLaunchChunk) && h2.n_targets() == nt;
         for (;;) {
             int32_t j = -1;
             {
@@ -321,7 +321,7 @@ public:
             if (!(ctxs[(size_t)w] = pooled_worker_ctx(w, w % devices))) return false;
         BgzfGpuStream gs;                       // the reader: header, read-ahead, block tables
         BamHeader hdr;
-        if (!gs.open(ctxs[0], path, hdr, workers + 2)) return false;
+        if (!gs.open(ctxs[0], path, hdr, workers + 2, BgzfGpuStream::kLaunchChunk)) return false;
         std::atomic<bool> failed{false};
         std::vector<std::thread> th;
         for (int w = 0; w < workers; ++w)

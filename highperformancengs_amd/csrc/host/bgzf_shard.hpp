@@ -32,7 +32,7 @@ public:
         std::vector<std::unique_ptr<Box>> box;
         for (int l = 0; l < L; ++l) box.emplace_back(new Box());
         BgzfGpuStream gs;                       // the reader: read-ahead, block tables
-        if (!gs.open_text(g.ctx(0), path, L + 2)) {
+        if (!gs.open_text(g.ctx(0), path, L + 2, BgzfGpuStream::kLaunchChunk)) {
             snprintf(why, why_cap, "reader not available");
             return false;
         }

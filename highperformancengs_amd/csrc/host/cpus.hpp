@@ -8,6 +8,10 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <mutex>
+
+#include "hpngs.h"
+
 namespace hpn {
 
 inline double wall_s()  // monotonic seconds, for the HPN_TIMING diagnostics
@@ -57,6 +61,59 @@ inline int usable_cpus()
         return (int)(cpus < 1 ? 1 : cpus);
     }();
     return n;
+}
+
+// The calling thread (and the threads it starts: they inherit its mask) onto the CPUs next to the context's device --
+// /sys/bus/pci/devices/<address>/local_cpulist, within what the process may use.  For the threads that FEED the device: file
+// readers filling pinned chunks, uploaders.  On a two-socket MI355X box a far-socket feeder moved 38 GB/s, a near-socket one
+// 51 GB/s (profiles/r05/numa_probe.txt: bam_sliding_count's ingest of a 10.6 GB BAM 0.40 -> 0.31 s).  Nothing happens where
+// the list is missing, covers every usable CPU, or leaves none; HPN_NUMA=0 switches it off.
+inline void bind_thread_near(hpn_ctx *ctx)
+{
+    static const bool off = [] { const char *e = getenv("HPN_NUMA"); return e && e[0] == '0'; }();
+    if (off || !ctx) return;
+    struct Near {
+        bool known = false, use = false;
+        cpu_set_t set;
+    };
+    static std::mutex m;
+    static Near near[64];
+    int device = 0;
+    if (hpn_ctx_device(ctx, &device) != HPN_OK || device < 0 || device >= 64) return;
+    Near n;
+    {
+        std::lock_guard<std::mutex> lk(m);
+        Near &slot = near[device];
+        if (!slot.known) {
+            slot.known = true;
+            char addr[32], path[96], list[4096];
+            cpu_set_t allowed;
+            if (hpn_ctx_pci_address(ctx, addr, (int)sizeof addr) == HPN_OK && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+                snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", addr);
+                if (FILE *f = fopen(path, "r")) {
+                    if (fgets(list, sizeof list, f)) {       // "64-127,192-255"
+                        CPU_ZERO(&slot.set);
+                        for (char *p = list; *p && *p != '\n';) {
+                            char *e;
+                            const long a = strtol(p, &e, 10);
+                            if (e == p) break;
+                            long b = a;
+                            if (*e == '-') b = strtol(e + 1, &e, 10);
+                            for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+                                if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &slot.set);
+                            p = *e == ',' ? e + 1 : e;
+                            if (*e != ',') break;
+                        }
+                        const int k = CPU_COUNT(&slot.set);
+                        slot.use = k >= 4 && k < CPU_COUNT(&allowed);   // (a handful of near CPUs is less than any CPU)
+                    }
+                    fclose(f);
+                }
+            }
+        }
+        n = slot;
+    }
+    if (n.use) (void)sched_setaffinity(0, sizeof n.set, &n.set);
 }
 
 }  // namespace hpn

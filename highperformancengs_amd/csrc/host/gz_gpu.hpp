@@ -328,6 +328,7 @@ private:
     }
     void produce()
     {
+        bind_thread_near(ctx_);
         for (uint32_t k = 0;; ++k) {
             Slot &sl = slot_[k & 1];
             {

@@ -26,6 +26,16 @@ namespace hpn {
     _exit(0);
 }
 
+// Any other way out of a tool once the device is in use (an error, a missing index): the same code the reference exits with,
+// without the runtime's exit handlers -- a helper thread may be inside the runtime at this moment (a context being made, the
+// reader ahead of the caller), and the runtime's own teardown crashes under it.
+[[noreturn]] inline void leave(int code)
+{
+    fflush(NULL);
+    if (getenv("HPN_FULL_EXIT")) exit(code);
+    _exit(code);
+}
+
 inline long long usec()
 {
     struct timeval tv;
@@ -286,7 +296,7 @@ inline void print_window_report(FILE *out, const std::vector<std::string> &names
 inline void die_hpn(hpn_ctx *ctx, int rc, const char *what)
 {
     fprintf(stderr, "%s: %s (%s)\n", what, hpn_strerror(rc), ctx ? hpn_ctx_last_error(ctx) : "");
-    exit(2);
+    leave(2);
 }
 
 }  // namespace hpn

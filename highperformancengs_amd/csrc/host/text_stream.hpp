@@ -103,13 +103,19 @@ public:
             if (guess < 65536) guess = 65536;
             if (guess < cap_) cap_ = (size_t)guess;
         }
-        for (int i = 0; i < nbuf; ++i) {
-            void *p = nullptr;
-            if (hpn_host_malloc(ctx_, cap_ + 2 * pad_ + 64, &p) != HPN_OK) break;
-            buf_.push_back((uint8_t *)p);
-            free_.push_back(i);
+        // ONE buffer now, the others when the reader first needs them (on its thread, beside the caller's work on the chunks before):
+        // pinning memory costs ~0.2 ms per MiB when it is made and as much again when the process ends (scripts/micro/startup_hip.hip,
+        // exit_hip.hip) -- three chunks of 88 MiB in a row were 50 ms in front of a BAM's first byte
+        nbuf_ = nbuf < 1 ? 1 : nbuf;
+        buf_.reserve((size_t)nbuf_);
+        {   // (pinned next to the device, like the ones the reader's thread makes: the caller's thread is put back where it was)
+            cpu_set_t was;
+            const bool have = sched_getaffinity(0, sizeof was, &was) == 0;
+            bind_thread_near(ctx_);
+            ok_ = grow();
+            if (have) (void)sched_setaffinity(0, sizeof was, &was);
         }
-        ok_ = (int)buf_.size() == nbuf && (fd_ >= 0 || in_.gz || in_.bz || in_.mz || in_.pz);
+        ok_ = ok_ && (fd_ >= 0 || in_.gz || in_.bz || in_.mz || in_.pz);
         if (ok_) th_ = std::thread([this] { loop(); });
     }
     ~TextPump()
@@ -184,6 +190,15 @@ private:
         cv_.notify_all();
         if (th_.joinable()) th_.join();
     }
+    bool grow()       // one more pinned buffer (constructor, then the reader's thread; buf_ is only read by that thread while it runs)
+    {
+        void *p = nullptr;
+        if (hpn_host_malloc(ctx_, cap_ + 2 * pad_ + 64, &p) != HPN_OK) return false;
+        std::lock_guard<std::mutex> lk(m_);
+        buf_.push_back((uint8_t *)p);
+        free_.push_back((int)buf_.size() - 1);
+        return true;
+    }
 
     size_t fill(uint8_t *dst)
     {
@@ -232,8 +247,15 @@ private:
 
     void loop()
     {
+        bind_thread_near(ctx_);     // (the pread threads of fill() start from this one: the pinned chunks are filled next to the device)
         for (;;) {
             int idx;
+            bool more;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                more = free_.empty() && !stop_ && (int)buf_.size() < nbuf_;
+            }
+            if (more && !grow()) nbuf_ = (int)buf_.size();       // (no more pinned memory: the reader goes on with what it has)
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [this] { return !free_.empty() || stop_; });
@@ -262,7 +284,7 @@ private:
     size_t cap_, pad_;
     int fd_ = -1;
     uint64_t pos_ = 0;   // (declared after cap_, pad_: the constructor initialises them in this order)
-    int read_threads_ = 0;
+    int read_threads_ = 0, nbuf_ = 1;
     InStream in_;
     bool ok_ = false, handed_over_ = false;
     std::vector<uint8_t *> buf_;

@@ -129,6 +129,20 @@ int hpn_ctx_device(const hpn_ctx *c, int *device)
     return HPN_OK;
 }
 
+int hpn_ctx_pci_address(const hpn_ctx *c, char *buf, int len)
+{
+    if (!c || !buf || len < 16) return HPN_E_ARG;
+    buf[0] = 0;
+    if (hipDeviceGetPCIBusId(buf, len, c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        buf[0] = 0;
+        return HPN_E_HIP;
+    }
+    for (char *p = buf; *p; ++p)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');   // (sysfs names are lower case)
+    return HPN_OK;
+}
+
 const char *hpn_ctx_last_error(const hpn_ctx *c) { return c ? c->err : "null context"; }
 
 int hpn_ctx_last_kernel_ms(hpn_ctx *c, int family, float *ms)

@@ -11,7 +11,9 @@
 // -r / -s are parsed and unused, as in the reference (:281-285).
 #include <err.h>
 #include <getopt.h>
+#include <fcntl.h>
 #include <libgen.h>
+#include <sys/stat.h>
 
 #include <thread>
 
@@ -27,12 +29,12 @@ using namespace hpn;
 // The bedGraph text of a finished target, from the device to the file, on the writer's thread: through a context (= a stream)
 // of its own, so that the copies run beside the kernels that already ingest the next target.  First a device-to-device copy
 // into the fetcher's own buffer (a millisecond per GB) -- after it the library's text buffer is free for the next target's
-// hpn_depth_bedgraph_format (taken() tells) --, then pinned slices of 64 MiB to the file, slice k written while k + 1 is copied.
+// hpn_depth_bedgraph_format (taken() tells) --, then pinned slices of 16 MiB to the file, slice k written while k + 1 is copied.
 struct TextFetcher {
     hpn_ctx *cx = nullptr;
     void *pin[2] = {nullptr, nullptr}, *d_own = nullptr;
     size_t own_cap = 0;
-    static constexpr size_t kSlice = (size_t)64 << 20;
+    static constexpr size_t kSlice = (size_t)16 << 20;    // (pinned memory costs ~0.4 ms per MiB over a process's life)
     bool tried = false;
     std::mutex m;
     std::condition_variable cv;
@@ -89,6 +91,14 @@ struct TextFetcher {
         const uint8_t *src = (const uint8_t *)d_own;
         uint64_t at = 0, prev = 0;
         int k = 0;
+        {   // the target's text has a known size: the file's blocks are asked for at once (one writer thread fills a file at 14 GB/s,
+            // at 18 with its blocks there: scripts/micro/close_cost.cpp -- the writer is what the last target waits for)
+            struct stat sb;
+            fflush(out);
+            const int fd = fileno(out);
+            const off_t here = fd >= 0 ? lseek(fd, 0, SEEK_CUR) : -1;
+            if (here >= 0 && n >= ((uint64_t)64 << 20) && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) (void)posix_fallocate(fd, here, (off_t)n);
+        }
         if (n && hpn_memcpy_d2h(cx, pin[0], src, n < kSlice ? n : kSlice) != HPN_OK) return false;
         while (at < n) {
             const uint64_t len = n - at < kSlice ? n - at : kSlice;
@@ -144,6 +154,7 @@ int main(int argc, char *argv[])
     const char *outfile = "-";
     uint32_t window = 20000;
     int wig = 0;
+    stamp("main");
     if (argc < 2) usage(argv[0]);
     int opt;
     while ((opt = getopt(argc, argv, "o:w:r:s:Wh?")) != -1) {
@@ -171,6 +182,7 @@ int main(int argc, char *argv[])
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
     const bool timing = getenv("HPN_TIMING") != nullptr;
     if (timing) fprintf(stderr, "[hpn] context at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
+    stamp("context created");
 
     char suffix[64];
     // the bedGraph lines are formatted on the device (hpn_depth_bedgraph_format); HPN_BEDGRAPH_HOST=1: from the runs, on the host
@@ -190,6 +202,7 @@ int main(int argc, char *argv[])
             err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
         }
         if (timing) fprintf(stderr, "[hpn] %s open at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
+        stamp("input open");
         std::string nm = infiles[i];
         snprintf(suffix, sizeof suffix, ".%u.bedGraph", i + 1);
         FILE *bedGraph = fcreat_outfile(basename(&nm[0]), suffix);
@@ -204,7 +217,7 @@ int main(int argc, char *argv[])
         }
         if (!index_exists(infiles[i])) {
             fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
-            exit(1);
+            leave(1);
         }
         if (try_multi) {   // one worker per GPU, targets largest first, results written here in target order
             try_multi = false;
@@ -250,6 +263,7 @@ int main(int argc, char *argv[])
             const char *name = hdr.target_name[j].c_str();
             if ((rc = hpn_depth_begin_w(ctx, j, tlen, BAM_DEF_MASK, (uint32_t)window)) != HPN_OK) die_hpn(ctx, rc, "hpn_depth_begin");   // sorted input: swept while it streams
             if (timing && j == 0) fprintf(stderr, "[hpn] first target begun at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
+            if (j == 0) stamp("first target begun");
             if (dev_text && fetch_aside && j == 0) copy.start(ctx);
             t0 = wall_s();
             rc = bam.feed(j);
@@ -315,22 +329,29 @@ int main(int argc, char *argv[])
             t_print += wall_s() - t0;
             fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
         }
+        stamp("last target handed to the writer");
         t0 = wall_s();
         if (printer.joinable()) printer.join();
         t_print += wall_s() - t0;
+        stamp("writer done");
         if (copy.maker.joinable()) copy.maker.join();
         if (getenv("HPN_TIMING"))
             fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  waiting for the writer %.3f s%s\n",
                     bam.on_gpu() ? "GPU" : "host", t_feed, t_finish, t_print, redo ? "  (abandoned: not decodable on the GPU)" : "");
+        stamp("writer joined, timing line out");
         fclose(bedGraph);
+        stamp("bedGraph closed");
         fclose(depth);
         if (wig) {
             fclose(WIG);
             fclose(chrSize);
         }
+        stamp("outputs closed");
+        if (!redo && i + 1 == n_in) bam.abandon();   // (the last input: its read-ahead is not taken apart, the process ends)
         if (!redo) break;  // else: the outputs are re-created (truncated) by the host pass
       }
       fprintf(stderr, "Converted %s to wig format at %.3f s\n", infiles[i], (double)(usec() - begin) / CLOCKS_PER_SEC);
     }
+    stamp("finished");
     quick_exit_ok();
 }

@@ -91,7 +91,7 @@ int main(int argc, char *argv[])
         FILE *chrSize = fcreat_outfile(outfile, suffix);
         if (!index_exists(infiles[i])) {
             fprintf(stderr, "bam2bed: BAM indexing file is not available.\n");
-            exit(1);
+            leave(1);
         }
         std::vector<hpn_run> runs(1u << 20);
         std::vector<double> bins;

@@ -96,8 +96,10 @@ int main(int argc, char *argv[])
     const int n_in = argc - optind;
     const long long begin = usec();
     hpn_ctx *ctx = nullptr;
+    stamp("main (options read)");
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    stamp("context created");
 
     // results of the first input: the only one the report uses
     BamHeader hdr0;
@@ -110,6 +112,7 @@ int main(int argc, char *argv[])
         BamReader bam;
         BamHeader hdr;
         if (!bam.open(infiles[i], hdr)) err(1, "bam2bed: Fail to open BAM file %s\n", infiles[i]);
+        stamp("host reader open (header)");
         std::vector<uint64_t> off((size_t)hdr.n_targets() + 1, 0);
         for (int32_t t = 0; t < hdr.n_targets(); ++t) off[t + 1] = off[t] + (uint64_t)(hdr.target_len[t] / (uint32_t)window + 1);
         if (hdr.n_targets() == 0) off.push_back(0);
@@ -168,10 +171,20 @@ int main(int argc, char *argv[])
             if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, multi_done ? "" : "  (abandoned)");
         }
         if (!multi_done && whole && bam_gpu_enabled()) {
-            BgzfGpuStream gs;
+            // (on the heap: after the tool's last input the stream is not taken apart -- pinned chunks, the upload context and its
+            // buffers are ~0.1 s of unpinning and queue destruction in front of an _exit that hands all of it back anyway)
+            BgzfGpuStream *gsp = new BgzfGpuStream;
+            struct Drop {
+                BgzfGpuStream *p;
+                bool keep;
+                ~Drop() { if (!keep) delete p; }
+            } drop{gsp, i + 1 == n_in};
+            BgzfGpuStream &gs = *gsp;
             BamHeader h2;
             if (gs.open(ctx, infiles[i], h2)) {
-                gs.prefer_rounds(8);
+                gs.prefer_rounds(22);
+                gs.start();
+                stamp("GPU stream open, reading ahead");
                 hpn_raw_info info;
                 int r;
                 while ((r = gs.next(&info)) == 1)
@@ -184,6 +197,7 @@ int main(int argc, char *argv[])
             }
         }
         if (getenv("HPN_TIMING") && !multi_done) fprintf(stderr, "[hpn] %s ingest\n", on_gpu ? "GPU" : "host");
+        stamp("ingest done");
         BamBatch batch, one;
         bool more = !on_gpu && !multi_done;
         // -r: bam_fetch reads from where the index says the region's first record can be, up to the first record that
@@ -272,5 +286,6 @@ int main(int argc, char *argv[])
         fclose(out);
     }
     fprintf(stderr, "Done output %s.txt at %.3f s\n", outfile, (double)(usec() - begin) / CLOCKS_PER_SEC);
+    stamp("finished");
     quick_exit_ok();
 }

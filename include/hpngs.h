@@ -63,6 +63,11 @@ int hpn_ctx_set_stream(hpn_ctx *ctx, void *hip_stream);
 int hpn_ctx_sync(hpn_ctx *ctx);
 /* The HIP ordinal the context was created on (a helper context for uploads beside it: host/gz_gpu.hpp). */
 int hpn_ctx_device(const hpn_ctx *ctx, int *device);
+/* The device's PCI address ("0000:c1:00.0" + NUL; HPN_E_ARG when `len` < 16).  What a host needs to keep the threads that
+ * feed the device on the CPUs next to it: /sys/bus/pci/devices/<address>/local_cpulist (host/cpus.hpp: on a two-socket box a
+ * reader on the far socket moves 38 GB/s to the device, one on the near socket 51 -- profiles/r05/numa_probe.txt).  The
+ * reference has no counterpart: its readers are the threads of kt_for, wherever the scheduler puts them (klib/kthread.c:48). */
+int hpn_ctx_pci_address(const hpn_ctx *ctx, char *buf, int len);
 const char *hpn_ctx_last_error(const hpn_ctx *ctx);
 /* Milliseconds the device spent in the most recent kernel launch group of the
  * given family, measured with hipEvents on the context's stream (valid after
