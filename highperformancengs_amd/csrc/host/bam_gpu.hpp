@@ -349,7 +349,7 @@ public:
 private:
     static bool ahead_enabled()
     {
-        const char *e = getenv("HPN_BAM_AHEAD");
+        const char *e = test_env("HPN_BAM_AHEAD");
         return !(e && e[0] == '0');
     }
     // Up to rounds_ chunks of the file: parsed, their bytes on the device.  st == nullptr: into dev_ through the caller's context
@@ -585,7 +585,7 @@ private:
     // kLaunchChunk: ~4,500 blocks, most of one round of the chip's 6,144 decoder waves.
     static size_t default_chunk(size_t asked = 0)
     {
-        if (const char *e = getenv("HPN_BAM_CHUNK")) return (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
+        if (const char *e = test_env("HPN_BAM_CHUNK")) return (size_t)atoll(e) < 65536 + 64 ? 65536 + 64 : (size_t)atoll(e);
         return asked ? asked : (size_t)32 << 20;
     }
 public:
@@ -593,7 +593,7 @@ public:
 private:
     static int rounds_env()
     {
-        const char *e = getenv("HPN_BAM_ROUNDS");
+        const char *e = test_env("HPN_BAM_ROUNDS");
         const int v = e ? atoi(e) : 0;
         return v < 0 ? 0 : v > 64 ? 64 : v;
     }

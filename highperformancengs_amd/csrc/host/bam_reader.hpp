@@ -147,7 +147,7 @@ private:
         memset(&zs, 0, sizeof zs);
         const bool zs_ok = inflateInit2(&zs, -15) == Z_OK;
         FastInflate fi;
-        const bool fast_ok = !(getenv("HPN_FAST_INFLATE") && getenv("HPN_FAST_INFLATE")[0] == '0');
+        const bool fast_ok = !(test_env("HPN_FAST_INFLATE") && test_env("HPN_FAST_INFLATE")[0] == '0');
         for (;;) {
             Slot *s = nullptr;
             {

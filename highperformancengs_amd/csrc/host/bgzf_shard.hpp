@@ -36,7 +36,7 @@ public:
             snprintf(why, why_cap, "reader not available");
             return false;
         }
-        TextRelay relay(tally_flags);
+        TextRelay relay(tally_flags, (uint32_t)L);
         std::atomic<bool> failed{false};
         std::atomic<uint64_t> bytes{0};
         std::vector<std::thread> th;

@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "hpngs.h"
+#include "knobs.hpp"
 
 namespace hpn {
 

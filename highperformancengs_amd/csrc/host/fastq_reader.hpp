@@ -93,7 +93,7 @@ inline bool gzip_has_second_member(int fd, bool any_size = false)
 {
     struct stat sb;
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return true;
-    if (getenv("HPN_PGZ_FORCE")) return false;  // tests: any gzip file through the two-pass reader
+    if (test_env("HPN_PGZ_FORCE")) return false;  // tests: any gzip file through the two-pass reader
     if (sb.st_size < (4 << 20) && !any_size) return true;  // not worth the threads
     const size_t n = (size_t)sb.st_size < ((size_t)64 << 20) ? (size_t)sb.st_size : (size_t)64 << 20;
     void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -139,7 +139,7 @@ inline InStream open_input_stream(const char *name)
         if (fd == -1) fprintf(stderr, "Failed to create input file (%s)", name);
         uint8_t h[18] = {0};  // BGZF: gzip member with the 'BC' extra subfield first (SAM spec 4.1)
         if (fd != -1 && pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) &&
-            h[12] == 'B' && h[13] == 'C' && !getenv("HPN_NO_BGZF")) {
+            h[12] == 'B' && h[13] == 'C' && !test_env("HPN_NO_BGZF")) {
             auto bz = std::make_shared<BgzfReader>();
             const long share = usable_cpus() / text_workers_in_flight();
             if (bz->open(name, getenv("HPN_BGZF_THREADS") ? 0 : (int)(share < 1 ? 1 : share > 16 ? 16 : share))) {
@@ -150,7 +150,7 @@ inline InStream open_input_stream(const char *name)
         }
         long cpus = usable_cpus() / text_workers_in_flight();
         // gzip with no second member in sight: one deflate stream, inflated in parallel by the two-pass reader
-        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_PGZ") && !getenv("HPN_NO_MGZ") && (cpus >= 3 || getenv("HPN_PGZ_FORCE"))  /* the symbolic decode costs ~1.6x the plain one */ && !gzip_has_second_member(fd)) {
+        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !test_env("HPN_NO_PGZ") && !test_env("HPN_NO_MGZ") && (cpus >= 3 || test_env("HPN_PGZ_FORCE"))  /* the symbolic decode costs ~1.6x the plain one */ && !gzip_has_second_member(fd)) {
             auto pz = std::make_shared<PgzReader>();
             if (pz->open(name, getenv("HPN_GZ_THREADS") ? 0 : (int)(cpus > 16 ? 16 : cpus))) {
                 close(fd);
@@ -158,7 +158,7 @@ inline InStream open_input_stream(const char *name)
                 return in;
             }
         }
-        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !getenv("HPN_NO_MGZ")) {  // gzip: members inflated in parallel
+        if (fd != -1 && h[0] == 0x1f && h[1] == 0x8b && !test_env("HPN_NO_MGZ")) {  // gzip: members inflated in parallel
             auto mz = std::make_shared<MgzReader>();
             if (mz->open(name, getenv("HPN_GZ_THREADS") ? 0 : (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus))) {
                 close(fd);

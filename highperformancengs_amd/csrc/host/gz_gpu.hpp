@@ -88,7 +88,7 @@ public:
         if (!body) return give_up("no gzip header");
         threads_ = threads < 1 ? 1 : threads;
         {
-            const char *e = getenv("HPN_GZ_FIND");
+            const char *e = test_env("HPN_GZ_FIND");
             search_on_device_ = e ? !strcmp(e, "device") : threads_ < 6;
         }
         max_stretches_ = max_stretches < 1 ? 1 : max_stretches > 65535u ? 65535u : max_stretches;
@@ -97,7 +97,7 @@ public:
         // 24 K stretches on 15 cores).  One batch of 6,144 stretches of 1.2 MB holds 38 GB of symbol scratch + 12 GB of text at once:
         // measured on a 7.2 GB file 0.34 s of device time on a fresh box and 1.8 - 2.4 s on a box whose memory had been in use
         // (profiles/r04/e2e_tools_b.txt); four batches of a quarter of that run 0.10 s each on both.
-        if (!getenv("HPN_GZ_FIND") && size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10)) >= 2) search_on_device_ = true;
+        if (!test_env("HPN_GZ_FIND") && size_ / ((uint64_t)max_stretches_ * ((uint64_t)256 << 10)) >= 2) search_on_device_ = true;
         // symbols of scratch per stretch: from the expansion of the member's first megabytes (FASTQ is homogeneous; a
         // stretch that needs more is decoded again with twice the room)
         {
@@ -113,7 +113,7 @@ public:
         if (!stretch_bytes) {
             // as many stretches as the device calls may hold, so that every call fills the chip: a wavefront inflates ~4.5 MB
             // of text per second whatever the stretch size, so only the number of waves in flight matters
-            const char *e = getenv("HPN_GZ_STRETCH");
+            const char *e = test_env("HPN_GZ_STRETCH");
             // at most 1.5 MiB (~0.5 s of one wavefront; the search is per stretch, so few and long), less for text that
             // expands a lot: the symbol scratch is ~3 bytes per byte of text in flight
             uint64_t kMaxStretch = (uint64_t)((double)((uint64_t)3 << 19) * (ratio_ > 2.0 ? 2.0 / ratio_ : 1.0));
@@ -165,7 +165,7 @@ public:
         // default: measured -0.02 s of 0.57 on the 7.2 GB file (the one-workgroup history walk runs three times slower beside
         // 6,144 decoder waves), for a second set of symbol scratch -- and allocations of this size are what sometimes takes the
         // runtime seconds (profiles/r04/gz_stamps.txt: one run in six stalls 3.6 s in a 14 GB hipMalloc)
-        if (getenv("HPN_GZ_OVERLAP") && getenv("HPN_GZ_OVERLAP")[0] == '1')
+        if (test_env("HPN_GZ_OVERLAP") && test_env("HPN_GZ_OVERLAP")[0] == '1')
             ctx2_maker_ = std::thread([this, device] {            // (~30 ms, beside the first batch's upload)
                 if (hpn_ctx_create(device, &ctx2_) != HPN_OK) ctx2_ = nullptr;
             });
@@ -566,7 +566,7 @@ private:
     std::vector<hpn_span> spans_;
     std::vector<uint32_t> crcs_;
     uint32_t member_crc_ = 0;                       // CRC-32 of the current member's text so far
-    const bool check_crc_ = !(getenv("HPN_GZ_CRC") && getenv("HPN_GZ_CRC")[0] == '0');   // (timing experiments only)
+    const bool check_crc_ = !(test_env("HPN_GZ_CRC") && test_env("HPN_GZ_CRC")[0] == '0');   // (timing experiments only)
     bool done_ = false, grown_ = false;
     double ratio_ = 4.0;
     const char *why_ = "";

@@ -66,11 +66,11 @@ public:
             ratio_ = out / in < 1.0 ? 1.0 : out / in;
         }
         {
-            const char *e = getenv("HPN_GZ_FIND");
+            const char *e = test_env("HPN_GZ_FIND");
             search_on_device_ = e ? !strcmp(e, "device") : threads_ / g_.lanes() < 6;
         }
         // stretches as in GzGpuStream::open: every call fills the chip, 256 KiB .. 1.5 MiB of compressed bytes each
-        const char *e = getenv("HPN_GZ_STRETCH");
+        const char *e = test_env("HPN_GZ_STRETCH");
         uint64_t max_stretch = (uint64_t)((double)((uint64_t)3 << 19) * (ratio_ > 2.0 ? 2.0 / ratio_ : 1.0));
         if (max_stretch < ((uint64_t)512 << 10)) max_stretch = (uint64_t)512 << 10;
         const uint64_t calls = (size_ + S_ * max_stretch - 1) / (S_ * max_stretch);
@@ -79,7 +79,7 @@ public:
             // a device's share goes in as few batches as keep a batch's symbol scratch near 10 GB (lanes that share a device --
             // HPN_NGPU on a one-GPU box -- share its memory: their batches are that much smaller)
             const uint64_t fills = size_ / (S_ * (uint64_t)g_.lanes() * ((uint64_t)256 << 10));
-            if (!getenv("HPN_GZ_FIND") && fills >= 2) search_on_device_ = true;
+            if (!test_env("HPN_GZ_FIND") && fills >= 2) search_on_device_ = true;
             const double per_device = (double)size_ / (g_.distinct() ? (double)g_.lanes() : 1.0);
             uint64_t want = (uint64_t)(per_device * ratio_ * 2.8 / 10e9) + 1;
             // (per lane: the lanes of a device run side by side, so 1 / want of the device's share is in flight at a time)
@@ -92,7 +92,7 @@ public:
         if (stretch_ < 4096) stretch_ = 4096;
         n_slices_ = (size_ - body_byte_ + stretch_ - 1) / stretch_;
         // a file that does not fill every lane's chip once is spread evenly all the same: several devices half full beat one full one
-        if (!getenv("HPN_GZ_BATCH") && n_slices_ < S_ * (uint64_t)g_.lanes()) {
+        if (!test_env("HPN_GZ_BATCH") && n_slices_ < S_ * (uint64_t)g_.lanes()) {
             S_ = (n_slices_ + (uint64_t)g_.lanes() - 1) / (uint64_t)g_.lanes();
             if (S_ < 64) S_ = 64;
         }
@@ -106,8 +106,8 @@ public:
     int run(uint32_t tally_flags, bool *unusable)
     {
         *unusable = false;
-        relay_.reset(new TextRelay(tally_flags));
         const int L = g_.lanes();
+        relay_.reset(new TextRelay(tally_flags, (uint32_t)L));
         window_.assign(32768, 0);
         lanes_.clear();
         for (int l = 0; l < L; ++l) lanes_.emplace_back(new Lane());
@@ -506,10 +506,14 @@ private:
         if (!relay_->frame(ctx, b, (uint8_t *)ln.d_text + kFront, nb, ends_stream, ln.h_edge)) return fail(relay_->why());
         return true;
     }
+    // A library call failed in a lane (device memory for the symbol scratch -- ~2.8 x the expansion per compressed byte, and
+    // lanes may share a device --, a second HPN_E_CAPACITY, a HIP error): the ROUTE is abandoned, not the file -- the caller
+    // drops the lanes' partial counts and takes the one-context route, which gives up and falls back for the same conditions
+    // and reports a device that really is broken itself.
     bool fail_ctx(hpn_ctx *ctx)
     {
         snprintf(why_buf_, sizeof why_buf_, "%s", hpn_ctx_last_error(ctx));
-        stop(why_buf_, HPN_E_HIP);
+        stop(why_buf_);
         return false;
     }
     uint32_t sym_cap_now()
@@ -535,7 +539,7 @@ private:
     double ratio_ = 4.0;
     uint32_t sym_cap_ = 0;
     bool search_on_device_ = false;
-    const bool check_crc_ = !(getenv("HPN_GZ_CRC") && getenv("HPN_GZ_CRC")[0] == '0');
+    const bool check_crc_ = !(test_env("HPN_GZ_CRC") && test_env("HPN_GZ_CRC")[0] == '0');
     std::vector<std::unique_ptr<Lane>> lanes_;
     // the chains (all under m_)
     std::mutex m_;
@@ -568,7 +572,7 @@ inline int tally_gz_sharded(LaneGroup &g, const char *path, hpn_tally *acc, bool
     (void)hpn_inflate_slots(g.ctx(0), &slots);                        // stretches a chip decodes at once
     uint32_t per_call = (uint32_t)(slots / (uint32_t)text_workers_in_flight());
     if (!g.distinct()) per_call /= (uint32_t)g.lanes();              // lanes on ONE device (HPN_NGPU on a one-GPU box) share its decoder slots and its memory
-    if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
+    if (const char *e = test_env("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
     GzSharded gs(g, path, (int)(cpus < 1 ? 1 : cpus > 32 ? 32 : cpus), per_call < 1 ? 1 : per_call);
     if (!gs.open()) {
         if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] %s: gzip over %d lanes not taken: %s\n", path, g.lanes(), gs.why());

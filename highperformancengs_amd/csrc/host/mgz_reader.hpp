@@ -259,7 +259,7 @@ private:
     void inflate_member(const std::shared_ptr<Job> &j)
     {
         static const bool use_fast = [] {
-            const char *e = getenv("HPN_FAST_INFLATE");
+            const char *e = test_env("HPN_FAST_INFLATE");
             return !(e && e[0] == '0');
         }();
         if (use_fast) {

@@ -191,7 +191,7 @@ public:
             threads = (int)(n < 1 ? 1 : n > 16 ? 16 : n);
         }
         if (!chunk_bytes) {
-            const char *e = getenv("HPN_PGZ_CHUNK");
+            const char *e = test_env("HPN_PGZ_CHUNK");
             chunk_bytes = e ? (size_t)atoll(e) : (size_t)2 << 20;
         }
         if (chunk_bytes < 1024) chunk_bytes = 1024;

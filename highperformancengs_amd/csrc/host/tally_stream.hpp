@@ -129,7 +129,7 @@ inline bool is_bgzf_file(const char *path)
 }
 inline uint64_t bgzf_text_slice()   // HPN_BGZF_SLICE: tests cut small files into several calls
 {
-    const char *e = getenv("HPN_BGZF_SLICE");
+    const char *e = test_env("HPN_BGZF_SLICE");
     return e && atoll(e) >= 4096 ? (uint64_t)atoll(e) : (uint64_t)256 << 20;
 }
 inline int tally_bgzf_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *unusable)
@@ -182,10 +182,10 @@ inline bool is_plain_gzip_file(const char *path)  // gzip, not BGZF
     struct stat sb;
     const bool gz = pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 &&
                     !((h[3] & 4) && h[12] == 'B' && h[13] == 'C') && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
-    const bool force = getenv("HPN_GZ_GPU_FORCE") != nullptr;  // tests: small files too
+    const bool force = test_env("HPN_GZ_GPU_FORCE") != nullptr;  // tests: small files too
     // several members (cat a.gz b.gz) are decoded in one go (kernels/gz_inflate.hip); HPN_GZ_MEMBERS=0: such files go to the
     // host's member-parallel reader as before
-    const bool members_too = !(getenv("HPN_GZ_MEMBERS") && getenv("HPN_GZ_MEMBERS")[0] == '0');
+    const bool members_too = !(test_env("HPN_GZ_MEMBERS") && test_env("HPN_GZ_MEMBERS")[0] == '0');
     const bool ok = gz && (force || sb.st_size >= (8 << 20)) && (members_too || !gzip_has_second_member(fd, force));
     close(fd);
     return ok;
@@ -198,7 +198,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
     uint32_t slots = 5120;
     (void)hpn_inflate_slots(ctx, &slots);                             // stretches the chip decodes at once (24 decoder waves per CU: 6,144)
     uint32_t per_call = (uint32_t)(slots / (uint32_t)text_workers_in_flight());
-    if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);  // (tests: several device calls per file)
+    if (const char *e = test_env("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);  // (tests: several device calls per file)
     const double t0 = wall_s();
     if (!gs.open(ctx, path, (int)(cpus < 1 ? 1 : cpus > 16 ? 16 : cpus), per_call < 1 ? 1 : per_call)) {
         if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] gzip route on the GPU not taken: %s\n", gs.why());
@@ -208,7 +208,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
     // Highly compressible text (long matches) is cheap for the host's own two-pass reader: measured on a 308 MB file of
     // ratio 4.7 with 16 cores, 0.39 s there against 0.48 s here (the search and one round of wavefronts are ~0.2 s whatever
     // the size); at ratio 1.7 this route is twice as fast from 700 MB on.  Small, compressible, plenty of cores: the host.
-    if (!getenv("HPN_GZ_GPU_FORCE") && gs.ratio() > 3.5 && gs.file_bytes() < ((uint64_t)1 << 30) && cpus >= 12) {
+    if (!test_env("HPN_GZ_GPU_FORCE") && gs.ratio() > 3.5 && gs.file_bytes() < ((uint64_t)1 << 30) && cpus >= 12) {
         if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] gzip route on the GPU not taken: small and compressible (x%.1f), the host cores do it\n", gs.ratio());
         *unusable = true;
         return HPN_OK;
@@ -256,7 +256,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
 inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_long, LaneGroup *group = nullptr)
 {
     const bool is_stdin = strncmp(path, "-", 1) == 0 || !strcmp(path, "");
-    if (text_path_enabled() && !is_stdin && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(path)) {
+    if (text_path_enabled() && !is_stdin && bam_gpu_enabled() && !test_env("HPN_NO_BGZF") && is_bgzf_file(path)) {
         if (group && group->lanes() > 1) {      // chunks of whole blocks over one context per device (host/bgzf_shard.hpp)
             bool unusable = false;
             const int rc = tally_bgzf_sharded(*group, path, acc, &unusable);
@@ -266,7 +266,7 @@ inline int tally_file(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool *too_
         const int rc = tally_bgzf_on_gpu(ctx, path, acc, &unusable);
         if (!unusable) return rc;
     }
-    if (text_path_enabled() && !is_stdin && gz_gpu_enabled() && !getenv("HPN_NO_MGZ") && !getenv("HPN_NO_PGZ") && is_plain_gzip_file(path)) {
+    if (text_path_enabled() && !is_stdin && gz_gpu_enabled() && !test_env("HPN_NO_MGZ") && !test_env("HPN_NO_PGZ") && is_plain_gzip_file(path)) {
         if (group && group->lanes() > 1) {      // batches of its stretches over one context per device (host/gz_shard.hpp)
             bool unusable = false;
             const int rc = tally_gz_sharded(*group, path, acc, &unusable);

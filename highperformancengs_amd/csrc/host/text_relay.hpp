@@ -24,7 +24,8 @@ class TextRelay {
 public:
     static constexpr size_t kFront = 64;                          // writable bytes a batch's buffer has in front of its text
     static constexpr size_t kEdgeBytes = HPN_TEXT_PIECE_TAIL + 64;   // pinned scratch a lane brings (h_edge)
-    explicit TextRelay(uint32_t tally_flags = 0) : flags_(tally_flags) {}
+    // lanes: batch b is framed by lane b % lanes, which takes its batches one after the other (0: unknown, nothing is checked)
+    explicit TextRelay(uint32_t tally_flags = 0, uint32_t lanes = 0) : flags_(tally_flags), lanes_(lanes) {}
 
     bool aborted()
     {
@@ -121,6 +122,13 @@ public:
                 std::unique_lock<std::mutex> lk(m_);
                 bool ended = false;
                 for (uint64_t i = b + 1; tail < HPN_TEXT_PIECE_TAIL && !ended; ++i) {
+                    if (lanes_ && i >= b + lanes_ && !at(i).ready) {
+                        // the tail would have to come from a batch of THIS lane, which is published behind this very call (the lanes
+                        // between hold less than 4 KiB of text together: tiny BGZF blocks or gzip members, test-sized batches): give
+                        // the route up instead of waiting for ever
+                        lk.unlock();
+                        return fail("batches too short to frame across lanes");
+                    }
                     cv_.wait(lk, [&] { return at(i).ready || abort_; });
                     if (abort_) return false;
                     const Pub &nx = at(i);
@@ -175,7 +183,7 @@ private:
     }
     static uint64_t slice_bytes()   // HPN_TEXT_SLICE: tests cut small texts into several pieces
     {
-        const char *e = getenv("HPN_TEXT_SLICE");
+        const char *e = test_env("HPN_TEXT_SLICE");
         return e && atoll(e) >= 2 * (long long)HPN_TEXT_PIECE_TAIL ? (uint64_t)atoll(e) : (uint64_t)256 << 20;
     }
     bool fail(const char *why)
@@ -188,7 +196,7 @@ private:
         abort(hpn_ctx_last_error(ctx), HPN_E_HIP);
         return false;
     }
-    uint32_t flags_;
+    uint32_t flags_, lanes_ = 0;
     std::mutex m_;
     std::condition_variable cv_;
     bool abort_ = false;

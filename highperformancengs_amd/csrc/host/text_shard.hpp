@@ -135,7 +135,7 @@ private:
         if (e && !strcmp(e, "host")) return false;
         // one RCCL rank per device: lanes that share a device add on the host (HPN_COMM_SHARED_DEVICE=1, tests: hpn_comm_init_all
         // is asked all the same -- the RCCL stand-in of tests/stub accepts them, the real library refuses and the host adds)
-        const char *sh = getenv("HPN_COMM_SHARED_DEVICE");
+        const char *sh = test_env("HPN_COMM_SHARED_DEVICE");
         return (distinct_ || (sh && sh[0] == '1')) && ctx_.size() > 1;
     }
     std::vector<hpn_ctx *> ctx_;
@@ -146,13 +146,15 @@ private:
     std::thread comm_thread_;
 };
 
-// How many lanes for this input.  HPN_NGPU=n: n, whatever the input.  Otherwise plain regular files only (compressed
-// input is bounded by its inflate, which has its own routes), one lane per 2 GiB -- a context costs 15-30 ms to make
+// How many lanes for this input.  HPN_NGPU=n: n, whatever the input.  Otherwise: a plain regular file, or -- for callers that
+// have a route which inflates on the lanes' own devices (gz_lanes: the count tools, host/gz_shard.hpp / bgzf_shard.hpp) -- a
+// gzip file of 256 MiB or more, one lane per 512 MiB of it; for every other caller compressed input is ONE lane (fastq_trim: a
+// single host zlib reader would feed N lanes, which adds N contexts and nothing else).  Plain: one lane per 2 GiB -- a context costs 15-30 ms to make
 // and one lane already streams at the PCIe rate of its link --, at most `devices_for_me`.
 // pair_on_one_device (the count tools): with a single device, a plain file of 4 GiB or more still gets TWO lanes on it -- one lane's
 // copy over PCIe then runs beside the other's framing and tally (15.2 GB: 0.42 s against 0.49-0.53 s on one context; three or
 // four lanes only add contexts: scripts/e2e_lanes.sh).
-inline int shard_lanes_for(const char *path, int devices_for_me, bool pair_on_one_device = false)
+inline int shard_lanes_for(const char *path, int devices_for_me, bool pair_on_one_device = false, bool gz_lanes = false)
 {
     if (!text_path_enabled()) return 1;
     if (const char *e = getenv("HPN_NGPU")) return atoi(e) > 1 ? atoi(e) : 1;
@@ -166,7 +168,7 @@ inline int shard_lanes_for(const char *path, int devices_for_me, bool pair_on_on
     if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
         // gzip: the device inflate is the wall, and its batches spread over the devices (host/gz_shard.hpp, bam_gpu.hpp's
         // block fan-out for BGZF) -- one lane per 512 MiB of compressed bytes, from 256 MiB on
-        if (devices_for_me < 2 || sb.st_size < ((off_t)256 << 20)) return 1;
+        if (!gz_lanes || devices_for_me < 2 || sb.st_size < ((off_t)256 << 20)) return 1;
         const long long want = (long long)(sb.st_size >> 29) + 1;
         return (int)(want < devices_for_me ? want : devices_for_me);
     }
@@ -189,13 +191,14 @@ public:
     static int device_of(int ndev, int workers, int w) { return (w * (getenv("HPN_NGPU") ? 1 : cap(ndev, workers))) % ndev; }
 
     // own sits on device base + rel of the ndev devices base .. base + ndev - 1
-    WorkerLanes(hpn_ctx *own, int base, int rel, int ndev, int cap, bool pair_on_one_device = false)
-        : own_(own), base_(base), rel_(rel), ndev_(ndev), cap_(cap), pair_(pair_on_one_device)
+    // gz_lanes: the caller can inflate one gzip input on several devices (shard_lanes_for)
+    WorkerLanes(hpn_ctx *own, int base, int rel, int ndev, int cap, bool pair_on_one_device = false, bool gz_lanes = false)
+        : own_(own), base_(base), rel_(rel), ndev_(ndev), cap_(cap), pair_(pair_on_one_device), gz_lanes_(gz_lanes)
     {
     }
     LaneGroup *for_file(const char *path)
     {
-        const int want = shard_lanes_for(path, cap_, pair_);
+        const int want = shard_lanes_for(path, cap_, pair_, gz_lanes_);
         if (want < 2) return nullptr;
         if (!group_) group_.reset(new LaneGroup(own_, base_, rel_, ndev_, want));   // sized by the first input that is sharded, kept for the others
         return group_.get();
@@ -204,14 +207,14 @@ public:
 private:
     hpn_ctx *own_;
     int base_, rel_, ndev_, cap_;
-    bool pair_;
+    bool pair_, gz_lanes_;
     std::unique_ptr<LaneGroup> group_;
 };
 
 // Piece size of the sharded route: the chunk size of the plain route, never below two tails.
 inline size_t shard_piece_bytes(int lanes)
 {
-    const char *e = getenv("HPN_TEXT_CHUNK");
+    const char *e = test_env("HPN_TEXT_CHUNK");
     size_t c = e && atoll(e) >= 64 ? (size_t)atoll(e) : (size_t)32 << 20;
     if (!e && lanes > 4) c = (size_t)16 << 20;   // (lanes + 2) pinned buffers: keep the footprint near 200 MB
     return c < 2 * HPN_TEXT_PIECE_TAIL ? 2 * HPN_TEXT_PIECE_TAIL : c;
@@ -498,6 +501,7 @@ public:
         cv_.notify_all();
         if (th_.joinable()) th_.join();
     }
+    bool failed() const { return failed_; }     // (after finish(): a write did not go through)
 
 private:
     struct Job {
@@ -517,13 +521,14 @@ private:
                 todo_.erase(it);
                 ++next_;
             }
-            if (j.n) write_slab(out_, buf_[(size_t)j.idx], j.n);
+            if (j.n && !failed_ && !write_slab(out_, buf_[(size_t)j.idx], j.n)) failed_ = true;
             give_back(j.lane, j.idx);
         }
     }
     hpn_ctx *ctx_;
     FILE *out_;
     bool ok_ = false, stop_ = false, cancel_ = false;
+    std::atomic<bool> failed_{false};
     std::vector<void *> buf_;
     std::vector<std::deque<int>> lane_free_;
     std::map<uint64_t, Job> todo_;
@@ -561,6 +566,10 @@ inline int trim_text_sharded(LaneGroup &g, const char *path, int32_t S, int32_t 
     });
     const double t2 = wall_s();
     writer.finish();
+    if (writer.failed()) {          // (ENOSPC, EIO, a closed pipe: the output is incomplete -- not something to start over from)
+        fprintf(stderr, "fastq_trim: writing the output failed\n");
+        return HPN_E_STATE;
+    }
     if (run.status() != HPN_OK) {
         fprintf(stderr, "[hpn] %s: a lane failed: %s\n", path, run.failing_ctx() ? hpn_ctx_last_error(run.failing_ctx()) : "?");
         return run.status();

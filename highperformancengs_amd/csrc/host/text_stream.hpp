@@ -9,8 +9,12 @@
 // while the caller's thread submits the previous chunk.  The chunk that hits the end of
 // the data carries eof = true (it may be empty).
 #pragma once
+#include <errno.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <time.h>
+
+#include <atomic>
 
 #include <condition_variable>
 #include <deque>
@@ -31,7 +35,7 @@ inline bool text_path_enabled()
 // default chunk: the pinned footprint of a run stays near 100 MB however many workers there are
 inline size_t text_chunk_bytes()
 {
-    const char *e = getenv("HPN_TEXT_CHUNK");
+    const char *e = test_env("HPN_TEXT_CHUNK");
     const long long v = e ? atoll(e) : 0;
     if (v >= 64) return (size_t)v;
     const size_t c = ((size_t)32 << 20) / (size_t)text_workers_in_flight();
@@ -45,7 +49,7 @@ inline size_t text_chunk_bytes()
 // one lane per 4 GiB of input, four per device (= per PCIe link) at most.
 inline int text_workers(char **files, int n, int requested, int ndev = 1)
 {
-    if (!text_path_enabled() || getenv("HPN_ALL_WORKERS")) return requested;
+    if (!text_path_enabled() || test_env("HPN_ALL_WORKERS")) return requested;
     uint64_t plain = 0;
     for (int i = 0; i < n; ++i) {
         struct stat sb;
@@ -296,52 +300,32 @@ private:
     bool stop_ = false, done_ = false;
 };
 
-// A slab of output to a FILE.  To a regular file, slabs of megabytes go through pwrite on a few threads at the offsets they
-// belong to (one thread copies ~8 GB/s into the page cache -- fastq_trim wrote 15 GB behind a 16 GB input at that rate, the
-// longest step of the tool; HPN_WRITE_THREADS, default 4 within the process's CPUs); anything else through fwrite as before.
-inline void write_slab(FILE *out, const void *p, size_t n)
+// A slab of output to a FILE, from the ONE thread that writes that FILE.  Slabs of megabytes to a regular file go straight to
+// the descriptor at the file's position: the blocks asked for first (posix_fallocate: one writer fills a file at 14 GB/s, at 18
+// with its blocks there), then plain write() -- pieces of a slab written by several threads with pwrite were SLOWER on the
+// round's boxes (11.5 GB/s on 4 and 8 threads: writes to one file are serialised by the file system; scripts/micro/close_cost.cpp,
+// profiles/r05/close_cost.txt) and wrong on a descriptor opened O_APPEND (`fastq_trim -o - >> all.fq`: pwrite ignores its offset
+// there), so round 4's threads are gone.  Anything else through fwrite.  false: the bytes are not all in the file (ENOSPC, EIO,
+// a closed pipe): the writers below remember it and the tools leave with a non-zero code.
+inline bool write_slab(FILE *out, const void *p, size_t n)
 {
-    if (!n) return;
-    static const bool kDrop = getenv("HPN_TRIM_NOWRITE") != nullptr;       // (timing only: what the output file costs -- scripts/e2e_trim.py)
-    if (kDrop) return;
-    static const int kThreads = [] {
-        const char *e = getenv("HPN_WRITE_THREADS");
-        long t = e ? atol(e) : 4;
-        if (!e && t > usable_cpus() / text_workers_in_flight()) t = usable_cpus() / text_workers_in_flight();
-        return (int)(t < 1 ? 1 : t > 16 ? 16 : t);
-    }();
+    if (!n) return true;
+    static const bool kDrop = test_env("HPN_TRIM_NOWRITE") != nullptr;       // (test-hooks builds, timing only: what the output file costs)
+    if (kDrop) return true;
     struct stat sb;
     const int fd = fileno(out);
-    if (kThreads < 2 || n < ((size_t)4 << 20) || fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
-        fwrite(p, 1, n, out);
-        return;
-    }
-    fflush(out);
+    if (n < ((size_t)4 << 20) || fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return fwrite(p, 1, n, out) == n;
+    if (fflush(out) != 0) return false;
+    const int fl = fcntl(fd, F_GETFL);
     const off_t at = lseek(fd, 0, SEEK_CUR);
-    if (at < 0) {
-        fwrite(p, 1, n, out);
-        return;
+    if (fl >= 0 && !(fl & O_APPEND) && at >= 0) (void)posix_fallocate(fd, at, (off_t)n);   // (a file system without it: EOPNOTSUPP, nothing lost)
+    for (size_t done = 0; done < n;) {
+        const ssize_t k = write(fd, (const char *)p + done, n - done);
+        if (k < 0 && errno == EINTR) continue;
+        if (k <= 0) return false;
+        done += (size_t)k;
     }
-    const size_t piece = (n / (size_t)kThreads + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    std::vector<char> bad((size_t)kThreads, 0);
-    auto put = [&](int t) {
-        const size_t lo = (size_t)t * piece, hi = lo + piece < n ? lo + piece : n;
-        for (size_t done = lo; done < hi;) {
-            const ssize_t k = pwrite(fd, (const char *)p + done, hi - done, at + (off_t)done);
-            if (k <= 0) {
-                bad[(size_t)t] = 1;
-                return;
-            }
-            done += (size_t)k;
-        }
-    };
-    for (int t = 1; t < kThreads && (size_t)t * piece < n; ++t) th.emplace_back(put, t);
-    put(0);
-    for (auto &t : th) t.join();
-    bool failed = false;
-    for (char b : bad) failed = failed || b;
-    if (failed || lseek(fd, at + (off_t)n, SEEK_SET) < 0) fprintf(stderr, "write error on the output file\n");
+    return true;
 }
 
 // Output side of fastq_trim's fast path: pinned buffers the GPU result is copied into, written
@@ -391,6 +375,7 @@ public:
         cv_.notify_all();
         if (th_.joinable()) th_.join();
     }
+    bool failed() const { return failed_; }     // (after finish(): a write did not go through)
 
 private:
     void loop()
@@ -404,7 +389,7 @@ private:
                 job = todo_.front();
                 todo_.pop_front();
             }
-            if (job.second) write_slab(out_, buf_[(size_t)job.first], job.second);
+            if (job.second && !failed_ && !write_slab(out_, buf_[(size_t)job.first], job.second)) failed_ = true;
             {
                 std::lock_guard<std::mutex> lk(m_);
                 free_.push_back(job.first);
@@ -415,6 +400,7 @@ private:
     hpn_ctx *ctx_;
     FILE *out_;
     bool ok_ = false, stop_ = false;
+    std::atomic<bool> failed_{false};
     std::vector<void *> buf_;
     std::deque<int> free_;
     std::deque<std::pair<int, size_t>> todo_;

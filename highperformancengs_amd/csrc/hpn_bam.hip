@@ -186,7 +186,7 @@ int hpn_depth_finish(hpn_ctx *c, uint32_t W, hpn_run *runs, uint64_t runs_cap, u
         HPN_HIP(c, hipMemcpyAsync(&bad, c->w_misc.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipMemcpyAsync(sw_ctl, c->d_sw.p, sizeof sw_ctl, hipMemcpyDeviceToHost, c->stream));
         HPN_HIP(c, hipStreamSynchronize(c->stream));
-        if (getenv("HPN_SWEEP_DIAG") && sw_ctl[0]) {   // (DIAG_SWEEP_STAMPS builds leave eight words per swept tile in its stretch of d_diff)
+        if (test_env("HPN_SWEEP_DIAG") && sw_ctl[0]) {   // (DIAG_SWEEP_STAMPS builds leave eight words per swept tile in its stretch of d_diff)
             const uint32_t nt = sw_ctl[0];
             std::vector<uint32_t> st((size_t)nt * 8);
             if (hipMemcpy2D(st.data(), 32, c->d_diff.p, (size_t)depth_tile_size() * 4, 32, nt, hipMemcpyDeviceToHost) == hipSuccess) {

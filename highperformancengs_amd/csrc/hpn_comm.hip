@@ -56,7 +56,7 @@ void rccl_load(Rccl &r)
     // one beside it: RTLD_NOLOAD first asks for the copy that is mapped under either soname, and only a process
     // without any loads the system library.  HPN_RCCL_LIB names a file outright.
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    if (const char *e = getenv("HPN_RCCL_LIB")) r.h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    if (const char *e = test_env("HPN_RCCL_LIB")) r.h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
     for (int i = 0; !r.h && i < 2; ++i) r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     if (!r.h && dlsym(RTLD_DEFAULT, "ncclAllReduce")) r.h = dlopen(nullptr, RTLD_NOW);   // linked into the process under another name
     for (int i = 0; !r.h && i < 3; ++i) r.h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
@@ -136,7 +136,7 @@ const char *hpn_comm_library(void) { return rccl().path; }
 // (tests/stub/rccl_stub.cpp) it lets the grouped collective run with n = 2..8 "ranks" on a one-GPU box.
 static bool shared_device_allowed()
 {
-    const char *e = getenv("HPN_COMM_SHARED_DEVICE");
+    const char *e = test_env("HPN_COMM_SHARED_DEVICE");
     return e && e[0] == '1';
 }
 
@@ -201,9 +201,14 @@ int hpn_allreduce_u64_all(hpn_ctx **ctxs, uint64_t **d_vecs, int n, size_t n_wor
     if (e != ncclSuccess)
         return fail(ctxs[0], queued ? HPN_E_PARTIAL : HPN_E_RCCL, "grouped ncclAllReduce: %s (%d of %d enqueued)",
                     r.GetErrorString ? r.GetErrorString(e) : "?", queued, n);
+    // (all n in-place all-reduces are enqueued or done by now: a failure from here on leaves sums in the vectors, too)
     for (int i = 0; i < n; ++i) {
-        HPN_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
-        HPN_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+        hipError_t hs = hipSetDevice(ctxs[i]->device);
+        if (hs == hipSuccess) hs = hipStreamSynchronize(ctxs[i]->stream);
+        if (hs != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctxs[i], HPN_E_PARTIAL, "waiting for rank %d's all-reduce failed: %s (all %d were enqueued)", i, hipGetErrorString(hs), n);
+        }
     }
     return HPN_OK;
 }

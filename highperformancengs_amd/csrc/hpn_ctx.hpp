@@ -1,5 +1,6 @@
 // hpn_ctx.hpp -- the per-GPU context behind the C ABI (include/hpngs.h).
 #pragma once
+#include "host/knobs.hpp"
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>

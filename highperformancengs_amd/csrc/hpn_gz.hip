@@ -77,7 +77,7 @@ int hpn_gz_inflate_finish_dev(hpn_ctx *c, const uint8_t *d_window_in, uint8_t *d
         HPN_HIP(c, hipStreamSynchronize(c->stream));
         return HPN_OK;
     }
-    const bool dbg = getenv("HPN_GZ_DEBUG") != nullptr;
+    const bool dbg = test_env("HPN_GZ_DEBUG") != nullptr;
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     const double t1 = now();
     uint16_t *sym = (uint16_t *)c->g_sym.p;

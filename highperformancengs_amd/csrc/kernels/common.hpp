@@ -1,5 +1,6 @@
 // common.hpp -- device helpers shared by the gfx950 scan kernels.
 #pragma once
+#include "../host/knobs.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
 hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t approx_bytes,
                              u64 *d_acc, u64 *d_sched, int n_cu, hipStream_t st)
 {
-    const char *ev = getenv("HPN_K1_VARIANT"), *eg = getenv("HPN_K1_WG_PER_CU");
+    const char *ev = test_env("HPN_K1_VARIANT"), *eg = test_env("HPN_K1_WG_PER_CU");
     const int variant = ev ? atoi(ev) : 811;
     const int unroll = variant / 100;
     // workgroups (4 waves each) per CU.  Long launches: 2 -- same-session sweep over 158 GB: 2 -> 24.01 ms, 3 -> 24.35,

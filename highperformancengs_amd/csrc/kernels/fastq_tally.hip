@@ -503,7 +503,7 @@ hipError_t launch_tally_hist(const uint8_t *d_qual, const uint8_t *d_base, const
     // make the last round of turns a large part of the whole
     uint32_t big = HPN_HIST_BIG;
     while (big > 1 && nchunk < (uint64_t)8 * big * grid) big >>= 1;
-    if (const char *e = getenv("HPN_K1L_BIG")) {   // tests: turns of several chunks on batches that would not get them
+    if (const char *e = test_env("HPN_K1L_BIG")) {   // tests: turns of several chunks on batches that would not get them
         const int v = atoi(e);
         if (v >= 1 && v <= 64) big = (uint32_t)v;
     }

@@ -189,7 +189,7 @@ hipError_t launch_trim(const uint8_t *d_seq, const uint8_t *d_qual, const uint64
                        d_ticket_err, d_ticket_err + 1);
     if (n) {
         uint64_t want = (n + kTrimThreads - 1) / kTrimThreads;
-        const char *eg = getenv("HPN_TRIM_WG_PER_CU");  // A/B knob (scripts/k2_sweep.py)
+        const char *eg = test_env("HPN_TRIM_WG_PER_CU");  // A/B knob (scripts/k2_sweep.py)
         const uint64_t cap = (uint64_t)n_cu * (eg ? (uint64_t)atoi(eg) : 8);
         hipLaunchKernelGGL(k_trim_copy, dim3((unsigned)(want < cap ? want : cap)), dim3(kTrimThreads), 0, st, d_seq,
                            d_qual, d_off, d_out_off, n, S, E, d_beg, d_end, d_out_seq, d_out_qual);

@@ -749,7 +749,7 @@ hipError_t launch_gz_windows(const uint16_t *d_sym, uint32_t sym_cap, void *d_me
 {
     // (a call of more than half a chip-fill of stretches comes from a worker that has the device to itself: tally_gz_on_gpu
     // divides the chip's 5,120 slots among the workers in flight)
-    const char *how = getenv("HPN_GZ_WINDOWS");                  // groups / lds / global: tests and A/B runs
+    const char *how = test_env("HPN_GZ_WINDOWS");                  // groups / lds / global: tests and A/B runs
     if (d_groups && (how ? !strcmp(how, "groups") : n_chunks > (uint32_t)n_cu * 12u)) {
         const uint32_t ng = (n_chunks + kGzGroup - 1) / kGzGroup;
         uint16_t *gmaps = (uint16_t *)d_groups;

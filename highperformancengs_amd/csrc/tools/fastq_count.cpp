@@ -76,7 +76,7 @@ static void worker(int slot, int workers, FILE *out)
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
     if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] worker %d: context %.3f s\n", slot, wall_s() - t0);
     stamp("context created");
-    WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers), workers == 1);
+    WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers), workers == 1, true);
     for (int i; (i = g_next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, g.infiles[i], out);
 }
 

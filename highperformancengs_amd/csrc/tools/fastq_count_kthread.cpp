@@ -117,7 +117,7 @@ int main(int argc, char *argv[])
                 const int rel = WorkerLanes::device_of(g_ndev, nw, t);
                 const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
                 if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
-                WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, nw), nw == 1);
+                WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, nw), nw == 1, true);
                 for (long i; (i = next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, acc[(size_t)i], g.infiles[i]);
             });
         for (auto &t : th) t.join();

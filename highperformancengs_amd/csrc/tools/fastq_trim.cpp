@@ -94,12 +94,16 @@ int main(int argc, char *argv[])
         }
         return true;
     };
+    auto write_failed = [&]() {
+        fprintf(stderr, "fastq_trim: writing the output failed (%s)\n", errno ? strerror(errno) : "short write");
+        leave(2);
+    };
     auto start_over = [&] {
         fflush(out);
         if (ftruncate(fileno(out), 0) != 0 || fseek(out, 0, SEEK_SET) != 0) die_hpn(ctx, HPN_E_STATE, "fastq_trim: cannot rewind the output");
         reads = 0;
     };
-    if (!exact && to_file && from_file && bam_gpu_enabled() && !getenv("HPN_NO_BGZF") && is_bgzf_file(infile)) {
+    if (!exact && to_file && from_file && bam_gpu_enabled() && !test_env("HPN_NO_BGZF") && is_bgzf_file(infile)) {
         BgzfGpuStream gs;
         bool usable = gs.open_text(ctx, infile);
         if (usable) {
@@ -117,6 +121,7 @@ int main(int argc, char *argv[])
                 usable = cut_device_text(writer, gs.d_raw(), r == 0 ? 0 : bi.n_records, fin);  // text mode: n_records = bytes inflated
             }
             writer.finish();
+            if (writer.failed()) write_failed();
         }
         if (usable) done = true;
         else start_over();
@@ -125,20 +130,20 @@ int main(int argc, char *argv[])
     // Writing the trimmed text is as slow as the host's own two-pass inflate on 16 cores (1.1 s vs 1.25 s on 3 GB), so
     // this route is taken when the host has few cores (or when asked for: HPN_GZ_GPU=1)
     const char *want_gz_gpu = getenv("HPN_GZ_GPU");
-    const bool gz_on_gpu = gz_gpu_enabled() && (usable_cpus() <= 8 || (want_gz_gpu && want_gz_gpu[0] == '1') || getenv("HPN_GZ_GPU_FORCE"));
-    if (!done && !exact && to_file && from_file && gz_on_gpu && !getenv("HPN_NO_MGZ") && !getenv("HPN_NO_PGZ") &&
+    const bool gz_on_gpu = gz_gpu_enabled() && (usable_cpus() <= 8 || (want_gz_gpu && want_gz_gpu[0] == '1') || test_env("HPN_GZ_GPU_FORCE"));
+    if (!done && !exact && to_file && from_file && gz_on_gpu && !test_env("HPN_NO_MGZ") && !test_env("HPN_NO_PGZ") &&
         is_plain_gzip_file(infile)) {
         GzGpuStream gs;
         const long cpus = usable_cpus();
         uint32_t per_call = 5120;
         (void)hpn_inflate_slots(ctx, &per_call);                          // stretches the chip decodes at once
         const uint32_t slots = per_call;
-        if (const char *e = getenv("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
+        if (const char *e = test_env("HPN_GZ_BATCH")) per_call = (uint32_t)atol(e);
         // several device calls per file, so that the writer thread has text to write while the next part is inflated:
         // a quarter of the file per call, in stretches small enough to fill the chip each time
         size_t stretch = 0;
         struct stat sb;
-        if (!getenv("HPN_GZ_STRETCH") && stat(infile, &sb) == 0) {
+        if (!test_env("HPN_GZ_STRETCH") && stat(infile, &sb) == 0) {
             stretch = ((size_t)sb.st_size / 4 / slots + 65536) & ~(size_t)65535;
             stretch = stretch < ((size_t)256 << 10) ? (size_t)256 << 10 : stretch > ((size_t)1 << 20) ? (size_t)1 << 20 : stretch;
         }
@@ -158,6 +163,7 @@ int main(int argc, char *argv[])
                 usable = cut_device_text(writer, gs.d_text(), n, fin);
             }
             writer.finish();
+            if (writer.failed()) write_failed();
             if (getenv("HPN_TIMING"))
                 fprintf(stderr, usable ? "[hpn] gzip on the GPU: block starts %.3f s, upload %.3f s, device inflate %.3f s\n"
                                        : "[hpn] gzip route on the GPU abandoned (%.3f / %.3f / %.3f s)\n",
@@ -228,6 +234,7 @@ int main(int argc, char *argv[])
         }
         const double t4 = wall_s();
         writer.finish();
+        if (writer.failed()) write_failed();
         if (getenv("HPN_TIMING"))
             fprintf(stderr, "[hpn] waiting for reader / writer %.3f s  copy+frame+trim+copy back %.3f s  final drain %.3f s\n", t_wait,
                     t_gpu, wall_s() - t4);
@@ -290,6 +297,6 @@ int main(int argc, char *argv[])
     }
     fprintf(stderr, "Total_reads: %lu\nFinished in %.3f s\n", reads, (double)(usec() - begin) / CLOCKS_PER_SEC);
     in.close();
-    fclose(out);
+    if (ferror(out) | fclose(out)) write_failed();     // (the reference's fprintf never looks; a short output with exit code 0 helps nobody)
     quick_exit_ok();
 }

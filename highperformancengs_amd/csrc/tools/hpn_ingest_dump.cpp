@@ -70,7 +70,7 @@ int main(int argc, char **argv)
             if (n <= 0) break;
             fwrite(buf.data(), 1, (size_t)n, stdout);
         }
-        if (getenv("HPN_READER_STATS"))  // which reader produced the stream, and how
+        if (test_env("HPN_READER_STATS"))  // which reader produced the stream, and how
             fprintf(stderr, "reader=%s accepted=%lu gaps=%lu fallback=%d crc_failed=%d find_s=%.3f decode_s=%.3f translate_s=%.3f\n",
                     f.pz ? "pgz" : f.mz ? "mgz" : f.bz ? "bgzf" : "zlib", f.pz ? (unsigned long)f.pz->chunks_accepted() : 0ul,
                     f.pz ? (unsigned long)f.pz->gaps_decoded() : 0ul, f.pz ? (int)f.pz->fell_back() : 0, f.pz ? (int)f.pz->crc_failed() : 0,

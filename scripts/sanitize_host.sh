@@ -6,8 +6,8 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 LINK="-L$ROOT/highperformancengs_amd -lhpngs -lz -lpthread -Wl,-rpath,$ROOT/highperformancengs_amd -Wl,-rpath-link,/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib"
-g++ -O1 -g -std=c++17 -fsanitize=thread -I$ROOT/include $ROOT/highperformancengs_amd/csrc/tools/hpn_ingest_dump.cpp -o $T/tsan $LINK
-g++ -O1 -g -std=c++17 -fsanitize=address,undefined -I$ROOT/include $ROOT/highperformancengs_amd/csrc/tools/hpn_ingest_dump.cpp -o $T/asan $LINK
+g++ -O1 -g -std=c++17 -DHPN_TEST_HOOKS -fsanitize=thread -I$ROOT/include $ROOT/highperformancengs_amd/csrc/tools/hpn_ingest_dump.cpp -o $T/tsan $LINK
+g++ -O1 -g -std=c++17 -DHPN_TEST_HOOKS -fsanitize=address,undefined -I$ROOT/include $ROOT/highperformancengs_amd/csrc/tools/hpn_ingest_dump.cpp -o $T/asan $LINK
 python3 - "$T" <<'PY'
 import gzip, sys
 import numpy as np

@@ -6,8 +6,8 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
-g++ -O1 -g -std=c++17 -fsanitize=thread -I$ROOT/include $ROOT/tests/stub/shard_harness.cpp -o $T/tsan -lz -lpthread
-g++ -O1 -g -std=c++17 -fsanitize=address,undefined -I$ROOT/include $ROOT/tests/stub/shard_harness.cpp -o $T/asan -lz -lpthread
+g++ -O1 -g -std=c++17 -DHPN_TEST_HOOKS -fsanitize=thread -I$ROOT/include $ROOT/tests/stub/shard_harness.cpp -o $T/tsan -lz -lpthread
+g++ -O1 -g -std=c++17 -DHPN_TEST_HOOKS -fsanitize=address,undefined -I$ROOT/include $ROOT/tests/stub/shard_harness.cpp -o $T/asan -lz -lpthread
 python3 - "$T" <<'PY'
 import gzip, sys
 import numpy as np

@@ -41,6 +41,8 @@ int hpn_ctx_create(int device, hpn_ctx **ctx)
     return HPN_OK;
 }
 const char *hpn_ctx_last_error(const hpn_ctx *c) { return c->err; }
+int hpn_ctx_device(const hpn_ctx *, int *device) { return *device = 0, HPN_OK; }
+int hpn_ctx_pci_address(const hpn_ctx *, char *, int) { return HPN_E_NODEVICE; }      // (no device: bind_thread_near leaves the threads where they are)
 int hpn_host_malloc(hpn_ctx *, size_t bytes, void **p)
 {
     *p = malloc(bytes ? bytes : 1);

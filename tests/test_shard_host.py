@@ -18,7 +18,7 @@ def harness(tmp_path_factory):
     out = {}
     for tag, flags in (("plain", ["-O1"]), ("tsan", ["-O1", "-g", "-fsanitize=thread"])):
         exe = str(d / tag)
-        subprocess.check_call(["g++", "-std=c++17", *flags, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "stub", "shard_harness.cpp"),
+        subprocess.check_call(["g++", "-std=c++17", "-DHPN_TEST_HOOKS", *flags, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "stub", "shard_harness.cpp"),
                                "-o", exe, "-lz", "-lpthread"])
         out[tag] = exe
     return out
