@@ -90,6 +90,7 @@ def launch_ranks(a):
             else:
                 time.sleep(0.2)
     if failed is not None:
+        refused = procs[failed[0]].returncode == 2     # (a rank that REFUSED to run -- too few devices, a launcher that disagrees -- : its code is the job's)
         for r in live:   # exactly the processes started above, by pid
             procs[r].kill()
         for pr in procs:
@@ -98,7 +99,7 @@ def launch_ranks(a):
             except subprocess.TimeoutExpired:
                 pass
         print(f"[bench] rank {failed[0]} of {a.gpus} failed ({failed[1]}): no result", file=sys.stderr)
-        return 1
+        return 2 if refused else 1
     reader.join(timeout=30)
     lines = [l for l in (out0[0].decode() if out0 else "").splitlines() if l.startswith("{")]
     if not lines:
@@ -287,7 +288,15 @@ def main():
               file=sys.stderr)
     from highperformancengs_amd import api as _api
     rccl_lib = _api.comm_library() if be.name == "hip" and (allreduce.startswith("rccl") or world == 1) else None   # which librccl the native binding resolved to
-    rccl_ranks = be.rccl_ranks() if allreduce.startswith("rccl") else None   # ncclCommCount of this rank's communicator
+    # ranks in the communicator the sum goes through: ncclCommCount of the native one, else torch.distributed's group (backend
+    # "nccl" IS RCCL).  EVERY rank's figure must be `world`: a number from fewer ranks than --gpus is never printed.
+    rccl_ranks = be.rccl_ranks() if allreduce.startswith("rccl") else (dist.get_world_size() if world > 1 else None)
+    if world > 1:
+        seen = [int(x) for x in shard.gather_floats(float(rccl_ranks or 0), be.device)]
+        if any(x != world for x in seen):
+            if rank == 0:
+                print(f"bench.py: the collective spans {seen} ranks (per rank) where --gpus {world} asked for {world}: no result", file=sys.stderr)
+            sys.exit(3)
     kernel_ms = []
 
     def step():
@@ -312,6 +321,37 @@ def main():
     dt = shard.max_over_ranks(time.perf_counter() - t0, be.device)
     k_mine = sum(kernel_ms) / max(1, len(kernel_ms))
     k_ranks = shard.gather_floats(k_mine, be.device)   # every rank's mean kernel time, in rank order
+
+    # ---- the same kernel on reads of MIXED lengths (after the timed region; rank 0's figure is reported) --------------------
+    # The headline's reads are all 150 bp, which lets K1's offset pass add 1,024 equal lengths at once; trimmed data does not.
+    # Same resident quality bytes, offsets of lengths drawn like adapter / quality-trimmed reads: 70 % untouched (150), the rest
+    # uniform on 30..149.  Checked in closed form against the lengths themselves.
+    ragged = None
+    if be.name == "hip" and not a.full_matrix and n >= 1000:
+        g0 = torch.Generator(device="cuda").manual_seed(2025 + rank)
+        rl = torch.randint(30, 150, (n,), device="cuda", generator=g0, dtype=torch.int64)
+        keep = torch.rand(n, device="cuda", generator=g0) < 0.7
+        rl[keep] = L
+        del keep
+        ro = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(rl, 0, out=ro[1:])
+        tot = int(ro[-1].item())
+        want_hist = torch.bincount(rl, minlength=512).cpu().numpy()
+        del rl
+        r_ms = []
+        for i in range(4):
+            ctx.fastq_tally_dev(d_qual, ro, n, flags=0)
+            got = ctx.fastq_tally_fetch()
+            if i:
+                r_ms.append(ctx.last_kernel_ms(0))
+        assert got.total == tot and (got.seqlen == want_hist).all(), "K1 on ragged reads: SeqLen / sum differ from the lengths drawn"
+        r_k = sorted(r_ms)[len(r_ms) // 2]
+        r_bytes = tot + (n + 1) * 8
+        ragged = {"workload": f"the same {n:.3g} reads cut to mixed lengths (70 % {L}, 30 % uniform 30..{L - 1}: {tot / n:.1f} bp on average)",
+                  "kernel_ms": round(r_k, 4), "algorithmic_bytes_per_launch": r_bytes, "achieved": round(r_bytes / r_k / 1e6, 1),
+                  "frac": round(r_bytes / r_k / 1e6 / HBM_PEAK_GBS, 4), "exact": "SeqLen[512] and sum equal the lengths drawn"}
+        del ro
+        torch.cuda.empty_cache()
 
     # ---- result checks (after the timed region) ------------------------------------------------
     # closed form: every record of every rank counted once, at its length
@@ -371,7 +411,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_per_rank": [round(x, 4) for x in k_ranks],
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_ragged": ragged["frac"] if ragged else None, "ragged": ragged},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -143,6 +143,21 @@ inline hpn_ctx *pooled_worker_ctx(int worker, int device)
     return pool[(size_t)worker];
 }
 
+// One line per process on stderr when a BAM went over several workers: which devices did the work (no collective on this
+// path: whole targets per worker / per-window vectors added on the host).
+inline void say_workers_once(const char *what, int workers)
+{
+    static std::atomic<bool> said{false};
+    if (workers < 2 || said.exchange(true)) return;
+    std::vector<hpn_ctx *> c;
+    int devices = 1;
+    if (hpn_device_count(&devices) != HPN_OK || devices < 1) devices = 1;
+    for (int w = 0; w < workers; ++w) c.push_back(pooled_worker_ctx(w, w % devices));
+    char where[1024];
+    describe_devices(c.data(), workers, where, sizeof where);
+    fprintf(stderr, "[hpn] %s: %d workers on devices %s; results joined on the host%s\n", what, workers, where, workers > devices ? " (workers share a device)" : "");
+}
+
 struct TargetOut {
     std::vector<hpn_run> runs;
     std::vector<char> text;      // bedGraph lines formatted on the device (text_name given), instead of runs

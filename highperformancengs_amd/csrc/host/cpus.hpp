@@ -117,4 +117,21 @@ inline void bind_thread_near(hpn_ctx *ctx)
     if (n.use) (void)sched_setaffinity(0, sizeof n.set, &n.set);
 }
 
+// "0 (0000:05:00.0), 1 (0000:15:00.0)": the devices a set of lanes / workers is bound to, for the one line a multi-device
+// run leaves on stderr -- so that a first run on an 8-GPU node shows at a glance that eight DEVICES did the work.
+inline void describe_devices(hpn_ctx *const *ctxs, int n, char *buf, size_t cap)
+{
+    size_t at = 0;
+    buf[0] = 0;
+    for (int k = 0; k < n && at + 48 < cap; ++k) {
+        int device = -1;
+        char addr[32] = "?";
+        if (ctxs[k]) {
+            (void)hpn_ctx_device(ctxs[k], &device);
+            if (hpn_ctx_pci_address(ctxs[k], addr, (int)sizeof addr) != HPN_OK) snprintf(addr, sizeof addr, "?");
+        }
+        at += (size_t)snprintf(buf + at, cap - at, "%s%d (%s)", k ? ", " : "", device, addr);
+    }
+}
+
 }  // namespace hpn

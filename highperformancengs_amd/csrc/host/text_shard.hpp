@@ -95,6 +95,7 @@ public:
             if (rc == HPN_OK) rc = hpn_allreduce_u64_all(ctx_.data(), vec.data(), (int)ctx_.size(), HPN_TALLY_WORDS);
             if (rc == HPN_OK) {  // every lane now holds the sum: lane 0's is fetched, the others' are dropped
                 *how = "rccl";
+                say_once("rccl");
                 rc = hpn_fastq_tally_fetch(ctx_[0], acc);
                 for (size_t k = 1; k < ctx_.size(); ++k) drop(ctx_[k]);
                 return rc;
@@ -106,6 +107,7 @@ public:
             }
             fprintf(stderr, "[hpn] RCCL all-reduce failed (%s): the lanes' vectors are added on the host\n", hpn_ctx_last_error(ctx_[0]));
         }
+        say_once("host");
         int rc = HPN_OK;
         for (size_t k = 0; k < ctx_.size(); ++k) {  // hpn_fastq_tally_fetch ADDS: the host sum is the fetch itself
             const int r = hpn_fastq_tally_fetch(ctx_[k], acc);
@@ -123,6 +125,18 @@ public:
     int comm_status() const { return comm_started_ ? comm_rc_ : 1; }
 
 private:
+    // One line per process on stderr when an input went over several lanes: which devices, and who added the counts.
+    void say_once(const char *how)
+    {
+        static std::atomic<bool> said{false};
+        if (ctx_.size() < 2 || said.exchange(true)) return;
+        char where[1024];
+        describe_devices(ctx_.data(), (int)ctx_.size(), where, sizeof where);
+        int ranks = 0;
+        if (!strcmp(how, "rccl")) (void)hpn_comm_count(ctx_[0], &ranks);
+        if (ranks) fprintf(stderr, "[hpn] %d lanes on devices %s; counts summed by RCCL (%d ranks)\n", (int)ctx_.size(), where, ranks);
+        else fprintf(stderr, "[hpn] %d lanes on devices %s; counts summed on the host%s\n", (int)ctx_.size(), where, distinct_ ? "" : " (lanes share a device)");
+    }
     static void drop(hpn_ctx *c)
     {
         hpn_tally scratch;

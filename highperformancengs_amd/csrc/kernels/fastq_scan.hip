@@ -8,9 +8,9 @@
 // flat with 16-byte loads and SWAR compares; off[] is read once, as 16-byte
 // pairs, for the length histogram.
 //
-// Work = byte tiles (256 lanes x U x 16 B) followed by pair tiles, handed out in
-// chunks of 8 tiles from ONE device counter (fetched one chunk ahead, so the
-// atomic's latency hides under the current chunk).  All workgroups therefore
+// Work = byte tiles (256 lanes x U x 16 B) and pair tiles (the pair chunks spread
+// evenly among the byte chunks), handed out in chunks of 8 tiles from ONE device
+// counter (fetched one chunk ahead, so the atomic's latency hides under the current chunk).  All workgroups therefore
 // stream one compact, advancing window of HBM and finish together; a static
 // grid-stride split lets workgroups drift apart over a 158 GB launch and
 // cost 3 % (scripts/k1_split.py, profiles/r01).
@@ -119,13 +119,21 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
             hist_len(s_hist, p < npair && e + 1 < n, lb[k]);
         }
     };
-    auto do_tile = [&](uint64_t t) {  // (spreading the offset tiles among the byte tiles instead was no faster)
+    auto do_tile = [&](uint64_t t) {  // (the static split: byte tiles, then pair tiles)
         if (t < btiles) byte_tile(t);
         else pair_tile(t - btiles);
     };
 
     if (kDyn) {
-        const uint64_t nchunk = (tiles + kChunkTiles - 1) / kChunkTiles;
+        // Chunks of byte tiles with the chunks of pair tiles spread evenly among them (round 5; until then all pair tiles came last).
+        // A pair tile of reads of ONE length is a handful of loads and one LDS add; of ragged reads (trimmed data) it is 16 LDS
+        // atomics per lane, and with every workgroup in its pair tiles at the same time -- the end of the launch -- that phase ran
+        // at the speed of the LDS atomics, not of HBM (0.82 of peak on lengths 100..151 against 0.86 on 150).  Spread out, one
+        // workgroup in twenty is in a pair chunk while the others stream bytes.  The window the workgroups stream stays compact:
+        // a pair chunk's offsets belong to records whose bytes are being read at about the same time.
+        const uint64_t nb = (btiles + kChunkTiles - 1) / kChunkTiles, np = (ptiles + kChunkTiles - 1) / kChunkTiles;
+        const uint64_t nchunk = nb + np;
+        const uint32_t every = np ? (uint32_t)(nchunk / np) : 1u;       // (< 2^32 chunks: 2^32 x 256 KiB is a petabyte)
         if (tid == 0) s_chunk[0] = atomicAdd(&sched[0], (u64)1);
         __syncthreads();  // also orders the s_hist clear before its first use
         int par = 0;
@@ -133,8 +141,15 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
         while (c < nchunk) {
             u64 nxt = 0;
             if (tid == 0) nxt = atomicAdd(&sched[0], (u64)1);  // in flight while this chunk streams
-            const uint64_t t1 = min((c + 1) * kChunkTiles, tiles);
-            for (uint64_t t = c * kChunkTiles; t < t1; ++t) do_tile(t);
+            const uint32_t g = (uint32_t)c / every, r = (uint32_t)c - g * every;
+            if (g < np && r == every - 1) {                    // group g's last chunk: pair chunk g
+                const uint64_t t1 = min((uint64_t)(g + 1) * kChunkTiles, ptiles);
+                for (uint64_t t = (uint64_t)g * kChunkTiles; t < t1; ++t) pair_tile(t);
+            } else {
+                const uint64_t cb = c - (g < np ? g : np);     // pair chunks in front of this one
+                const uint64_t t1 = min((cb + 1) * kChunkTiles, btiles);
+                for (uint64_t t = cb * kChunkTiles; t < t1; ++t) byte_tile(t);
+            }
             if (tid == 0) s_chunk[par ^ 1] = nxt;
             __syncthreads();
             par ^= 1;

@@ -234,6 +234,7 @@ int main(int argc, char *argv[])
                 fprintf(stderr, "%s at %.3f s\n", name, (double)(usec() - begin) / CLOCKS_PER_SEC);
             }, dev_text);
             if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, done ? "" : "  (abandoned)");
+            if (done) say_workers_once("targets by worker", workers);
             fclose(bedGraph);
             fclose(depth);
             if (wig) {

@@ -169,6 +169,7 @@ int main(int argc, char *argv[])
                     return true;
                 });
             if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] GPU ingest on %d workers%s\n", workers, multi_done ? "" : "  (abandoned)");
+            if (multi_done) say_workers_once("record batches by worker", workers);
         }
         if (!multi_done && whole && bam_gpu_enabled()) {
             // (on the heap: after the tool's last input the stream is not taken apart -- pinned chunks, the upload context and its

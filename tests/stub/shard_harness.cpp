@@ -146,6 +146,7 @@ int hpn_fastq_tally_devptr(hpn_ctx *, uint64_t **p)
 }
 int hpn_comm_init_all(hpn_ctx **, int) { return HPN_E_RCCL; }     // no RCCL here: the lanes' sums are added on the host
 int hpn_allreduce_u64_all(hpn_ctx **, uint64_t **, int, size_t) { return HPN_E_RCCL; }
+int hpn_comm_count(hpn_ctx *, int *) { return HPN_E_STATE; }
 }
 
 #include "../../highperformancengs_amd/csrc/host/text_shard.hpp"
