@@ -40,6 +40,22 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     HPN_DPP_STEP(v, |=, 0x143, 0xc);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, kWave - 1);
 }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)      // (bound_ctrl off: a lane without a source keeps its own value)
+{
+#define HPN_DPP_MAXSTEP(ctrl, rows)                                                                     \
+    {                                                                                                   \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false); \
+        v = t > v ? t : v;                                                                              \
+    }
+    HPN_DPP_MAXSTEP(0x111, 0xf)
+    HPN_DPP_MAXSTEP(0x112, 0xf)
+    HPN_DPP_MAXSTEP(0x114, 0xf)
+    HPN_DPP_MAXSTEP(0x118, 0xf)
+    HPN_DPP_MAXSTEP(0x142, 0xa)
+    HPN_DPP_MAXSTEP(0x143, 0xc)
+#undef HPN_DPP_MAXSTEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, kWave - 1);
+}
 #undef HPN_DPP_STEP
 
 // n / W for n < 2^32 with M = 0xffffffff / W (made once): the estimate is short by at most one.  A 32-bit division is

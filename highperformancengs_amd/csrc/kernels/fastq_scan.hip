@@ -17,6 +17,8 @@
 // Bound: HBM read, 1 B per base + 8 B per record.  No MFMA: no contraction here.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tally_util.hpp"
 
 namespace hpn {
@@ -28,7 +30,8 @@ constexpr int kChunkTiles = 8;
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-template <int U, bool kNt, bool kDyn>
+// kSched: 0 = static grid-stride split, 1 = chunks from one counter, pair chunks last, 2 = ... pair chunks spread among the byte chunks
+template <int U, bool kNt, int kSched>
 __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__restrict__ qual,
                                                             const uint64_t *__restrict__ off, uint64_t n,
                                                             u64 *__restrict__ acc, u64 *__restrict__ sched)
@@ -111,21 +114,54 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
             if (lane_id() == 0) atomicAdd(&s_hist[first], (uint32_t)(2 * kWave * kPairPerThread));
             return;
         }
+        // Mixed lengths (trimmed reads).  Two lengths are counted with ballots into scalar registers and added once per tile by one
+        // lane: the span's LONGEST length (what trimming left untouched: 70 % of the lanes adding to one LDS address serialise) and
+        // the span's first; every other length adds by itself.  ~11 instructions per length (round 4's hist_len per row: ~20, and
+        // with two waves per SIMD a pair tile of ragged reads was bound by its instructions, not by HBM: 0.82 of peak).
+        // (a span that lies wholly inside the batch -- all but the batch's last -- skips the per-length validity tests)
+        const bool whole = __ballot(!(p_last < npair && e0 + 2 * p_last + 1 < n)) == 0;
+        auto ragged = [&](auto whole_tag) {
+            constexpr bool kWhole = decltype(whole_tag)::value;
+            auto ok = [&](int k, int second) {
+                if (kWhole) return true;
+                const uint64_t p = wbase + (uint64_t)k * kWave;
+                return p < npair && e0 + 2 * p + (uint64_t)second < n;
+            };
+            uint32_t mx = 0;
 #pragma unroll
-        for (int k = 0; k < kPairPerThread; ++k) {
-            const uint64_t p = wbase + (uint64_t)k * kWave;
-            const uint64_t e = e0 + 2 * p;
-            hist_len(s_hist, p < npair && e < n, la[k]);
-            hist_len(s_hist, p < npair && e + 1 < n, lb[k]);
-        }
+            for (int k = 0; k < kPairPerThread; ++k) {
+                if (ok(k, 0)) mx = la[k] > mx ? la[k] : mx;
+                if (ok(k, 1)) mx = lb[k] > mx ? lb[k] : mx;
+            }
+            const uint32_t m1 = wave_max(mx), m2 = first;
+            uint32_t n1 = 0, n2 = 0;
+            auto count = [&](bool valid, uint32_t len) {
+                const bool is1 = valid && len == m1, is2 = valid && len == m2;
+                n1 += (uint32_t)__builtin_popcountll(__ballot(is1));
+                n2 += (uint32_t)__builtin_popcountll(__ballot(is2));
+                if (valid && !is1 && !is2) atomicAdd(&s_hist[len], 1u);
+            };
+#pragma unroll
+            for (int k = 0; k < kPairPerThread; ++k) {
+                count(ok(k, 0), la[k]);
+                count(ok(k, 1), lb[k]);
+            }
+            if (lane_id() == 0) {
+                if (n1) atomicAdd(&s_hist[m1], n1);
+                if (n2 && m2 != m1) atomicAdd(&s_hist[m2], n2);
+            }
+        };
+        if (whole) ragged(std::true_type{});
+        else ragged(std::false_type{});
     };
     auto do_tile = [&](uint64_t t) {  // (the static split: byte tiles, then pair tiles)
         if (t < btiles) byte_tile(t);
         else pair_tile(t - btiles);
     };
 
+    constexpr bool kDyn = kSched != 0;
     if (kDyn) {
-        // Chunks of byte tiles with the chunks of pair tiles spread evenly among them (round 5; until then all pair tiles came last).
+        // kSched 2: chunks of byte tiles with the chunks of pair tiles spread evenly among them (round 5; until then all pair tiles came last).
         // A pair tile of reads of ONE length is a handful of loads and one LDS add; of ragged reads (trimmed data) it is 16 LDS
         // atomics per lane, and with every workgroup in its pair tiles at the same time -- the end of the launch -- that phase ran
         // at the speed of the LDS atomics, not of HBM (0.82 of peak on lengths 100..151 against 0.86 on 150).  Spread out, one
@@ -133,7 +169,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
         // a pair chunk's offsets belong to records whose bytes are being read at about the same time.
         const uint64_t nb = (btiles + kChunkTiles - 1) / kChunkTiles, np = (ptiles + kChunkTiles - 1) / kChunkTiles;
         const uint64_t nchunk = nb + np;
-        const uint32_t every = np ? (uint32_t)(nchunk / np) : 1u;       // (< 2^32 chunks: 2^32 x 256 KiB is a petabyte)
+        const uint32_t every = kSched == 2 && np ? (uint32_t)(nchunk / np) : 0u;       // (< 2^32 chunks: 2^32 x 256 KiB is a petabyte; 0: pair chunks last)
         if (tid == 0) s_chunk[0] = atomicAdd(&sched[0], (u64)1);
         __syncthreads();  // also orders the s_hist clear before its first use
         int par = 0;
@@ -141,12 +177,14 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
         while (c < nchunk) {
             u64 nxt = 0;
             if (tid == 0) nxt = atomicAdd(&sched[0], (u64)1);  // in flight while this chunk streams
-            const uint32_t g = (uint32_t)c / every, r = (uint32_t)c - g * every;
-            if (g < np && r == every - 1) {                    // group g's last chunk: pair chunk g
+            // which chunk is this: pair chunk g (the last chunk of group g of `every`), or the byte chunk behind g pair chunks
+            const uint32_t g = every ? (uint32_t)c / every : (c >= nb ? (uint32_t)(c - nb) : 0u);
+            const bool is_pair = every ? (g < np && (uint32_t)c - g * every == every - 1) : c >= nb;
+            if (is_pair) {
                 const uint64_t t1 = min((uint64_t)(g + 1) * kChunkTiles, ptiles);
                 for (uint64_t t = (uint64_t)g * kChunkTiles; t < t1; ++t) pair_tile(t);
             } else {
-                const uint64_t cb = c - (g < np ? g : np);     // pair chunks in front of this one
+                const uint64_t cb = every ? c - (g < np ? g : np) : c;
                 const uint64_t t1 = min((cb + 1) * kChunkTiles, btiles);
                 for (uint64_t t = cb * kChunkTiles; t < t1; ++t) byte_tile(t);
             }
@@ -205,8 +243,8 @@ __global__ __launch_bounds__(kScanThreads) void k_tally_scan(const uint8_t *__re
     }
 }
 
-// Tuning knobs for A/B runs (scripts/k1_sweep.py): HPN_K1_VARIANT = unroll*100 + nt*10 + dyn
-// (default 811: 8 loads in flight, non-temporal, dynamic chunks), HPN_K1_WG_PER_CU.
+// Tuning knobs for A/B runs (test-hooks builds; scripts/k1_sweep.py): HPN_K1_VARIANT = unroll*100 + nt*10 + sched
+// (default 811: 8 loads in flight, non-temporal, dynamic chunks with the pair chunks last; ..2: pair chunks spread out), HPN_K1_WG_PER_CU.
 hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint64_t n, uint64_t approx_bytes,
                              u64 *d_acc, u64 *d_sched, int n_cu, hipStream_t st)
 {
@@ -227,7 +265,7 @@ hipError_t launch_tally_scan(const uint8_t *d_qual, const uint64_t *d_off, uint6
     case U * 100 + NT * 10 + DYN: \
         hipLaunchKernelGGL((k_tally_scan<U, NT, DYN>), grid, block, 0, st, d_qual, d_off, n, d_acc, d_sched); \
         break;
-        HPN_K1(4, 1, 0) HPN_K1(4, 1, 1) HPN_K1(8, 0, 0) HPN_K1(8, 0, 1) HPN_K1(8, 1, 0) HPN_K1(8, 1, 1) HPN_K1(16, 1, 0)
+        HPN_K1(4, 1, 0) HPN_K1(4, 1, 1) HPN_K1(8, 0, 0) HPN_K1(8, 0, 1) HPN_K1(8, 1, 0) HPN_K1(8, 1, 1) HPN_K1(8, 1, 2) HPN_K1(16, 1, 0)
         HPN_K1(16, 1, 1)
 #undef HPN_K1
     default: return hipErrorInvalidValue;
