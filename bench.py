@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--full-matrix", action="store_true", help="also build Quality[128][512] (kthread -L path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip the exact check, the other kernels and the end-to-end legs")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the mixed-length K1 run behind the timed region (PMC passes: every k_tally_scan launch is then the headline's)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--rank-timeout", type=float, default=3000.0, help="launcher: seconds the N ranks may take together")
     return ap.parse_args()
@@ -327,7 +328,7 @@ def main():
     # Same resident quality bytes, offsets of lengths drawn like adapter / quality-trimmed reads: 70 % untouched (150), the rest
     # uniform on 30..149.  Checked in closed form against the lengths themselves.
     ragged = None
-    if be.name == "hip" and not a.full_matrix and n >= 1000:
+    if be.name == "hip" and not a.full_matrix and n >= 1000 and not a.no_ragged:
         g0 = torch.Generator(device="cuda").manual_seed(2025 + rank)
         rl = torch.randint(30, 150, (n,), device="cuda", generator=g0, dtype=torch.int64)
         keep = torch.rand(n, device="cuda", generator=g0) < 0.7

@@ -377,7 +377,7 @@ def host_link(td):
         j = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         j["h2d_best_GBps"] = max(v for k, v in j.items() if k.startswith("h2d_"))
         j["pread_best_GBps"] = max(v for k, v in j.items() if k.startswith("pread_pagecache"))
-        j["pipelined_best_GBps"] = max(v for k, v in j.items() if k.endswith("pipelined_GBps"))
+        j["pipelined_best_GBps"] = max(v for k, v in j.items() if "pipelined" in k)     # (incl. the pass with the threads next to the device)
         # ... and what ONE output file takes on this box (scripts/micro/write_bw.cpp: slabs of 128 MiB, pwrite on 1 / 4 threads; writes
         # to one file are serialised by the file system, 10 GB/s on the round's boxes): the ceiling of fastq_trim's output
         wexe = os.path.join(td, "write_bw")
@@ -406,8 +406,15 @@ def _price(leg, in_bytes, link):
     if leg.get("hpngs") and in_bytes:
         leg["input_bytes"] = int(in_bytes)
         leg["input_GBps"] = round(in_bytes / leg["hpngs"]["seconds"] / 1e9, 2)
+        # ... and net of the process's fixed cost (HIP init + context + exit, measured on a one-record file: startup_s) -- what the
+        # tool sustains while it streams; the runtime's fixed cost is 0.25 - 0.4 s per process on the round's boxes whatever the
+        # input (scripts/micro/startup_hip.hip, exit_hip.hip)
+        if leg.get("startup_s") and leg["hpngs"]["seconds"] > leg["startup_s"]:
+            leg["input_GBps_net_of_startup"] = round(in_bytes / (leg["hpngs"]["seconds"] - leg["startup_s"]) / 1e9, 2)
         if link:
             leg["link_frac"] = round(leg["input_GBps"] / link["pipelined_best_GBps"], 3)
+            if leg.get("input_GBps_net_of_startup"):
+                leg["link_frac_net_of_startup"] = round(leg["input_GBps_net_of_startup"] / link["pipelined_best_GBps"], 3)
             if leg.get("output_bytes") and link.get("file_write_best_GBps"):      # fastq_trim: the output file is the slower side
                 leg["output_GBps"] = round(leg["output_bytes"] / leg["hpngs"]["seconds"] / 1e9, 2)
                 leg["file_write_frac"] = round(leg["output_GBps"] / link["file_write_best_GBps"], 3)

@@ -3,8 +3,10 @@
 //   hipcc --offload-arch=gfx950 -O2 scripts/micro/h2d_bw.hip -o /tmp/h2d_bw -lpthread && /tmp/h2d_bw [scratch-file-dir]
 // Prints one JSON object: h2d GB/s on 1 / 2 / 4 streams (64 MiB and 256 MiB copies), pread GB/s on 1 / 4 / 8 / 16 threads, and
 // the two pipelined (pread on T threads while the previous buffer is copied) -- what text_stream.hpp's TextPump does.
+#include <ctype.h>
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,6 +51,37 @@ static double pread_rate(int fd, uint8_t *dst, size_t total, int threads)
     return total / (now() - t0) / 1e9;
 }
 
+// this thread (and those it starts) onto the CPUs next to device 0: /sys/bus/pci/devices/<address>/local_cpulist -- what the tools'
+// feeding threads do (host/cpus.hpp: bind_thread_near).  false: no such list, or it covers every CPU.
+static bool bind_near()
+{
+    char addr[32], path[96], list[4096];
+    if (hipDeviceGetPCIBusId(addr, sizeof addr, 0) != hipSuccess) return false;
+    for (char *p = addr; *p; ++p) *p = (char)tolower(*p);
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", addr);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed, near;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    CPU_ZERO(&near);
+    for (char *p = list; *p && *p != '\n';) {
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &near);
+        if (*e != ',') break;
+        p = e + 1;
+    }
+    if (CPU_COUNT(&near) < 4 || CPU_COUNT(&near) >= CPU_COUNT(&allowed)) return false;
+    return sched_setaffinity(0, sizeof near, &near) == 0;
+}
+
 int main(int argc, char **argv)
 {
     const size_t total = (size_t)2 << 30;      // 2 GiB moved per measurement
@@ -87,13 +120,16 @@ int main(int argc, char **argv)
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return 1;
     pread_rate(fd, h, total, 8);      // warm the page cache
+    for (int pass = 0; pass < 2; ++pass) {          // pass 1: the same with the threads on the CPUs next to the device
+    const char *sfx = pass ? "_near" : "";
+    if (pass && !bind_near()) break;
     for (int t : {1, 4, 8, 16}) {
         double best = 0;
         for (int rep = 0; rep < 3; ++rep) {
             const double r = pread_rate(fd, h, total, t);
             best = r > best ? r : best;
         }
-        printf("\"pread_pagecache_x%d_GBps\": %.2f, ", t, best);
+        printf("\"pread_pagecache_x%d%s_GBps\": %.2f, ", t, sfx, best);
     }
     // ---- both at once: buffer k is copied while buffer k + 1 is read (two pinned halves of 256 MiB) ----
     for (int t : {4, 8, 16}) {
@@ -120,7 +156,8 @@ int main(int argc, char **argv)
             }
             CK(hipStreamSynchronize(st[0]));
         }
-        printf("\"pread_x%d_and_h2d_pipelined_GBps\": %.2f, ", t, done / (now() - t0) / 1e9);
+        printf("\"pread_x%d_and_h2d_pipelined%s_GBps\": %.2f, ", t, sfx, done / (now() - t0) / 1e9);
+    }
     }
     close(fd);
     unlink(path.c_str());
