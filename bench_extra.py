@@ -357,8 +357,13 @@ def _gz_single_member(buf, pieces, threads):
 
 def _timed(cmd, cwd, env=None):
     t0 = time.perf_counter()
-    p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **(env or {})})
+    p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "HPN_TIMING": "1", **(env or {})})
     return time.perf_counter() - t0, p
+
+
+def _hpn_lines(p, k=3):
+    """The tool's own stage lines (HPN_TIMING=1 on stderr): where the run's wall went, beside the wall itself."""
+    return [l[:300] for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[hpn]")][-k:]
 
 
 def _outputs(d, inputs):
@@ -455,7 +460,7 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
         for f in _outputs(wd, inputs):
             os.unlink(os.path.join(wd, f))
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
-        res = {"leg": label, "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode},
+        res = {"leg": label, "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode, "tool_lines": _hpn_lines(p)},
                "reference": None, "startup_s": round(t_start, 3), "startup_share": round(t_start / dt, 3)}
         if keep_sizes:     # outputs of many GB: (size, CRC-32) instead of the bytes
             out = {}
@@ -544,10 +549,20 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
 
 def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
     legs = []
-    td = tempfile.mkdtemp(prefix="hpn_e2e_")
+    # scratch for the legs' files: the usual temporary directory; where that has less than 70 GiB free (a box whose disk holds
+    # somebody's leftovers) and /dev/shm has room, /dev/shm -- said in the first leg ("scratch"), because files there are written
+    # without the disk file system's per-file serialisation (the fastq_trim legs' output side)
+    base = tempfile.gettempdir()
+    try:
+        if shutil.disk_usage(base).free < (70 << 30) and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (120 << 30):
+            base = "/dev/shm"
+    except OSError:
+        pass
+    td = tempfile.mkdtemp(prefix="hpn_e2e_", dir=base)
     try:
         link = host_link(td)
-        legs.append({"leg": "host link of this box (scripts/micro/h2d_bw.hip): pinned H2D, pread from the page cache, both pipelined", "host_link": link})
+        legs.append({"leg": "host link of this box (scripts/micro/h2d_bw.hip): pinned H2D, pread from the page cache, both pipelined", "host_link": link,
+                     "scratch": base})
         text = _fastq_text(ctx, reads, L, 31)
         raw = text.tobytes()
         del text
@@ -576,6 +591,8 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
                         os.unlink(os.path.join(wd, f))
                 dt, p = _timed([exe] + args_of(wd), wd)
                 res[who] = {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode}
+                if who == "hpngs":
+                    res[who]["tool_lines"] = _hpn_lines(p)
                 outs[who] = (wd, _outputs(wd, inputs), p.stdout)
             if len(outs) == 2:
                 a, b = outs["hpngs"], outs["reference"]
@@ -657,7 +674,8 @@ def _c4_file_legs(cores, td):
         how = {("bam2depth", ""): " (default: one worker)", ("bam2depth", "3"): " with the targets over three workers on the one device (HPN_NGPU=3)",
                ("bam_sliding_count", ""): " (default: one worker)", ("bam_sliding_count", "3"): " with the record batches over three workers on the one device (HPN_NGPU=3)"}[(tool, env.get("HPN_NGPU", ""))]
         leg = {"leg": f"{tool} -w {W}{how}, {shape}",
-               "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(n_reads * 150 / dt / 1e9, 3), "rc": p.returncode}, "reference": None}
+               "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(n_reads * 150 / dt / 1e9, 3), "rc": p.returncode,
+                         "tool_lines": [l for l in _hpn_lines(p, 40) if "record index" not in l][-3:]}, "reference": None}
         if tool == "bam2depth":
             ok, n_runs = True, 0
             with open(os.path.join(wd, "hg38.bam.1.bedGraph"), "rb") as fb, open(os.path.join(wd, "d.1.depth"), "rb") as fd:

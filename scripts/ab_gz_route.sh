@@ -1,5 +1,5 @@
 # fastq_count on the 7.2 GB three-member .fastq.gz: the default route against its test-hooks variants (second decode context,
-# batch sizes)  -> gpurun_out/r05/ab_gz_route.txt     (after scripts/prof_r05_tools.sh, which makes /tmp/r05in/gz3.fq.gz)
+# batch sizes)  -> gpurun_out/r05/ab_gz_route.txt     (after KEEP_INPUTS=1 scripts/prof_r05_tools.sh, which makes /tmp/r05in/gz3.fq.gz)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05; mkdir -p $O; out=$PWD/$O/ab_gz_route.txt; : > $out
 B=$PWD/highperformancengs_amd/testhooks/bin
 cd /tmp/r05in || exit 1
@@ -11,3 +11,4 @@ t HPN_GZ_BATCH=2048
 t HPN_GZ_BATCH=3072 HPN_GZ_OVERLAP=1
 t HPN_GZ_STRETCH=524288
 cat $out
+rm -rf /tmp/r05in     # (boxes are reused: leave the disk as it was found)

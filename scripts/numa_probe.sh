@@ -17,3 +17,4 @@ for n in $(seq 0 $((nodes - 1))); do
   which numactl > /dev/null 2>&1 && t "numactl cpu+mem node$n" numactl --cpunodebind=$n --membind=$n $B/bam_sliding_count -w 20000 -o s hg38.bam
 done
 cat $out
+rm -rf /tmp/r05in     # (boxes are reused: leave the disk as it was found)

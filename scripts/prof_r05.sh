@@ -30,3 +30,4 @@ timeout 600 python3 scripts/pmc.py k_bgzf_inflate "$G1" "$G2" -- python3 scripts
 echo "== k_gz_sym_inflate (scripts/bench_gz_inflate.py: 7.57 GB of text per launch)" >> $O/pmc_inflate.txt
 timeout 600 python3 scripts/pmc.py k_gz_sym_inflate "$G1" "$G2" -- python3 scripts/bench_gz_inflate.py >> $O/pmc_inflate.txt 2>&1
 ls -la $O
+rm -rf /tmp/abw

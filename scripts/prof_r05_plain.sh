@@ -36,3 +36,4 @@ HPN_TIMING=2 wall "fastq_count_kthread -t 8 (8 x 4.08 GB)" $B/fastq_count_kthrea
 HPN_NUMA=0 HPN_TIMING=1 wall "HPN_NUMA=0 fastq_count big.fq" $B/fastq_count big.fq
 HPN_NUMA=0 HPN_TIMING=1 wall "HPN_NUMA=0 fastq_count_kthread -t 8" $B/fastq_count_kthread -t 8 -o m.tsv p0.fq p1.fq p2.fq p3.fq p4.fq p5.fq p6.fq p7.fq
 cat $out
+[ -z "$KEEP_INPUTS" ] && rm -rf /tmp/r05in /tmp/r05pl     # (boxes are reused: leave the disk as it was found)

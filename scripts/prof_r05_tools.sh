@@ -43,3 +43,4 @@ prof() { n=$1; shift
 }
 [ -z "$NOPROF" ] && { prof gz_tool $B/fastq_count gz3.fq.gz; HPN_NGPU=1 prof bam2depth $B/bam2depth -w 20000 -o d hg38.bam; HPN_NGPU=1 prof bam_sliding_count $B/bam_sliding_count -w 20000 -o s hg38.bam; }
 cat $out
+[ -z "$KEEP_INPUTS" ] && rm -rf /tmp/r05in /tmp/r05pl     # (boxes are reused: leave the disk as it was found)

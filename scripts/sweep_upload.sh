@@ -1,5 +1,5 @@
 # bam_sliding_count on the 10.6 GB BAM under read-thread counts and chunk sizes: what feeds the device fastest?  -> gpurun_out/r05/sweep_upload.txt
-# (after scripts/prof_r05_tools.sh, which makes /tmp/r05in/hg38.bam)
+# (after KEEP_INPUTS=1 scripts/prof_r05_tools.sh, which makes /tmp/r05in/hg38.bam)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05; mkdir -p $O; out=$PWD/$O/sweep_upload.txt; : > $out
 B=$PWD/highperformancengs_amd/testhooks/bin      # (HPN_BAM_CHUNK / HPN_BAM_ROUNDS are test-hooks switches)
 cd /tmp/r05in
@@ -15,3 +15,4 @@ t HPN_BAM_CHUNK=67108864 HPN_BAM_ROUNDS=11 HPN_READ_THREADS=12
 t HPN_BAM_ROUNDS=11
 t HPN_BAM_ROUNDS=44
 cat $out
+rm -rf /tmp/r05in     # (boxes are reused: leave the disk as it was found)

@@ -480,3 +480,53 @@ def test_gzip_on_the_gpu_checks_every_member_like_gzread(manifest, case, why, tm
     p, files = _run(c["tool"], ["-t", "1"] + list(c["args"]), [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path,
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_TIMING": "1"})
     assert p.stdout == expected("count_multi") and b"gzip on the GPU: inflate + frame + tally" in p.stderr, p.stderr.decode()
+
+
+def _reads_file(path, n, L, seed):
+    seq, qual, off = orc.synth_soa(seed, 0, n, L, L)
+    s, q = seq.reshape(n, L), qual.reshape(n, L)
+    with open(path, "wb") as fh:
+        for i in range(n):
+            fh.write(b"@read%d/1\n" % i + s[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n")
+
+
+def test_trim_appending_to_a_file_that_has_content(tmp_path):
+    """`fastq_trim ... -o - >> all.fq`: stdout is a regular file opened O_APPEND and the slabs are megabytes.  Round 4's writer
+    cut such slabs into pieces for several pwrite threads, and pwrite ignores its offset on an O_APPEND descriptor: the pieces
+    landed in arrival order (round-4 advisor).  The writer is one thread with plain write() now (host/text_stream.hpp:
+    write_slab): what was there stays, what follows is the run's output byte for byte.  Reference: fprintf in order, fastq_trim.c:101."""
+    n, L = 60000, 150                                    # ~19 MB in, ~17 MB out: several slabs of more than 4 MiB
+    _reads_file(tmp_path / "r.fq", n, L, 4242)
+    p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", "r.fq", "-s", "5", "-e", "140", "-o", "fresh"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    want = open(tmp_path / "fresh.trim.fastq", "rb").read()
+    assert len(want) > (12 << 20)
+    head = b"@kept\nACGT\n+\nIIII\n" * 1000
+    with open(tmp_path / "all.fq", "wb") as f:
+        f.write(head)
+    for env in ({}, {"HPN_NGPU": "2"}):
+        with open(tmp_path / "all.fq", "ab") as f:
+            p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", "r.fq", "-s", "5", "-e", "140", "-o", "-"], cwd=tmp_path, stdout=f, stderr=subprocess.PIPE,
+                               env={**os.environ, **env})
+        assert p.returncode == 0, p.stderr.decode()
+        head += want
+        assert open(tmp_path / "all.fq", "rb").read() == head, env
+
+
+def test_a_write_that_fails_ends_the_tool_with_a_code(tmp_path):
+    """/dev/full takes no byte (ENOSPC).  The reference's fprintf never looks and exits 0 with a short output; here a write that
+    does not go through ends fastq_trim with exit code 2 and a line on stderr (round-4 advisor: it printed a message and exited 0)."""
+    _reads_file(tmp_path / "r.fq", 20000, 150, 77)
+    with open("/dev/full", "wb") as f:
+        p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", "r.fq", "-s", "5", "-e", "140", "-o", "-"], cwd=tmp_path, stdout=f, stderr=subprocess.PIPE)
+    assert p.returncode == 2 and b"writing the output failed" in p.stderr, (p.returncode, p.stderr.decode()[-500:])
+
+
+def test_feeders_next_to_the_device_or_not_same_bytes(manifest, tmp_path):
+    """HPN_NUMA=0 leaves the reader / uploader threads where the scheduler puts them (host/cpus.hpp: bind_thread_near); the outputs
+    cannot depend on it.  Two golden cases per tool family on both settings."""
+    for case in ("count_syn_100", "trim_syn_100", "depth_rand", "sliding_rand"):
+        for k, env in enumerate(({"HPN_NUMA": "0"}, {"HPN_NUMA": "1"})):
+            d = tmp_path / f"{case}_{k}"
+            d.mkdir()
+            _check(manifest, case, d, env)
