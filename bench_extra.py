@@ -361,6 +361,17 @@ def _timed(cmd, cwd, env=None):
     return time.perf_counter() - t0, p
 
 
+def _settle():
+    """Inputs written a moment ago are still dirty in the page cache, and the kernel's write-back of 16 GB runs beside whatever
+    reads them next: a leg timed in those seconds streamed its file at half the rate of the same leg a few seconds later
+    (profiles/r05/numa_pagecache_probe.txt: always the second run behind the file's creation).  A file a tool is given has
+    normally been on disk for a while: flush first, then time."""
+    try:
+        os.sync()
+    except OSError:
+        pass
+
+
 def _hpn_lines(p, k=3):
     """The tool's own stage lines (HPN_TIMING=1 on stderr): where the run's wall went, beside the wall itself."""
     return [l[:300] for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[hpn]")][-k:]
@@ -448,6 +459,7 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
                 fs.write(blk.data)
             del blk
     torch.cuda.empty_cache()
+    _settle()
     names8 = [f"s{i}.fq" for i in range(8)]
     for nm in names8:
         os.symlink(os.path.join(td, "small.fq"), os.path.join(td, nm))
@@ -572,6 +584,7 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
                 f.write(blob)
         sizes = {k: len(v) for k, v in files.items()}
         del files, raw
+        _settle()
         bases = reads * L
 
         def pair(label, tool, args_of, inputs, unit_bases, warm=True):
@@ -651,6 +664,7 @@ def _c4_file_legs(cores, td):
     t0 = time.perf_counter()
     bam, prefix = c4.synth(td, "hg38.bam", tg, max(2, cores - 1))
     t_synth = time.perf_counter() - t0
+    _settle()
     soa = c4.Soa(prefix, len(tg))
     for ext in (".tid", ".pos", ".flag", ".kind", ".seq4"):
         os.unlink(prefix + ext)

@@ -342,6 +342,7 @@ public:
         for (int w = 0; w < workers; ++w)
             th.emplace_back([&, w] {
                 hpn_ctx *ctx = ctxs[(size_t)w];
+                bind_thread_near(ctx);
                 BgzfDevice dev(ctx);
                 bool ok = setup(w, ctx);
                 Box &b = *box[(size_t)w];

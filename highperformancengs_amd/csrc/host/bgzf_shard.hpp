@@ -43,6 +43,7 @@ public:
         for (int l = 0; l < L; ++l)
             th.emplace_back([&, l] {
                 hpn_ctx *ctx = g.ctx(l);
+                bind_thread_near(ctx);
                 BgzfDevice dev(ctx);
                 dev.set_out_pad(TextRelay::kFront, HPN_TEXT_PIECE_TAIL + 64);
                 void *h_edge = nullptr;

@@ -2,9 +2,11 @@
 // to the cgroup CPU quota (a container may show 256 online CPUs and be throttled to 16).
 // Thread pools sized by the online-CPU count alone oversubscribe such a box and run slower.
 #pragma once
+#include <dirent.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -64,15 +66,68 @@ inline int usable_cpus()
     return n;
 }
 
+// "64-127,192-255" -> the CPUs of that list this thread may run on
+inline int parse_cpulist(const char *list, const cpu_set_t &allowed, cpu_set_t *out)
+{
+    CPU_ZERO(out);
+    for (const char *p = list; *p && *p != '\n';) {
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, out);
+        if (*e != ',') break;
+        p = e + 1;
+    }
+    return CPU_COUNT(out);
+}
+
+// First line of a tool's main(), BEFORE the first runtime call: where the process can see the render nodes of devices that all sit
+// next to ONE set of CPUs (/dev/dri/renderD* -> /sys/class/drm/<node>/device/local_cpulist; a one-GPU container, or GPUs of one
+// socket), the main thread -- the only thread so far -- moves there, so that the runtime's own threads and the memory it
+// allocates while it starts (staging buffers, signals, kernel arguments) are next to the device as well.  Binding only after the
+// first context exists left a 16.5 GB file streaming in 0.33 s or 0.65 s from run to run, depending on where the process had
+// happened to start; a process started on the device's socket streamed it in 0.33 s every time
+// (profiles/r05/numa_pagecache_probe.txt).  Devices on both sockets, no /dev/dri, HPN_NUMA=0: nothing happens.
+inline void bind_before_runtime()
+{
+    const char *off = getenv("HPN_NUMA");
+    if (off && off[0] == '0') return;
+    cpu_set_t allowed, all_near;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    CPU_ZERO(&all_near);
+    int nodes = 0;
+    if (DIR *d = opendir("/dev/dri")) {
+        while (struct dirent *e = readdir(d)) {
+            if (strncmp(e->d_name, "renderD", 7) != 0) continue;
+            char path[320], list[4096];
+            snprintf(path, sizeof path, "/sys/class/drm/%s/device/local_cpulist", e->d_name);
+            FILE *f = fopen(path, "r");
+            if (!f) continue;
+            cpu_set_t one;
+            if (fgets(list, sizeof list, f) && parse_cpulist(list, allowed, &one) > 0) {
+                CPU_OR(&all_near, &all_near, &one);
+                ++nodes;
+            }
+            fclose(f);
+        }
+        closedir(d);
+    }
+    const int k = CPU_COUNT(&all_near);
+    if (nodes > 0 && k >= 4 && k < CPU_COUNT(&allowed)) (void)sched_setaffinity(0, sizeof all_near, &all_near);
+}
+
 // The calling thread (and the threads it starts: they inherit its mask) onto the CPUs next to the context's device --
 // /sys/bus/pci/devices/<address>/local_cpulist, within what the process may use.  For the threads that FEED the device: file
 // readers filling pinned chunks, uploaders.  On a two-socket MI355X box a far-socket feeder moved 38 GB/s, a near-socket one
 // 51 GB/s (profiles/r05/numa_probe.txt: bam_sliding_count's ingest of a 10.6 GB BAM 0.40 -> 0.31 s).  Nothing happens where
 // the list is missing, covers every usable CPU, or leaves none; HPN_NUMA=0 switches it off.
-inline void bind_thread_near(hpn_ctx *ctx)
+inline bool near_cpus(hpn_ctx *ctx, cpu_set_t *out)
 {
     static const bool off = [] { const char *e = getenv("HPN_NUMA"); return e && e[0] == '0'; }();
-    if (off || !ctx) return;
+    if (off || !ctx) return false;
     struct Near {
         bool known = false, use = false;
         cpu_set_t set;
@@ -80,7 +135,7 @@ inline void bind_thread_near(hpn_ctx *ctx)
     static std::mutex m;
     static Near near[64];
     int device = 0;
-    if (hpn_ctx_device(ctx, &device) != HPN_OK || device < 0 || device >= 64) return;
+    if (hpn_ctx_device(ctx, &device) != HPN_OK || device < 0 || device >= 64) return false;
     Near n;
     {
         std::lock_guard<std::mutex> lk(m);
@@ -93,19 +148,7 @@ inline void bind_thread_near(hpn_ctx *ctx)
                 snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", addr);
                 if (FILE *f = fopen(path, "r")) {
                     if (fgets(list, sizeof list, f)) {       // "64-127,192-255"
-                        CPU_ZERO(&slot.set);
-                        for (char *p = list; *p && *p != '\n';) {
-                            char *e;
-                            const long a = strtol(p, &e, 10);
-                            if (e == p) break;
-                            long b = a;
-                            if (*e == '-') b = strtol(e + 1, &e, 10);
-                            for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
-                                if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &slot.set);
-                            p = *e == ',' ? e + 1 : e;
-                            if (*e != ',') break;
-                        }
-                        const int k = CPU_COUNT(&slot.set);
+                        const int k = parse_cpulist(list, allowed, &slot.set);
                         slot.use = k >= 4 && k < CPU_COUNT(&allowed);   // (a handful of near CPUs is less than any CPU)
                     }
                     fclose(f);
@@ -114,7 +157,38 @@ inline void bind_thread_near(hpn_ctx *ctx)
         }
         n = slot;
     }
-    if (n.use) (void)sched_setaffinity(0, sizeof n.set, &n.set);
+    if (n.use) *out = n.set;
+    return n.use;
+}
+inline void bind_thread_near(hpn_ctx *ctx)
+{
+    cpu_set_t near;
+    if (near_cpus(ctx, &near)) (void)sched_setaffinity(0, sizeof near, &near);
+}
+// ... and EVERY thread the process has now (the runtime's own helpers among them; threads made later inherit from their makers):
+// for a process whose work is on ONE device.  Measured on a two-socket box (profiles/r05/numa_pagecache_probe.txt): with only the
+// feeders bound a 16.5 GB file streamed in 0.32 - 0.65 s from run to run, with the whole process on the device's socket in
+// 0.324 - 0.332 s, wherever the file's page cache lay.
+inline void bind_process_near(hpn_ctx *ctx)
+{
+    cpu_set_t near;
+    if (!near_cpus(ctx, &near)) return;
+    if (DIR *d = opendir("/proc/self/task")) {
+        while (struct dirent *e = readdir(d)) {
+            const long tid = atol(e->d_name);
+            if (tid > 0) (void)sched_setaffinity((pid_t)tid, sizeof near, &near);
+        }
+        closedir(d);
+    }
+    (void)sched_setaffinity(0, sizeof near, &near);
+}
+// What a tool calls once it has its (first) context: the whole process when the node has one device or the run is held to one
+// (HPN_DEVICE), else just this thread -- the other devices' lanes and workers bind their own threads.
+inline void bind_for_device(hpn_ctx *ctx)
+{
+    int n = 0;
+    if (getenv("HPN_DEVICE") || (hpn_device_count(&n) == HPN_OK && n == 1)) bind_process_near(ctx);
+    else bind_thread_near(ctx);
 }
 
 // "0 (0000:05:00.0), 1 (0000:15:00.0)": the devices a set of lanes / workers is bound to, for the one line a multi-device

@@ -113,8 +113,8 @@ public:
         for (int l = 0; l < L; ++l) lanes_.emplace_back(new Lane());
         std::vector<std::thread> th;
         for (int l = 0; l < L; ++l) {
-            th.emplace_back([this, l] { produce(l); });
-            th.emplace_back([this, l] { consume(l); });
+            th.emplace_back([this, l] { bind_thread_near(g_.ctx(l)); produce(l); });
+            th.emplace_back([this, l] { bind_thread_near(g_.ctx(l)); consume(l); });
         }
         for (auto &t : th) t.join();
         for (auto &ln : lanes_) release(*ln);

@@ -278,7 +278,11 @@ public:
     void run(Second second)
     {
         std::vector<std::thread> th;
-        for (int l = 0; l < g_.lanes(); ++l) th.emplace_back([this, l, &second] { lane(l, second); });
+        for (int l = 0; l < g_.lanes(); ++l)
+            th.emplace_back([this, l, &second] {
+                bind_thread_near(g_.ctx(l));      // (a lane's thread and the reader it starts: next to the lane's device)
+                lane(l, second);
+            });
         dispatch();
         for (auto &t : th) t.join();
     }

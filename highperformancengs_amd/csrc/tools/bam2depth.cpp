@@ -151,6 +151,7 @@ static bool index_exists(const char *bam)
 
 int main(int argc, char *argv[])
 {
+    bind_before_runtime();     // (host/cpus.hpp: next to the device before the runtime starts)
     const char *outfile = "-";
     uint32_t window = 20000;
     int wig = 0;
@@ -180,6 +181,7 @@ int main(int argc, char *argv[])
     hpn_ctx *ctx = nullptr;
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    bind_for_device(ctx);
     const bool timing = getenv("HPN_TIMING") != nullptr;
     if (timing) fprintf(stderr, "[hpn] context at %.3f s\n", (double)(usec() - begin) / CLOCKS_PER_SEC);
     stamp("context created");

@@ -46,6 +46,7 @@ static bool index_exists(const char *bam)
 
 int main(int argc, char *argv[])
 {
+    bind_before_runtime();     // (host/cpus.hpp: next to the device before the runtime starts)
     const char *outfile = "-";
     uint32_t window = 20000;
     if (argc < 2) usage(argv[0]);
@@ -71,6 +72,7 @@ int main(int argc, char *argv[])
     hpn_ctx *ctx = nullptr;
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    bind_for_device(ctx);
 
     char suffix[64];
     for (int i = 0; i < n_in; ++i) {

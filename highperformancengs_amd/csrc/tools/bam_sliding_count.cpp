@@ -73,6 +73,7 @@ static bool parse_region(const BamHeader &h, const char *str, int *ref, int *beg
 
 int main(int argc, char *argv[])
 {
+    bind_before_runtime();     // (host/cpus.hpp: next to the device before the runtime starts)
     const char *outfile = "out", *region = "-";
     int window = 20000;
     if (argc < 2) usage(argv[0]);
@@ -99,6 +100,7 @@ int main(int argc, char *argv[])
     stamp("main (options read)");
     int rc = hpn_ctx_create(getenv("HPN_DEVICE") ? atoi(getenv("HPN_DEVICE")) : 0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    bind_for_device(ctx);
     stamp("context created");
 
     // results of the first input: the only one the report uses

@@ -74,6 +74,7 @@ static void worker(int slot, int workers, FILE *out)
     const int rel = WorkerLanes::device_of(g_ndev, workers, slot);
     const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    bind_for_device(ctx);
     if (getenv("HPN_TIMING")) fprintf(stderr, "[hpn] worker %d: context %.3f s\n", slot, wall_s() - t0);
     stamp("context created");
     WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, workers), workers == 1, true);
@@ -82,6 +83,7 @@ static void worker(int slot, int workers, FILE *out)
 
 int main(int argc, char *argv[])
 {
+    bind_before_runtime();     // (host/cpus.hpp: next to the device before the runtime starts)
     stamp("main");
     g.outfile = "-";
     g.thread = (int)sysconf(_SC_NPROCESSORS_ONLN);

@@ -70,6 +70,7 @@ static void count_file(hpn_ctx *ctx, WorkerLanes &lanes, FileAcc &fa, const char
 
 int main(int argc, char *argv[])
 {
+    bind_before_runtime();     // (host/cpus.hpp: next to the device before the runtime starts)
     g.outfile = "-";
     g.thread = (int)sysconf(_SC_NPROCESSORS_ONLN);
     int opt;
@@ -117,6 +118,7 @@ int main(int argc, char *argv[])
                 const int rel = WorkerLanes::device_of(g_ndev, nw, t);
                 const int rc = hpn_ctx_create(g_dev0 + rel, &ctx);
                 if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+                bind_for_device(ctx);
                 WorkerLanes lanes(ctx, g_dev0, rel, g_ndev, WorkerLanes::cap(g_ndev, nw), nw == 1, true);
                 for (long i; (i = next.fetch_add(1)) < g.numInfiles;) count_file(ctx, lanes, acc[(size_t)i], g.infiles[i]);
             });

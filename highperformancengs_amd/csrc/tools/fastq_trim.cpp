@@ -34,6 +34,7 @@ static void usage(const char *prog)
 
 int main(int argc, char *argv[])
 {
+    bind_before_runtime();     // (host/cpus.hpp: next to the device before the runtime starts)
     const char *infile = "-", *outfile = "-";
     int start = 0, end = 400;
     if (argc < 2) usage(argv[0]);
@@ -61,6 +62,7 @@ int main(int argc, char *argv[])
     else if (hpn_device_count(&ndev) != HPN_OK || ndev < 1) ndev = 1;
     int rc = hpn_ctx_create(dev0, &ctx);
     if (rc != HPN_OK) die_hpn(nullptr, rc, "hpn_ctx_create");
+    bind_for_device(ctx);
 
     FILE *out = fcreat_outfile(outfile, ".trim.fastq");
     unsigned long reads = 0;

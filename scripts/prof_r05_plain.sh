@@ -22,6 +22,7 @@ for k in range(8):
             raw.tofile(f)
 ctx.close()
 PY
+sync
 fi
 ls -l /tmp/r05pl >> $out
 B=$GRAFT_REPO_ROOT/highperformancengs_amd/bin

@@ -24,6 +24,7 @@ with open("/tmp/r05in/gz3.fq.gz", "wb") as f:
 tg = c4.targets(lambda n, l: 30.0 if n in ("chr21", "chrM") else 3.0)
 c4.synth("/tmp/r05in", "hg38.bam", tg, 15, soa=False)
 PY
+sync
 fi
 ls -l /tmp/r05in >> $out
 B=$GRAFT_REPO_ROOT/highperformancengs_amd/bin
