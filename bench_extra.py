@@ -381,11 +381,20 @@ def _outputs(d, inputs):
     return sorted(f for f in os.listdir(d) if f not in inputs and not f.endswith("_hits.png"))
 
 
+def _exe_dir(td):
+    """Where helper programs are built: the scratch directory, unless that is under /dev/shm (mounted noexec)."""
+    if os.path.realpath(td).startswith("/dev/shm"):
+        d = os.path.join(tempfile.gettempdir(), "hpn_bench_exe")
+        os.makedirs(d, exist_ok=True)
+        return d
+    return td
+
+
 def host_link(td):
     """What feeds the plain-text legs on THIS box: pinned host -> device copies and pread out of the page cache into pinned memory
     (scripts/micro/h2d_bw.hip, built and run here).  Every end-to-end leg is priced against it: input_GBps / link_GBps = link_frac.
     None when the micro-benchmark cannot be built or run (the legs then carry no link_frac)."""
-    exe = os.path.join(td, "h2d_bw")
+    exe = os.path.join(_exe_dir(td), "h2d_bw")
     try:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "scripts", "micro", "h2d_bw.hip"), "-o", exe, "-lpthread"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
@@ -396,7 +405,7 @@ def host_link(td):
         j["pipelined_best_GBps"] = max(v for k, v in j.items() if "pipelined" in k)     # (incl. the pass with the threads next to the device)
         # ... and what ONE output file takes on this box (scripts/micro/write_bw.cpp: slabs of 128 MiB, pwrite on 1 / 4 threads; writes
         # to one file are serialised by the file system, 10 GB/s on the round's boxes): the ceiling of fastq_trim's output
-        wexe = os.path.join(td, "write_bw")
+        wexe = os.path.join(_exe_dir(td), "write_bw")
         try:
             subprocess.check_call(["g++", "-O2", os.path.join(ROOT, "scripts", "micro", "write_bw.cpp"), "-o", wexe, "-lpthread"],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
@@ -561,12 +570,12 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
 
 def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
     legs = []
-    # scratch for the legs' files: the usual temporary directory; where that has less than 70 GiB free (a box whose disk holds
+    # scratch for the legs' files: the usual temporary directory; where that has less than 62 GiB free (a box whose disk holds
     # somebody's leftovers) and /dev/shm has room, /dev/shm -- said in the first leg ("scratch"), because files there are written
     # without the disk file system's per-file serialisation (the fastq_trim legs' output side)
     base = tempfile.gettempdir()
     try:
-        if shutil.disk_usage(base).free < (70 << 30) and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (120 << 30):
+        if shutil.disk_usage(base).free < (62 << 30) and os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (120 << 30):
             base = "/dev/shm"
     except OSError:
         pass
@@ -631,7 +640,7 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
         except Exception as e:  # noqa: BLE001  (disk or memory of the box: the short legs above stand)
             legs.append({"leg": "steady state", "failed": str(e)[:300]})
         # ---- BAM --------------------------------------------------------------------------------------------------
-        synth = os.path.join(td, "bam_synth")
+        synth = os.path.join(_exe_dir(td), "bam_synth")
         subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "scripts", "bam_synth.cpp"), "-o", synth, "-lz", "-lpthread"])
         contig = bam_reads * 150 // 30 // 2                         # two contigs at 30x
         subprocess.check_call([synth, os.path.join(td, "s.bam"), str(bam_reads), "2", str(contig), str(cores)])

@@ -26,6 +26,11 @@ def targets(depth_of):
 
 
 def build_synth(workdir):
+    # (the generator is BUILT where programs may run: a work directory under /dev/shm is usually mounted noexec)
+    import tempfile
+    if os.path.realpath(workdir).startswith("/dev/shm"):
+        workdir = os.path.join(tempfile.gettempdir(), "hpn_c4_exe")
+        os.makedirs(workdir, exist_ok=True)
     exe = os.path.join(workdir, "bam_synth")
     if not os.path.exists(exe):
         subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "scripts", "bam_synth.cpp"), "-o", exe, "-lz", "-lpthread"])
