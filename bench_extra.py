@@ -372,6 +372,15 @@ def _settle():
         pass
 
 
+def _quiet():
+    """A GPU process that has just exited is still being taken apart by the driver for 0.1 - 0.2 s, and a process that starts in
+    that time pays for it: hipInit 55 -> 120 - 240 ms, the first stream 22 -> 40 - 58 ms (scripts/startup_probe3.sh,
+    profiles/r05/startup_pagecache.txt: the first run behind a pause is the fast one, every run right behind another is slow;
+    scripts/prof_r05_tools.sh with PAUSE=1 / 0: 0.51 against 0.67 s for the same tool on the same file).  Every timed run of a
+    tool here starts a second after the GPU process before it ended: the tool is timed, not its predecessor's teardown."""
+    time.sleep(1.0)
+
+
 def _hpn_lines(p, k=3):
     """The tool's own stage lines (HPN_TIMING=1 on stderr): where the run's wall went, beside the wall itself."""
     return [l[:300] for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[hpn]")][-k:]
@@ -458,7 +467,10 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
     rec = 14 + 2 * L
     with open(os.path.join(td, "one.fq"), "wb") as f:
         f.write(_fastq_text(ctx, 1, L, 5).tobytes())
-    t_start = min(_timed([os.path.join(BIN, "fastq_count"), "one.fq"], td)[0] for _ in range(3))
+    t_start = 1e9
+    for _ in range(3):
+        _quiet()
+        t_start = min(t_start, _timed([os.path.join(BIN, "fastq_count"), "one.fq"], td)[0])
     # 16.3 GB as four generator blocks (host memory stays near 4 GB); the first block alone is small.fq
     with open(os.path.join(td, "big.fq"), "wb") as fb, open(os.path.join(td, "small.fq"), "wb") as fs:
         for k in range(4):
@@ -480,6 +492,7 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
         _timed([os.path.join(BIN, tool)] + args, wd, env)
         for f in _outputs(wd, inputs):
             os.unlink(os.path.join(wd, f))
+        _quiet()
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
         res = {"leg": label, "hpngs": {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode, "tool_lines": _hpn_lines(p)},
                "reference": None, "startup_s": round(t_start, 3), "startup_share": round(t_start / dt, 3)}
@@ -536,6 +549,7 @@ def _steady_state_legs(ctx, cores, td, pair, L, link=None):
     wd = tempfile.mkdtemp(prefix="mates_", dir=td)
     for nm in ("m1.fq", "m2.fq"):
         os.symlink(os.path.join(td, nm), os.path.join(wd, nm))
+    _quiet()
     t0 = time.perf_counter()
     ps = [subprocess.Popen([os.path.join(BIN, "fastq_trim"), "-i", nm, "-s", "5", "-e", "140", "-o", nm[:2]], cwd=wd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
           for nm in ("m1.fq", "m2.fq")]
@@ -611,6 +625,8 @@ def e2e_legs(ctx, cores, reads=8_000_000, L=150, bam_reads=4_000_000):
                     _timed([exe] + args_of(wd), wd)
                     for f in _outputs(wd, inputs):
                         os.unlink(os.path.join(wd, f))
+                if who == "hpngs":
+                    _quiet()
                 dt, p = _timed([exe] + args_of(wd), wd)
                 res[who] = {"seconds": round(dt, 3), "gbases_per_s": round(unit_bases / dt / 1e9, 3), "rc": p.returncode}
                 if who == "hpngs":
@@ -693,6 +709,7 @@ def _c4_file_legs(cores, td):
                             ("bam_sliding_count", ["-w", str(W), "-o", "s", "hg38.bam"], {"HPN_NGPU": "3"})):
         wd = tempfile.mkdtemp(prefix="c4_", dir=td)
         os.symlink(bam, os.path.join(wd, "hg38.bam")), os.symlink(bam + ".bai", os.path.join(wd, "hg38.bam.bai"))
+        _quiet()
         dt, p = _timed([os.path.join(BIN, tool)] + args, wd, env)
         how = {("bam2depth", ""): " (default: one worker)", ("bam2depth", "3"): " with the targets over three workers on the one device (HPN_NGPU=3)",
                ("bam_sliding_count", ""): " (default: one worker)", ("bam_sliding_count", "3"): " with the record batches over three workers on the one device (HPN_NGPU=3)"}[(tool, env.get("HPN_NGPU", ""))]

@@ -1,6 +1,7 @@
 // startup_hip.hip -- where a process's fixed HIP cost goes: stamps around the first runtime calls.
 //   hipcc --offload-arch=gfx950 -O2 scripts/micro/startup_hip.hip -o /tmp/startup_hip && /tmp/startup_hip
 #include <hip/hip_runtime.h>
+#include <sys/prctl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
@@ -9,6 +10,7 @@ static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); r
 __global__ void k(int *p) { p[threadIdx.x] = threadIdx.x; }
 int main(int argc, char **argv)
 {
+    if (getenv("NO_THP")) prctl(PR_SET_THP_DISABLE, 1, 0, 0, 0);     // (does the runtime's start wait for huge pages to be made?)
     const double t0 = now();
     double t = t0;
     auto stamp = [&](const char *w) { const double n = now(); printf("%-28s %7.1f ms  (at %7.1f)\n", w, (n - t) * 1e3, (n - t0) * 1e3); t = n; };

@@ -28,7 +28,7 @@ ls -l /tmp/r05pl >> $out
 B=$GRAFT_REPO_ROOT/highperformancengs_amd/bin
 cd /tmp/r05pl
 wall() { l=$1; shift
-  for i in 1 2 3; do s=$(date +%s%N); "$@" > /tmp/r05pl/out.txt 2> /tmp/r05pl/err.txt; e=$(date +%s%N); echo "$l run $i: $(( (e - s) / 1000000 )) ms" >> $out; done
+  for i in 1 2 3; do sleep ${PAUSE:-0}; s=$(date +%s%N); "$@" > /tmp/r05pl/out.txt 2> /tmp/r05pl/err.txt; e=$(date +%s%N); echo "$l run $i: $(( (e - s) / 1000000 )) ms" >> $out; done
   grep -E "^\[hpn" /tmp/r05pl/err.txt | tail -${STAMPS:-40} >> $out; tail -2 /tmp/r05pl/out.txt | cut -c1-200 >> $out
 }
 HPN_TIMING=2 wall "fastq_count big.fq (16.3 GB)" $B/fastq_count big.fq

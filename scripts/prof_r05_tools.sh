@@ -31,7 +31,7 @@ B=$GRAFT_REPO_ROOT/highperformancengs_amd/bin
 cd /tmp/r05in && export TMPDIR=/tmp
 wall() { # label, command...
   l=$1; shift
-  for i in 1 2 3; do rm -f d.1.depth s.txt hg38.bam.1.bedGraph; s=$(date +%s%N); "$@" > /dev/null 2> /tmp/r05in/err.txt; e=$(date +%s%N); echo "$l run $i: $(( (e - s) / 1000000 )) ms" >> $out; done
+  for i in 1 2 3; do rm -f d.1.depth s.txt hg38.bam.1.bedGraph; sleep ${PAUSE:-0}; s=$(date +%s%N); "$@" > /dev/null 2> /tmp/r05in/err.txt; e=$(date +%s%N); echo "$l run $i: $(( (e - s) / 1000000 )) ms" >> $out; done
   grep -E "^\[hpn" /tmp/r05in/err.txt | tail -${STAMPS:-40} >> $out
 }
 HPN_TIMING=2 wall "fastq_count gz3.fq.gz" $B/fastq_count gz3.fq.gz
