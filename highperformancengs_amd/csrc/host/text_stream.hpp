@@ -301,7 +301,7 @@ private:
 };
 
 // A slab of output to a FILE, from the ONE thread that writes that FILE.  Slabs of megabytes to a regular file go straight to
-// the descriptor at the file's position: the blocks asked for first (posix_fallocate: one writer fills a file at 14 GB/s, at 18
+// the descriptor at the file's position: the blocks asked for first (fallocate: one writer fills a file at 14 GB/s, at 18
 // with its blocks there), then plain write() -- pieces of a slab written by several threads with pwrite were SLOWER on the
 // round's boxes (11.5 GB/s on 4 and 8 threads: writes to one file are serialised by the file system; scripts/micro/close_cost.cpp,
 // profiles/r05/close_cost.txt) and wrong on a descriptor opened O_APPEND (`fastq_trim -o - >> all.fq`: pwrite ignores its offset
@@ -318,7 +318,9 @@ inline bool write_slab(FILE *out, const void *p, size_t n)
     if (fflush(out) != 0) return false;
     const int fl = fcntl(fd, F_GETFL);
     const off_t at = lseek(fd, 0, SEEK_CUR);
-    if (fl >= 0 && !(fl & O_APPEND) && at >= 0) (void)posix_fallocate(fd, at, (off_t)n);   // (a file system without it: EOPNOTSUPP, nothing lost)
+    // (fallocate(2), not posix_fallocate: where the file system cannot do it the call fails at once -- glibc's emulation would write
+    // every block with zeros first)
+    if (fl >= 0 && !(fl & O_APPEND) && at >= 0) (void)fallocate(fd, 0, at, (off_t)n);
     for (size_t done = 0; done < n;) {
         const ssize_t k = write(fd, (const char *)p + done, n - done);
         if (k < 0 && errno == EINTR) continue;

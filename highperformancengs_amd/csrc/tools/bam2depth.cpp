@@ -97,7 +97,7 @@ struct TextFetcher {
             fflush(out);
             const int fd = fileno(out);
             const off_t here = fd >= 0 ? lseek(fd, 0, SEEK_CUR) : -1;
-            if (here >= 0 && n >= ((uint64_t)64 << 20) && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) (void)posix_fallocate(fd, here, (off_t)n);
+            if (here >= 0 && n >= ((uint64_t)64 << 20) && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) (void)fallocate(fd, 0, here, (off_t)n);   // (fallocate(2): fails at once where the file system cannot; no zero-writing emulation)
         }
         if (n && hpn_memcpy_d2h(cx, pin[0], src, n < kSlice ? n : kSlice) != HPN_OK) return false;
         while (at < n) {

@@ -71,7 +71,8 @@ def main():
     out["cycle_row_identical_to_ours"] = ours_cycle == ref_row
     # ---- the 1e9-read file ----
     runs = []
-    for rep in range(2):
+    for rep in range(3):
+        time.sleep(20 if rep else 2)      # (the file was just written / the run before has just freed ~100 GB of device memory: let both settle)
         t0 = time.perf_counter()
         p = subprocess.run([os.path.join(BIN, "fastq_count"), "c2.fq.gz"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "HPN_TIMING": os.environ.get("C2_TIMING", "1")})
         dt = time.perf_counter() - t0
