@@ -84,6 +84,22 @@ inline int parse_cpulist(const char *list, const cpu_set_t &allowed, cpu_set_t *
     return CPU_COUNT(out);
 }
 
+// The CPUs the process could use when it started (asked for the first time on the first line of main(), before anything is bound):
+// what every later "next to device k" is cut from -- a lane for a device on the OTHER socket must not be cut from the mask its
+// maker's thread has meanwhile been narrowed to.
+inline const cpu_set_t &initial_cpus()
+{
+    static const cpu_set_t m = [] {
+        cpu_set_t s;
+        if (sched_getaffinity(0, sizeof s, &s) != 0) {
+            CPU_ZERO(&s);
+            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &s);
+        }
+        return s;
+    }();
+    return m;
+}
+
 // First line of a tool's main(), BEFORE the first runtime call: where the process can see the render nodes of devices that all sit
 // next to ONE set of CPUs (/dev/dri/renderD* -> /sys/class/drm/<node>/device/local_cpulist; a one-GPU container, or GPUs of one
 // socket), the main thread -- the only thread so far -- moves there, so that the runtime's own threads and the memory it
@@ -95,8 +111,8 @@ inline void bind_before_runtime()
 {
     const char *off = getenv("HPN_NUMA");
     if (off && off[0] == '0') return;
-    cpu_set_t allowed, all_near;
-    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    const cpu_set_t allowed = initial_cpus();
+    cpu_set_t all_near;
     CPU_ZERO(&all_near);
     int nodes = 0;
     if (DIR *d = opendir("/dev/dri")) {
@@ -143,8 +159,8 @@ inline bool near_cpus(hpn_ctx *ctx, cpu_set_t *out)
         if (!slot.known) {
             slot.known = true;
             char addr[32], path[96], list[4096];
-            cpu_set_t allowed;
-            if (hpn_ctx_pci_address(ctx, addr, (int)sizeof addr) == HPN_OK && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+            const cpu_set_t allowed = initial_cpus();
+            if (hpn_ctx_pci_address(ctx, addr, (int)sizeof addr) == HPN_OK) {
                 snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", addr);
                 if (FILE *f = fopen(path, "r")) {
                     if (fgets(list, sizeof list, f)) {       // "64-127,192-255"
