@@ -106,8 +106,8 @@ inline int multi_gpu_workers()
     return n;
 }
 
-// ... and for one file: no more workers than the file has batches' worth of bytes (a context costs ~0.1 s to make; a 600 MB
-// BAM is seven batches of 88 MB).  With ONE device a file of 2 GiB or more still gets three workers on it: one's upload and
+// ... and for one file: as many workers as the file is worth (cpus.hpp: lanes_worth -- a worker costs ~80 ms to set up, the
+// driver makes hardware queues one after the other; a 10 GB BAM is worth two devices, a 93 GB one six).  With ONE device a file of 2 GiB or more still gets three workers on it: one's upload and
 // block-table walk run beside another's inflate and a third's record kernels (hg38-shaped 10.6 GB BAM: bam_sliding_count 1.80 ->
 // 1.24-1.31 s, bam2depth 1.88 -> 1.77 s; profiles/r03/bench.json).
 // by_target: the tool hands whole TARGETS to its workers (bam2depth, bam2wig: each worker seeks to its targets and reads them with
@@ -124,8 +124,8 @@ inline int multi_gpu_workers_for(const char *path, bool /*by_target*/ = false)
             // (round 3 gave a large file three workers on ONE device here: batches in turn hid the copies behind the kernels.  The
             // one-stream route now reads ahead on a context of its own (host/bam_gpu.hpp) and is the faster one on one device:
             // 0.83 - 0.91 s against 0.96 - 1.04 s on the 10.6 GB file, 2.5 against 3.5 s on the 47 GB one: profiles/r04)
-            const long batches = (long)(sb.st_size / ((off_t)88 << 20)) + 1;
-            if (batches < n) n = (int)batches;
+            // (a worker = two contexts, its chunks and stage buffers, ~80 ms, while one device ingests ~32 GB/s of BAM: 2.5 GB)
+            n = lanes_worth((uint64_t)sb.st_size, (uint64_t)2560 << 20, n);
         }
     }
     return n;

@@ -4,6 +4,7 @@
 #pragma once
 #include <dirent.h>
 #include <sched.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,6 +65,18 @@ inline int usable_cpus()
         return (int)(cpus < 1 ? 1 : cpus);
     }();
     return n;
+}
+
+// How many devices an input of `bytes` is worth.  A lane (or worker) is not free: its context's hardware queue, its upload context
+// and its pinned chunks cost 60 - 100 ms, and the driver makes queues one after the other whatever thread asks
+// (profiles/r05/startup_hip.txt, exit_hip.txt) -- while ONE device streams `unit` bytes in that time.  With k lanes the stream
+// takes T1 / k and the set-up k x c: the sum is least at k = sqrt(T1 / c) = sqrt(bytes / unit).  (Rounds 3 - 4 gave a lane per
+// 2 GiB: eight lanes for a 16 GB file that one device streams in 0.33 s.)
+inline int lanes_worth(uint64_t bytes, uint64_t unit, int devices)
+{
+    int k = 1;
+    while (k < devices && (uint64_t)(k + 1) * (uint64_t)k * unit <= bytes) ++k;      // k (k + 1) <= bytes / unit: k ~ sqrt
+    return k;
 }
 
 // "64-127,192-255" -> the CPUs of that list this thread may run on

@@ -162,8 +162,8 @@ private:
 
 // How many lanes for this input.  HPN_NGPU=n: n, whatever the input.  Otherwise: a plain regular file, or -- for callers that
 // have a route which inflates on the lanes' own devices (gz_lanes: the count tools, host/gz_shard.hpp / bgzf_shard.hpp) -- a
-// gzip file of 256 MiB or more, one lane per 512 MiB of it; for every other caller compressed input is ONE lane (fastq_trim: a
-// single host zlib reader would feed N lanes, which adds N contexts and nothing else).  Plain: one lane per 2 GiB -- a context costs 15-30 ms to make
+// gzip file of 256 MiB or more, as many lanes as the file is worth (cpus.hpp: lanes_worth); for every other caller compressed input is ONE lane (fastq_trim: a
+// single host zlib reader would feed N lanes, which adds N contexts and nothing else).  Plain: as many lanes as the file is worth (lanes_worth) -- a context costs 15-30 ms to make
 // and one lane already streams at the PCIe rate of its link --, at most `devices_for_me`.
 // pair_on_one_device (the count tools): with a single device, a plain file of 4 GiB or more still gets TWO lanes on it -- one lane's
 // copy over PCIe then runs beside the other's framing and tally (15.2 GB: 0.42 s against 0.49-0.53 s on one context; three or
@@ -181,14 +181,14 @@ inline int shard_lanes_for(const char *path, int devices_for_me, bool pair_on_on
     if (fd >= 0) close(fd);
     if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
         // gzip: the device inflate is the wall, and its batches spread over the devices (host/gz_shard.hpp, bam_gpu.hpp's
-        // block fan-out for BGZF) -- one lane per 512 MiB of compressed bytes, from 256 MiB on
+        // block fan-out for BGZF) -- from 256 MiB on, as many lanes as the file is worth
         if (!gz_lanes || devices_for_me < 2 || sb.st_size < ((off_t)256 << 20)) return 1;
-        const long long want = (long long)(sb.st_size >> 29) + 1;
-        return (int)(want < devices_for_me ? want : devices_for_me);
+        // (a lane here = two contexts and the symbol scratch, ~0.1 s, while one device takes ~20 GB/s of compressed bytes)
+        return lanes_worth((uint64_t)sb.st_size, (uint64_t)2 << 30, devices_for_me);
     }
-    const long long lanes = (long long)(sb.st_size >> 31) + 1;
-    if (devices_for_me < 2) return lanes >= 3 ? 2 : 1;
-    return (int)(lanes < devices_for_me ? lanes : devices_for_me);
+    if (devices_for_me < 2) return sb.st_size >= ((off_t)4 << 30) ? 2 : 1;
+    // (a lane = a context, a reader and its pinned chunks, ~70 ms, while one device streams ~45 GB/s of plain text: 3.2 GB)
+    return lanes_worth((uint64_t)sb.st_size, (uint64_t)3200 << 20, devices_for_me);
 }
 
 // What one worker (one kt_for worker of the reference = one thread + its own context) may spread an input over: the
