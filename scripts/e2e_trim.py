@@ -1,5 +1,6 @@
 """fastq_trim on ONE plain 16.3 GB FASTQ -> t.trim.fastq (the bench's steady-state trim leg), with the tool's own timing lines and
-the knobs of its host side: lanes (HPN_NGPU), writer threads (HPN_WRITE_THREADS), piece size (HPN_TEXT_PIECE).
+the knobs of its host side: lanes (HPN_NGPU).  (Round 4 also swept writer threads -- HPN_WRITE_THREADS -- and the piece size;
+the writer is one thread since round 5: host/text_stream.hpp write_slab.)
    python scripts/e2e_trim.py > gpurun_out/e2e_trim_r04.txt"""
 import os
 import subprocess
@@ -14,6 +15,7 @@ import highperformancengs_amd as hp  # noqa: E402
 import bench_extra  # noqa: E402
 
 BIN = os.path.join(ROOT, "highperformancengs_amd", "bin")
+HOOKS = os.path.join(ROOT, "highperformancengs_amd", "testhooks", "bin")      # (HPN_TRIM_NOWRITE is a test-hooks switch: host/knobs.hpp)
 td = tempfile.mkdtemp(prefix="e2e_trim_")
 ctx = hp.Context(0)
 with open(os.path.join(td, "big.fq"), "wb") as fb:
@@ -25,7 +27,7 @@ ctx.close()
 torch.cuda.empty_cache()
 print(f"big.fq: {os.path.getsize(os.path.join(td, 'big.fq')) / 1e9:.1f} GB")
 sizes = set()
-for env in ({}, {"HPN_NGPU": "1"}, {"HPN_WRITE_THREADS": "8"}, {"HPN_WRITE_THREADS": "2"}, {"HPN_NGPU": "3"}, {"HPN_NGPU": "1", "HPN_WRITE_THREADS": "8"},
+for env in ({}, {"HPN_NGPU": "1"}, {"HPN_NGPU": "3"},
             {"HPN_TRIM_NOWRITE": "1"}):
     best, err = 1e9, ""
     for _ in range(2):
@@ -33,7 +35,7 @@ for env in ({}, {"HPN_NGPU": "1"}, {"HPN_WRITE_THREADS": "8"}, {"HPN_WRITE_THREA
         if os.path.exists(out):
             os.unlink(out)
         t0 = time.perf_counter()
-        p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", "big.fq", "-s", "5", "-e", "140", "-o", "t"], cwd=td,
+        p = subprocess.run([os.path.join(HOOKS if "HPN_TRIM_NOWRITE" in env else BIN, "fastq_trim"), "-i", "big.fq", "-s", "5", "-e", "140", "-o", "t"], cwd=td,
                            env={**os.environ, "HPN_TIMING": "1", **env}, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.perf_counter() - t0
         if dt < best:
