@@ -60,7 +60,7 @@ struct ByteSink {
     // output bytes at `from` (< base, the first position of the chunk being assembled) for the lanes that ask
     __device__ __forceinline__ uint32_t fetch(bool ask, int32_t from, uint32_t base, uint32_t val)
     {
-        if (__ballot(ask && (uint32_t)from >= safe)) {
+        if (__builtin_amdgcn_ballot_w64(ask && (uint32_t)from >= safe)) {
             // the source reaches into bytes this wave stored a moment ago: wait for those stores
             // (workgroup scope = this CU's vector cache: a counter wait, no cache invalidate)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

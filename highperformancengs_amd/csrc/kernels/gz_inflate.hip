@@ -70,7 +70,7 @@ struct SymSink {
     // stretch, whose byte this position will be) for the lanes that ask
     __device__ __forceinline__ uint32_t fetch(bool ask, int32_t from, uint32_t base, uint32_t val)
     {
-        if (__ballot(ask && from >= (int32_t)safe)) {
+        if (__builtin_amdgcn_ballot_w64(ask && from >= (int32_t)safe)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             safe = base;
         }

@@ -335,13 +335,13 @@ __device__ __forceinline__ void assemble(InfLds &s, Sink &sink, bool mine, uint3
         const int32_t from = (int32_t)(sink.op + p) - (int32_t)d;   // a copy: of this position (may lie in front of a gzip stretch)
         const bool near = copy && from >= (int32_t)(sink.op + c0);
 #ifndef DIAG_NOFETCH
-        if (__ballot(copy && !near)) val = sink.fetch(copy && !near, from, sink.op + c0, val);
+        if (__builtin_amdgcn_ballot_w64(copy && !near)) val = sink.fetch(copy && !near, from, sink.op + c0, val);
 #endif
         uint32_t ref = near ? (uint32_t)from - (sink.op + c0) : ~0u;   // lane of this chunk still to be copied from; ~0: val is final
 #ifdef DIAG_NOJUMP
         while (false) {
 #else
-        while (__ballot(ref != ~0u)) {
+        while (__builtin_amdgcn_ballot_w64(ref != ~0u)) {
 #endif
             const uint32_t rv = from_lane(val, ref), rr = from_lane(ref, ref);
             if (ref != ~0u) {
@@ -377,9 +377,9 @@ __device__ __forceinline__ uint32_t emit(InfLds &s, Sink &sink, Queue &q, uint32
     const uint32_t upto = wave_prefix(units), total = lane_of(upto, kWave - 1), rel = upto - units;
     const uint32_t dist = is_match ? w >> 16 : 0u;
     q.head = (q.head + take) & (kQueue - 1u), q.n -= take;
-    const u64 matches = __ballot(is_match);
+    const u64 matches = __builtin_amdgcn_ballot_w64(is_match);
     if constexpr (Sink::kDry) sink.lits(mine && !is_match, units == 2u, 0u, w);   // nothing is stored: the sink only looks at the literals
-    if (__ballot(is_match && !sink.in_reach(sink.op + rel, dist))) return 14;
+    if (__builtin_amdgcn_ballot_w64(is_match && !sink.in_reach(sink.op + rel, dist))) return 14;
     if (sink.op + total > sink.out_len) return 12;
     if constexpr (!Sink::kDry) {
         if (matches == 0) sink.lits(mine, units == 2u, sink.op + rel, w);
@@ -399,8 +399,11 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
     const uint32_t kind = (w.el >> 4) & 15u, bits = w.el & 15u;
     // what the symbol starting here would be, and where the one behind it starts
     uint32_t nxt = lane + bits, word = (w.el & 0xffff0000u) | (kind + 1u);
-    bool emits = kind <= kLit2;
-    if (__ballot(kind == kLen)) {                     // (same in every lane: windows of literals skip this)
+    // (which lanes hold a symbol this window could take, as a lane mask in scalar registers from the start: a bool that is merged
+    // behind the branch below comes back from the compiler as v_cndmask + v_cmp per use)
+    u64 emit_mask = __builtin_amdgcn_ballot_w64(kind <= kLit2);
+    const u64 len_lanes = __builtin_amdgcn_ballot_w64(kind == kLen);
+    if (len_lanes) {                                  // (same in every lane: windows of literals skip this)
         const uint32_t xb = (w.el >> 8) & 15u, o2 = bits + xb;                     // o2: where the distance code starts
         const uint32_t len = (w.el >> 16) + ((w.lo >> bits) & ((1u << xb) - 1u));
         const uint32_t d32 = __builtin_amdgcn_alignbit(w.hi, w.lo, o2);            // 32 bits from there on (o2 <= 20)
@@ -408,14 +411,15 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
         if ((ed & 0xf0u) == (kSub << 4)) ed = s.dist[(ed >> 16) + ((d32 >> kDistRoot) & ((1u << ((ed >> 8) & 15u)) - 1u))] + kDistRoot;
         const uint32_t db = ed & 15u, dxb = (ed >> 8) & 15u;
         const uint32_t dist = (ed >> 16) + ((d32 >> db) & ((1u << dxb) - 1u));     // db + dxb <= 28
+        // anything but a distance code behind a length: the chain stops at that lane with an error
+        emit_mask |= len_lanes & __builtin_amdgcn_ballot_w64((ed & 0xf0u) == (kDist << 4));
         if (kind == kLen) {
             nxt = lane + o2 + db + dxb;
-            emits = (ed & 0xf0u) == (kDist << 4);     // anything else is not a distance code: the chain stops here with an error
             word = len | dist << 16;
         }
     }
     // the chain's fixed point: a lane whose symbol this window does not take, or whose symbol ends the window
-    const uint32_t hop = emits && nxt < (uint32_t)kWave ? nxt : lane;
+    const uint32_t hop = __builtin_amdgcn_inverse_ballot_w64(emit_mask) && nxt < (uint32_t)kWave ? nxt : lane;
     u64 on = 1;
     uint32_t f = 0;
     // (measured and not kept, round 4: the chain's second, third and fourth successors worked out in the lanes first -- three
@@ -427,10 +431,12 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
         f = d;
         if (d == c) break;
     }
-    const u64 taken = on & __ballot(emits);
+    // (ballot / inverse ballot as the builtins: a lane mask in an SGPR pair IS the condition -- HIP's __ballot goes through a
+    // v_cndmask + v_cmp, and testing the lane's bit of a 64-bit scalar costs three vector instructions)
+    const u64 taken = on & emit_mask;
     // the taken lanes' words, in stream order, behind what is queued
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
-    if ((taken >> lane) & 1u) s.queue[(q.head + q.n + below) & (kQueue - 1u)] = word;
+    if (__builtin_amdgcn_inverse_ballot_w64(taken)) s.queue[(q.head + q.n + below) & (kQueue - 1u)] = word;
     q.n += (uint32_t)__builtin_popcountll(taken);
     // the chain's last lane: its symbol was taken and ends in or behind the window's last bit, or it is the end-of-block code,
     // or an error (a length without a distance code behind it: 13; not a code at all: 15)
