@@ -41,9 +41,10 @@ __device__ __forceinline__ uint32_t mk(uint32_t value, uint32_t extra, uint32_t 
 
 constexpr uint32_t kQueue = 128;               // decoded symbols waiting for their output positions (emit())
 struct InfLds {
+    uint32_t ring[kRing / 4 + 2];   // (+ copies of words 0 and 1 behind the last: a window reads three neighbouring words; FIRST in the
+                                    // struct: a two-word LDS read has 8-bit offsets, the tables' single reads take theirs in 16 bits)
     uint32_t lit[kLitSize];
     uint32_t dist[kDistSize];
-    uint32_t ring[kRing / 4 + 2];   // (+ copies of words 0 and 1 behind the last: a window reads three neighbouring words)
     union {
         struct {                    // while a block's code tables are built
             uint8_t lens[384];      // code lengths being assembled (19 code-length codes | 286 + 30 lengths from offset 32)
@@ -392,8 +393,8 @@ __device__ __forceinline__ uint32_t emit(InfLds &s, Sink &sink, Queue &q, uint32
 }
 
 // One window.  -> how it ended; o = bits consumed (the symbol at o is still to be decoded, except behind an end-of-block code).
-enum { kWinNext = 0, kWinEob = 1, kWinError = 3 };
-__device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint32_t &o, uint32_t &err)
+enum { kWinNext = 0, kWinEob = 1, kWinError = 3, kWinErrLen = 4 };
+__device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint32_t &o)
 {
     const uint32_t lane = (uint32_t)lane_id();
     const uint32_t kind = (w.el >> 4) & 15u, bits = w.el & 15u;
@@ -443,8 +444,7 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
     const uint32_t fe = lane_of(w.el, f), fn = lane_of(nxt, f), fk = (fe >> 4) & 15u;
     const bool last_taken = (taken >> f) & 1u;
     o = last_taken || fk == kEob ? fn : f;           // (an end-of-block code's nxt = lane + bits, too)
-    if (!last_taken && fk != kEob) err = fk == kLen ? 13 : 15;
-    return last_taken ? kWinNext : fk == kEob ? kWinEob : kWinError;
+    return last_taken ? kWinNext : fk == kEob ? kWinEob : fk == kLen ? kWinErrLen : kWinError;     // (the error code: decode_symbols)
 }
 
 // Decodes symbols from p on until the block's end-of-block code (-> true: p is behind it) or an error (-> false, err set).
@@ -469,10 +469,13 @@ __device__ __forceinline__ bool decode_symbols(InfLds &s, Bits &b, Pos &p, const
             }
             const Win w = window(s, p.byte * 8u + p.bit);
             uint32_t o;
-            how = walk(s, w, q, o, err);
+            how = walk(s, w, q, o);
             p.byte += (p.bit + o) >> 3, p.bit = (p.bit + o) & 7u;
         } while (how == kWinNext && q.n < (uint32_t)kWave);
-        if (how == kWinError) return false;
+        if (how >= kWinError) {
+            err = how == kWinErrLen ? 13 : 15;
+            return false;
+        }
         sink.pin_state();
         if (q.n >= (uint32_t)kWave) {                 // (a window adds at most 64: the queue holds 128)
             if ((err = emit(s, sink, q, kWave)) != 0) return false;
