@@ -248,6 +248,8 @@ __device__ __forceinline__ void seek(InfLds &s, Bits &b, Pos p, const uint8_t *_
     refill(s, b, in, in_len);
     drop(b, p.bit);
 }
+// bits [at, at + n) of v, n = 0 .. 31 (one v_bfe_u32 with offset and width in registers; the shift-and-mask form is two or three)
+__device__ __forceinline__ uint32_t bits_of(uint32_t v, uint32_t at, uint32_t n) { return __builtin_amdgcn_ubfe(v, at, n); }
 struct Win {
     uint32_t lo, hi;     // the 64 bits of the stream from bit (p + lane) on
     uint32_t el;         // the literal/length entry for them (a code longer than the root table already resolved)
@@ -265,7 +267,7 @@ __device__ __forceinline__ Win window(const InfLds &s, uint32_t bitpos)
     w.el = s.lit[w.lo & ((1u << kLitRoot) - 1u)];
     // a code longer than the root table: the lane that holds one takes the second-level entry itself and counts the root's
     // bits into it -- the walk sees a plain entry of up to 15 bits (rare length codes and the 256-symbol alphabets of BAM blocks)
-    if ((w.el & 0xf0u) == (kSub << 4)) w.el = s.lit[(w.el >> 16) + ((w.lo >> kLitRoot) & ((1u << ((w.el >> 8) & 15u)) - 1u))] + kLitRoot;
+    if ((w.el & 0xf0u) == (kSub << 4)) w.el = s.lit[(w.el >> 16) + bits_of(w.lo, kLitRoot, (w.el >> 8) & 15u)] + kLitRoot;
     return w;
 }
 __device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -406,12 +408,12 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
     const u64 len_lanes = __builtin_amdgcn_ballot_w64(kind == kLen);
     if (len_lanes) {                                  // (same in every lane: windows of literals skip this)
         const uint32_t xb = (w.el >> 8) & 15u, o2 = bits + xb;                     // o2: where the distance code starts
-        const uint32_t len = (w.el >> 16) + ((w.lo >> bits) & ((1u << xb) - 1u));
+        const uint32_t len = (w.el >> 16) + bits_of(w.lo, bits, xb);
         const uint32_t d32 = __builtin_amdgcn_alignbit(w.hi, w.lo, o2);            // 32 bits from there on (o2 <= 20)
         uint32_t ed = s.dist[d32 & ((1u << kDistRoot) - 1u)];
-        if ((ed & 0xf0u) == (kSub << 4)) ed = s.dist[(ed >> 16) + ((d32 >> kDistRoot) & ((1u << ((ed >> 8) & 15u)) - 1u))] + kDistRoot;
+        if ((ed & 0xf0u) == (kSub << 4)) ed = s.dist[(ed >> 16) + bits_of(d32, kDistRoot, (ed >> 8) & 15u)] + kDistRoot;
         const uint32_t db = ed & 15u, dxb = (ed >> 8) & 15u;
-        const uint32_t dist = (ed >> 16) + ((d32 >> db) & ((1u << dxb) - 1u));     // db + dxb <= 28
+        const uint32_t dist = (ed >> 16) + bits_of(d32, db, dxb);                  // db + dxb <= 28
         // anything but a distance code behind a length: the chain stops at that lane with an error
         emit_mask |= len_lanes & __builtin_amdgcn_ballot_w64((ed & 0xf0u) == (kDist << 4));
         if (kind == kLen) {
