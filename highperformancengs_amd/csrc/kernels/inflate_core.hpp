@@ -434,8 +434,8 @@ __device__ __forceinline__ uint32_t walk(InfLds &s, const Win &w, Queue &q, uint
         f = d;
         if (d == c) break;
     }
-    // (ballot / inverse ballot as the builtins: a lane mask in an SGPR pair IS the condition -- HIP's __ballot goes through a
-    // v_cndmask + v_cmp, and testing the lane's bit of a 64-bit scalar costs three vector instructions)
+    // (the mask stays in scalar registers: `taken` needs no vector instruction, and the inverse ballot makes it the store's exec
+    // mask -- testing the lane's bit of a 64-bit scalar costs three vector instructions)
     const u64 taken = on & emit_mask;
     // the taken lanes' words, in stream order, behind what is queued
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
