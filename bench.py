@@ -402,7 +402,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"fastq_count on {n:.3g} x {L} bp synthetic reads per GPU, resident in HBM "
-                                   f"(BASELINE configs[1]; gzip inflate is host work, excluded)",
+                                   f"(BASELINE configs[1]; inflate and PCIe are outside the timed region: extra.end_to_end has them)",
                        "reads_per_gpu": n, "read_len": L, "kernel": "k_tally_hist" if a.full_matrix else "k_tally_scan",
                        "outputs": "SeqLen[512], sum, Q20, Q30" + (", Quality[128][512]" if a.full_matrix else ""),
                        "parallelism": f"record-block shard x{world}", "allreduce": allreduce,
