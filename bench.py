@@ -328,15 +328,16 @@ def main():
     # Same resident quality bytes, offsets of lengths drawn like adapter / quality-trimmed reads: 70 % untouched (150), the rest
     # uniform on 30..149.  Checked in closed form against the lengths themselves.
     ragged = None
-    if be.name == "hip" and not a.full_matrix and n >= 1000 and not a.no_ragged:
+    if be.name == "hip" and not a.full_matrix and n >= 1000 and not a.no_ragged and L > 30:
         g0 = torch.Generator(device="cuda").manual_seed(2025 + rank)
-        rl = torch.randint(30, 150, (n,), device="cuda", generator=g0, dtype=torch.int64)
+        rl = torch.randint(30, L, (n,), device="cuda", generator=g0, dtype=torch.int64)   # 30 .. L-1: never beyond a read's bytes
         keep = torch.rand(n, device="cuda", generator=g0) < 0.7
         rl[keep] = L
         del keep
         ro = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
         torch.cumsum(rl, 0, out=ro[1:])
         tot = int(ro[-1].item())
+        assert tot <= d_qual.numel(), "ragged offsets reach beyond the resident quality bytes"
         want_hist = torch.bincount(rl, minlength=512).cpu().numpy()
         del rl
         r_ms = []

@@ -633,9 +633,12 @@ public:
     bool on_gpu() const { return (bool)gpu_; }
     // The tool's last input is done: nothing is taken apart (pinned chunks, the upload context and its buffers: ~0.1 s of
     // unpinning and queue destruction in front of an _exit that hands all of it back anyway).
+    // (HPN_FULL_EXIT: the process will run exit handlers -- a profiler's -- and a read-ahead thread still inside the runtime at
+    // that moment crashes its teardown: the stream is stopped and taken apart the ordinary way)
     void abandon()
     {
-        (void)gpu_.release();
+        if (getenv("HPN_FULL_EXIT")) gpu_.reset();
+        else (void)gpu_.release();
     }
 
     // HPN_OK, an hpn_status, or 1 = the GPU ingest gave up (re-run the file with try_gpu = false)

@@ -43,17 +43,16 @@ inline long long usec()
     return (((long long)tv.tv_sec) * 1000000) + tv.tv_usec;
 }
 
-// fopen_output_stream (IO_stream.h:69-83): "-"-prefixed or empty name = stdout.
+// Where a tool's output goes (the rule of IO_stream.h:69-83): a name that is empty or begins with '-' means standard output,
+// anything else is created or truncated, mode 0666.  A file that cannot be made is reported on stderr with the reference's
+// words (no newline) and the caller gets whatever fdopen makes of -1, as there.
 inline FILE *fopen_output_stream(const char *filename)
 {
-    int fd;
-    if (strncmp(filename, "-", 1) == 0 || !strcmp(filename, "")) {
-        fd = STDOUT_FILENO;
-    } else {
-        fd = open(filename, O_CREAT | O_WRONLY | O_TRUNC, 0666);
-        if (fd == -1) fprintf(stderr, "Failed to create output file (%s)", filename);
-    }
-    return fdopen(fd, "wb");
+    const std::string name(filename ? filename : "");
+    if (name.empty() || name[0] == '-') return fdopen(STDOUT_FILENO, "wb");
+    const int made = ::open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (made < 0) fprintf(stderr, "Failed to create output file (%s)", name.c_str());
+    return fdopen(made, "wb");
 }
 
 // fcreat_outfile (IO_stream.h:92-97): prefix + suffix, through the rule above.

@@ -44,6 +44,7 @@ int hpn_ctx_create(int device, hpn_ctx **out)
 {
     if (!out) return HPN_E_ARG;
     *out = nullptr;
+    hpn::warn_unread_env();
     int k = 0;
     if (hipGetDeviceCount(&k) != hipSuccess || k <= 0) {
         (void)hipGetLastError();

@@ -72,7 +72,8 @@ struct TextFetcher {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return !busy; });
     }
-    bool fetch(const uint8_t *d_text, uint64_t n, FILE *out)
+    // 0: written; 1: the copy from the device failed; 2: the file could not be written
+    int fetch(const uint8_t *d_text, uint64_t n, FILE *out)
     {
         bool ok = true;
         if (n > own_cap) {
@@ -87,28 +88,38 @@ struct TextFetcher {
             busy = false;
         }
         cv.notify_all();
-        if (!ok) return false;
+        if (!ok) return 1;
         const uint8_t *src = (const uint8_t *)d_own;
         uint64_t at = 0, prev = 0;
         int k = 0;
+        if (fflush(out) != 0) return 2;
+        const int fd = fileno(out);
         {   // the target's text has a known size: the file's blocks are asked for at once (one writer thread fills a file at 14 GB/s,
-            // at 18 with its blocks there: scripts/micro/close_cost.cpp -- the writer is what the last target waits for)
+            // at 18 with its blocks there: scripts/micro/close_cost.cpp -- the writer is what the last target waits for).  The
+            // file's SIZE is left alone (FALLOC_FL_KEEP_SIZE): a write that fails later leaves a short file, not a full-size one
+            // with zeros at its end; nothing is asked for on a descriptor that appends (its position is not where it writes).
             struct stat sb;
-            fflush(out);
-            const int fd = fileno(out);
             const off_t here = fd >= 0 ? lseek(fd, 0, SEEK_CUR) : -1;
-            if (here >= 0 && n >= ((uint64_t)64 << 20) && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) (void)fallocate(fd, 0, here, (off_t)n);   // (fallocate(2): fails at once where the file system cannot; no zero-writing emulation)
+            const int fl = fd >= 0 ? fcntl(fd, F_GETFL) : -1;
+            if (here >= 0 && fl >= 0 && !(fl & O_APPEND) && n >= ((uint64_t)64 << 20) && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode))
+                (void)fallocate(fd, FALLOC_FL_KEEP_SIZE, here, (off_t)n);   // (fallocate(2): fails at once where the file system cannot; no zero-writing emulation)
         }
-        if (n && hpn_memcpy_d2h(cx, pin[0], src, n < kSlice ? n : kSlice) != HPN_OK) return false;
+        if (n && hpn_memcpy_d2h(cx, pin[0], src, n < kSlice ? n : kSlice) != HPN_OK) return 1;
         while (at < n) {
             const uint64_t len = n - at < kSlice ? n - at : kSlice;
-            if (hpn_ctx_sync(cx) != HPN_OK) return false;                  // slice k is here
+            if (hpn_ctx_sync(cx) != HPN_OK) return 1;                  // slice k is here
             prev = at, at += len;
-            if (at < n && hpn_memcpy_d2h(cx, pin[(k + 1) & 1], src + at, n - at < kSlice ? n - at : kSlice) != HPN_OK) return false;
-            fwrite(pin[k & 1], 1, (size_t)(at - prev), out);
+            if (at < n && hpn_memcpy_d2h(cx, pin[(k + 1) & 1], src + at, n - at < kSlice ? n - at : kSlice) != HPN_OK) return 1;
+            const char *p = (const char *)pin[k & 1];
+            for (size_t done = 0, want = (size_t)(at - prev); done < want;) {      // (the stream is flushed: straight to the descriptor)
+                const ssize_t w = fd >= 0 ? write(fd, p + done, want - done) : -1;
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) return 2;
+                done += (size_t)w;
+            }
             ++k;
         }
-        return true;
+        return 0;
     }
     void release()
     {
@@ -314,9 +325,10 @@ int main(int argc, char *argv[])
             if (by_fetcher) copy.hand_over();
             printer = std::thread([=, &runs, &win, &text] {
                 if (by_fetcher) {
-                    if (!copy.fetch(d_text, text_bytes, bedGraph)) {
-                        fprintf(stderr, "bam2depth: copying the bedGraph text of %s from the device failed\n", name);
-                        _exit(1);
+                    const int fr = copy.fetch(d_text, text_bytes, bedGraph);
+                    if (fr) {
+                        fprintf(stderr, fr == 2 ? "bam2depth: writing the bedGraph text of %s failed\n" : "bam2depth: copying the bedGraph text of %s from the device failed\n", name);
+                        _exit(fr);
                     }
                 } else if (dev_text) {
                     fwrite(text.data(), 1, text.size(), bedGraph);
@@ -342,14 +354,19 @@ int main(int argc, char *argv[])
             fprintf(stderr, "[hpn] %s ingest + scatter %.3f s  scan+fetch runs %.3f s  waiting for the writer %.3f s%s\n",
                     bam.on_gpu() ? "GPU" : "host", t_feed, t_finish, t_print, redo ? "  (abandoned: not decodable on the GPU)" : "");
         stamp("writer joined, timing line out");
-        fclose(bedGraph);
+        // (a stream that met ENOSPC / EIO says so here at the latest: a short bedGraph must not leave with exit code 0)
+        bool wrote = !ferror(bedGraph) && fclose(bedGraph) == 0;
         stamp("bedGraph closed");
-        fclose(depth);
+        wrote = (!ferror(depth) && fclose(depth) == 0) && wrote;
         if (wig) {
-            fclose(WIG);
-            fclose(chrSize);
+            wrote = (!ferror(WIG) && fclose(WIG) == 0) && wrote;
+            wrote = (!ferror(chrSize) && fclose(chrSize) == 0) && wrote;
         }
         stamp("outputs closed");
+        if (!wrote) {
+            fprintf(stderr, "bam2depth: writing the outputs of %s failed\n", infiles[i]);
+            leave(2);
+        }
         if (!redo && i + 1 == n_in) bam.abandon();   // (the last input: its read-ahead is not taken apart, the process ends)
         if (!redo) break;  // else: the outputs are re-created (truncated) by the host pass
       }

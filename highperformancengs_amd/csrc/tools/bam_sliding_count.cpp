@@ -181,7 +181,7 @@ int main(int argc, char *argv[])
                 BgzfGpuStream *p;
                 bool keep;
                 ~Drop() { if (!keep) delete p; }
-            } drop{gsp, i + 1 == n_in};
+            } drop{gsp, i + 1 == n_in && !getenv("HPN_FULL_EXIT")};   // (a full exit runs handlers: no thread may be left in the runtime)
             BgzfGpuStream &gs = *gsp;
             BamHeader h2;
             if (gs.open(ctx, infiles[i], h2)) {

@@ -42,25 +42,25 @@ FASTQ_ROUTE_CASES = [c for c in CASES if c.startswith(("count_", "kthread_", "tr
 BAM_ROUTE_CASES = [c for c in CASES if c.startswith(("depth_", "wig_", "sliding_")) and not c.endswith(NO_ROUTE)]
 
 
-def _run(tool, args, inputs, cwd, env=None, stdin=None):
+def _run(tool, args, inputs, cwd, env=None, stdin=None, bindir=BIN):
     for src in inputs:
         shutil.copy(src, cwd)
         if src.endswith(".bam"):
             shutil.copy(src + ".bai", cwd)
     before = set(os.listdir(cwd))
-    p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    p = subprocess.run([os.path.join(bindir, tool)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env={**os.environ, **(env or {})}, stdin=open(stdin, "rb") if stdin else subprocess.DEVNULL)
     return p, sorted(set(os.listdir(cwd)) - before)
 
 
-def _check(manifest, case, tmp_path, env=None, force_t1=True):
+def _check(manifest, case, tmp_path, env=None, force_t1=True, bindir=BIN):
     """Run golden case `case` through the tool here and compare return code, stdout and every file with the reference's."""
     c = manifest[case]
     args = list(c["args"])
     if force_t1 and c["tool"] == "fastq_count" and "-t" not in args and c["inputs"]:
         args = ["-t", "1"] + args  # rows are printed in completion order; one at a time = input order
     p, files = _run(c["tool"], args, [os.path.join(GOLDEN, i) for i in c["inputs"]], tmp_path, env,
-                    os.path.join(GOLDEN, c["stdin"]) if c.get("stdin") else None)
+                    os.path.join(GOLDEN, c["stdin"]) if c.get("stdin") else None, bindir)
     assert p.returncode == c["returncode"], p.stderr.decode()
     got = b"".join(sorted(p.stdout.splitlines(keepends=True))) if c.get("unordered") else p.stdout
     assert got == expected(case), p.stderr.decode()
@@ -75,6 +75,35 @@ def _check(manifest, case, tmp_path, env=None, force_t1=True):
 @pytest.mark.parametrize("case", CASES)
 def test_drop_in(manifest, case, tmp_path):
     _check(manifest, case, tmp_path)
+
+
+# Half of the route coverage below runs on the test-hooks build (the same sources with -DHPN_TEST_HOOKS: csrc/host/knobs.hpp;
+# tests/conftest.py swaps it in whenever a test sets one of the 31 switches).  With NO switch set that build must be the shipped
+# one: every golden case through testhooks/bin gives the reference's bytes as well, so whatever a switched route does differently
+# comes from test_env() alone.  (no reference counterpart.)
+@pytest.mark.parametrize("case", CASES)
+def test_hooks_build_with_no_switch_set_is_the_shipped_one(manifest, case, tmp_path):
+    from conftest import HOOKS_BIN, TEST_KNOBS
+    clean = {k: v for k, v in os.environ.items() if k not in TEST_KNOBS}
+    c = manifest[case]
+    args = list(c["args"])
+    if c["tool"] == "fastq_count" and "-t" not in args and c["inputs"]:
+        args = ["-t", "1"] + args
+    for src in [os.path.join(GOLDEN, i) for i in c["inputs"]]:
+        shutil.copy(src, tmp_path)
+        if src.endswith(".bam"):
+            shutil.copy(src + ".bai", tmp_path)
+    before = set(os.listdir(tmp_path))
+    stdin = open(os.path.join(GOLDEN, c["stdin"]), "rb") if c.get("stdin") else subprocess.DEVNULL
+    p = subprocess.Popen([os.path.join(HOOKS_BIN, c["tool"])] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=stdin, env=clean)
+    out, errb = p.communicate()
+    files = sorted(set(os.listdir(tmp_path)) - before)
+    assert p.returncode == c["returncode"], errb.decode()
+    got = b"".join(sorted(out.splitlines(keepends=True))) if c.get("unordered") else out
+    assert got == expected(case), errb.decode()
+    assert files == c["files"]
+    for f in files:
+        assert open(tmp_path / f, "rb").read() == expected(case, f), f
 
 
 # The FASTQ tools frame regular text on the GPU (hpn_fastq_text_*) and everything else with
