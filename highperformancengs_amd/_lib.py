@@ -109,6 +109,7 @@ SYMBOLS = [
     ("hpn_fastq_trim_points_dev", _int, [_vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("hpn_fastq_text_begin", _int, [_vp]),
     ("hpn_fastq_text_count", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
+    ("hpn_fastq_text_count_inplace", _int, [_vp, _vp, _u64, _int, _u32, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_records", _int, [_vp, _vp, _u64, _int, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_trim", _int, [_vp, _vp, _u64, _int, _i32, _i32, _vp, _u64, C.POINTER(TextInfo)]),
     ("hpn_fastq_text_piece_lines", _int, [_vp, _vp, _u64, _u32, _u64, _int, C.POINTER(TextPiece)]),

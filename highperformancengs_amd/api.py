@@ -204,6 +204,13 @@ class Context:
                  "hpn_fastq_text_count")
         return info
 
+    def text_count_inplace(self, d_text, nbytes, last=False, flags=0):
+        """A chunk of FASTQ text that lies on the device, framed where it lies (8192 writable bytes in front of d_text)."""
+        info = _lib.TextInfo()
+        self._ck(self.L.hpn_fastq_text_count_inplace(self.h, _ptr(d_text) if d_text is not None else None, int(nbytes), int(bool(last)), flags,
+                                                     C.byref(info)), "hpn_fastq_text_count_inplace")
+        return info
+
     def text_records(self, chunk, last=False):
         """One chunk of FASTQ text -> hpn_text_info with the records it completes (gzfastq_sample's count_read)."""
         chunk, n = self._text(chunk)

@@ -37,6 +37,9 @@ inline bool gz_gpu_enabled()
     return !(e && e[0] == '0');
 }
 
+constexpr size_t kTextPad = 8192;     // room in front of a batch's text for the framer's carried bytes
+constexpr uint64_t kGzOversub = 1;    // stretches per decoder slot and batch (HPN_GZ_OVERSUB in test-hooks builds)
+
 class GzGpuStream {
 public:
     ~GzGpuStream()
@@ -138,6 +141,22 @@ public:
             if (!e && stretch_bytes > kMaxStretch) stretch_bytes = (size_t)kMaxStretch;  // (symbol scratch: ~12 bytes per compressed byte in flight)
         }
         if (stretch_bytes < 4096) stretch_bytes = 4096;
+        // More stretches than decoder slots (round 6): the device TAKES stretches one by one (k_gz_sym_inflate's counter), so a
+        // batch of `over` shorter stretches per slot -- the same bytes -- does not end with the slot whose one stretch was the
+        // slow one.  What it costs: the search and the histories are per stretch.
+        if (!test_env("HPN_GZ_STRETCH")) {
+            const char *o = test_env("HPN_GZ_OVERSUB");
+            uint64_t over = o ? (uint64_t)atoi(o) : kGzOversub;
+            if (over < 1) over = 1;
+            uint64_t cut = (stretch_bytes / over + 4095) & ~(uint64_t)4095;
+            if (cut < ((uint64_t)128 << 10)) cut = (uint64_t)128 << 10;
+            if (cut < stretch_bytes) {
+                const uint64_t per_slot = stretch_bytes / cut;
+                uint64_t ms = (uint64_t)max_stretches_ * per_slot;
+                max_stretches_ = ms > 65535u ? 65535u : (uint32_t)ms;
+                stretch_bytes = (size_t)cut;
+            }
+        }
         stretch_ = stretch_bytes;
         sym_cap_ = cap_for(ratio_ * 1.4);
         {   // what a device call holds, at its largest (symbol scratch grown once, compressed bytes, text): within half of the
@@ -171,7 +190,7 @@ public:
             });
         return true;
     }
-    const uint8_t *d_text() const { return (const uint8_t *)d_text_; }
+    const uint8_t *d_text() const { return (const uint8_t *)d_text_ + kTextPad; }   // (kTextPad writable bytes in front: hpn_fastq_text_count_inplace)
     const char *why() const { return why_; }  // what made open() / next() give up
     double ratio() const { return ratio_; }     // text bytes per compressed byte over the member's first megabytes
     uint64_t members() const { return n_members_; }   // gzip members met so far
@@ -226,8 +245,8 @@ public:
         uint64_t want = (uint64_t)((double)comp_bytes * ratio_ * 1.25) + ((uint64_t)8 << 20);
         hpn_gz_info info;
         for (int attempt = 0;; ++attempt) {
-            if (!reserve(ctx_, d_text_, cap_text_, want + 64)) return give_up("device memory (text)") - 1;
-            const int rc = hpn_gz_inflate_finish_dev(cx, batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
+            if (!reserve(ctx_, d_text_, cap_text_, want + 64 + kTextPad)) return give_up("device memory (text)") - 1;
+            const int rc = hpn_gz_inflate_finish_dev(cx, batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_ + kTextPad, cap_text_ - 64 - kTextPad,
                                                      (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
             if (rc == HPN_E_CAPACITY && attempt == 0) {  // more text than guessed: once more with room for it (the symbols stay)
                 want = info.n_bytes;
@@ -241,7 +260,7 @@ public:
         if ((info.status == 12 || info.status == 14 || info.status == 1) && (!grown_ || sl.begun_cap < sym_cap_)) {  // out of room: once more with twice as much
             if (!grown_) grown_ = true, sym_cap_ = cap_for(ratio_ * 3.0);
             const int rc = hpn_gz_inflate_dev(cx, (const uint8_t *)d_comp_, (const hpn_gz_chunk *)d_chunks_, n, sym_cap_,
-                                              batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_, cap_text_ - 64,
+                                              batch_ ? (const uint8_t *)d_win_[batch_ & 1] : nullptr, (uint8_t *)d_text_ + kTextPad, cap_text_ - 64 - kTextPad,
                                               (uint8_t *)d_win_[(batch_ + 1) & 1], &info);
             if (rc != HPN_OK) return give_up(hpn_ctx_last_error(cx)) - 1;
         }
@@ -272,7 +291,7 @@ public:
             for (uint32_t k = 0; k < nm; ++k) spans_.push_back(hpn_span{at, members_[k].text_end - at}), at = members_[k].text_end;
             spans_.push_back(hpn_span{at, info.n_bytes - at});          // the piece of the member that goes on in the next batch
             crcs_.resize(spans_.size());
-            if (check_crc_ && hpn_crc32_dev(ctx_, (const uint8_t *)d_text_, spans_.data(), (uint32_t)spans_.size(), crcs_.data()) != HPN_OK)
+            if (check_crc_ && hpn_crc32_dev(ctx_, (const uint8_t *)d_text_ + kTextPad, spans_.data(), (uint32_t)spans_.size(), crcs_.data()) != HPN_OK)
                 return give_up("CRC-32 kernel") - 1;
             for (uint32_t k = 0; k < nm; ++k) {
                 const uint64_t end = total_ + members_[k].text_end;

@@ -217,7 +217,9 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
     stamp("gzip route open");
     const uint32_t flags = acc->qual_hist ? HPN_TALLY_QUAL_HIST : 0;
     int rc = hpn_fastq_text_begin(ctx);
-    const uint64_t slice = (uint64_t)256 << 20;
+    // the batch's text is framed where it lies (hpn_fastq_text_count_inplace: no copy into a slot), 1 GiB at a time (round 5:
+    // 256 MiB slices copied first -- 60 calls a batch, each with its launches, its wait and its 2 x 256 MiB of copy traffic)
+    const uint64_t slice = (uint64_t)1 << 30;
     while (rc == HPN_OK && !*unusable) {
         uint64_t n = 0;
         const int r = gs.next(&n);
@@ -230,7 +232,7 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
         for (uint64_t at = 0; rc == HPN_OK && !*unusable && (at < n || (fin && n == 0));) {
             const uint64_t k = n - at < slice ? n - at : slice;
             hpn_text_info info;
-            rc = hpn_fastq_text_count(ctx, gs.d_text() + at, k, fin && at + k == n, flags, &info);
+            rc = hpn_fastq_text_count_inplace(ctx, gs.d_text() + at, k, fin && at + k == n, flags, &info);
             if (rc == HPN_OK && info.irregular) *unusable = true;
             at += k;
             if (n == 0) break;

@@ -90,8 +90,8 @@ int hpn_ctx_destroy(hpn_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     Scratch *ss[] = {&c->s_a, &c->s_b, &c->s_c, &c->s_d, &c->s_e, &c->s_f, &c->s_g, &c->s_h, &c->d_diff, &c->d_runs,
                      &c->d_win, &c->d_ws, &c->d_tidx, &c->d_text, &c->w_off, &c->w_bins, &c->w_len, &c->w_gc, &c->w_misc, &c->w_todo, &c->t_slot[0], &c->t_slot[1],
-                     &c->t_nl, &c->t_off, &c->t_status, &c->t_pq, &c->t_ps, &c->t_out, &c->r_counts, &c->r_bases, &c->r_off,
-                     &c->r_tid, &c->r_pos, &c->r_flag, &c->r_lq, &c->r_soff, &c->r_info, &c->g_sym, &c->g_meta, &c->g_windows, &c->g_summary, &c->g_bounds,
+                     &c->t_nl, &c->t_off, &c->t_status, &c->t_pq, &c->t_ps, &c->t_out, &c->t_carrybuf, &c->r_counts, &c->r_bases, &c->r_off,
+                     &c->r_tid, &c->r_pos, &c->r_flag, &c->r_lq, &c->r_soff, &c->r_info, &c->r_list, &c->g_sym, &c->g_meta, &c->g_windows, &c->g_summary, &c->g_bounds,
                      &c->g_crc, &c->b_ticket, &c->d_sw, &c->d_win_sw, &c->g_groups};
     for (Scratch *s : ss)
         if (s->p) (void)hipFree(s->p);

@@ -32,10 +32,12 @@ hipError_t launch_window_add(const int32_t *tid_a, const int32_t *pos, const uin
                              u64 *n_count, uint32_t *bad, uint32_t *todo, int n_cu, hipStream_t st);
 size_t window_todo_words(uint64_t n);
 uint32_t depth_tile_size();
+size_t raw_list_words(uint64_t stream_len, uint32_t n_blocks);
 hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *status,
-                            uint32_t *starts, uint32_t *counts, u64 *exits, int32_t *lo, int32_t *hi, u64 *bases, int32_t *info, hipStream_t st);
-hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *starts,
-                            const uint32_t *counts, const u64 *bases, uint64_t *rec_off, hipStream_t st);
+                            uint32_t *starts, uint32_t *counts, u64 *exits, int32_t *lo, int32_t *hi, u64 *bases, int32_t *info, u64 *list,
+                            uint64_t list_words, hipStream_t st);
+hipError_t launch_raw_index(const void *blocks, uint32_t n_blocks, const uint32_t *counts, const u64 *bases, const u64 *list,
+                            uint64_t *rec_off, hipStream_t st);
 hipError_t launch_raw_fields(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, int32_t *tid, int32_t *pos, uint32_t *flag,
                              int32_t *l_qseq, uint64_t *seq_off, int n_cu, hipStream_t st);
 }  // namespace hpn
@@ -305,13 +307,17 @@ int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block
     if ((rc = scratch_reserve(c, c->r_counts, n_blocks * (sizeof(u64) + 4 * sizeof(uint32_t)) + 64)) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->r_bases, (n_blocks + 1) * sizeof(u64))) != HPN_OK) return rc;
     if ((rc = scratch_reserve(c, c->r_info, 64)) != HPN_OK) return rc;
+    // the records' offsets as the walk meets them (k_raw_count), block by block: sized for BGZF's blocks (64 KiB inflated at most)
+    // behind a carried record of up to 4 MiB -- a walk that would write beyond it flags the call instead (the host reader's then)
+    const size_t list_words = raw_list_words(n_blocks * 65536ull + ((uint64_t)4 << 20) + first_off, (uint32_t)n_blocks);
+    if ((rc = scratch_reserve(c, c->r_list, list_words * sizeof(u64))) != HPN_OK) return rc;
     u64 *d_exits = (u64 *)c->r_counts.p;
     uint32_t *d_counts = (uint32_t *)(d_exits + n_blocks), *d_starts = d_counts + n_blocks;
     int32_t *d_lo = (int32_t *)(d_starts + n_blocks), *d_hi = d_lo + n_blocks;
     const int32_t init[6] = {0, INT32_MAX, INT32_MIN, 0, -1, -1};      // [4..5]: u64 ~0 = no unfinished record at the call's end
     HPN_HIP(c, hipMemcpyAsync(c->r_info.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
     HPN_HIP(c, launch_raw_count(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_status, d_starts, d_counts, d_exits, d_lo, d_hi,
-                                (u64 *)c->r_bases.p, (int32_t *)c->r_info.p, c->stream));
+                                (u64 *)c->r_bases.p, (int32_t *)c->r_info.p, (u64 *)c->r_list.p, list_words, c->stream));
     int32_t h[6];
     u64 total = 0;
     hpn_bgzf_block last;
@@ -337,7 +343,7 @@ int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block
     }
     if ((info->flags & 3u) || total == 0) return HPN_OK;  // nothing indexed: the caller decodes this file on the host (flags), or waits for more bytes
     if ((rc = scratch_reserve(c, c->r_off, total * sizeof(uint64_t))) != HPN_OK) return rc;
-    HPN_HIP(c, launch_raw_index(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_starts, d_counts, (const u64 *)c->r_bases.p,
+    HPN_HIP(c, launch_raw_index(d_blocks, (uint32_t)n_blocks, d_counts, (const u64 *)c->r_bases.p, (const u64 *)c->r_list.p,
                                 (uint64_t *)c->r_off.p, c->stream));
     c->r_n = total;
     return HPN_OK;

@@ -66,17 +66,18 @@ struct hpn_ctx {
     uint32_t win_W = 0;
     uint64_t win_total = 0;
     // raw-text front end: two device slots (carry area + chunk), line index, offsets, packed lines
-    hpn::Scratch t_slot[2], t_nl, t_off, t_status, t_pq, t_ps, t_out;
+    hpn::Scratch t_slot[2], t_nl, t_off, t_status, t_pq, t_ps, t_out, t_carrybuf;
     uint32_t *t_state = nullptr;    // device state block of the framing kernels
     uint32_t *h_tstate = nullptr;   // pinned mirror
     bool t_open = false;
     int t_cur = 0;
     uint32_t t_carry = 0, t_tail = 0;  // carry bytes and where they start in slot[t_cur ^ 1]
+    bool t_carry_saved = false;        // ... or, behind a chunk framed in place, in t_carrybuf
     // a piece between hpn_fastq_text_piece_lines and _count / _trim
     int p_state = 0, p_last = 0;
     uint32_t p_begin = 0, p_end = 0, p_limit = 0, p_head = 0, p_nl_cap = 0;
     // records indexed in place in inflated BGZF blocks (hpn_bam_raw_*)
-    hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info;
+    hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info, r_list;
     hpn::Scratch g_crc;   // hpn_crc32_dev: block table + block CRCs
     hpn::Scratch b_ticket;   // hpn_bgzf_inflate_dev: the kernel's block counter
     hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds, g_groups;  // gzip: symbols, per-stretch results, histories, member ends

@@ -39,8 +39,12 @@ struct Framed {
 
 // Copy the chunk behind the carried-over bytes, index the lines, validate and scan the
 // records, wait for the verdict.  On return the caller's `text` buffer is free again.
+// in_place (round 6): `text` is DEVICE memory with kCarryCap writable bytes in front of it, and is framed where it lies -- only
+// the carried bytes (< 8 KiB) are copied, in front of it; they are kept in a buffer of their own between calls, so the caller may
+// overwrite the text as soon as the call returns.  (The gzip route's text is on the device already: the copy into a slot was
+// 2 x 15.9 GB of traffic per 9.3 GB batch, 5.7 ms of its ~250: profiles/r06/kernel_stats_gz_tool_members.csv, __amd_rocclr_copyBuffer.)
 int text_frame(hpn_ctx *c, const void *text, uint64_t nbytes, int last, bool trim, uint32_t S, uint32_t E,
-               hpn_text_info *info, Framed *f)
+               hpn_text_info *info, Framed *f, bool in_place = false)
 {
     if (!c->t_open) return fail(c, HPN_E_STATE, "hpn_fastq_text_begin first (or the stream was closed by an irregular chunk)");
     if (nbytes >= (1ull << 31) - 2 * kCarryCap) return fail(c, HPN_E_ARG, "chunk of %llu bytes (limit 2^31 - 16 KiB)", (unsigned long long)nbytes);
@@ -54,12 +58,14 @@ int text_frame(hpn_ctx *c, const void *text, uint64_t nbytes, int last, bool tri
     const int cur = c->t_cur;
     const uint32_t carry = c->t_carry;
     const uint32_t begin = kCarryCap - carry, end = kCarryCap + (uint32_t)nbytes;
-    if ((rc = scratch_reserve(c, c->t_slot[cur], (size_t)end + 64)) != HPN_OK) return rc;
-    uint8_t *slot = (uint8_t *)c->t_slot[cur].p;
+    if (in_place && !text) return fail(c, HPN_E_ARG, "text is NULL");
+    if (!in_place && (rc = scratch_reserve(c, c->t_slot[cur], (size_t)end + 64)) != HPN_OK) return rc;
+    if ((rc = scratch_reserve(c, c->t_carrybuf, kCarryCap)) != HPN_OK) return rc;
+    uint8_t *slot = in_place ? (uint8_t *)const_cast<void *>(text) - kCarryCap : (uint8_t *)c->t_slot[cur].p;
     if (carry)
-        HPN_HIP(c, hipMemcpyAsync(slot + begin, (const uint8_t *)c->t_slot[cur ^ 1].p + c->t_tail, carry,
+        HPN_HIP(c, hipMemcpyAsync(slot + begin, c->t_carry_saved ? (const uint8_t *)c->t_carrybuf.p : (const uint8_t *)c->t_slot[cur ^ 1].p + c->t_tail, carry,
                                   hipMemcpyDeviceToDevice, c->stream));
-    if (nbytes) HPN_HIP(c, hipMemcpyAsync(slot + kCarryCap, text, nbytes, hipMemcpyDefault, c->stream));
+    if (nbytes && !in_place) HPN_HIP(c, hipMemcpyAsync(slot + kCarryCap, text, nbytes, hipMemcpyDefault, c->stream));
     // one line per 4 bytes is the most the index is sized for (HPN_TEXT_DENSE beyond)
     const uint32_t nl_cap = (((end - begin) / 4u) + 16u) & ~3u;
     if ((rc = scratch_reserve(c, c->t_nl, (size_t)nl_cap * sizeof(uint32_t) + 64)) != HPN_OK) return rc;
@@ -92,6 +98,11 @@ int text_frame(hpn_ctx *c, const void *text, uint64_t nbytes, int last, bool tri
     c->t_carry = (uint32_t)info->carry_bytes;
     c->t_tail = h[kTsConsumed];
     c->t_cur = cur ^ 1;
+    c->t_carry_saved = false;
+    if (in_place && c->t_carry) {   // (on the stream: in front of whatever the caller lets write over the text next)
+        HPN_HIP(c, hipMemcpyAsync(c->t_carrybuf.p, slot + c->t_tail, c->t_carry, hipMemcpyDeviceToDevice, c->stream));
+        c->t_carry_saved = true;
+    }
     if (last) c->t_open = false;
     return HPN_OK;
 }
@@ -107,6 +118,7 @@ int hpn_fastq_text_begin(hpn_ctx *c)
     c->t_cur = 0;
     c->t_carry = 0;
     c->t_tail = 0;
+    c->t_carry_saved = false;
     return HPN_OK;
 }
 
@@ -125,6 +137,25 @@ int hpn_fastq_text_count(hpn_ctx *c, const void *text, uint64_t nbytes, int last
                                   nuc ? (uint8_t *)c->t_ps.p : nullptr, c->n_cu, c->stream));
     return tally_launch(c, (const uint8_t *)c->t_pq.p, nuc ? (const uint8_t *)c->t_ps.p : nullptr, (const uint64_t *)c->t_off.p,
                         f.n, f.total, flags);
+}
+
+int hpn_fastq_text_count_inplace(hpn_ctx *c, const uint8_t *d_text, uint64_t nbytes, int last, uint32_t flags, hpn_text_info *info)
+{
+    if (!c || !info) return HPN_E_ARG;
+    if (flags & ~(HPN_TALLY_QUAL_HIST | HPN_TALLY_NUC_HIST)) return fail(c, HPN_E_ARG, "unknown flags 0x%x", flags);
+    HPN_HIP(c, hipSetDevice(c->device));
+    Framed f;
+    int rc = text_frame(c, d_text, nbytes, last, false, 0, 0, info, &f, true);
+    if (rc != HPN_OK || info->irregular || f.n == 0) return rc;
+    const bool nuc = flags & HPN_TALLY_NUC_HIST;
+    if ((rc = scratch_reserve(c, c->t_pq, f.total + 64)) != HPN_OK) return rc;
+    if (nuc && (rc = scratch_reserve(c, c->t_ps, f.total + 64)) != HPN_OK) return rc;
+    HPN_HIP(c, launch_text_gather(f.slot, (const uint32_t *)c->t_nl.p, (const uint64_t *)c->t_off.p, f.n, (uint8_t *)c->t_pq.p,
+                                  nuc ? (uint8_t *)c->t_ps.p : nullptr, c->n_cu, c->stream));
+    rc = tally_launch(c, (const uint8_t *)c->t_pq.p, nuc ? (const uint8_t *)c->t_ps.p : nullptr, (const uint64_t *)c->t_off.p, f.n, f.total, flags);
+    // (the gather reads the text: it has to be through before the caller may write over it)
+    if (rc == HPN_OK) HPN_HIP(c, hipStreamSynchronize(c->stream));
+    return rc;
 }
 
 int hpn_fastq_text_records(hpn_ctx *c, const void *text, uint64_t nbytes, int last, hpn_text_info *info)

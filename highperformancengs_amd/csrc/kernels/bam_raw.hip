@@ -19,7 +19,7 @@
 //   k_raw_starts   per block: where its first record starts (wave per block; block 0: given)
 //   k_raw_count    per block: number of records that START in it, smallest / largest refID, where its chain leaves it
 //   k_raw_scan     exclusive scan of the per-block counts + the proof (one workgroup; a batch has ~10^4 blocks)
-//   k_raw_index    per block: byte offset of every record -> rec_off[]
+//   k_raw_index    per block: the offsets k_raw_count wrote down, laid one after the other -> rec_off[]
 //   k_raw_fields   per record: refID, pos, flag, l_seq, offset of the packed sequence
 //                  (the SoA view k_window_add takes; the sequence stays where it is)
 // K3 (bam2depth.c:86-110) reads core fields and CIGAR in place through RawRecs (bam_depth.hip).
@@ -130,7 +130,9 @@ struct RawWalk {
     int32_t lo, hi;
     u64 exit;          // | kTailBit
 };
-__device__ __forceinline__ RawWalk walk_block(const uint8_t *__restrict__ raw, uint64_t at, uint64_t end, uint64_t stream_len)
+// (list: where the records' stream offsets go, one after the other -- see k_raw_count; may be null)
+__device__ __forceinline__ RawWalk walk_block(const uint8_t *__restrict__ raw, uint64_t at, uint64_t end, uint64_t stream_len, u64 *__restrict__ list = nullptr,
+                                              uint64_t list_room = 0)
 {
     RawWalk w = {0u, INT32_MAX, INT32_MIN, 0ull};
     while (at < end) {
@@ -146,12 +148,130 @@ __device__ __forceinline__ RawWalk walk_block(const uint8_t *__restrict__ raw, u
         }
         const int32_t tid = (int32_t)ld32(raw + at + 4u);
         w.lo = tid < w.lo ? tid : w.lo, w.hi = tid > w.hi ? tid : w.hi;
+        if (list) {
+            if (w.n >= list_room) {                      // (cannot happen for blocks of BGZF's 64 KiB: the list is sized for them)
+                w.n |= kBroken;
+                break;
+            }
+            list[w.n] = at;
+        }
         at += step;
         ++w.n;
     }
     w.exit = at;
     return w;
 }
+
+// ---- the walk with the records ahead in flight (round 6) -------------------------------------------------------------------------
+// walk_block above waits twice per record: for the fixed part (block_size tells where the next record is), then for the byte
+// that must be the name's NUL -- and k_raw_index walked every chain a second time to write the offsets down: 0.62 + 0.27 ms per
+// 1.2 GB launch (4.4 M records, ~230 to a block), the largest kernels of the BAM tools behind the inflater
+// (profiles/r05/kernel_stats_bam2depth_final.csv).  A chain is a chain -- a lane cannot know where record k + 1 starts before it has
+// record k's block_size, and a round trip of 64 lanes reading 64 blocks is ~2 us -- but reads of one length and one kind of
+// CIGAR give records of ONE SIZE, so a lane bets on it: with record k in hand it asks for the 80 bytes at k + 1 and k + 2 (the
+// fixed part and a name of up to 44 characters with its NUL: one request, no second one for the NUL) assuming both are as long
+// as k.  While the bet holds, what a record needs was asked for two records earlier and three records go by per round trip;
+// when a record is longer or shorter than its predecessor the lane asks again and waits once.  The records' offsets are written
+// down as they are met (list: block b's at raw_list_base(b), one after the other; two records never share a slot because a
+// record is at least 36 bytes), so the index is a copy, not a second walk.  Same results as walk_block, record for record
+// (tests/test_bam_raw_gpu.py).
+struct RawHead {           // the first 80 bytes of a record: block_size | refID pos bin_mq_nl | flag_nc l_seq next_refID next_pos | read_name ...
+    u32 v[5];
+    uint32_t have;         // how many of them lie in the stream (0: fewer than the 36 of the fixed part)
+};
+__device__ __forceinline__ RawHead head_at(const uint8_t *__restrict__ raw, uint64_t at, uint64_t stream_len)
+{
+    RawHead h;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) h.v[k] = u32{0, 0, 0, 0};
+    h.have = 0;
+    if (at + 80u <= stream_len) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) __builtin_memcpy(&h.v[k], raw + at + 16 * k, 16);
+        h.have = 80u;
+    } else if (at + 36u <= stream_len) {      // the stream's last records: the fixed part alone (the NUL is read where it lies)
+        __builtin_memcpy(&h.v[0], raw + at, 16);
+        __builtin_memcpy(&h.v[1], raw + at + 16, 16);
+        uint32_t c;
+        __builtin_memcpy(&c, raw + at + 32, 4);
+        h.v[2][0] = c;
+        h.have = 36u;
+    }
+    return h;
+}
+// byte i (< 80) of the 80 (no indexed register access: a select per word)
+__device__ __forceinline__ uint32_t head_byte(const RawHead &h, uint32_t i)
+{
+    uint32_t w = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 20u; ++k) w = (i >> 2) == k ? h.v[k >> 2][k & 3u] : w;
+    return (w >> (8u * (i & 3u))) & 255u;
+}
+// record_at on a record whose first bytes are in registers: 0 = no record, 2 = cannot tell (the stream ends inside its fixed part
+// or its name), 1 = a record, *step bytes long
+__device__ __forceinline__ int head_check(const uint8_t *__restrict__ raw, uint64_t at, const RawHead &h, uint64_t room, uint32_t *step)
+{
+    if (room < 36u) return 2;
+    const uint32_t bs = h.v[0][0];
+    if (bs < 32u || bs > (1u << 28)) return 0;
+    const int32_t tid = (int32_t)h.v[0][1], pos = (int32_t)h.v[0][2], mtid = (int32_t)h.v[1][2], mpos = (int32_t)h.v[1][3];
+    const uint32_t l_name = h.v[0][3] & 255u, n_cigar = h.v[1][0] & 0xffffu, l_seq = h.v[1][1];
+    if (tid < -1 || pos < -1 || mtid < -1 || mpos < -1 || l_name == 0u || l_seq > 0x7fffffffu) return 0;
+    if (32ull + l_name + 4ull * n_cigar + (((uint64_t)l_seq + 1u) >> 1) + (uint64_t)l_seq > (uint64_t)bs) return 0;
+    if (room < 36u + l_name) return 2;
+    const uint32_t nul_at = 35u + l_name;
+    const uint32_t nul = nul_at < h.have ? head_byte(h, nul_at) : (uint32_t)raw[at + nul_at];   // (a name beyond 44 characters: read where it lies)
+    if (nul != 0u) return 0;                                 // read_name is NUL-terminated
+    *step = 4u + bs;
+    return 1;
+}
+__device__ __forceinline__ RawWalk walk_block_ahead(const uint8_t *__restrict__ raw, uint64_t at, uint64_t end, uint64_t stream_len, u64 *__restrict__ list,
+                                                    uint64_t list_room)
+{
+    RawWalk w = {0u, INT32_MAX, INT32_MIN, 0ull};
+    if (at >= end) {
+        w.exit = at;
+        return w;
+    }
+    RawHead cur = head_at(raw, at, stream_len);
+    RawHead p1 = cur, p2 = cur;                // what lies at p1_at / p2_at: the next record and the one after it IF sizes repeat
+    uint64_t p1_at = ~0ull, p2_at = ~0ull;
+    while (at < end) {
+        uint32_t step = 0;
+        const int r = head_check(raw, at, cur, stream_len - at, &step);
+        if (r == 0 || w.n >= list_room) {
+            w.n |= kBroken;
+            break;
+        }
+        if (r == 2 || at + step > stream_len) {          // the record is not whole in this call: it starts the next one
+            at |= kTailBit;
+            break;
+        }
+        const uint64_t next = at + step;
+        const int32_t tid = (int32_t)cur.v[0][1];
+        w.lo = tid < w.lo ? tid : w.lo, w.hi = tid > w.hi ? tid : w.hi;
+        list[w.n] = at;
+        ++w.n;
+        if (next >= end) {
+            at = next;
+            break;
+        }
+        // the next record: the bet of two records ago, of the last one, or asked for now; and the bets for the two behind it
+        const RawHead nx = next == p1_at ? p1 : next == p2_at ? p2 : head_at(raw, next, stream_len);
+        const uint64_t q1 = next + step, q2 = q1 + step;
+        const RawHead n1 = q1 == p2_at ? p2 : q1 < end ? head_at(raw, q1, stream_len) : cur;
+        const RawHead n2 = q2 < end ? head_at(raw, q2, stream_len) : cur;
+        p1 = n1, p1_at = q1 < end ? q1 : ~0ull;
+        p2 = n2, p2_at = q2 < end ? q2 : ~0ull;
+        at = next, cur = nx;
+    }
+    w.exit = at;
+    return w;
+}
+
+// where block b's records go in the list: a record takes at least 36 bytes of the stream, so the records that start in
+// [0, out_off) are at most out_off / 36 (+ one that a block's chain may count across its start, + slack): slots never meet
+__host__ __device__ __forceinline__ uint64_t raw_list_base(uint64_t out_off, uint32_t b) { return b ? out_off / 36u + 2ull * b : 0ull; }
 
 // info words: [0] flags (1 = an impossible record on the chain, 2 = a block failed to inflate, 4 = records run across block ends
 // (packed BAM)), [1] min refID, [2] max refID (as int32), [3] unused; u64 at info + 4: stream offset of the call's unfinished
@@ -160,7 +280,8 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_count(const uint8_t *__rest
                                                            uint32_t n_blocks, uint64_t first_abs,
                                                            const uint32_t *__restrict__ status, const uint32_t *__restrict__ starts,
                                                            uint32_t *__restrict__ counts, u64 *__restrict__ exits, int32_t *__restrict__ lo,
-                                                           int32_t *__restrict__ hi, int32_t *__restrict__ info)
+                                                           int32_t *__restrict__ hi, int32_t *__restrict__ info, u64 *__restrict__ list,
+                                                           uint64_t list_words)
 {
     const uint32_t b = blockIdx.x * kRawThreads + threadIdx.x;
     if (b >= n_blocks) return;
@@ -174,7 +295,8 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_count(const uint8_t *__rest
     // a block without a start (its predecessor's record runs over it whole, or it lies behind the call's last whole record)
     // counts nothing; whether that is right is k_raw_scan's to say
     const uint64_t at = b == 0 ? first_abs : starts[b] == kNoStart ? end : blk.out_off + starts[b];
-    const RawWalk w = walk_block(raw, at, end, stream_len);
+    const uint64_t lb = raw_list_base(blk.out_off, b);
+    const RawWalk w = walk_block_ahead(raw, at, end, stream_len, list + lb, lb < list_words ? list_words - lb : 0ull);
     counts[b] = w.n, exits[b] = w.exit, lo[b] = w.lo, hi[b] = w.hi;
 }
 
@@ -188,7 +310,8 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_count(const uint8_t *__rest
 __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ raw, uint32_t *__restrict__ counts, uint32_t n_blocks,
                                                    u64 *__restrict__ bases, const RawBlock *__restrict__ blocks, uint64_t first_abs,
                                                    uint32_t *__restrict__ starts, const u64 *__restrict__ exits,
-                                                   const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int32_t *__restrict__ info)
+                                                   const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int32_t *__restrict__ info,
+                                                   u64 *__restrict__ list, uint64_t list_words)
 {
     __shared__ u64 s_wave[16];
     __shared__ u64 s_carry, s_from, s_tail;
@@ -241,7 +364,8 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
                 const u64 own = i0 + k == 0 ? first_abs : s_start[k] == kNoStart ? ~0ull : s_off[k] + s_start[k];
                 if (own != from) {                                  // no guess, or not where the chain arrives: walked here
                     ++s_rewalked;
-                    const RawWalk w = walk_block(raw, from, end, stream_len);
+                    const uint64_t lb = raw_list_base(s_off[k], i0 + k);
+                    const RawWalk w = walk_block(raw, from, end, stream_len, list + lb, lb < list_words ? list_words - lb : 0ull);   // (its list again, from where the chain arrives)
                     s_cnt[k] = w.n, s_exit[k] = w.exit, s_lo[k] = w.lo, s_hi[k] = w.hi;
                     s_start[k] = (uint32_t)(from - s_off[k]);
                 }
@@ -284,20 +408,16 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
     }
 }
 
-__global__ __launch_bounds__(kRawThreads) void k_raw_index(const uint8_t *__restrict__ raw, const RawBlock *__restrict__ blocks,
-                                                           uint32_t n_blocks, uint64_t first_abs, const uint32_t *__restrict__ starts,
+// rec_off[]: the blocks' lists one after the other (bases[] from the scan).  A wave per block, coalesced both ways.
+__global__ __launch_bounds__(kRawThreads) void k_raw_index(const RawBlock *__restrict__ blocks, uint32_t n_blocks,
                                                            const uint32_t *__restrict__ counts, const u64 *__restrict__ bases,
-                                                           uint64_t *__restrict__ rec_off)
+                                                           const u64 *__restrict__ list, uint64_t *__restrict__ rec_off)
 {
-    const uint32_t b = blockIdx.x * kRawThreads + threadIdx.x;
+    const uint32_t b = blockIdx.x * (kRawThreads / kWave) + (uint32_t)wave_id();
     if (b >= n_blocks) return;
-    const RawBlock blk = blocks[b];
-    uint64_t at = b == 0 ? first_abs : blk.out_off + starts[b];
-    u64 r = bases[b];
-    for (uint32_t k = 0, n = counts[b]; k < n; ++k) {
-        rec_off[r++] = at;
-        at += 4u + ld32(raw + at);
-    }
+    const u64 *from = list + raw_list_base(blocks[b].out_off, b);
+    uint64_t *to = rec_off + bases[b];
+    for (uint32_t k = (uint32_t)lane_id(), n = counts[b]; k < n; k += kWave) to[k] = from[k];
 }
 
 // bam1_core_t on disk (bam.h:178-187) behind block_size: refID, pos, bin_mq_nl, flag_nc, l_seq, ...
@@ -318,24 +438,28 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_fields(const uint8_t *__res
     }
 }
 
+size_t raw_list_words(uint64_t stream_len, uint32_t n_blocks) { return (size_t)(stream_len / 36u + 2ull * n_blocks + 4096u); }
+
 hipError_t launch_raw_count(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *status,
-                            uint32_t *starts, uint32_t *counts, u64 *exits, int32_t *lo, int32_t *hi, u64 *bases, int32_t *info, hipStream_t st)
+                            uint32_t *starts, uint32_t *counts, u64 *exits, int32_t *lo, int32_t *hi, u64 *bases, int32_t *info, u64 *list,
+                            uint64_t list_words, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_raw_starts, dim3(n_blocks), dim3(kWave), 0, st, raw, (const RawBlock *)blocks, n_blocks, status, starts);
     hipLaunchKernelGGL(k_raw_count, dim3((n_blocks + kRawThreads - 1) / kRawThreads), dim3(kRawThreads), 0, st, raw,
-                       (const RawBlock *)blocks, n_blocks, first_abs, status, starts, counts, exits, lo, hi, info);
+                       (const RawBlock *)blocks, n_blocks, first_abs, status, starts, counts, exits, lo, hi, info, list, list_words);
     hipLaunchKernelGGL(k_raw_scan, dim3(1), dim3(1024), 0, st, raw, counts, n_blocks, bases, (const RawBlock *)blocks, first_abs, starts,
-                       exits, lo, hi, info);
+                       exits, lo, hi, info, list, list_words);
     return hipGetLastError();
 }
 
-hipError_t launch_raw_index(const uint8_t *raw, const void *blocks, uint32_t n_blocks, uint64_t first_abs, const uint32_t *starts,
-                            const uint32_t *counts, const u64 *bases, uint64_t *rec_off, hipStream_t st)
+hipError_t launch_raw_index(const void *blocks, uint32_t n_blocks, const uint32_t *counts, const u64 *bases, const u64 *list,
+                            uint64_t *rec_off, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_raw_index, dim3((n_blocks + kRawThreads - 1) / kRawThreads), dim3(kRawThreads), 0, st, raw,
-                       (const RawBlock *)blocks, n_blocks, first_abs, starts, counts, bases, rec_off);
+    constexpr uint32_t per = kRawThreads / kWave;
+    hipLaunchKernelGGL(k_raw_index, dim3((n_blocks + per - 1) / per), dim3(kRawThreads), 0, st, (const RawBlock *)blocks, n_blocks, counts,
+                       bases, list, rec_off);
     return hipGetLastError();
 }
 

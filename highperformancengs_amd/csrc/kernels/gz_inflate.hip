@@ -18,6 +18,7 @@
 // Bounds: k_gz_sym_inflate by instruction issue like k_bgzf_inflate (the same decoder: symbols 64 bit
 // offsets at a time, inflate_core.hpp); the other two are small streaming passes.  CRC-32 is not checked here (ISIZE is,
 // by the caller); anything malformed sets a status and the host readers take the file.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_E
 {
     __shared__ InfLds s;
     const int lane = lane_id();
-    for (uint32_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
+    // Stretches are TAKEN (round 6; k_bgzf_inflate's blocks since round 4): a wave's first stretch is its own index, every further
+    // one comes from a counter (n_bounds[1], cleared with the member count) -- with more stretches than decoder slots the launch no
+    // longer ends with the wave that was dealt the slow ones.  No counter (a caller without a member list): dealt by stride.
+    for (uint32_t ci = blockIdx.x; ci < n_chunks;) {
         const GzChunk ck = chunks[ci];
         const uint8_t *in = comp + ck.in_off;
         uint16_t *out = symbuf + (uint64_t)ci * sym_cap;
@@ -222,6 +226,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_E
             m.end_bit = pos, m.text_off = 0;
             meta[ci] = m;
         }
+        if (n_bounds) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(n_bounds + 1, 1u);
+            ci = gridDim.x + uni(__shfl(t, 0, kWave));
+        } else {
+            ci += gridDim.x;
+        }
     }
 }
 
@@ -248,6 +259,15 @@ struct TextCheck {     // a sink that keeps nothing
     __device__ __forceinline__ bool in_reach(uint32_t at, uint32_t dist) const { return dist <= at + kGzHist; }
 };
 
+// How much of a proposed block is decoded before it is believed (units of output).  Round 4: 4,096 -- 0.6 ms of one wave per
+// slice, as much as the scan in front of it.  A header that parses, three COMPLETE Huffman codes (the code-length code's Kraft sum,
+// build()'s completeness test for the literal/length and the distance code) and 1,024 units of text in a row are no accident
+// either, and a start is proven by the stretch before it arriving there anyway (k_gz_sym_inflate, status 20).
+#ifndef HPN_GZ_TRIAL_SYMBOLS
+#define HPN_GZ_TRIAL_SYMBOLS 1024
+#endif
+constexpr uint32_t kGzTrialSymbols = HPN_GZ_TRIAL_SYMBOLS;
+
 // does a dynamic block that decodes to text start at bit p, with something that begins like a block behind it?
 __device__ __forceinline__ bool gz_trial(InfLds &s, const uint8_t *__restrict__ comp, uint64_t comp_len, uint64_t p)
 {
@@ -269,12 +289,11 @@ __device__ __forceinline__ bool gz_trial(InfLds &s, const uint8_t *__restrict__ 
     TextCheck all{1u << 20, 0u, 0u, 0u};
     if (!decode_symbols(s, b, at, in, in_len, all, err) || all.op == 0 || all.bad) return false;
 #else
-    // The block's first 4,096 symbols, not the block to its end (round 4): a header that parses, complete code tables and 4,096
-    // symbols of text are no accident, and the start is proven by the stretch before it arriving there anyway -- while a block of
-    // FASTQ text is ~10^5 symbols, ~15 ms of one wave: the search re-decoded a quarter of what the inflate kernel decodes
-    // (k_gz_find_starts 30.7 ms beside 76 ms of k_gz_sym_inflate per batch, profiles/r04/kernel_stats_gz_tool.csv).
-    TextCheck all{4096u, 0u, 0u, 0u};
-    if (!decode_symbols(s, b, at, in, in_len, all, err)) return err == 12u && !all.bad && all.op != 0;   // (12: the 4,096 symbols are through)
+    // The block's first kGzTrialSymbols units, not the block to its end (round 4): a block of FASTQ text is ~10^5 symbols, ~15 ms
+    // of one wave -- the search re-decoded a quarter of what the inflate kernel decodes (k_gz_find_starts 30.7 ms beside 76 ms of
+    // k_gz_sym_inflate per batch, profiles/r04/kernel_stats_gz_tool.csv).
+    TextCheck all{kGzTrialSymbols, 0u, 0u, 0u};
+    if (!decode_symbols(s, b, at, in, in_len, all, err)) return err == 12u && !all.bad && all.op != 0;   // (12: the symbols are through)
     if (all.op == 0 || all.bad) return false;
 #endif
     // ... and the next block must at least begin like one (header parses, tables build, the first symbols decode to text):
@@ -301,6 +320,38 @@ __device__ __forceinline__ bool gz_trial(InfLds &s, const uint8_t *__restrict__ 
     return !some.bad;
 }
 
+// The scan (round 6).  Round 4's loop looked at 64 bit positions per pass -- two unaligned 8-byte loads per lane and the whole
+// header test, Kraft sum included, in every lane for every position: ~2.3 vector instructions per position behind a load's
+// latency, and a batch's search took 13 ms of a wave per slice (profiles/r05/kernel_stats_gz_tool_final.csv: 19 % of the
+// gzip route's device time).  Now a lane owns a BYTE: one 16-byte load (the next pass's is in flight while this one is
+// looked at) serves its eight bit positions; the three cheap header tests (BFINAL 0 / BTYPE 2, HLIT <= 29, HDIST <= 29: one
+// add and one masked compare, see below) leave one position in nine, and only those pay for the Kraft sum of the code-length
+// code -- 512 positions per pass at ~0.8 instructions per position.  What passes is tried in stream order as before.
+struct GzFindDiag {   // -DHPN_FIND_DIAG builds: what the search spent where (summed over the slices of a launch)
+    unsigned long long passes, trials, hits, clk_scan, clk_false, clk_true;
+};
+#ifdef HPN_FIND_DIAG
+__device__ GzFindDiag g_find_diag;
+#endif
+
+// Kraft sum of the code-length code whose 3-bit lengths start 17 bits behind bit `sh` of the 128 bits (a0 .. a3), `hclen` of
+// them (RFC 1951 3.2.7): 128 = complete.  Lengths beyond hclen are masked to 0, and a length of 0 counts nothing.
+__device__ __forceinline__ uint32_t gz_kraft(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t sh, uint32_t hclen)
+{
+    const uint32_t s = 17u + sh;                                                    // 17 .. 24
+    uint32_t y0 = __builtin_amdgcn_alignbit(a1, a0, s), y1 = __builtin_amdgcn_alignbit(a2, a1, s);
+    const uint32_t nb = 3u * hclen;                                                 // 12 .. 57 bits of lengths
+    y0 &= nb >= 32u ? 0xffffffffu : (1u << nb) - 1u;
+    y1 &= nb > 32u ? (1u << (nb - 32u)) - 1u : 0u;
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 10u; ++i) k += (128u >> ((y0 >> (3u * i)) & 7u)) & 127u;
+    k += (128u >> ((y0 >> 30 | y1 << 2) & 7u)) & 127u;                              // length 10 lies across the two words
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) k += (128u >> ((y1 >> (1u + 3u * i)) & 7u)) & 127u;
+    return k;
+}
+
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_EU, 8))) void k_gz_find_starts(const uint8_t *__restrict__ comp, uint64_t comp_len, const GzSlice *__restrict__ slices,
                                                           uint32_t n, uint64_t *__restrict__ found)
 {
@@ -309,26 +360,74 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_E
     for (uint32_t si = blockIdx.x; si < n; si += gridDim.x) {
         const uint64_t lo = uni64(slices[si].lo), hi = uni64(slices[si].hi);
         uint64_t hit = ~0ull;
-        for (uint64_t p0 = lo; p0 < hi && hit == ~0ull; p0 += kWave) {
-            const uint64_t p = p0 + lane;
-            uint64_t w0, w1;                          // 128 bits from the byte p lies in (the buffer is padded)
-            __builtin_memcpy(&w0, comp + (p >> 3), 8);
-            __builtin_memcpy(&w1, comp + (p >> 3) + 8, 8);
-            const uint32_t sh = (uint32_t)(p & 7u);
-            const uint64_t v0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
-            bool ok = p < hi && (p >> 3) + 16 <= comp_len && (v0 & 7u) == 4u && ((v0 >> 3) & 31u) <= 29u && ((v0 >> 8) & 31u) <= 29u;
-            const uint32_t hclen = (uint32_t)(v0 >> 13 & 15u) + 4u;
-            uint64_t x = (v0 >> 17) | ((w1 >> sh) << 47);
-            uint32_t kraft = 0;
+#ifdef HPN_FIND_DIAG
+        unsigned long long d_pass = 0, d_trial = 0, d_false = 0, d_true = 0;
+        const unsigned long long d_t0 = clock64();
+#endif
+        // the 16 bytes from byte B on; nothing where a header's 81 bits would not fit any more (the old test: byte + 16 <= comp_len)
+        auto fetch = [&](uint64_t B) {
+            u32 v = {0, 0, 0, 0};
+            if (B + 16u <= comp_len) __builtin_memcpy(&v, comp + B, 16);
+            return v;
+        };
+        uint64_t b0 = lo >> 3;                              // the pass's first byte; lane k looks at byte b0 + k
+        u32 cur = fetch(b0 + lane);
+        for (; b0 * 8u < hi && hit == ~0ull; b0 += kWave) {
+            const u32 w = cur;
+            cur = fetch(b0 + kWave + lane);                 // (in flight while this pass is looked at)
+            const uint64_t B = b0 + lane;
+            // BFINAL = 0, BTYPE = 2 (bits 0-2 = 4), HLIT <= 29 (bits 3-7: not 30, 31 = bits 4-7 not all ones), HDIST <= 29 (bits
+            // 8-12 likewise: bits 9-12): adding 1 to each of the two 4-bit fields carries into the (masked-out) bit above it
+            // exactly when the field is all ones -- one mask, one add, one masked compare per position
+            uint32_t m8 = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 19u; ++i, x >>= 3) kraft += i < hclen ? (128u >> (x & 7u)) & 127u : 0u;   // length 0: unused
-            ok = ok && kraft == 128u;
-            for (uint64_t m = __ballot(ok); m && hit == ~0ull; m &= m - 1) {
-                const uint64_t q = p0 + (uint64_t)__builtin_ctzll(m);
-                if (gz_trial(s, comp, comp_len, q)) hit = q;
+            for (uint32_t sh = 0; sh < 8u; ++sh) {
+                const uint32_t v = __builtin_amdgcn_alignbit(w[1], w[0], sh);
+                const uint32_t t = (v & (7u | 0xfu << 4 | 0xfu << 9)) + (1u << 4 | 1u << 9);
+                m8 |= (t & (7u | 1u << 8 | 1u << 13)) == 4u ? 1u << sh : 0u;
+            }
+            // positions outside [lo, hi) (the first and the last pass), and bytes that had no room
+            {
+                const uint64_t p = B * 8u;
+                if (p < lo) m8 = p + 8u <= lo ? 0u : m8 & (0xffu << (uint32_t)(lo - p));
+                if (p + 8u > hi) m8 = p >= hi ? 0u : m8 & ((1u << (uint32_t)(hi - p)) - 1u);
+                if (B + 16u > comp_len) m8 = 0u;
+            }
+            uint32_t k8 = 0;
+            while (__builtin_amdgcn_ballot_w64(m8 != 0u)) {
+                if (m8) {
+                    const uint32_t sh = (uint32_t)__builtin_ctz(m8);
+                    m8 &= m8 - 1u;
+                    const uint32_t hclen = ((__builtin_amdgcn_alignbit(w[1], w[0], sh) >> 13) & 15u) + 4u;
+                    if (gz_kraft(w[0], w[1], w[2], sh, hclen) == 128u) k8 |= 1u << sh;
+                }
+            }
+#ifdef HPN_FIND_DIAG
+            ++d_pass;
+#endif
+            for (uint64_t m = __builtin_amdgcn_ballot_w64(k8 != 0u); m && hit == ~0ull; m &= m - 1) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                for (uint32_t km = lane_of(k8, l); km && hit == ~0ull; km &= km - 1u) {
+                    const uint64_t q = (b0 + l) * 8u + (uint32_t)__builtin_ctz(km);
+#ifdef HPN_FIND_DIAG
+                    const unsigned long long c0 = clock64();
+                    const bool ok = gz_trial(s, comp, comp_len, q);
+                    ++d_trial;
+                    (ok ? d_true : d_false) += clock64() - c0;
+                    if (ok) hit = q;
+#else
+                    if (gz_trial(s, comp, comp_len, q)) hit = q;
+#endif
+                }
             }
         }
         if (lane == 0) found[si] = hit;
+#ifdef HPN_FIND_DIAG
+        if (lane == 0) {
+            atomicAdd(&g_find_diag.passes, d_pass), atomicAdd(&g_find_diag.trials, d_trial), atomicAdd(&g_find_diag.hits, hit != ~0ull ? 1ull : 0ull);
+            atomicAdd(&g_find_diag.clk_scan, clock64() - d_t0 - d_false - d_true), atomicAdd(&g_find_diag.clk_false, d_false), atomicAdd(&g_find_diag.clk_true, d_true);
+        }
+#endif
     }
 }
 
@@ -740,7 +839,17 @@ hipError_t launch_gz_find_starts(const uint8_t *d_comp, uint64_t comp_len, const
 {
     if (n == 0) return hipSuccess;
     const uint32_t cap = (uint32_t)n_cu * kInflateWavesPerCu;
+#ifdef HPN_FIND_DIAG
+    GzFindDiag z{};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_find_diag), &z, sizeof z);
+#endif
     hipLaunchKernelGGL(k_gz_find_starts, dim3(n < cap ? n : cap), dim3(kWave), 0, st, d_comp, comp_len, (const GzSlice *)d_slices, n, d_found);
+#ifdef HPN_FIND_DIAG
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(&z, HIP_SYMBOL(g_find_diag), sizeof z);
+    fprintf(stderr, "[find diag] %u slices: %llu passes of 512 positions, %llu trials (%llu hits); clocks per slice: scan %.0f, false trials %.0f, the true trial %.0f\n", n,
+            z.passes, z.trials, z.hits, (double)z.clk_scan / n, (double)z.clk_false / n, (double)z.clk_true / n);
+#endif
     return hipGetLastError();
 }
 size_t gz_groups_bytes(uint32_t n_chunks) { return (size_t)((n_chunks + kGzGroup - 1) / kGzGroup) * kGzHist * 3 + 64; }   // maps (u16) + histories (u8)

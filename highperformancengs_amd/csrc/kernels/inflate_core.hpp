@@ -535,16 +535,54 @@ __device__ __forceinline__ uint32_t block_tables(InfLds &s, Bits &b, const uint8
         refill(s, b, in, in_len);
         const uint32_t hlit = take(b, 5) + 257u, hdist = take(b, 5) + 1u, hclen = take(b, 4) + 4u;
         if (hlit > 286u || hdist > 30u) return 5;
-        if (lane < 19) s.lens[lane] = 0;
-        for (uint32_t i = 0; i < hclen; ++i) {
-            refill(s, b, in, in_len);
-            const uint32_t v = take(b, 3);
-            s.lens[kClOrder[i]] = (uint8_t)v;
+        // The code-length code (RFC 1951 3.2.7: up to 19 symbols, lengths 0..7), built in registers (round 6).  build() below is
+        // made for 286 symbols: serial loops whose every step is an LDS round trip -- ~28 K clocks for these 19, which is what a
+        // false candidate of the block-start search cost above all (k_gz_find_starts tries ~40 a slice: 80 K clocks each,
+        // profiles/r06/find_diag.txt).  Here lane i holds symbol i's length: how many codes a length has is a ballot, a symbol's
+        // code is its length's first code + its rank among the lanes of that length, and the 128 entries are written symbol by
+        // symbol by the lanes side by side.  Over-subscribed or incomplete: 6, as before (inftrees.c accepts neither here).
+        u64 cl = 0;
+        for (uint32_t got = 0; got < 3u * hclen;) {
+            refill(s, b, in, in_len);                                   // (at least 32 bits)
+            const uint32_t n = 3u * hclen - got < 30u ? 3u * hclen - got : 30u;
+            cl |= (u64)take(b, n) << got;
+            got += n;
         }
-        // the code-length code decodes with the distance table's storage (7-bit root is enough)
-        if (!build(s, s.dist, kDistSize, 7, 0, 19, false, [](uint32_t sym, uint32_t nb) { return mk(sym, 0, kLit, nb); })) return 6;
+        {
+            const uint32_t i = (uint32_t)lane;
+            // where symbol i's length stands in the stream (the inverse of 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
+            const uint32_t j = i >= 16u ? i - 16u : i == 0u ? 3u : i < 8u ? 19u - 2u * i : 2u * i - 12u;
+            const uint32_t len = i < 19u && j < hclen ? (uint32_t)(cl >> (3u * j)) & 7u : 0u;
+            uint32_t code = 0, left = 1, first = 0, rank = 0;
+            bool over = false;
+#pragma unroll
+            for (uint32_t l = 1; l <= 7u; ++l) {
+                const u64 m = __builtin_amdgcn_ballot_w64(len == l);
+                const uint32_t c = (uint32_t)__builtin_popcountll(m);
+                left <<= 1;
+                over = over || c > left;
+                left -= over ? 0u : c;
+                if (len == l) first = code, rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                code = (code + c) << 1;
+            }
+            if (over || left != 0u) return 6;
+            const uint32_t mine = rev(first + rank, len ? len : 1u), entry = mk(i, 0, kLit, len);
+            for (u64 used = __builtin_amdgcn_ballot_w64(len != 0u); used; used &= used - 1u) {
+                const uint32_t sym = (uint32_t)__builtin_ctzll(used);
+                const uint32_t r = lane_of(mine, sym), e = lane_of(entry, sym), l = e & 15u;
+                for (uint32_t k = (uint32_t)lane; k < (128u >> l); k += kWave) s.dist[r + (k << l)] = e;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the entries were written by other lanes)
+            __builtin_amdgcn_wave_barrier();
+        }
         uint32_t i = 0, prev = 0;
         const uint32_t total = hlit + hdist;
+        // Kraft sums of the two codes as their lengths come in (units of 2^-15): an over-subscribed code is refused HERE, with the
+        // code build() would refuse it with -- but before the rest of the lengths are decoded and counted.  Real blocks never get
+        // there; the block-start search's false candidates (k_gz_find_starts: ~40 per slice whose code-length code happens to be
+        // complete) nearly all do, within their first dozen lengths: 98 K clocks per false candidate before (decode ~300 lengths,
+        // count them in build()), profiles/r06/find_diag.txt.
+        uint32_t k_lit = 0, k_dist = 0;
         while (i < total) {
             refill(s, b, in, in_len);
             const uint32_t e = lookup(s.dist, 7, b);
@@ -560,10 +598,18 @@ __device__ __forceinline__ uint32_t block_tables(InfLds &s, Bits &b, const uint8
                 rep = 11u + take(b, 7), val = 0;
             }
             if (i + rep > total) return 9;
+            if (val) {
+                const uint32_t in_lit = i < hlit ? (rep < hlit - i ? rep : hlit - i) : 0u;
+                k_lit += in_lit * (32768u >> val), k_dist += (rep - in_lit) * (32768u >> val);
+                if (k_lit > 32768u || k_dist > 32768u) return 11;
+            }
             for (uint32_t k = (uint32_t)lane; k < rep; k += kWave) s.lens[32 + i + k] = (uint8_t)val;
             i += rep, prev = val;
         }
         if (s.lens[32 + 256] == 0) return 10;  // no end-of-block code
+        // incomplete codes: build() refuses them below unless the code is a single symbol of length 1 (sum 1/2) or, for distances,
+        // empty -- sums that cannot be either are refused here, before the lengths are counted
+        if ((k_lit < 32768u && k_lit != 16384u) || (k_dist < 32768u && k_dist != 16384u && k_dist != 0u)) return 11;
         if (!build(s, s.lit, kLitSize, kLitRoot, 32, hlit, true, lit_payload) ||
             !build(s, s.dist, kDistSize, kDistRoot, 32 + hlit, hdist, true, dist_payload))
             return 11;

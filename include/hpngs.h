@@ -228,6 +228,13 @@ int hpn_fastq_text_begin(hpn_ctx *ctx);
  * hpn_fastq_tally_dev (collect with hpn_fastq_tally_fetch).  tally_flags: HPN_TALLY_*. */
 int hpn_fastq_text_count(hpn_ctx *ctx, const void *text, uint64_t nbytes, int last, uint32_t tally_flags,
                          hpn_text_info *info);
+/* The same for text that lies on the device already (a batch inflated there: hpn_gz_inflate_dev, hpn_bgzf_inflate_dev),
+ * framed WHERE IT LIES: d_text must have 8192 writable bytes of device memory in front of it (the carried bytes of the
+ * chunk before are laid there) and 64 readable bytes behind d_text + nbytes; nothing else is copied.  The text may be
+ * overwritten as soon as the call returns.  Chunks framed in place and chunks framed by hpn_fastq_text_count may follow each
+ * other in one stream. */
+int hpn_fastq_text_count_inplace(hpn_ctx *ctx, const uint8_t *d_text, uint64_t nbytes, int last, uint32_t tally_flags,
+                                 hpn_text_info *info);
 /* gzfastq_sample.c:214-225 count_read: the same four gzgets per record with nothing but i++ in the
  * loop (its "total_reads_num").  Frames the chunk like hpn_fastq_text_count and tallies nothing:
  * info->n_records of every chunk add up to the reference's i (= the ReadCount column of fastq_count

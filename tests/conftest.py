@@ -22,7 +22,7 @@ USER_KNOBS = {"HPN_DEVICE", "HPN_NGPU", "HPN_TIMING", "HPN_FULL_EXIT", "HPN_NUMA
               "HPN_TEXT", "HPN_BAM_GPU", "HPN_GZ_GPU", "HPN_BEDGRAPH_HOST", "HPN_DEPTH_LOOKAHEAD", "HPN_ALLREDUCE"}
 TEST_KNOBS = {"HPN_RCCL_LIB", "HPN_COMM_SHARED_DEVICE", "HPN_TRIM_NOWRITE", "HPN_ALL_WORKERS", "HPN_BAM_AHEAD", "HPN_BAM_CHUNK", "HPN_BAM_ROUNDS",
               "HPN_BGZF_SLICE", "HPN_FAST_INFLATE", "HPN_GZ_BATCH", "HPN_GZ_CRC", "HPN_GZ_DEBUG", "HPN_GZ_FIND", "HPN_GZ_GPU_FORCE", "HPN_GZ_MEMBERS",
-              "HPN_GZ_OVERLAP", "HPN_GZ_STRETCH", "HPN_GZ_WINDOWS", "HPN_K1L_BIG", "HPN_K1_VARIANT", "HPN_K1_WG_PER_CU", "HPN_NO_BGZF", "HPN_NO_MGZ",
+              "HPN_GZ_OVERLAP", "HPN_GZ_OVERSUB", "HPN_GZ_STRETCH", "HPN_GZ_WINDOWS", "HPN_K1L_BIG", "HPN_K1_VARIANT", "HPN_K1_WG_PER_CU", "HPN_NO_BGZF", "HPN_NO_MGZ",
               "HPN_NO_PGZ", "HPN_PGZ_CHUNK", "HPN_PGZ_FORCE", "HPN_READER_STATS", "HPN_SWEEP_DIAG", "HPN_TEXT_CHUNK", "HPN_TEXT_SLICE",
               "HPN_TRIM_WG_PER_CU"}
 

@@ -277,3 +277,64 @@ def test_record_count_equals_the_reference_read_count(ctx, name, manifest):
     ctx.text_begin()
     ctx.text_records(b"@a\nAC\n+\nII\n", last=True)
     assert ctx.fastq_tally_fetch().total == 0
+
+
+# ---- text that lies on the device already, framed where it lies (hpn_fastq_text_count_inplace, round 6) -----------------------
+# The gzip route's batches are device text: the framer takes them in place (8192 writable bytes in front of the chunk for the
+# carried bytes) instead of copying every chunk into a slot.  Same counts as the oracle's gzgets loop for any chunking, the same
+# irregular reports, the text may be overwritten behind each call (the next batch's inflate does), and chunks framed in place
+# and chunks handed over the ordinary way may follow each other.  (Reference loop: fastq_count.c:112-118.)
+def _count_inplace(ctx, text, size, mix=False, clobber=False):
+    import torch
+    from highperformancengs_amd import _lib
+    parts = _chunks(text, size) + [b""]
+    ctx.text_begin()
+    n = 0
+    keep = []
+    for i, p in enumerate(parts):
+        last = i == len(parts) - 1
+        if mix and i % 3 == 1:
+            info = ctx.text_count(p, last=last, flags=_lib.TALLY_QUAL_HIST)
+        else:
+            buf = torch.full((8192 + len(p) + 64,), 0x41, dtype=torch.uint8, device="cuda")      # ('A's around it: never a newline)
+            if len(p):
+                buf[8192:8192 + len(p)] = torch.from_numpy(np.frombuffer(p, np.uint8).copy()).cuda()
+            info = ctx.text_count_inplace(buf[8192:], len(p), last=last, flags=_lib.TALLY_QUAL_HIST)
+            if clobber:
+                buf.fill_(10)           # the caller writes over the text at once (here: newlines everywhere)
+            keep.append(buf)
+        if info.irregular:
+            try:
+                ctx.fastq_tally_fetch()
+            except Exception:
+                pass
+            return None, info.irregular, n
+        n += info.n_records
+    return ctx.fastq_tally_fetch(qual_hist=True), 0, n
+
+
+@pytest.mark.parametrize("size", [None, 31, 100, 4099, 70001])
+@pytest.mark.parametrize("name", FASTQS)
+def test_count_in_place_any_chunking(ctx, name, size):
+    path = golden_path("fastq", name)
+    text = _text(path)
+    rc, want = orc.count_stream(path)
+    want_res, want_flags, want_n = _count(ctx, text, size, tail_call=True)
+    res, flags, n = _count_inplace(ctx, text, size)
+    assert (flags != 0) == (want_flags != 0)
+    if name in REGULAR:
+        assert flags == 0, f"{name}: fast path refused (flags {flags})"
+    if flags == 0:
+        assert rc == 0 and n == want_n
+        _assert_counts(res, want)
+
+
+@pytest.mark.parametrize("mix,clobber", [(True, False), (False, True), (True, True)])
+def test_count_in_place_mixed_with_copied_chunks_and_overwritten_text(ctx, mix, clobber):
+    path = golden_path("fastq", "syn_var_a.fq")
+    text = _text(path)
+    rc, want = orc.count_stream(path)
+    for size in (997, 65536):
+        res, flags, n = _count_inplace(ctx, text, size, mix=mix, clobber=clobber)
+        assert flags == 0 and rc == 0
+        _assert_counts(res, want)
