@@ -245,7 +245,161 @@ def _bam_kernel_legs(ctx, reps, legs):
     assert int(gc.sum()) == want_gc, (int(gc.sum()), want_gc)
     legs.append(_leg("K5 k_window_add: per-window count / GC / length (bam_sliding_count fetch_func + cal_GC)",
                      statistics.median(ts5), n * (12 + (L + 1) // 2), bytes_touched=n * (20 + (L + 1) // 2), records=n))   # 8(d): n x (12 B + ceil(l_qseq / 2)); the SoA view also holds flag and the 8-byte seq_off
+    try:
+        _bam_raw_legs(ctx, reps, legs, d, ncig, TL, L, (bins, gc, ln, nc))
+    except Exception as e:  # noqa: BLE001  (the SoA legs above stand on their own)
+        legs.append({"kernel": "raw BAM route", "failed": str(e)[:300]})
     del d, tid, pos, fl, cigar, cigar_off, m_per
+    torch.cuda.empty_cache()
+
+
+def _raw_stream(d, ncig, a, b, L):
+    """Records a .. b-1 of the SoA batch as BAM records (bam.h:178-187 behind block_size; name "r%09d", mapq 30, mate unset,
+    qualities 30) back to back: what BGZF blocks inflate to.  -> (uint8 stream, int64 record sizes)"""
+    import torch
+    m = b - a
+    nb = (L + 1) // 2
+    nc_ = ncig[a:b].to(torch.int64)
+    size = 36 + 11 + 4 * nc_ + nb + L
+    W = 36 + 11 + 12 + nb + L
+    mat = torch.zeros((m, W), dtype=torch.uint8, device="cuda")
+
+    def le(col, v, k):
+        for j in range(k):
+            mat[:, col + j] = ((v >> (8 * j)) & 255).to(torch.uint8)
+    le(0, size - 4, 4)
+    le(8, d.pos[a:b].to(torch.int64), 4)
+    mat[:, 12], mat[:, 13] = 11, 30
+    le(16, nc_, 2)
+    le(18, d.flag[a:b].to(torch.int64), 2)
+    le(20, torch.full((m,), L, dtype=torch.int64, device="cuda"), 4)
+    mat[:, 24:32] = 255
+    idx = torch.arange(a, b, device="cuda", dtype=torch.int64)
+    mat[:, 36] = ord("r")
+    for k in range(9):
+        mat[:, 37 + k] = (48 + (idx // 10 ** (8 - k)) % 10).to(torch.uint8)
+    c0 = d.cigar_off[a:b].to(torch.int64)
+    for j in range(3):
+        w = d.cigar[torch.clamp(c0 + j, max=d.cigar.numel() - 1)].to(torch.int64)
+        w = torch.where(nc_ > j, w, torch.zeros_like(w))
+        le(47 + 4 * j, w, 4)
+    seq = d.seq4[a * nb:b * nb].view(m, nb)
+    for k in (1, 2, 3):
+        rows = nc_ == k
+        if bool(rows.any()):
+            s0 = 47 + 4 * k
+            mat[rows, s0:s0 + nb] = seq[rows]
+            mat[rows, s0 + nb:s0 + nb + L] = 30
+    keep = torch.arange(W, device="cuda")[None, :] < size[:, None]
+    return mat[keep], size
+
+
+def _bam_raw_legs(ctx, reps, legs, d, ncig, TL, L, want_window):
+    """The route the BAM tools take: the same chr1-at-30x records held as inflated BAM bytes, indexed in place
+    (k_raw_starts / _count / _scan / _index: bam_read1's walk, samtools-0.1.19 bam.c:191) and read in place by the depth and
+    the window kernels -- in launches of 4.4 M records (~1.2 GB of inflated bytes, 19 K blocks), as host/bam_gpu.hpp makes them."""
+    import torch
+    n = int(d.pos.numel())
+    per_block, per_launch = 230, 230 * 19_130
+    nb = (L + 1) // 2
+    parts, sizes = [], []
+    for a in range(0, n, 4_000_000):
+        st, sz = _raw_stream(d, ncig, a, min(n, a + 4_000_000), L)
+        parts.append(st), sizes.append(sz)
+    stream = torch.cat(parts + [torch.zeros(4096, dtype=torch.uint8, device="cuda")])
+    size = torch.cat(sizes)
+    del parts, sizes
+    rec_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    rec_off[1:] = torch.cumsum(size, 0)
+    stream_len = int(rec_off[-1].item())
+    BL = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
+    launches = []
+    for a in range(0, n, per_launch):
+        b = min(n, a + per_launch)
+        starts = rec_off[a:b:per_block].cpu().numpy()
+        ends = np.append(starts[1:], int(rec_off[b].item()))
+        tab = np.zeros(len(starts), BL)
+        tab["out_off"], tab["out_len"] = starts - starts[0], ends - starts
+        launches.append((int(starts[0]), int(ends[-1] - starts[0]), b - a, torch.from_numpy(tab.view(np.uint8).copy()).cuda(),
+                         torch.zeros(len(starts), dtype=torch.int32, device="cuda")))
+    n_ops = int(d.cigar.numel())
+    # ---- the index alone ----
+    t_idx = []
+    for r in range(reps + 1):
+        tot = 0.0
+        for off, ln_, cnt, d_tab, d_st in launches:
+            info = ctx.bam_raw_index_dev(stream[off:], d_tab, d_tab.numel() // 24, 0, d_st)
+            ctx.sync()
+            assert info.flags == 0 and info.n_records == cnt, (info.flags, info.n_records, cnt)
+            tot += ctx.last_kernel_ms(6)
+        if r:
+            t_idx.append(tot)
+    legs.append(_leg("raw BAM route, record index: k_raw_starts + k_raw_count + k_raw_scan + k_raw_index on inflated BAM bytes (bam_read1's walk)",
+                     statistics.median(t_idx), n * 44, bytes_touched=n * (128 + 16), records=n, launches=len(launches), stream_bytes=stream_len,
+                     ms_per_launch=round(statistics.median(t_idx) / len(launches), 4),
+                     note="algorithmic: 36 B of fixed fields + 8 B of rec_off per record; bytes_touched: a 128-byte line per record + the offset written twice (list, rec_off); "
+                          "kernel_ms includes the host's look at the counts between k_raw_scan and k_raw_index (one read-back per launch)"))
+    # ---- bam2depth on the raw records: k_depth_index<RawRecs> + k_depth_sweep<RawRecs> per launch, then the finish ----
+    t_add, t_fin = [], []
+    runs_raw = win_raw = None
+    for r in range(reps + 1):
+        ctx._ck(ctx.L.hpn_depth_begin_w(ctx.h, 0, TL, 0x704, 20000), "hpn_depth_begin_w")
+        tot = 0.0
+        for off, ln_, cnt, d_tab, d_st in launches:
+            ctx.bam_raw_index_dev(stream[off:], d_tab, d_tab.numel() // 24, 0, d_st)
+            ctx._ck(ctx.L.hpn_depth_add_raw_dev(ctx.h, C.c_void_p(stream[off:].data_ptr())), "hpn_depth_add_raw_dev")
+            ctx.sync()
+            tot += ctx.last_kernel_ms(2)
+        runs_raw, win_raw = ctx.depth_finish(TL, 20000, runs_cap=1 << 27)
+        if r:
+            t_add.append(tot), t_fin.append(ctx.last_kernel_ms(2))
+    m_bases = int(win_raw.sum())
+    assert int(((runs_raw[:, 1] - runs_raw[:, 0]).astype(np.int64) * runs_raw[:, 2]).sum()) == m_bases
+    # the same records through the SoA sweep: the same runs
+    ctx._ck(ctx.L.hpn_depth_begin_w(ctx.h, 0, TL, 0x704, 20000), "hpn_depth_begin_w")
+    keep_alive = []
+    bsoa = ctx._batch(d, keep_alive)
+    ctx._ck(ctx.L.hpn_depth_add_dev(ctx.h, C.byref(bsoa)), "hpn_depth_add_dev")
+    runs_soa, win_soa = ctx.depth_finish(TL, 20000, runs_cap=1 << 27)
+    same = bool(np.array_equal(runs_soa, runs_raw) and np.array_equal(win_soa, win_raw))
+    assert same, "raw-record route and SoA route give different runs"
+    k34 = n * 16 + 4 * n_ops + 8 * int(((d.cigar & 15) == 0).sum().item()) + (TL + 1 + (1 << 21)) * 4 + 12 * len(runs_raw) + 8 * len(win_raw)
+    legs.append(_leg("raw BAM route, bam2depth: k_depth_index<RawRecs> + k_depth_sweep<RawRecs> per launch of 4.4 M records (+ k_depth_scan over the last tiles)",
+                     statistics.median(t_add) + statistics.median(t_fin), k34, add_ms=round(statistics.median(t_add), 4),
+                     finish_ms=round(statistics.median(t_fin), 4), records=n, launches=len(launches), runs=len(runs_raw), identical_to_soa_route=same))
+    del runs_raw, win_raw, runs_soa, win_soa
+    # ---- bam_sliding_count on the raw records: k_raw_fields + k_window_add (sequence read in place) ----
+    off_w = np.array([0, TL // 20000 + 1], np.uint64)
+    t_f, t_w = [], []
+    res = None
+    for r in range(reps + 1):
+        ctx._ck(ctx.L.hpn_window_begin(ctx.h, 1, off_w.ctypes.data_as(C.c_void_p), 20000), "hpn_window_begin")
+        tf = tw = 0.0
+        for off, ln_, cnt, d_tab, d_st in launches:
+            ctx.bam_raw_index_dev(stream[off:], d_tab, d_tab.numel() // 24, 0, d_st)
+            ctx._ck(ctx.L.hpn_window_add_raw_dev(ctx.h, C.c_void_p(stream[off:].data_ptr())), "hpn_window_add_raw_dev")
+            ctx.sync()
+            tf += ctx.last_kernel_ms(7)
+            tw += ctx.last_kernel_ms(3)
+        tot = int(off_w[-1])
+        bins, gc, ln = np.zeros(tot, np.uint32), np.zeros(tot, np.uint64), np.zeros(tot, np.uint32)
+        touched, ncnt = np.zeros(1, np.uint8), C.c_uint64(0)
+        ctx._ck(ctx.L.hpn_window_finish(ctx.h, bins.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p),
+                                        touched.ctypes.data_as(C.c_void_p), C.byref(ncnt)), "hpn_window_finish")
+        res = (bins, gc, ln, ncnt.value)
+        if r:
+            t_f.append(tf), t_w.append(tw)
+    wb, wg, wl, wn = want_window
+    same_w = bool(np.array_equal(res[0], wb) and np.array_equal(res[1], wg) and np.array_equal(res[2], wl) and res[3] == wn)
+    assert same_w, "raw-record route and SoA route give different window counts"
+    ms = statistics.median(t_f) + statistics.median(t_w)
+    legs.append(_leg("raw BAM route, bam_sliding_count: k_raw_fields + k_window_add with the sequence read in place",
+                     ms, n * (12 + nb), bytes_touched=n * (8 + 28 + 24 + 2 * 128), fields_ms=round(statistics.median(t_f), 4),
+                     window_add_ms=round(statistics.median(t_w), 4), records=n, launches=len(launches),
+                     records_per_ms_window_add=round(n / statistics.median(t_w)), identical_to_soa_route=same_w,
+                     note="bytes_touched: rec_off + the field view written and read + the two 128-byte lines a record's fixed part and sequence lie in "
+                          "(records of ~280 bytes: 4 of every 5 lines of the stream are fetched whatever is read from them)"))
+    del stream, rec_off, size, launches
     torch.cuda.empty_cache()
 
 

@@ -358,7 +358,12 @@ private:
     {
         // (the FIRST launch of a file read front to back is six chunks: what waits for the first records -- bam2depth's first
         // target, the writer behind it -- starts that much earlier; the launches behind it take rounds_)
-        const int limit = launches_ == 0 && rounds_ > 6 && !rounds_env() ? 6 : rounds_;
+        // Round 6: and they GROW -- 6, then half of rounds_, then rounds_ = 44 chunks (1.4 GB compressed, ~2.5 GB inflated: six
+        // blocks per decoder wave instead of three).  A launch ends with its slowest blocks while the other decoders idle: by the
+        // profiles 0.33 GB launches run at 81 GB/s of inflated bytes, 1.2 GB launches at 86, one launch of 3.85 GB at 98
+        // (profiles/r05/kernel_stats_bam2depth_final.csv, kernel_stats_bgzf_inflate.csv); the upload of 44 chunks takes as long as
+        // their inflate, so the pipeline stays balanced.
+        const int limit = rounds_env() ? rounds_ : launches_ == 0 && rounds_ > 6 ? 6 : launches_ == 1 && rounds_ > 22 ? rounds_ / 2 : rounds_;
         ++launches_;
         for (int taken = 0; taken < limit;) {         // several chunks under one inflate launch
             TextPump::Chunk c;
@@ -597,7 +602,7 @@ private:
         const int v = e ? atoi(e) : 0;
         return v < 0 ? 0 : v > 64 ? 64 : v;
     }
-    int rounds_ = rounds_env() ? rounds_env() : 22;
+    int rounds_ = rounds_env() ? rounds_env() : 44;
     uint32_t launches_ = 0;
     std::vector<uint8_t> carry_;
     BgzfDevice dev_;

@@ -46,7 +46,7 @@ inline size_t text_chunk_bytes()
 // hundred MB/s per file, so every file gets its worker, as in the reference.  Plain files
 // stream at tens of GB/s per worker: a few lanes saturate PCIe, and each further GPU context
 // only adds start-up (15-30 ms of hardware-queue creation each, serialised by the driver) --
-// one lane per 4 GiB of input, four per device (= per PCIe link) at most.
+// one lane per 8 GiB of input, two per device (= per PCIe link) at most.
 inline int text_workers(char **files, int n, int requested, int ndev = 1)
 {
     if (!text_path_enabled() || test_env("HPN_ALL_WORKERS")) return requested;
@@ -62,8 +62,12 @@ inline int text_workers(char **files, int n, int requested, int ndev = 1)
         if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return requested;
         plain += (uint64_t)sb.st_size;
     }
-    int lanes = (int)(plain >> 32) + 1;
-    if (lanes > 4 * (ndev < 1 ? 1 : ndev)) lanes = 4 * (ndev < 1 ? 1 : ndev);
+    // (round 6: one lane per 8 GiB, two per device.  ONE worker streams a plain file at 49 GB/s of the link's 51 - 53
+    // (profiles/r05/plain_a.txt), two reach it; the third and fourth of rounds 3 - 5 only added their contexts' set-up --
+    // 30 ms each, one after the other in the driver -- to a run that is otherwise the process's start plus bytes / link:
+    // profiles/r06/plain8_timeline.txt)
+    int lanes = (int)(plain >> 33) + 1;
+    if (lanes > 2 * (ndev < 1 ? 1 : ndev)) lanes = 2 * (ndev < 1 ? 1 : ndev);
     return lanes < requested ? lanes : requested;
 }
 

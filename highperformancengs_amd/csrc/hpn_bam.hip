@@ -316,6 +316,8 @@ int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block
     int32_t *d_lo = (int32_t *)(d_starts + n_blocks), *d_hi = d_lo + n_blocks;
     const int32_t init[6] = {0, INT32_MAX, INT32_MIN, 0, -1, -1};      // [4..5]: u64 ~0 = no unfinished record at the call's end
     HPN_HIP(c, hipMemcpyAsync(c->r_info.p, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_beg[kFamRaw], c->stream));
+    c->ev_valid[kFamRaw] = false;
     HPN_HIP(c, launch_raw_count(d_raw, d_blocks, (uint32_t)n_blocks, first_off, d_status, d_starts, d_counts, d_exits, d_lo, d_hi,
                                 (u64 *)c->r_bases.p, (int32_t *)c->r_info.p, (u64 *)c->r_list.p, list_words, c->stream));
     int32_t h[6];
@@ -345,6 +347,8 @@ int hpn_bam_raw_index_dev(hpn_ctx *c, const uint8_t *d_raw, const hpn_bgzf_block
     if ((rc = scratch_reserve(c, c->r_off, total * sizeof(uint64_t))) != HPN_OK) return rc;
     HPN_HIP(c, launch_raw_index(d_blocks, (uint32_t)n_blocks, d_counts, (const u64 *)c->r_bases.p, (const u64 *)c->r_list.p,
                                 (uint64_t *)c->r_off.p, c->stream));
+    HPN_HIP(c, hipEventRecord(c->ev_end[kFamRaw], c->stream));       // (family 6: the four index kernels and the host's look at the counts between them)
+    c->ev_valid[kFamRaw] = true;
     c->r_n = total;
     return HPN_OK;
 }
@@ -380,8 +384,11 @@ int hpn_window_add_raw_dev(hpn_ctx *c, const uint8_t *d_raw)
             (rc = scratch_reserve(c, c->r_flag, n * 4)) != HPN_OK || (rc = scratch_reserve(c, c->r_lq, n * 4)) != HPN_OK ||
             (rc = scratch_reserve(c, c->r_soff, n * 8)) != HPN_OK)
             return rc;
+        HPN_HIP(c, hipEventRecord(c->ev_beg[kFamRawFields], c->stream));
         HPN_HIP(c, launch_raw_fields(d_raw, (const uint64_t *)c->r_off.p, n, (int32_t *)c->r_tid.p, (int32_t *)c->r_pos.p,
                                      (uint32_t *)c->r_flag.p, (int32_t *)c->r_lq.p, (uint64_t *)c->r_soff.p, c->n_cu, c->stream));
+        HPN_HIP(c, hipEventRecord(c->ev_end[kFamRawFields], c->stream));
+        c->ev_valid[kFamRawFields] = true;
         c->r_fields = true;
     }
     hpn_bam_batch b;

@@ -29,7 +29,7 @@ struct Scratch {
     size_t cap = 0;
 };
 
-enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamText = 4, kFamInflate = 5, kFamCount = 6 };
+enum { kFamTally = 0, kFamTrim = 1, kFamDepth = 2, kFamWindow = 3, kFamText = 4, kFamInflate = 5, kFamRaw = 6, kFamRawFields = 7, kFamCount = 8 };
 
 }  // namespace hpn
 

@@ -162,66 +162,50 @@ __device__ __forceinline__ RawWalk walk_block(const uint8_t *__restrict__ raw, u
     return w;
 }
 
-// ---- the walk with the records ahead in flight (round 6) -------------------------------------------------------------------------
+// ---- the walk with the next records in flight (round 6) ---------------------------------------------------------------------------
 // walk_block above waits twice per record: for the fixed part (block_size tells where the next record is), then for the byte
 // that must be the name's NUL -- and k_raw_index walked every chain a second time to write the offsets down: 0.62 + 0.27 ms per
 // 1.2 GB launch (4.4 M records, ~230 to a block), the largest kernels of the BAM tools behind the inflater
-// (profiles/r05/kernel_stats_bam2depth_final.csv).  A chain is a chain -- a lane cannot know where record k + 1 starts before it has
-// record k's block_size, and a round trip of 64 lanes reading 64 blocks is ~2 us -- but reads of one length and one kind of
-// CIGAR give records of ONE SIZE, so a lane bets on it: with record k in hand it asks for the 80 bytes at k + 1 and k + 2 (the
-// fixed part and a name of up to 44 characters with its NUL: one request, no second one for the NUL) assuming both are as long
-// as k.  While the bet holds, what a record needs was asked for two records earlier and three records go by per round trip;
-// when a record is longer or shorter than its predecessor the lane asks again and waits once.  The records' offsets are written
-// down as they are met (list: block b's at raw_list_base(b), one after the other; two records never share a slot because a
-// record is at least 36 bytes), so the index is a copy, not a second walk.  Same results as walk_block, record for record
-// (tests/test_bam_raw_gpu.py).
-struct RawHead {           // the first 80 bytes of a record: block_size | refID pos bin_mq_nl | flag_nc l_seq next_refID next_pos | read_name ...
-    u32 v[5];
-    uint32_t have;         // how many of them lie in the stream (0: fewer than the 36 of the fixed part)
+// (profiles/r05/kernel_stats_bam2depth_final.csv).  A chain is a chain -- a lane cannot know where record k + 1 starts before it
+// has record k's block_size, and a round trip of 64 lanes reading 64 blocks is ~2 us -- so what can be is taken off it:
+//   * reads of one length and one kind of CIGAR give records of ONE SIZE: with record k in hand the lane asks for the fixed part
+//     of k + 1 AND, betting that k + 1 is as long as k, of k + 2; while the bet holds a fixed part was asked for two records
+//     before it is needed;
+//   * the NUL byte is asked for when the record is met and LOOKED AT two records later: a record is counted (its offset written
+//     down, its refID taken) only then, so the answer is the same, but nothing waits for that byte;
+//   * the offsets go to a list as the records are counted (block b's at raw_list_base(b), one after the other; two records never
+//     share a slot because a record is at least 36 bytes), so the index is a copy, not a second walk.
+// Same results as walk_block, record for record (tests/test_bam_raw_gpu.py).  Measured and dropped on the way: the first 80 bytes
+// of three records in flight (name and NUL inside one request): 0.78 ms per launch against 0.56 for the plain look-ahead -- five
+// 64-way divergent 16-byte loads per record cost more than the round trips they saved (profiles/r06/tools_b.txt).
+struct RawHead {           // the 36 bytes of a record's fixed part: block_size | refID pos bin_mq_nl | flag_nc l_seq next_refID next_pos
+    u32 a, b;              // bytes 0..15, 16..31
+    uint32_t c;            // bytes 32..35
 };
 __device__ __forceinline__ RawHead head_at(const uint8_t *__restrict__ raw, uint64_t at, uint64_t stream_len)
 {
     RawHead h;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) h.v[k] = u32{0, 0, 0, 0};
-    h.have = 0;
-    if (at + 80u <= stream_len) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) __builtin_memcpy(&h.v[k], raw + at + 16 * k, 16);
-        h.have = 80u;
-    } else if (at + 36u <= stream_len) {      // the stream's last records: the fixed part alone (the NUL is read where it lies)
-        __builtin_memcpy(&h.v[0], raw + at, 16);
-        __builtin_memcpy(&h.v[1], raw + at + 16, 16);
-        uint32_t c;
-        __builtin_memcpy(&c, raw + at + 32, 4);
-        h.v[2][0] = c;
-        h.have = 36u;
+    h.a = u32{0, 0, 0, 0}, h.b = u32{0, 0, 0, 0}, h.c = 0;
+    if (at + 36u <= stream_len) {
+        __builtin_memcpy(&h.a, raw + at, 16);
+        __builtin_memcpy(&h.b, raw + at + 16, 16);
+        __builtin_memcpy(&h.c, raw + at + 32, 4);
     }
     return h;
 }
-// byte i (< 80) of the 80 (no indexed register access: a select per word)
-__device__ __forceinline__ uint32_t head_byte(const RawHead &h, uint32_t i)
-{
-    uint32_t w = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 20u; ++k) w = (i >> 2) == k ? h.v[k >> 2][k & 3u] : w;
-    return (w >> (8u * (i & 3u))) & 255u;
-}
-// record_at on a record whose first bytes are in registers: 0 = no record, 2 = cannot tell (the stream ends inside its fixed part
-// or its name), 1 = a record, *step bytes long
-__device__ __forceinline__ int head_check(const uint8_t *__restrict__ raw, uint64_t at, const RawHead &h, uint64_t room, uint32_t *step)
+// record_at on a fixed part that is in registers, up to the name's NUL: 0 = no record, 2 = cannot tell (the stream ends inside it),
+// 1 = a record if the byte at *nul_at is 0, *step bytes long
+__device__ __forceinline__ int head_check(const RawHead &h, uint64_t room, uint32_t *step, uint32_t *nul_at)
 {
     if (room < 36u) return 2;
-    const uint32_t bs = h.v[0][0];
+    const uint32_t bs = h.a[0];
     if (bs < 32u || bs > (1u << 28)) return 0;
-    const int32_t tid = (int32_t)h.v[0][1], pos = (int32_t)h.v[0][2], mtid = (int32_t)h.v[1][2], mpos = (int32_t)h.v[1][3];
-    const uint32_t l_name = h.v[0][3] & 255u, n_cigar = h.v[1][0] & 0xffffu, l_seq = h.v[1][1];
+    const int32_t tid = (int32_t)h.a[1], pos = (int32_t)h.a[2], mtid = (int32_t)h.b[2], mpos = (int32_t)h.b[3];
+    const uint32_t l_name = h.a[3] & 255u, n_cigar = h.b[0] & 0xffffu, l_seq = h.b[1];
     if (tid < -1 || pos < -1 || mtid < -1 || mpos < -1 || l_name == 0u || l_seq > 0x7fffffffu) return 0;
     if (32ull + l_name + 4ull * n_cigar + (((uint64_t)l_seq + 1u) >> 1) + (uint64_t)l_seq > (uint64_t)bs) return 0;
     if (room < 36u + l_name) return 2;
-    const uint32_t nul_at = 35u + l_name;
-    const uint32_t nul = nul_at < h.have ? head_byte(h, nul_at) : (uint32_t)raw[at + nul_at];   // (a name beyond 44 characters: read where it lies)
-    if (nul != 0u) return 0;                                 // read_name is NUL-terminated
+    *nul_at = 35u + l_name;
     *step = 4u + bs;
     return 1;
 }
@@ -229,42 +213,61 @@ __device__ __forceinline__ RawWalk walk_block_ahead(const uint8_t *__restrict__ 
                                                     uint64_t list_room)
 {
     RawWalk w = {0u, INT32_MAX, INT32_MIN, 0ull};
-    if (at >= end) {
-        w.exit = at;
-        return w;
-    }
-    RawHead cur = head_at(raw, at, stream_len);
-    RawHead p1 = cur, p2 = cur;                // what lies at p1_at / p2_at: the next record and the one after it IF sizes repeat
-    uint64_t p1_at = ~0ull, p2_at = ~0ull;
-    while (at < end) {
-        uint32_t step = 0;
-        const int r = head_check(raw, at, cur, stream_len - at, &step);
-        if (r == 0 || w.n >= list_room) {
-            w.n |= kBroken;
-            break;
+    // records met and not yet counted: their NUL bytes are on their way (the older one in slot 0)
+    uint64_t p_at[2] = {0, 0};
+    int32_t p_tid[2] = {0, 0};
+    uint32_t p_nul[2] = {0, 0};
+    uint32_t pending = 0;
+    bool broken = false;
+    // count the oldest pending record; false: it is no record (its name does not end in NUL) or the list is full -- the chain ends AT it
+    auto count_oldest = [&]() -> bool {
+        if (p_nul[0] != 0u || w.n >= list_room) {
+            at = p_at[0], broken = true, pending = 0;
+            return false;
         }
-        if (r == 2 || at + step > stream_len) {          // the record is not whole in this call: it starts the next one
-            at |= kTailBit;
-            break;
-        }
-        const uint64_t next = at + step;
-        const int32_t tid = (int32_t)cur.v[0][1];
-        w.lo = tid < w.lo ? tid : w.lo, w.hi = tid > w.hi ? tid : w.hi;
-        list[w.n] = at;
+        w.lo = p_tid[0] < w.lo ? p_tid[0] : w.lo, w.hi = p_tid[0] > w.hi ? p_tid[0] : w.hi;
+        list[w.n] = p_at[0];
         ++w.n;
-        if (next >= end) {
-            at = next;
-            break;
+        p_at[0] = p_at[1], p_tid[0] = p_tid[1], p_nul[0] = p_nul[1];
+        --pending;
+        return true;
+    };
+    uint32_t how = 0;                          // how the chain ended: 0 = at the block's end, 1 = an impossible record, 2 = the call's unfinished tail
+    if (at < end) {
+        RawHead cur = head_at(raw, at, stream_len);
+        RawHead guess = cur;                   // the fixed part at `guess_at`: where the record after next starts if sizes repeat
+        uint64_t guess_at = ~0ull;
+        while (at < end) {
+            uint32_t step = 0, nul_at = 0;
+            const int r = head_check(cur, stream_len - at, &step, &nul_at);
+            if (r != 1) {
+                how = r == 0 ? 1u : 2u;
+                break;
+            }
+            const uint32_t nul = raw[at + nul_at];                                  // (looked at two records from now)
+            const uint64_t next = at + step;
+            const RawHead nx = next == guess_at ? guess : head_at(raw, next, stream_len);
+            const bool ahead = next < end && next + step < end;
+            const uint64_t g_at = ahead ? next + step : ~0ull;
+            const RawHead g = ahead ? head_at(raw, g_at, stream_len) : cur;
+            if (pending == 2u && !count_oldest()) break;
+            if (next > stream_len) {                                                // whole only in the next call -- unless its name already fails
+                if (nul != 0u) how = 1u;
+                else how = 2u;
+                break;
+            }
+            p_at[pending] = at, p_tid[pending] = (int32_t)cur.a[1], p_nul[pending] = nul;
+            ++pending;
+            at = next, cur = nx, guess = g, guess_at = g_at;
         }
-        // the next record: the bet of two records ago, of the last one, or asked for now; and the bets for the two behind it
-        const RawHead nx = next == p1_at ? p1 : next == p2_at ? p2 : head_at(raw, next, stream_len);
-        const uint64_t q1 = next + step, q2 = q1 + step;
-        const RawHead n1 = q1 == p2_at ? p2 : q1 < end ? head_at(raw, q1, stream_len) : cur;
-        const RawHead n2 = q2 < end ? head_at(raw, q2, stream_len) : cur;
-        p1 = n1, p1_at = q1 < end ? q1 : ~0ull;
-        p2 = n2, p2_at = q2 < end ? q2 : ~0ull;
-        at = next, cur = nx;
     }
+    if (!broken) {
+        const uint64_t stop = at;                      // where the chain stands if everything pending is a record
+        while (pending && count_oldest()) {}
+        if (!broken) at = stop;
+    }
+    if (broken || how == 1u) w.n |= kBroken;
+    else if (how == 2u) at |= kTailBit;
     w.exit = at;
     return w;
 }

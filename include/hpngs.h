@@ -72,7 +72,9 @@ const char *hpn_ctx_last_error(const hpn_ctx *ctx);
 /* Milliseconds the device spent in the most recent kernel launch group of the
  * given family, measured with hipEvents on the context's stream (valid after
  * the matching fetch/sync). Families: 0 tally, 1 trim, 2 depth, 3 window,
- * 4 text framing, 5 BGZF inflate. */
+ * 4 text framing, 5 BGZF inflate, 6 record index of hpn_bam_raw_index_dev (its four
+ * kernels and the host's look at the counts between them), 7 the field view
+ * hpn_window_add_raw_dev makes of the indexed records. */
 int hpn_ctx_last_kernel_ms(hpn_ctx *ctx, int family, float *ms);
 
 /* ---- memory helpers (thin wrappers; callers may use their own allocator) ---- */

@@ -3,7 +3,7 @@
 # file and on a C2-like file of many members; the search / CRC micro-benchmark; rocprofv3 over the tool.  -> gpurun_out/r06_gz/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r06_gz; mkdir -p $O /dev/shm/gzp
+O=$GRAFT_REPO_ROOT/gpurun_out/r06_gz; mkdir -p $O /dev/shm/gzp; : > $O/ab_gz_tool.txt; : > $O/bench_gz_find.txt
 CYC=${R06_CYCLES:-40}
 python3 - <<PY
 import os, sys
@@ -38,18 +38,18 @@ run() {  # label, bindir, env...
   for f in gz3.fq.gz members.fq.gz; do
     for rep in 1 2; do
       sleep 1.5
-      s=$(date +%s.%N)
+      s=$(date +%s%N)
       row=$(env HPN_TIMING=1 "$@" $bin/fastq_count $f 2> /tmp/err.txt | tail -1)
-      e=$(date +%s.%N)
-      echo "$label $f rep$rep wall $(echo "$e - $s" | bc) s | $row | $(grep 'gzip on the GPU' /tmp/err.txt | tail -1)" >> $O/ab_gz_tool.txt
+      e=$(date +%s%N)
+      echo "$label $f rep$rep wall $(( (e - s) / 1000000 )) ms | $row | $(grep 'gzip on the GPU' /tmp/err.txt | tail -1)" >> $O/ab_gz_tool.txt
     done
   done
 }
 R=$GRAFT_REPO_ROOT
 run r05 $R/build_ab/r05/bin
 run tree $R/highperformancengs_amd/bin
-for o in 2 3 4; do run hooks_oversub$o $R/highperformancengs_amd/testhooks/bin HPN_GZ_OVERSUB=$o; done
-run hooks_nocrc $R/highperformancengs_amd/testhooks/bin HPN_GZ_CRC=0
+run r05 $R/build_ab/r05/bin
+run tree $R/highperformancengs_amd/bin
 cat $O/ab_gz_tool.txt
 # ---- the search and the CRC alone ----
 cd $R
@@ -58,7 +58,6 @@ for v in r05 tree finddiag; do
   echo "== $v" >> $O/bench_gz_find.txt
   HPN_LIB=$lib timeout 600 python3 scripts/bench_gz_find.py >> $O/bench_gz_find.txt 2>&1
 done
-HPN_LIB=$R/build_ab/finddiag/libhpngs.so timeout 600 python3 scripts/bench_gz_find.py 18432 524288 >> $O/bench_gz_find.txt 2>&1
 cat $O/bench_gz_find.txt
 # ---- rocprofv3 over the tool ----
 cd /dev/shm/gzp

@@ -296,6 +296,26 @@ def test_crc32_of_spans_equals_zlib():
     ctx.close()
 
 
+def test_crc32_every_alignment_of_the_column_kernel():
+    """Round 6's k_crc32_blocks folds 32-bit columns down rows of 4 KiB and lays a short block against the END of its 64 KiB:
+    every length around a row and a block, at every offset inside a 16-byte piece, against zlib (what gzread checks behind the
+    reference's gzgets, IO_stream.h:122-136)."""
+    import zlib
+    import torch
+    import highperformancengs_amd as hp
+    ctx = hp.Context(0)
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, 400_000, dtype=np.uint8)
+    d = torch.from_numpy(data).cuda()
+    lens = list(range(0, 70)) + [4079, 4080, 4081, 4095, 4096, 4097, 8191, 8192, 8193, 61439, 61440, 61441, 65519, 65520, 65535, 65536, 65537,
+                                 69631, 69632, 131071, 131072, 131073, 200_000]
+    spans = [(o, n) for n in lens for o in (0, 1, 3, 15, 16, 17, 4095)]
+    got = ctx.crc32_dev(d, spans)
+    bad = [(o, n) for (o, n), c in zip(spans, got) if c != zlib.crc32(data[o:o + n].tobytes())]
+    assert not bad, bad[:10]
+    ctx.close()
+
+
 @pytest.mark.parametrize("how,n_cuts", [("lds", 60), ("global", 60), ("groups", 60), ("groups", 130), ("groups", 700)])
 def test_histories_in_lds_and_in_memory(request, how, n_cuts):
     """k_gz_windows_lds (calls that have the chip to themselves), k_gz_windows and the three-step form (k_gz_win_maps / _chain /
@@ -370,3 +390,42 @@ def test_block_starts_found_on_the_device(ctx):
                 out = d.decompress(tail)
             except zlib.error as e:                     # a match reaching in front of the start is the only excuse
                 assert "distance too far back" in str(e), e
+
+
+@pytest.mark.parametrize("level", [1, 4, 6, 9])
+def test_block_starts_at_any_bit_of_an_unflushed_stream(ctx, level):
+    """Round 6's search (a lane owns a byte: eight bit positions per 16-byte load, the cheap header test first, the Kraft sum
+    for what it leaves): on ONE deflate stream without flush points -- block starts at arbitrary bits, as in a .fastq.gz -- slices
+    that begin at every bit offset of a byte and end at every bit offset must report a position inside the slice from which zlib
+    decodes on (or nothing, when the slice holds no start); the same slice asked twice gives the same answer.  What gzread does
+    behind the reference's gzgets (IO_stream.h:122-136) starts at the member's first bit; these are the seams of the device route."""
+    rng = np.random.default_rng(100 + level)
+    text = _fastq(rng, 40000, 150)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = c.compress(text) + c.flush()
+    d_comp = torch.from_numpy(np.frombuffer(comp + bytes(512), np.uint8).copy()).cuda()
+    nbits = len(comp) * 8
+    slices = []
+    for k in range(48):
+        lo = int(rng.integers(0, nbits - 800_000)) + k % 8
+        slices.append((lo, int(rng.integers(300_000, 700_000)) + (k * 3) % 8))
+    slices += [(0, 0), (nbits - 64, 64), (5, 1), (nbits - 7, 7)]
+    found = ctx.gz_find_starts_dev(d_comp, len(comp), slices)
+    again = ctx.gz_find_starts_dev(d_comp, len(comp), slices)
+    assert [int(x) for x in found] == [int(x) for x in again]
+    bits = np.unpackbits(np.frombuffer(comp, np.uint8), bitorder="little")
+    hits = 0
+    for (lo, n), f in zip(slices, found):
+        f = int(f)
+        if f == (1 << 64) - 1:
+            continue
+        assert lo <= f < lo + n, (lo, n, f)
+        hits += 1
+        tail = np.packbits(bits[f:f + 8 * 120_000], bitorder="little").tobytes()
+        d = zlib.decompressobj(-15)
+        try:
+            out = d.decompress(tail, 60_000)
+            assert len(out) >= 30_000 or d.eof
+        except zlib.error as e:             # a match reaching in front of the start is the only excuse
+            assert "distance too far back" in str(e), (f, e)
+    assert hits >= 44, hits                 # slices of 300 K bits and more of FASTQ hold a block start (blocks are ~16 K symbols)
