@@ -179,12 +179,24 @@ hipError_t launch_crc32_blocks(const uint8_t *d_data, const void *d_blocks, uint
 uint32_t crc_fold_blocks(const uint32_t *crcs, uint64_t n_blocks, uint64_t total_len)
 {
     static const CrcPow pw = crc_pow_table();
-    static const uint32_t x_block = crc_xpow8(pw, kCrcBlock);
+    // c * x^(8 kCrcBlock) by four look-ups (round 6: the bit-serial crc_mul per block was 24 ms of one host core per 16 GB batch of
+    // the gzip route -- 242,000 blocks -- on the caller's thread, between two batches: profiles/r06/c2_gz_1e9.json's gap)
+    struct BlockStep {
+        uint32_t t[4][256];
+        BlockStep(const CrcPow &p)
+        {
+            const uint32_t x_block = crc_xpow8(p, kCrcBlock);
+            for (uint32_t k = 0; k < 4; ++k)
+                for (uint32_t b = 0; b < 256; ++b) t[k][b] = crc_mul(b << (8u * k), x_block);
+        }
+    };
+    static const BlockStep step(pw);
     uint32_t c = 0;
     uint64_t left = total_len;
     for (uint64_t k = 0; k < n_blocks; ++k) {
         const uint64_t len = left < kCrcBlock ? left : kCrcBlock;
-        c = crc_mul(len == kCrcBlock ? x_block : crc_xpow8(pw, len), c) ^ crcs[k];
+        c = (len == kCrcBlock ? step.t[0][c & 255u] ^ step.t[1][(c >> 8) & 255u] ^ step.t[2][(c >> 16) & 255u] ^ step.t[3][c >> 24]
+                              : crc_mul(crc_xpow8(pw, len), c)) ^ crcs[k];
         left -= len;
     }
     return total_len ? c ^ crc_mul(crc_xpow8(pw, total_len), 0xffffffffu) ^ 0xffffffffu : 0u;
