@@ -145,7 +145,8 @@ def _fastq_kernel_legs(ctx, reps, legs):
     torch.cuda.empty_cache()
 
 
-def _bam_kernel_legs(ctx, reps, legs):
+def _bam_kernel_legs(ctx, reps, legs, raw_only=False):
+    """raw_only: the raw-record legs alone, nothing compared with the SoA route (PMC passes: scripts/bench_raw_legs.py raw)"""
     import torch
     # ---- BAM: chr1-sized target at 30x (SURVEY §8d CIGAR / flag mix) ------------------------------------------
     TL, L = 248_956_422, 150
@@ -176,6 +177,9 @@ def _bam_kernel_legs(ctx, reps, legs):
     d.seq_off = torch.arange(n + 1, device="cuda", dtype=torch.int64) * ((L + 1) // 2)
     d.seq4 = torch.randint(0, 256, (n * ((L + 1) // 2),), device="cuda", generator=g, dtype=torch.uint8)
     n_ops, n_m = int(cigar.numel()), int(((cigar & 15) == 0).sum().item())
+    if raw_only:
+        _bam_raw_legs(ctx, reps, legs, d, ncig, TL, L, None)
+        return
     keep_alive, ts3, ts4, tsw, tsf_ = [], [], [], [], []
     ANY = 0x80000000            # HPN_DEPTH_ANY_ORDER: nothing swept early -> the two kernels of round 2, timed on their own
     for r in range(reps + 1):
@@ -356,13 +360,16 @@ def _bam_raw_legs(ctx, reps, legs, d, ncig, TL, L, want_window):
     m_bases = int(win_raw.sum())
     assert int(((runs_raw[:, 1] - runs_raw[:, 0]).astype(np.int64) * runs_raw[:, 2]).sum()) == m_bases
     # the same records through the SoA sweep: the same runs
-    ctx._ck(ctx.L.hpn_depth_begin_w(ctx.h, 0, TL, 0x704, 20000), "hpn_depth_begin_w")
-    keep_alive = []
-    bsoa = ctx._batch(d, keep_alive)
-    ctx._ck(ctx.L.hpn_depth_add_dev(ctx.h, C.byref(bsoa)), "hpn_depth_add_dev")
-    runs_soa, win_soa = ctx.depth_finish(TL, 20000, runs_cap=1 << 27)
-    same = bool(np.array_equal(runs_soa, runs_raw) and np.array_equal(win_soa, win_raw))
-    assert same, "raw-record route and SoA route give different runs"
+    same = None
+    runs_soa = win_soa = None
+    if want_window is not None:
+        ctx._ck(ctx.L.hpn_depth_begin_w(ctx.h, 0, TL, 0x704, 20000), "hpn_depth_begin_w")
+        keep_alive = []
+        bsoa = ctx._batch(d, keep_alive)
+        ctx._ck(ctx.L.hpn_depth_add_dev(ctx.h, C.byref(bsoa)), "hpn_depth_add_dev")
+        runs_soa, win_soa = ctx.depth_finish(TL, 20000, runs_cap=1 << 27)
+        same = bool(np.array_equal(runs_soa, runs_raw) and np.array_equal(win_soa, win_raw))
+        assert same, "raw-record route and SoA route give different runs"
     k34 = n * 16 + 4 * n_ops + 8 * int(((d.cigar & 15) == 0).sum().item()) + (TL + 1 + (1 << 21)) * 4 + 12 * len(runs_raw) + 8 * len(win_raw)
     legs.append(_leg("raw BAM route, bam2depth: k_depth_index<RawRecs> + k_depth_sweep<RawRecs> per launch of 4.4 M records (+ k_depth_scan over the last tiles)",
                      statistics.median(t_add) + statistics.median(t_fin), k34, add_ms=round(statistics.median(t_add), 4),
@@ -389,9 +396,11 @@ def _bam_raw_legs(ctx, reps, legs, d, ncig, TL, L, want_window):
         res = (bins, gc, ln, ncnt.value)
         if r:
             t_f.append(tf), t_w.append(tw)
-    wb, wg, wl, wn = want_window
-    same_w = bool(np.array_equal(res[0], wb) and np.array_equal(res[1], wg) and np.array_equal(res[2], wl) and res[3] == wn)
-    assert same_w, "raw-record route and SoA route give different window counts"
+    same_w = None
+    if want_window is not None:
+        wb, wg, wl, wn = want_window
+        same_w = bool(np.array_equal(res[0], wb) and np.array_equal(res[1], wg) and np.array_equal(res[2], wl) and res[3] == wn)
+        assert same_w, "raw-record route and SoA route give different window counts"
     ms = statistics.median(t_f) + statistics.median(t_w)
     legs.append(_leg("raw BAM route, bam_sliding_count: k_raw_fields + k_window_add with the sequence read in place",
                      ms, n * (12 + nb), bytes_touched=n * (8 + 28 + 24 + 2 * 128), fields_ms=round(statistics.median(t_f), 4),

@@ -265,6 +265,12 @@ public:
         if (!pump_->ok()) return false;
         skip_ = start_;
         dev_.allow_carry(true);                 // one stream, batches in file order: records may run from one launch into the next
+        {   // launches of 44 chunks only where the file is long enough to pay for them: a launch twice as long also ends the file
+            // with twice the work behind the last upload and starts it with a longer ramp (+ 20 - 50 ms of wall on a 10.6 GB
+            // file, measured: profiles/r06/tools_c.txt), while the decoders' better rate is worth 4 % of the device time
+            struct stat sb;
+            if (!rounds_env() && stat(path, &sb) == 0 && (uint64_t)sb.st_size < ((uint64_t)32 << 30)) rounds_ = 22;
+        }
         return true;
     }
 
@@ -358,8 +364,8 @@ private:
     {
         // (the FIRST launch of a file read front to back is six chunks: what waits for the first records -- bam2depth's first
         // target, the writer behind it -- starts that much earlier; the launches behind it take rounds_)
-        // Round 6: and they GROW -- 6, then half of rounds_, then rounds_ = 44 chunks (1.4 GB compressed, ~2.5 GB inflated: six
-        // blocks per decoder wave instead of three).  A launch ends with its slowest blocks while the other decoders idle: by the
+        // Round 6: and, for files of 32 GiB and more, they GROW -- 6, then 22, then rounds_ = 44 chunks (1.4 GB compressed, ~2.5 GB
+        // inflated: six blocks per decoder wave instead of three).  A launch ends with its slowest blocks while the other decoders idle: by the
         // profiles 0.33 GB launches run at 81 GB/s of inflated bytes, 1.2 GB launches at 86, one launch of 3.85 GB at 98
         // (profiles/r05/kernel_stats_bam2depth_final.csv, kernel_stats_bgzf_inflate.csv); the upload of 44 chunks takes as long as
         // their inflate, so the pipeline stays balanced.

@@ -185,7 +185,6 @@ int main(int argc, char *argv[])
             BgzfGpuStream &gs = *gsp;
             BamHeader h2;
             if (gs.open(ctx, infiles[i], h2)) {
-                gs.prefer_rounds(44);
                 gs.start();
                 stamp("GPU stream open, reading ahead");
                 hpn_raw_info info;

@@ -1,3 +1,2 @@
-hipcc -O3 --offload-arch=gfx950 scripts/micro/cumask.hip -o /tmp/cumask 2>/dev/null
-for nb in 16 32 64; do /tmp/cumask $nb; done 2>&1 | tee gpurun_out/cumask.txt
-echo "=== plain"; timeout 900 bash scripts/prof_r06_plain.sh b 2>&1 | grep -E "run [0-9]|^\[hpn\] p|lanes|Finished" | cut -c1-220
+timeout 300 python -m pytest tests/test_abi_c.py -q -m gpu -k rccl 2>&1 | tail -40
+( time timeout 3300 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) 2>&1 | tail -20

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The BAM kernel legs of bench.py on their own (bench_extra._bam_kernel_legs: the SoA legs and the raw-record route the tools
-take), for rocprofv3 / PMC passes:   python3 scripts/bench_raw_legs.py [reps]   -> one JSON object per leg"""
+take), for rocprofv3 / PMC passes:   python3 scripts/bench_raw_legs.py [reps] [raw]   -> one JSON object per leg ("raw": the raw-record legs alone)"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ import bench_extra  # noqa: E402
 
 ctx = hp.Context(0)
 legs = []
-bench_extra._bam_kernel_legs(ctx, int(sys.argv[1]) if len(sys.argv) > 1 else 3, legs)
+bench_extra._bam_kernel_legs(ctx, int(sys.argv[1]) if len(sys.argv) > 1 else 3, legs, raw_only=len(sys.argv) > 2 and sys.argv[2] == "raw")
 for l in legs:
     print(json.dumps(l), flush=True)
 ctx.close()

@@ -19,5 +19,5 @@ prof bench_k1 python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-extra
 prof bam_legs python3 $GRAFT_REPO_ROOT/scripts/bench_raw_legs.py 2
 cd $GRAFT_REPO_ROOT
 timeout 600 python3 scripts/pmc.py k_tally_scan "FETCH_SIZE" "WRITE_SIZE" -- python3 bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-ragged > $O/pmc_k1.txt 2>&1
-timeout 900 python3 scripts/pmc.py k_raw_starts,k_raw_count,k_raw_scan,k_raw_index,k_raw_fields,k_window_add,k_depth_index,k_depth_sweep,k_depth_tiles,k_depth_scan "FETCH_SIZE" "WRITE_SIZE" -- python3 scripts/bench_raw_legs.py 1 > $O/pmc_raw_route.txt 2>&1
+timeout 900 python3 scripts/pmc.py k_raw_starts,k_raw_count,k_raw_scan,k_raw_index,k_raw_fields,k_window_add,k_depth_index,k_depth_sweep,k_depth_tiles,k_depth_scan "FETCH_SIZE" "WRITE_SIZE" -- python3 scripts/bench_raw_legs.py 1 raw > $O/pmc_raw_route.txt 2>&1
 ls -la $O

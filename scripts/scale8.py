@@ -162,7 +162,7 @@ def rccl_of_the_c_tools():
     if cc.returncode:
         return {"built": False, "why": cc.stdout.decode()[-300:]}
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    return {"built": True, "rc": p.returncode, "librccl": p.stdout.decode().strip(), "stderr": p.stderr.decode()[-300:]}
+    return {"built": True, "rc": p.returncode, "librccl": (p.stdout.decode().strip().splitlines() or [""])[-1], "stderr": p.stderr.decode()[-300:]}
 
 
 def main():

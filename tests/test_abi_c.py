@@ -100,7 +100,7 @@ def test_a_process_without_torch_resolves_the_real_rccl(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.startswith("HPN_")}
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()
-    path = p.stdout.decode().strip()
+    path = p.stdout.decode().strip().splitlines()[-1]            # (RCCL may print its version banner on stdout first)
     assert os.path.basename(path).startswith("librccl.so") and os.path.isfile(path), path
     assert "stub" not in path and "torch" not in path, path        # the system's library, not the test stand-in, not torch's copy
     # ... and nothing of torch was in that process
