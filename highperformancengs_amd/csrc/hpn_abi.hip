@@ -29,6 +29,7 @@ const char *hpn_strerror(int status)
 int hpn_device_count(int *n)
 {
     if (!n) return HPN_E_ARG;
+    hpn::warn_unread_env();
     int k = 0;
     hipError_t e = hipGetDeviceCount(&k);
     if (e != hipSuccess) {

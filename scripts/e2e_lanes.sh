@@ -13,7 +13,7 @@ rec = np.concatenate([names, nl, s, plus, q, nl], axis=1).tobytes()
 with open('/tmp/big.fq','wb') as fh:
     for _ in range(24): fh.write(rec)
 PY
-B=highperformancengs_amd/bin
+B=highperformancengs_amd/testhooks/bin
 cat /tmp/big.fq > /dev/null
 HPN_TIMING=1 $B/fastq_count /tmp/big.fq > /dev/null 2>&1
 for l in 1 2 3 4; do for t in 6 8 12; do for c in 16777216 33554432; do

@@ -9,7 +9,7 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN, REF = os.path.join(ROOT, "highperformancengs_amd", "bin"), os.path.join(ROOT, "oracle", "_ref")
+BIN, REF = os.path.join(ROOT, "highperformancengs_amd", "testhooks", "bin")   # (the build that reads test / timing switches), os.path.join(ROOT, "oracle", "_ref")
 L = C.CDLL(os.path.join(ROOT, "oracle", "liborc.so"))
 L.orc_synth_write_fastq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
 reads, rl = int(float(sys.argv[1])) if len(sys.argv) > 1 else 4_000_000, 150

@@ -15,7 +15,7 @@ with open('/tmp/big.fq','wb') as fh:
     for _ in range(24): fh.write(rec)
 print('bytes', os.path.getsize('/tmp/big.fq'))
 PY
-B=highperformancengs_amd/bin
+B=highperformancengs_amd/testhooks/bin
 cat /tmp/big.fq > /dev/null
 for t in 4 6 8 12 16; do
   for c in 33554432 67108864; do

@@ -2,6 +2,7 @@
 """A/B sweep of k_tally_scan variants, interleaved rounds in ONE process (MI355X guide rule 24).
 HPN_K1_VARIANT = unroll*100 + nt*10 + dyn, HPN_K1_WG_PER_CU = workgroups per CU.  Prints median/min ms."""
 import os
+os.environ.setdefault("HPN_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "highperformancengs_amd", "testhooks", "libhpngs.so"))   # (HPN_K1_* are test-hooks switches)
 import statistics
 import sys
 

@@ -6,7 +6,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-B = os.path.join(ROOT, "highperformancengs_amd", "bin")
+B = os.path.join(ROOT, "highperformancengs_amd", "testhooks", "bin")   # (the build that reads test / timing switches)
 open("/tmp/empty.fq", "w").close()
 open("/tmp/one.fq", "w").write("@a\nACGT\n+\nIIII\n")
 

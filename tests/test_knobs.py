@@ -48,3 +48,22 @@ def test_the_hooks_build_has_them():
     for path in glob.glob(os.path.join(HOOKS_BIN, "*")):
         seen |= _names_in(path)
     assert TEST_KNOBS <= seen, sorted(TEST_KNOBS - seen)
+
+
+def test_the_shipped_build_names_variables_it_does_not_read(tmp_path):
+    """A test switch set against the shipped binaries measures the default and calls it a sweep: the shipped build says
+    once per process which HPN_* variables it does not read -- without naming any test switch in its own strings -- and stays quiet
+    about the user knobs; the hooks build reads them and says nothing.  (Runs without a GPU: the line comes before the device is
+    looked for.)"""
+    (tmp_path / "x.fq").write_bytes(b"@r\nACGT\n+\nIIII\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("HPN_")}
+    env.update({"HPN_GZ_STRETCH": "4096", "HPN_TIMING": "1", "HPN_NOT_A_KNOB": "1"})
+    # (through a shell: tests/conftest.py hands a child whose environment holds a test switch the hooks build -- here the shipped
+    # one is the point)
+    p = subprocess.run(["/bin/sh", "-c", "exec " + os.path.join(BIN, "fastq_count") + " x.fq"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    err = p.stderr.decode()
+    assert "HPN_GZ_STRETCH is set but this build does not read it" in err and "HPN_NOT_A_KNOB is set" in err, err
+    assert "HPN_TIMING is set" not in err
+    assert err.count("HPN_GZ_STRETCH is set") == 1
+    q = subprocess.run([os.path.join(HOOKS_BIN, "fastq_count"), "x.fq"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert "does not read it" not in q.stderr.decode()
