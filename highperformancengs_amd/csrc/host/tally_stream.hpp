@@ -219,7 +219,8 @@ inline int tally_gz_on_gpu(hpn_ctx *ctx, const char *path, hpn_tally *acc, bool 
     int rc = hpn_fastq_text_begin(ctx);
     // the batch's text is framed where it lies (hpn_fastq_text_count_inplace: no copy into a slot), 1 GiB at a time (round 5:
     // 256 MiB slices copied first -- 60 calls a batch, each with its launches, its wait and its 2 x 256 MiB of copy traffic)
-    const uint64_t slice = (uint64_t)1 << 30;
+    uint64_t slice = (uint64_t)1 << 30;
+    if (const char *e = test_env("HPN_TEXT_SLICE")) slice = (uint64_t)atoll(e) < 64 ? 64 : (uint64_t)atoll(e);   // (tests: several slices in a small batch)
     while (rc == HPN_OK && !*unusable) {
         uint64_t n = 0;
         const int r = gs.next(&n);

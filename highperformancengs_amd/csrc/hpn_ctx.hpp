@@ -78,6 +78,8 @@ struct hpn_ctx {
     uint32_t p_begin = 0, p_end = 0, p_limit = 0, p_head = 0, p_nl_cap = 0;
     // records indexed in place in inflated BGZF blocks (hpn_bam_raw_*)
     hpn::Scratch r_counts, r_bases, r_off, r_tid, r_pos, r_flag, r_lq, r_soff, r_info, r_list;
+    std::vector<int32_t> r_h_lo, r_h_hi;      // the indexed batch's blocks on the host: smallest / largest refID, ...
+    std::vector<unsigned long long> r_h_bases; // ... number of their first record (and one behind the last block's)
     hpn::Scratch g_crc;   // hpn_crc32_dev: block table + block CRCs
     hpn::Scratch b_ticket;   // hpn_bgzf_inflate_dev: the kernel's block counter
     hpn::Scratch g_sym, g_meta, g_windows, g_summary, g_bounds, g_groups;  // gzip: symbols, per-stretch results, histories, member ends

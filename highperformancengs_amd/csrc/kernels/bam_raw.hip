@@ -162,35 +162,28 @@ __device__ __forceinline__ RawWalk walk_block(const uint8_t *__restrict__ raw, u
     return w;
 }
 
-// ---- the walk with the next records in flight (round 6) ---------------------------------------------------------------------------
+// ---- the walk, one round trip and three loads per record (round 6) --------------------------------------------------------------
 // walk_block above waits twice per record: for the fixed part (block_size tells where the next record is), then for the byte
 // that must be the name's NUL -- and k_raw_index walked every chain a second time to write the offsets down: 0.62 + 0.27 ms per
 // 1.2 GB launch (4.4 M records, ~230 to a block), the largest kernels of the BAM tools behind the inflater
-// (profiles/r05/kernel_stats_bam2depth_final.csv).  A chain is a chain -- a lane cannot know where record k + 1 starts before it
-// has record k's block_size, and a round trip of 64 lanes reading 64 blocks is ~2 us -- so what can be is taken off it:
-//   * reads of one length and one kind of CIGAR give records of ONE SIZE: with record k in hand the lane asks for the fixed part
-//     of k + 1 AND, betting that k + 1 is as long as k, of k + 2; while the bet holds a fixed part was asked for two records
-//     before it is needed;
-//   * the NUL byte is asked for when the record is met and LOOKED AT two records later: a record is counted (its offset written
-//     down, its refID taken) only then, so the answer is the same, but nothing waits for that byte;
-//   * the offsets go to a list as the records are counted (block b's at raw_list_base(b), one after the other; two records never
-//     share a slot because a record is at least 36 bytes), so the index is a copy, not a second walk.
-// Same results as walk_block, record for record (tests/test_bam_raw_gpu.py).  Measured and dropped on the way: the first 80 bytes
-// of three records in flight (name and NUL inside one request): 0.78 ms per launch against 0.56 for the plain look-ahead -- five
-// 64-way divergent 16-byte loads per record cost more than the round trips they saved (profiles/r06/tools_b.txt).
-struct RawHead {           // the 36 bytes of a record's fixed part: block_size | refID pos bin_mq_nl | flag_nc l_seq next_refID next_pos
-    u32 a, b;              // bytes 0..15, 16..31
-    uint32_t c;            // bytes 32..35
+// (profiles/r05/kernel_stats_bam2depth_final.csv).  What a record costs here turned out to be its LOAD INSTRUCTIONS, not its round
+// trips: a lane per block means 64 lanes reading 64 different lines, ~0.45 us per such instruction and wave whatever is asked
+// for.  So: the record's fixed part is two 16-byte loads (round 5: eight narrow ones), the next record's fixed part and this
+// record's NUL byte are asked for together (one wait per record), and the offsets are written down as the records are counted
+// (list: block b's at raw_list_base(b), one after the other; two records never share a slot because a record is at least 36
+// bytes), so the index is a copy, not a second walk.  Measured on the way and dropped, each slower for its extra loads
+// (docs/kernels/bam_raw_index.md): betting on records of one size (the record after next asked for early), the first 80 bytes of
+// three records in flight, three records to a round trip.  Same results as walk_block, record for record (tests/test_bam_raw_gpu.py).
+struct RawHead {           // the first 32 bytes of a record: block_size | refID pos bin_mq_nl | flag_nc l_seq next_refID next_pos
+    u32 a, b;
 };
 __device__ __forceinline__ RawHead head_at(const uint8_t *__restrict__ raw, uint64_t at, uint64_t stream_len)
 {
+    // (where the fixed part does not fit the stream's first bytes are loaded instead and never looked at: head_check sees the room)
+    const uint8_t *p = raw + (at + 36u <= stream_len ? at : 0ull);
     RawHead h;
-    h.a = u32{0, 0, 0, 0}, h.b = u32{0, 0, 0, 0}, h.c = 0;
-    if (at + 36u <= stream_len) {
-        __builtin_memcpy(&h.a, raw + at, 16);
-        __builtin_memcpy(&h.b, raw + at + 16, 16);
-        __builtin_memcpy(&h.c, raw + at + 32, 4);
-    }
+    __builtin_memcpy(&h.a, p, 16);
+    __builtin_memcpy(&h.b, p + 16, 16);
     return h;
 }
 // record_at on a fixed part that is in registers, up to the name's NUL: 0 = no record, 2 = cannot tell (the stream ends inside it),
@@ -213,61 +206,44 @@ __device__ __forceinline__ RawWalk walk_block_ahead(const uint8_t *__restrict__ 
                                                     uint64_t list_room)
 {
     RawWalk w = {0u, INT32_MAX, INT32_MIN, 0ull};
-    // records met and not yet counted: their NUL bytes are on their way (the older one in slot 0)
-    uint64_t p_at[2] = {0, 0};
-    int32_t p_tid[2] = {0, 0};
-    uint32_t p_nul[2] = {0, 0};
-    uint32_t pending = 0;
-    bool broken = false;
-    // count the oldest pending record; false: it is no record (its name does not end in NUL) or the list is full -- the chain ends AT it
-    auto count_oldest = [&]() -> bool {
-        if (p_nul[0] != 0u || w.n >= list_room) {
-            at = p_at[0], broken = true, pending = 0;
-            return false;
+    if (at >= end) {
+        w.exit = at;
+        return w;
+    }
+    RawHead cur = head_at(raw, at, stream_len);
+    while (at < end) {
+        uint32_t step = 0, nul_at = 0;
+        const int r = head_check(cur, stream_len - at, &step, &nul_at);
+        if (r == 0) {
+            w.n |= kBroken;
+            break;
         }
-        w.lo = p_tid[0] < w.lo ? p_tid[0] : w.lo, w.hi = p_tid[0] > w.hi ? p_tid[0] : w.hi;
-        list[w.n] = p_at[0];
+        if (r == 2) {
+            at |= kTailBit;
+            break;
+        }
+        const uint64_t next = at + step;
+        uint32_t nul;                                                              // (a whole word, asked for together with ...
+        __builtin_memcpy(&nul, raw + at + nul_at, 4);
+        const RawHead nx = head_at(raw, next < end ? next : 0ull, stream_len);    // ... the next record's fixed part: one wait)
+        // (both asked for before either is looked at: without the two lines below the compiler tests the NUL first and asks for
+        // the fixed part behind that test -- two round trips per record again)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::"v"(nul), "v"(nx.a[0]), "v"(nx.b[0]));
+        if ((nul & 255u) != 0u || w.n >= list_room) {                              // read_name is NUL-terminated (record_at's last test)
+            w.n |= kBroken;
+            break;
+        }
+        if (next > stream_len) {                                                   // the record is not whole in this call: it starts the next one
+            at |= kTailBit;
+            break;
+        }
+        const int32_t tid = (int32_t)cur.a[1];
+        w.lo = tid < w.lo ? tid : w.lo, w.hi = tid > w.hi ? tid : w.hi;
+        list[w.n] = at;
         ++w.n;
-        p_at[0] = p_at[1], p_tid[0] = p_tid[1], p_nul[0] = p_nul[1];
-        --pending;
-        return true;
-    };
-    uint32_t how = 0;                          // how the chain ended: 0 = at the block's end, 1 = an impossible record, 2 = the call's unfinished tail
-    if (at < end) {
-        RawHead cur = head_at(raw, at, stream_len);
-        RawHead guess = cur;                   // the fixed part at `guess_at`: where the record after next starts if sizes repeat
-        uint64_t guess_at = ~0ull;
-        while (at < end) {
-            uint32_t step = 0, nul_at = 0;
-            const int r = head_check(cur, stream_len - at, &step, &nul_at);
-            if (r != 1) {
-                how = r == 0 ? 1u : 2u;
-                break;
-            }
-            const uint32_t nul = raw[at + nul_at];                                  // (looked at two records from now)
-            const uint64_t next = at + step;
-            const RawHead nx = next == guess_at ? guess : head_at(raw, next, stream_len);
-            const bool ahead = next < end && next + step < end;
-            const uint64_t g_at = ahead ? next + step : ~0ull;
-            const RawHead g = ahead ? head_at(raw, g_at, stream_len) : cur;
-            if (pending == 2u && !count_oldest()) break;
-            if (next > stream_len) {                                                // whole only in the next call -- unless its name already fails
-                if (nul != 0u) how = 1u;
-                else how = 2u;
-                break;
-            }
-            p_at[pending] = at, p_tid[pending] = (int32_t)cur.a[1], p_nul[pending] = nul;
-            ++pending;
-            at = next, cur = nx, guess = g, guess_at = g_at;
-        }
+        at = next, cur = nx;
     }
-    if (!broken) {
-        const uint64_t stop = at;                      // where the chain stands if everything pending is a record
-        while (pending && count_oldest()) {}
-        if (!broken) at = stop;
-    }
-    if (broken || how == 1u) w.n |= kBroken;
-    else if (how == 2u) at |= kTailBit;
     w.exit = at;
     return w;
 }
@@ -313,7 +289,7 @@ __global__ __launch_bounds__(kRawThreads) void k_raw_count(const uint8_t *__rest
 __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ raw, uint32_t *__restrict__ counts, uint32_t n_blocks,
                                                    u64 *__restrict__ bases, const RawBlock *__restrict__ blocks, uint64_t first_abs,
                                                    uint32_t *__restrict__ starts, const u64 *__restrict__ exits,
-                                                   const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, int32_t *__restrict__ info,
+                                                   int32_t *__restrict__ lo, int32_t *__restrict__ hi, int32_t *__restrict__ info,
                                                    u64 *__restrict__ list, uint64_t list_words)
 {
     __shared__ u64 s_wave[16];
@@ -394,6 +370,8 @@ __global__ __launch_bounds__(1024) void k_raw_scan(const uint8_t *__restrict__ r
         for (int w = 0; w < wave_id(); ++w) before += s_wave[w];
         if (i < n_blocks) {
             bases[i] = before + inc - v, counts[i] = (uint32_t)v, starts[i] = s_start[threadIdx.x];
+            // (the proven chain's refID range per block, too: hosts pick a target's records by it -- hpn_depth_add_raw_dev)
+            lo[i] = v ? s_lo[threadIdx.x] : INT32_MAX, hi[i] = v ? s_hi[threadIdx.x] : INT32_MIN;
             if (v) my_lo = s_lo[threadIdx.x] < my_lo ? s_lo[threadIdx.x] : my_lo, my_hi = s_hi[threadIdx.x] > my_hi ? s_hi[threadIdx.x] : my_hi;
         }
         __syncthreads();

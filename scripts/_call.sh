@@ -1,14 +1,4 @@
 mkdir -p gpurun_out/r06
-echo "=== soak (damaged streams)"; timeout 900 python3 scripts/soak_inflate_damaged.py 200 2>&1 | grep -v amdgpu.ids | tail -5 | tee gpurun_out/r06/soak_inflate.txt
-echo "=== soak (valid streams)"; timeout 900 python3 scripts/soak_inflate.py 2>&1 | grep -v amdgpu.ids | tail -5 | tee -a gpurun_out/r06/soak_inflate.txt
-echo "=== scale8 dry run"; SCALE8_GB=4 SCALE8_DEPTH=1 timeout 1500 bash scripts/scale8.sh > gpurun_out/r06/scale8_dry.log 2>&1; tail -3 gpurun_out/r06/scale8_dry.log | cut -c1-300
-python3 - <<'PY'
-import json
-j=json.load(open("gpurun_out/scale8.json"))
-print("devices", j["devices"], j["note"]); print(j["rccl_of_the_c_tools"])
-for b in j["bench"]: print(b["gpus"], b["rc"], b["wall_s"], (b["line"] or {}).get("value"), (b["line"] or {}).get("config",{}).get("rccl_ranks"))
-for f in j["fastq_count"]:
-    print(f["input"]); 
-    for r in f["runs"]: print("  ", r)
-print(json.dumps(j["bam"])[:1500])
-PY
+timeout 1500 python -m pytest tests/test_bam_raw_gpu.py tests/test_bam_gpu.py tests/test_c4_files_gpu.py -q -m gpu 2>&1 | tail -3
+NOGZ=1 timeout 900 bash scripts/prof_r06_tools.sh g 2>&1 | grep -E "run [0-9]|outputs|k_raw_count|k_raw_index" | cut -c1-60,100-230
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl -o pl -- python3 $GRAFT_REPO_ROOT/scripts/bench_raw_legs.py 1 raw > /tmp/pl.txt 2>/dev/null; grep -h "k_raw" $(find /tmp/pl -name "*kernel_stats.csv") | cut -c1-40,200-330

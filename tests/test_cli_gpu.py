@@ -451,6 +451,10 @@ def test_single_member_gzip_is_inflated_on_the_gpu(tmp_path):
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "7"},
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "40000", "HPN_GZ_FIND": "device"},
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "100000", "HPN_GZ_BATCH": "5", "HPN_GZ_FIND": "device"},
+                    # a batch's text framed WHERE IT LIES in several slices (round 6: hpn_fastq_text_count_inplace; the carried bytes of a
+                    # slice are laid over the tail of the slice before, of a batch's last slice in front of the next batch's text)
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "60000", "HPN_GZ_BATCH": "9", "HPN_TEXT_SLICE": "70001"},
+                    {"HPN_GZ_GPU_FORCE": "1", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "3", "HPN_TEXT_SLICE": "4099"},
                     # the same file over several lanes (host/gz_shard.hpp): batches in turn, windows / member state / lines handed on
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_NGPU": "3", "HPN_GZ_STRETCH": "40000", "HPN_GZ_BATCH": "7", "HPN_TEXT_SLICE": "300000"},
                     {"HPN_GZ_GPU_FORCE": "1", "HPN_NGPU": "2", "HPN_GZ_STRETCH": "150000", "HPN_GZ_BATCH": "4", "HPN_GZ_FIND": "device"},
