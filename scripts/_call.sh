@@ -1,4 +1,10 @@
 mkdir -p gpurun_out/r06
-timeout 1500 python -m pytest tests/test_bam_raw_gpu.py tests/test_bam_gpu.py tests/test_c4_files_gpu.py -q -m gpu 2>&1 | tail -3
-NOGZ=1 timeout 900 bash scripts/prof_r06_tools.sh g 2>&1 | grep -E "run [0-9]|outputs|k_raw_count|k_raw_index" | cut -c1-60,100-230
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl -o pl -- python3 $GRAFT_REPO_ROOT/scripts/bench_raw_legs.py 1 raw > /tmp/pl.txt 2>/dev/null; grep -h "k_raw" $(find /tmp/pl -name "*kernel_stats.csv") | cut -c1-40,200-330
+python bench.py > gpurun_out/r06/bench.json 2> gpurun_out/r06/bench.err
+python3 - <<'PY'
+import json
+b=json.loads(open("gpurun_out/r06/bench.json").read().strip().splitlines()[-1])
+print({k:b[k] for k in ("value","ms_per_step")}, b["roofline"]["frac"], b["roofline"].get("frac_ragged"), b["cpu_baseline"]["value"])
+for l in b["extra"]["end_to_end"]:
+    h=l.get("hpngs") or {}
+    print(l["leg"][:90], h.get("seconds"), l.get("outputs_identical"), l.get("link_frac"))
+PY
