@@ -28,8 +28,9 @@
 namespace hpn {
 
 constexpr int kTxtThreads = 256;
+constexpr int kLinesThreads = 512;                              // k_text_lines (256: 0.295, 512: 0.266, 1024: 0.258 ms per GiB)
 constexpr int kTxtRows = 16;                                    // 16-byte words per thread
-constexpr uint32_t kTxtTile = kTxtThreads * kTxtRows * 16;      // bytes per workgroup
+constexpr uint32_t kTxtTile = kLinesThreads * kTxtRows * 16;    // bytes per workgroup of k_text_lines
 constexpr int kRecPerThread = 4;
 constexpr uint32_t kRecTile = kTxtThreads * kRecPerThread;      // records per workgroup
 
@@ -45,6 +46,22 @@ __device__ __forceinline__ uint32_t pack4(uint32_t m)  // 0x80 flags of 4 bytes 
     return ((((m >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
 }
 
+// 0x80 in exactly the bytes of x that are '\n' (the high bit of x ^ 0x0a.. is the high bit of x)
+__device__ __forceinline__ uint32_t newline_flags(uint32_t x)
+{
+    return ~((((x ^ 0x0a0a0a0au) & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+// the 0x80 flags of two dwords -> 8 bits in byte order.  g holds a's flags at bits 8j and b's at 8j + 4; the 24-bit
+// multiply (full rate; v_mul_lo_u32 is not) moves bytes 0..2 of both to bits 16 + j and 20 + j -- every partial product
+// lands on a bit of its own, so nothing carries --, byte 3 of both is shifted there.
+__device__ __forceinline__ uint32_t pack8(uint32_t fa, uint32_t fb)
+{
+    const uint32_t g = (fa >> 7) | (fb >> 3);
+    uint32_t prod;  // (written as g * 0x10204 the compiler drops the 24-bit mask -- the bits looked at below do not need it -- and takes v_mul_lo_u32)
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(prod) : "v"(g), "s"(0x10204u));
+    return ((prod | ((g >> 5) & 0x00880000u)) >> 16) & 0xffu;
+}
+
 __device__ __forceinline__ uint32_t wave_excl_scan32(uint32_t v, uint32_t &total)
 {
     uint32_t inc = v;
@@ -57,81 +74,141 @@ __device__ __forceinline__ uint32_t wave_excl_scan32(uint32_t v, uint32_t &total
     return inc - v;
 }
 
+// inclusive prefix sum over the lanes of a wave (DPP: shifts inside rows of 16, then row broadcasts; see wave_sum)
+__device__ __forceinline__ uint32_t wave_incl_dpp(uint32_t v)
+{
+#define HPN_DPP_ADD(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
+    HPN_DPP_ADD(0x111, 0xf);
+    HPN_DPP_ADD(0x112, 0xf);
+    HPN_DPP_ADD(0x114, 0xf);
+    HPN_DPP_ADD(0x118, 0xf);
+    HPN_DPP_ADD(0x142, 0xa);
+    HPN_DPP_ADD(0x143, 0xc);
+#undef HPN_DPP_ADD
+    return v;
+}
+
+constexpr int kTxtLoads = 16;  // 16-byte loads a lane has in flight (8 at six waves per SIMD: no faster, it spills)
+constexpr uint32_t kTxtWaveBytes = kTxtTile / (kLinesThreads / kWave);  // a wave's contiguous part of a tile
+constexpr uint32_t kTxtRowBytes = kWave * 16u;                         // what one load instruction of a wave covers
+
+// The '\n' masks of a lane's 16 words (word k at base + k * kTxtRowBytes).  kEdge: the tile holds `begin`, `end`,
+// the stream's last byte or `own_end` -- every word is cut to [begin, end) and counted up to own_end; otherwise the
+// words are whole and `own_all` says whether the tile lies in front of own_end.
+template <bool kEdge>
+__device__ __forceinline__ void line_masks(const uint8_t *__restrict__ slot, uint32_t base, uint32_t begin, uint32_t end, int last,
+                                           uint32_t own_end, bool own_all, uint32_t (&mask)[kTxtRows], uint32_t &nul,
+                                           uint32_t &own, uint32_t *__restrict__ st)
+{
+#pragma unroll
+    for (int h = 0; h < kTxtRows; h += kTxtLoads) {
+        u32 w[kTxtLoads];
+#pragma unroll
+        for (int i = 0; i < kTxtLoads; ++i) {
+            const uint32_t p = base + (uint32_t)(h + i) * kTxtRowBytes;
+            if (!kEdge || p < end) w[i] = load_stream16((const u32 *)(slot + p));
+            else w[i] = u32{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < kTxtLoads; ++i) {
+            const uint32_t p = base + (uint32_t)(h + i) * kTxtRowBytes;
+            uint32_t m = 0, z = 0;
+            if (!kEdge) {  // whole words: 3 + 2 instructions per dword, 7 per pair of dwords (the exact form below: ~26 per dword)
+                m = pack8(newline_flags(w[i][0]), newline_flags(w[i][1])) | (pack8(newline_flags(w[i][2]), newline_flags(w[i][3])) << 8);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) nul |= (w[i][d] - 0x01010101u) & ~w[i][d];  // & 0x80808080 != 0 <=> a byte of some word was 0
+                if (own_all) own += (uint32_t)__builtin_popcount(m);
+                mask[h + i] = m;
+                continue;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                m |= pack4(zero_bytes(w[i][d] ^ 0x0a0a0a0au)) << (4 * d);
+                z |= pack4(zero_bytes(w[i][d])) << (4 * d);
+            }
+            if (p < end) {
+                const uint32_t lo = p < begin ? begin - p : 0u;
+                const uint32_t hi = end - p >= 16u ? 16u : end - p;
+                const uint32_t valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                m &= valid;
+                if (z & valid) nul |= 0x80u;  // (the whole words keep their zero-byte flags in the bytes' high bits)
+                if (own_end > p) own += (uint32_t)__builtin_popcount(own_end - p >= 16u ? m : m & ((1u << (own_end - p)) - 1u));
+                if (last && end > begin && end - 1u >= p && end - 1u - p < 16u) {  // this word holds the last byte of the stream
+                    if (!((m >> (end - 1u - p)) & 1u)) {
+                        m |= 1u << hi;  // virtual '\n' at position end
+                        st[kTsUnterminated] = 1u;
+                    }
+                }
+            } else {
+                m = 0;
+            }
+            mask[h + i] = m;
+        }
+    }
+}
+
 // text = slot[begin, end).  With `last`, a final line that lacks its '\n' is closed by a
 // virtual one at position `end` (state word kTsUnterminated tells the record kernel).
 // own_end (pieces of one stream framed by several contexts, hpn_fastq_text_piece_*): the '\n' at
 // positions < own_end are also counted into kTsOwnLines -- what this piece adds to the stream's
 // line count, and how many record starts it can own; 0: not a piece.
-__global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__restrict__ slot, uint32_t begin,
+//
+// A tile is 64 KiB, a wave's part of it 16 contiguous KiB: load k of a wave covers 1 KiB.  Newlines are numbered
+// in (wave, load, lane, bit) order = by position.  Inside a wave: the counts of two loads share one DPP prefix sum
+// (16 bits each: at most 17 per lane), eight of them before the look-back, so that what stays live across the
+// look-back is 16 masks + 8 packed offsets (the first form of this kernel held 256 VGPRs: two waves per SIMD).
+__global__ __launch_bounds__(kLinesThreads) void k_text_lines(const uint8_t *__restrict__ slot, uint32_t begin,
                                                             uint32_t end, int last, uint32_t own_end,
                                                             uint32_t *__restrict__ nl, uint32_t nl_cap,
                                                             u64 *__restrict__ status, uint32_t *__restrict__ st)
 {
-    __shared__ uint32_t s_w[kTxtRows][kTxtThreads / kWave];
+    __shared__ uint32_t s_w[kLinesThreads / kWave];
     __shared__ u64 s_excl;
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     if (tid == 0) s_tile = atomicAdd(&st[kTsTicket1], 1u);  // tiles in start order (look-back never waits on a tile not yet running)
     __syncthreads();
     const uint32_t tile = s_tile;
-    const uint32_t a0 = begin & ~15u;
-    uint32_t mask[kTxtRows], cnt[kTxtRows], nul = 0, own = 0;
+    uint32_t nul = 0, own = 0;
+    bool dense = false;
+    const uint32_t lo_t = (begin & ~15u) + tile * kTxtTile;
+    const u64 hi_t = (u64)lo_t + kTxtTile;
+    const uint32_t base = lo_t + (uint32_t)wave_id() * kTxtWaveBytes + (uint32_t)lane_id() * 16u;
+    const bool inner = lo_t >= begin && hi_t + (last ? 1u : 0u) <= end && (own_end == 0u || own_end >= hi_t || own_end <= lo_t);
+    uint32_t mask[kTxtRows];
+    if (inner) line_masks<false>(slot, base, begin, end, last, own_end, own_end >= hi_t, mask, nul, own, st);
+    else line_masks<true>(slot, base, begin, end, last, own_end, false, mask, nul, own, st);
+
+    uint32_t ex[kTxtRows / 2], rows_before = 0;  // ex: where the lane's newlines of two loads start inside the wave's
 #pragma unroll
-    for (int k = 0; k < kTxtRows; ++k) {
-        const uint32_t p = a0 + tile * kTxtTile + (uint32_t)(k * kTxtThreads + tid) * 16u;
-        uint32_t m = 0;
-        if (p < end) {
-            const u32 w = load_stream16((const u32 *)(slot + p));
-            uint32_t z = 0;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                m |= pack4(zero_bytes(w[d] ^ 0x0a0a0a0au)) << (4 * d);
-                z |= pack4(zero_bytes(w[d])) << (4 * d);
-            }
-            const uint32_t lo = p < begin ? begin - p : 0u;
-            const uint32_t hi = end - p >= 16u ? 16u : end - p;
-            const uint32_t valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            m &= valid;
-            nul |= z & valid;
-            if (own_end > p) own += (uint32_t)__builtin_popcount(own_end - p >= 16u ? m : m & ((1u << (own_end - p)) - 1u));
-            if (last && end > begin && end - 1u >= p && end - 1u - p < 16u) {  // this word holds the last byte of the stream
-                if (!((m >> (end - 1u - p)) & 1u)) {
-                    m |= 1u << hi;  // virtual '\n' at position end
-                    st[kTsUnterminated] = 1u;
-                }
-            }
-        }
-        mask[k] = m;
-        cnt[k] = (uint32_t)__builtin_popcount(m);
+    for (int k = 0; k < kTxtRows; k += 2) {
+        const uint32_t c0 = (uint32_t)__builtin_popcount(mask[k]), c1 = (uint32_t)__builtin_popcount(mask[k + 1]);
+        const uint32_t inc = wave_incl_dpp(c0 | (c1 << 16));
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
+        const uint32_t e0 = rows_before + (inc & 0xffffu) - c0;
+        const uint32_t e1 = rows_before + (t & 0xffffu) + (inc >> 16) - c1;
+        ex[k / 2] = e0 | (e1 << 16);
+        rows_before += (t & 0xffffu) + (t >> 16);
     }
-    uint32_t excl[kTxtRows];
-#pragma unroll
-    for (int k = 0; k < kTxtRows; ++k) {
-        uint32_t wt;
-        excl[k] = wave_excl_scan32(cnt[k], wt);
-        if (lane_id() == kWave - 1) s_w[k][wave_id()] = wt;
-    }
+    if (lane_id() == 0) s_w[wave_id()] = rows_before;
     __syncthreads();
-    uint32_t aggregate = 0, before[kTxtRows];
+    uint32_t aggregate = 0, before = 0;
 #pragma unroll
-    for (int k = 0; k < kTxtRows; ++k) {
-#pragma unroll
-        for (int w = 0; w < kTxtThreads / kWave; ++w) {
-            if (w == wave_id()) before[k] = aggregate;
-            aggregate += s_w[k][w];
-        }
+    for (int w = 0; w < kLinesThreads / kWave; ++w) {
+        if (w == wave_id()) before = aggregate;
+        aggregate += s_w[w];
     }
     if (wave_id() == 0) {
-        const u64 ex = scan_lookback(status, tile, aggregate, &st[kTsErr]);
-        if (lane_id() == 0) s_excl = ex;
+        const u64 e = scan_lookback(status, tile, aggregate, &st[kTsErr]);
+        if (lane_id() == 0) s_excl = e;
     }
     __syncthreads();
-    const u64 tile_base = s_excl;
-    bool dense = false;
+    const u64 wave_base64 = s_excl + before;
+    const uint32_t wave_base = wave_base64 < nl_cap ? (uint32_t)wave_base64 : nl_cap;  // (nl_cap + 17408 < 2^32: a chunk is < 2^31 bytes)
 #pragma unroll
     for (int k = 0; k < kTxtRows; ++k) {
-        const uint32_t p = a0 + tile * kTxtTile + (uint32_t)(k * kTxtThreads + tid) * 16u;
-        u64 g = tile_base + before[k] + excl[k];
+        const uint32_t p = base + (uint32_t)k * kTxtRowBytes;
+        uint32_t g = wave_base + ((ex[k / 2] >> (16 * (k & 1))) & 0xffffu);
         uint32_t m = mask[k];
         while (m) {
             const int j = __builtin_ctz(m);
@@ -141,16 +218,15 @@ __global__ __launch_bounds__(kTxtThreads) void k_text_lines(const uint8_t *__res
             ++g;
         }
     }
-    if (nul) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_NUL);
+    if (tile == gridDim.x - 1 && tid == 0) {
+        const u64 n = s_excl + aggregate;
+        st[kTsLines] = n > nl_cap ? nl_cap : (uint32_t)n;
+    }
+    if (nul & 0x80808080u) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_NUL);
     if (dense) atomicOr(&st[kTsFlags], (uint32_t)HPN_TEXT_DENSE);
     if (own_end) {   // (wave-uniform branch; one atomic per wave that saw any)
-        uint32_t wt;
-        (void)wave_excl_scan32(own, wt);
+        const uint32_t wt = wave_sum(own);
         if (wt && lane_id() == 0) atomicAdd(&st[kTsOwnLines], wt);
-    }
-    if (tile == gridDim.x - 1 && tid == 0) {
-        const u64 n = tile_base + aggregate;
-        st[kTsLines] = n > nl_cap ? nl_cap : (uint32_t)n;
     }
 }
 
@@ -412,7 +488,7 @@ hipError_t launch_text_lines(const uint8_t *d_slot, uint32_t begin, uint32_t end
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_state, 0, kTsWords * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_text_lines, dim3((unsigned)t1), dim3(kTxtThreads), 0, st, d_slot, begin, end, last, own_end, d_nl,
+    hipLaunchKernelGGL(k_text_lines, dim3((unsigned)t1), dim3(kLinesThreads), 0, st, d_slot, begin, end, last, own_end, d_nl,
                        nl_cap, d_status, d_state);
     return hipGetLastError();
 }

@@ -789,34 +789,46 @@ __global__ __launch_bounds__(1024) void k_gz_win_apply(const uint16_t *__restric
     }
 }
 
-// symbols -> bytes: blockIdx.y = stretch, the x blocks stride over its symbols (8 per thread and step)
+// symbols -> bytes: blockIdx.y = stretch, the x blocks stride over its symbols (16 per thread and step).  The stretch's
+// 32 KiB of history lie in LDS: a placeholder is a ds_read_u8, not a second trip to memory behind the symbols' own
+// (names and other text repeated record after record are placeholders all the way down a stretch, not only in its
+// first 32 KiB: a copy of a placeholder is a placeholder).
 constexpr int kGzTrThreads = 256;
+constexpr int kGzTrBlocks = 16;   // per stretch: the history is read into LDS once per ~100 KB of text
 __global__ __launch_bounds__(kGzTrThreads) void k_gz_translate(const uint16_t *__restrict__ symbuf, uint32_t sym_cap,
                                                                const GzMeta *__restrict__ meta, const uint8_t *__restrict__ windows,
                                                                uint8_t *__restrict__ text)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[kGzHist];
     const uint32_t k = blockIdx.y;
     const uint32_t n = meta[k].n_out;
     const uint16_t *sym = symbuf + (uint64_t)k * sym_cap;  // 16-byte aligned when sym_cap % 8 == 0
     const uint8_t *wk = windows + (uint64_t)k * kGzHist;
     uint8_t *dst = text + meta[k].text_off;
-    const uint32_t groups = n / 8u;
+    const uint32_t groups = n / 16u;
+    if (blockIdx.x * kGzTrThreads >= groups && blockIdx.x != 0) return;
+    for (uint32_t i = threadIdx.x * 16u; i < kGzHist; i += kGzTrThreads * 16u) *reinterpret_cast<u32 *>(s_win + i) = *reinterpret_cast<const u32 *>(wk + i);
+    __syncthreads();
+    auto byte_of = [&](uint32_t e) -> uint32_t { return e < 256u ? e : (uint32_t)s_win[(e - 256u) & (kGzHist - 1u)]; };
     for (uint32_t g = blockIdx.x * kGzTrThreads + threadIdx.x; g < groups; g += gridDim.x * kGzTrThreads) {
-        const u32 v = *reinterpret_cast<const u32 *>(sym + (uint64_t)g * 8u);
-        uint8_t o[8];
+        const u32 v0 = *reinterpret_cast<const u32 *>(sym + (uint64_t)g * 16u), v1 = *reinterpret_cast<const u32 *>(sym + (uint64_t)g * 16u + 8u);
+        u32 o;
+        if (((v0[0] | v0[1] | v0[2] | v0[3] | v1[0] | v1[1] | v1[2] | v1[3]) & 0xff00ff00u) == 0u) {  // bytes only: the low bytes of the 16 halves
+            o[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x06040200u);
+            o[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x06040200u);
+            o[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x06040200u);
+            o[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x06040200u);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t a = v[q] & 0xffffu, c = v[q] >> 16;
-            o[2 * q] = a < 256u ? (uint8_t)a : wk[a - 256u];
-            o[2 * q + 1] = c < 256u ? (uint8_t)c : wk[c - 256u];
+            for (int q = 0; q < 2; ++q) {
+                o[q] = byte_of(v0[2 * q] & 0xffffu) | byte_of(v0[2 * q] >> 16) << 8 | byte_of(v0[2 * q + 1] & 0xffffu) << 16 | byte_of(v0[2 * q + 1] >> 16) << 24;
+                o[2 + q] = byte_of(v1[2 * q] & 0xffffu) | byte_of(v1[2 * q] >> 16) << 8 | byte_of(v1[2 * q + 1] & 0xffffu) << 16 | byte_of(v1[2 * q + 1] >> 16) << 24;
+            }
         }
-        __builtin_memcpy(dst + (uint64_t)g * 8u, o, 8);  // dst is not aligned in general
+        __builtin_memcpy(dst + (uint64_t)g * 16u, &o, 16);  // dst is not aligned in general
     }
     if (blockIdx.x == 0)
-        for (uint32_t i = groups * 8u + threadIdx.x; i < n; i += kGzTrThreads) {
-            const uint32_t a = sym[i];
-            dst[i] = a < 256u ? (uint8_t)a : wk[a - 256u];
-        }
+        for (uint32_t i = groups * 16u + threadIdx.x; i < n; i += kGzTrThreads) dst[i] = (uint8_t)byte_of(sym[i]);
 }
 
 // d_bounds: [0] = count (uint32, cleared here), entries from byte 16 on; nullptr: a final block ends its stretch (one member)
@@ -884,7 +896,7 @@ hipError_t launch_gz_translate(const uint16_t *d_sym, uint32_t sym_cap, const vo
                                uint8_t *d_text, hipStream_t st)
 {
     if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_translate, dim3(64, n_chunks), dim3(kGzTrThreads), 0, st, d_sym, sym_cap, (const GzMeta *)d_meta, d_windows,
+    hipLaunchKernelGGL(k_gz_translate, dim3(kGzTrBlocks, n_chunks), dim3(kGzTrThreads), 0, st, d_sym, sym_cap, (const GzMeta *)d_meta, d_windows,
                        d_text);
     return hipGetLastError();
 }

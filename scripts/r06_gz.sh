@@ -3,7 +3,8 @@
 # file and on a C2-like file of many members; the search / CRC micro-benchmark; rocprofv3 over the tool.  -> gpurun_out/r06_gz/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r06_gz; mkdir -p $O /dev/shm/gzp; : > $O/ab_gz_tool.txt; : > $O/bench_gz_find.txt
+BASE=${R06_BASE:-r05}   # the build the tree is compared with (build_ab/<name>/{libhpngs.so,bin})
+O=$GRAFT_REPO_ROOT/gpurun_out/${R06_OUT:-r06_gz}; mkdir -p $O /dev/shm/gzp; : > $O/ab_gz_tool.txt; : > $O/bench_gz_find.txt
 CYC=${R06_CYCLES:-40}
 python3 - <<PY
 import os, sys
@@ -46,14 +47,14 @@ run() {  # label, bindir, env...
   done
 }
 R=$GRAFT_REPO_ROOT
-run r05 $R/build_ab/r05/bin
+run $BASE $R/build_ab/$BASE/bin
 run tree $R/highperformancengs_amd/bin
-run r05 $R/build_ab/r05/bin
+run $BASE $R/build_ab/$BASE/bin
 run tree $R/highperformancengs_amd/bin
 cat $O/ab_gz_tool.txt
 # ---- the search and the CRC alone ----
 cd $R
-for v in r05 tree finddiag; do
+for v in $BASE tree ${R06_FINDDIAG-finddiag}; do
   lib=""; [ $v != tree ] && lib=$R/build_ab/$v/libhpngs.so
   echo "== $v" >> $O/bench_gz_find.txt
   HPN_LIB=$lib timeout 600 python3 scripts/bench_gz_find.py >> $O/bench_gz_find.txt 2>&1
