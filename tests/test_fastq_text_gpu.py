@@ -338,3 +338,81 @@ def test_count_in_place_mixed_with_copied_chunks_and_overwritten_text(ctx, mix, 
         res, flags, n = _count_inplace(ctx, text, size, mix=mix, clobber=clobber)
         assert flags == 0 and rc == 0
         _assert_counts(res, want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_damage_deep_inside_a_large_text_is_detected_or_exact(ctx, tmp_path, seed):
+    """The same contract on text of several tiles (k_text_lines takes whole words on every tile but a call's first and last:
+    another code path than the small texts above reach) -- a NUL, a lost or an extra newline far from both ends."""
+    rng = np.random.default_rng(7000 + seed)
+    text = bytearray(b"".join(_random_fastq(rng, 6000, 40, 151)))      # ~1.2 MB: nine tiles of 128 KiB
+    nls = np.flatnonzero(np.frombuffer(bytes(text), np.uint8) == 10)
+    at = int(rng.integers(len(text) // 4, 3 * len(text) // 4))
+    kind = seed % 4
+    if kind == 0:
+        text[at] = 0
+    elif kind == 1:
+        del text[int(nls[np.searchsorted(nls, at)])]
+    elif kind == 2:
+        text.insert(at, 10)
+    else:   # nothing: the undamaged text must be taken by the fast path
+        pass
+    text = bytes(text)
+    p = tmp_path / "d.fq"
+    p.write_bytes(text)
+    rc, want = orc.count_stream(str(p))
+    for size in (None, 300_000):
+        res, flags, _ = _count(ctx, text, size, tail_call=bool(size))
+        if kind == 0:
+            assert flags != 0, "a NUL byte inside a whole-word tile went unnoticed"
+        if kind == 3:
+            assert flags == 0
+        if res is not None:
+            assert rc == 0
+            _assert_counts(res, want)
+        res, flags, _ = _count_inplace(ctx, text, size)
+        if kind == 0:
+            assert flags != 0
+        if res is not None:
+            assert rc == 0
+            _assert_counts(res, want)
+
+
+@pytest.mark.parametrize("tiles,newline_at_end", [(1, True), (1, False), (3, True), (3, False)])
+def test_text_that_ends_exactly_on_a_tile_boundary(ctx, tmp_path, tiles, newline_at_end):
+    """In place the text starts 16-byte aligned, so nbytes = k * 128 KiB puts the stream's last byte on a tile's last byte:
+    with a final newline, and with the virtual one an unterminated last line gets (position `end`, one past the tile)."""
+    rng = np.random.default_rng(tiles * 2 + newline_at_end)
+    want_len = tiles * 131072
+    recs, size = [], 0
+    while True:
+        r = _random_fastq(rng, 1, 60, 120)[0]
+        if size + len(r) > want_len - 400:
+            break
+        recs.append(r), (size := size + len(r))
+    rest = want_len - size + (0 if newline_at_end else 1)      # the last record fills the rest exactly
+    l = (rest - len(b"@last\n\n+\n\n")) // 2
+    assert 1 <= l < 400
+    pad = rest - 10 - 2 * l                                      # 0 or 1: a longer name
+    recs.append(b"@last" + b"x" * pad + b"\n" + b"A" * l + b"\n+\n" + b"I" * l + b"\n")
+    text = b"".join(recs)
+    if not newline_at_end:
+        text = text[:-1]
+    assert len(text) == want_len
+    p = tmp_path / "e.fq"
+    p.write_bytes(text)
+    rc, want = orc.count_stream(str(p))
+    assert rc == 0
+    for size in (None, 131072):
+        res, flags, n = _count_inplace(ctx, text, size)
+        assert flags == 0 and n == len(recs)
+        _assert_counts(res, want)
+    # ... and as ONE call that is also the stream's last (the helper above ends every stream with an empty call)
+    import torch
+    from highperformancengs_amd import _lib
+    buf = torch.full((8192 + len(text) + 64,), 0x41, dtype=torch.uint8, device="cuda")
+    buf[8192:8192 + len(text)] = torch.from_numpy(np.frombuffer(text, np.uint8).copy()).cuda()
+    ctx.text_begin()
+    info = ctx.text_count_inplace(buf[8192:], len(text), last=True, flags=_lib.TALLY_QUAL_HIST)
+    assert info.irregular == 0 and info.n_records == len(recs)
+    _assert_counts(ctx.fastq_tally_fetch(qual_hist=True), want)
