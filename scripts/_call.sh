@@ -1,4 +1,2 @@
-mkdir -p gpurun_out/r06
-timeout 1500 python3 scripts/c2_gz_1e9.py > gpurun_out/r06/c2_gz_1e9_b.json 2> gpurun_out/r06/c2_gz_1e9_b.err
-tail -c 1500 gpurun_out/r06/c2_gz_1e9_b.json; tail -5 gpurun_out/r06/c2_gz_1e9_b.err
-rm -rf /dev/shm/c2gz_*
+HPN_AB_STRETCHES=6144:6144 bash scripts/ab_inflate.sh diag_NOASSEMBLE diag_NOFETCH diag_NOJUMP diag_NOPUT
+grep -v "^Traceback\|^  File\|^    " gpurun_out/ab_inflate.txt | cut -c1-330

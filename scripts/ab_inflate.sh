@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of the two inflate kernels: the tree's library against variant builds under build_ab/<name>/libhpngs.so
-# (scripts/ab_build.sh, copied there so that they travel with gpurun).  Output: gpurun_out/ab_inflate.txt
-# HPN_AB_STRETCHES: stretches of the gzip benchmark, "tree:variant" (each library at its own chip-fill), default 4608:4608
+# (scripts/ab_variant.sh).  Output: gpurun_out/ab_inflate.txt
+# AB_STRETCHES: stretches of the gzip benchmark, "tree:variant" (each library at its own chip-fill), default 6144:6144
 mkdir -p gpurun_out /tmp/abw
 out=gpurun_out/ab_inflate.txt
 : > $out
-ns=${HPN_AB_STRETCHES:-4608:4608}
+ns=${AB_STRETCHES:-6144:6144}
 g++ -O2 -std=c++17 scripts/bam_synth.cpp -o /tmp/abw/bam_synth -lz -lpthread
 /tmp/abw/bam_synth /tmp/abw/a.bam --targets chr1:120000000:14000000 12 >/dev/null 2>&1
 ls -l /tmp/abw/a.bam >> $out
