@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r06
-timeout 1500 python3 scripts/soak_raw_walk.py 4000 2>&1 | tail -5 | tee gpurun_out/r06/soak_raw_walk.txt
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+timeout 2400 python -m pytest tests -x -q -m gpu > /tmp/pt.log 2>&1; echo "rc=$?"; grep -E "passed|failed|rror" /tmp/pt.log | tail -5
