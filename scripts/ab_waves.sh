@@ -1,4 +1,5 @@
 #!/bin/bash
+# the inflate benchmarks with and without the wave-uniform state pinned to SGPRs (build_ab/nopin) -> gpurun_out/ab_waves.txt (round 3)
 mkdir -p gpurun_out
 out=gpurun_out/ab_waves.txt
 : > $out

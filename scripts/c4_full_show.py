@@ -1,3 +1,4 @@
+"""Prints the runs of a c4_full.py / c2_gz_1e9.py JSON one per line:  python scripts/c4_full_show.py profiles/r06/c4_full.json"""
 import json, sys
 j = json.load(open(sys.argv[1]))
 print(j.get("input"), j.get("input_made_in_s"), "identical:", j.get("outputs_identical"), j.get("skipped"))

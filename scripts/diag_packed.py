@@ -1,3 +1,4 @@
+"""Probe: a small two-contig BAM in samtools' layout and in packed blocks (records across block boundaries) through bam_sliding_count, the ingest's HPN_TIMING lines side by side."""
 import os, subprocess, sys, tempfile
 sys.path.insert(0, "tests")
 import c4

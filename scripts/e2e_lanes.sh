@@ -1,3 +1,4 @@
+# one 7.6 GB plain FASTQ through fastq_count over lanes (HPN_NGPU) x pread threads x chunk sizes, and through fastq_trim over 1 / 2 / 3 lanes with the outputs compared (round 4 probe)
 set -e
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'

@@ -1,3 +1,4 @@
+"""K1 / K1L on ragged reads (lengths 100..151): wall and kernel time of one pass with and without the Quality matrix, totals checked (probe)."""
 import sys, time
 sys.path.insert(0, ".")
 import torch, numpy as np

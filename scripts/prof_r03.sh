@@ -1,3 +1,4 @@
+# Round 3's evidence, collected in one session on the GPU box -> gpurun_out/r03/ (copy to profiles/r03/)
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
