@@ -1883,8 +1883,10 @@ hipError_t launch_bedgraph_text(const hpn_run *runs, uint64_t n_runs, const char
     const uint64_t nt = bedgraph_tiles(n_runs);
     u64 *tile_base = (u64 *)ws + 2;
     uint32_t *wave_tot = (uint32_t *)(tile_base + ((nt + 2) & ~(uint64_t)1));      // (16-byte aligned: read as whole words)
-    const uint64_t cap = (uint64_t)n_cu * 8;
-    hipLaunchKernelGGL(k_bedgraph_sizes, dim3((unsigned)(nt < cap ? nt : cap)), dim3(kFmtThreads), 0, st, runs, n_runs, name_len, nt, wave_tot, tile_base);
+    // (a workgroup per tile: 0.167 -> 0.135 ms per 67 M lines against eight workgroups per CU looping over the tiles -- the pass is
+    // short and latency-bound, more of it in flight is all it wants; the runs of several pieces asked for together: no gain)
+    (void)n_cu;
+    hipLaunchKernelGGL(k_bedgraph_sizes, dim3((unsigned)nt), dim3(kFmtThreads), 0, st, runs, n_runs, name_len, nt, wave_tot, tile_base);
     hipLaunchKernelGGL(k_bedgraph_offsets, dim3(1), dim3(1024), 0, st, tile_base, nt, (u64 *)ws + 1);
     hipLaunchKernelGGL(k_bedgraph_text, dim3((unsigned)nt), dim3(kFmtThreads), 0, st, runs, n_runs, nm, name_len, d_long_name, out, wave_tot, tile_base);
     return hipGetLastError();
