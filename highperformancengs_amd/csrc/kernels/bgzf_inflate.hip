@@ -148,6 +148,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_E
             if (!decode_symbols(s, b, p, in, in_len, sink, err)) break;
             seek(s, b, p, in, in_len);
         }
+        // the FINAL block must end inside the payload too (bytes behind in_len are read as zeros, and seven zero bits are the
+        // end-of-block code of a fixed-Huffman block: a payload cut short inside that code decoded to the stated length --
+        // zlib calls such a stream unfinished; scripts/soak_inflate_damaged.py, round 431 of 1,000)
+        if (!err && b.in_pos - (b.bc >> 3) > in_len) err = 17;
         if (!err && sink.op != out_len) err = 16;
         if (lane == 0) status[bi] = err;
     }

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(HPN_INF_E
         }
         uint64_t pos = (uint64_t)b.in_pos * 8u - b.bc;
         if (!err && last) pos = (pos + 7u) & ~(uint64_t)7u;          // the trailer is byte-aligned
+        if (!err && last && pos > (uint64_t)in_len * 8u) err = 17;   // the final block ends behind the input (bytes there read as zeros: k_bgzf_inflate's note)
         if (!err && !last && !arrived) err = 21;                      // cannot happen: the loop only leaves on one of these
         // a final block inside a stretch that was given an end: the member ends before the next stretch's start, which
         // therefore is not proven by this one (a second member, or bytes behind the stream): the caller hands the file back

@@ -222,3 +222,29 @@ def test_window_decoder_fuzz(ctx, seed):
     assert all(s != 0 or len(p) == 0 for s, p in zip(st, payloads[:8]))
     got, st = run(ctx, streams[:8], [len(p) + 1 for p in payloads[:8]])
     assert st.all()
+
+
+@pytest.mark.parametrize("cut", [1, 2])
+def test_payload_cut_inside_the_last_end_of_block_code_is_refused(ctx, cut):
+    """Bytes behind in_len are read as zeros, and seven zero bits are the end-of-block code of a fixed-Huffman block: a payload
+    that lost its last byte(s) decoded to the stated length with status 0 -- zlib calls such a stream unfinished.  (Found by
+    scripts/soak_inflate_damaged.py in its 431st round.)"""
+    import torch
+    rng = np.random.default_rng(5)
+    payload = bytes(rng.integers(65, 91, 3000, dtype=np.uint8))
+    whole = raw_deflate(payload, 6, zlib.Z_FIXED)
+    for s in (whole, whole[:-cut]):
+        d = zlib.decompressobj(-15)
+        z = d.decompress(s) + d.flush()
+        blocks = np.array([[0, len(s) | (len(payload) << 32), 0]], np.uint64)
+        d_comp = torch.from_numpy(np.frombuffer(s + bytes(64), np.uint8).copy()).cuda()
+        d_blocks = torch.from_numpy(blocks.view(np.int64)).cuda()
+        d_out = torch.full((len(payload) + 128,), 0xAA, dtype=torch.uint8, device="cuda")
+        d_status = torch.full((1,), 999, dtype=torch.int32, device="cuda")
+        ctx.bgzf_inflate_dev(d_comp, d_blocks, 1, d_out, d_status)
+        ctx.sync()
+        st = int(d_status.cpu()[0])
+        if d.eof:
+            assert st == 0 and bytes(d_out[:len(payload)].cpu().numpy()) == payload == z
+        else:
+            assert st != 0, "a stream zlib calls unfinished was taken"
