@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Soak of the BAM tools (bam2depth -W, bam2wig, bam_sliding_count: BGZF inflate on the device, records read in place, depth /
+window kernels, device-side bedGraph text) on random BAM FILES the tests do not hold: 1 - 4 targets with names of 1 - 60
+characters, 2 - 40 K records with CIGARs put together from every operation (M I D N S H P = X) and lengths 1 - 300, all the
+flag bits the filters look at, read names of 1 - 200 characters, every nibble code in the sequences, reads without a sequence
+-- written samtools' way (records never cross a block) or htsjdk's (bamio.repack_bam, blocks of a random size), at a random
+zlib level, run with random chunk / launch sizes and 1 - 3 workers.  Every output file must equal the oracle's text for the
+records as the Python decoder (highperformancengs_amd/bamio.py) reads them back from the file.
+
+    python3 scripts/soak_bam_tools.py [N=60] [first=0]  -> one JSON line (files first .. first + N - 1 of the seeded sequence)"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+from highperformancengs_amd import bamio  # noqa: E402
+
+BIN = os.path.join(ROOT, "highperformancengs_amd", "testhooks", "bin")
+CODES = "=ACMGRSVTWYHKDBN"
+
+
+def random_cigar(rng):
+    ops = "MIDNSHP=X"
+    n = int(rng.integers(1, 7))
+    out = []
+    for k in range(n):
+        op = "M" if rng.random() < 0.5 else ops[int(rng.integers(0, len(ops)))]
+        ln = int(rng.integers(1, 12)) if op in "IDP" and rng.random() < 0.7 else int(rng.integers(1, 301))
+        if op == "N":
+            ln = int(rng.integers(1, 1500))
+        out.append((ln, op))
+    if not any(o in "MIS=X" for _, o in out):
+        out.append((int(rng.integers(1, 150)), "M"))
+    return out
+
+
+def make_bam(rng, path):
+    n_ref = int(rng.integers(1, 5))
+    refs = []
+    for t in range(n_ref):
+        name = "".join(chr(int(c)) for c in rng.integers(48, 123, int(rng.integers(1, 61)))).replace("\\", "_").replace("`", "_")
+        name = "".join(ch if ch.isalnum() or ch in "._-" else "_" for ch in name) + str(t)
+        refs.append((name, int(rng.integers(3000, 2_500_000))))
+    n = int(rng.integers(2000, 40000))
+    lens = np.array([l for _, l in refs], np.float64)
+    tid = np.sort(rng.choice(n_ref, size=n, p=lens / lens.sum()))
+    cigs = [random_cigar(rng) for _ in range(int(rng.integers(3, 14)))]
+    recs = []
+    pos_all = np.zeros(n, np.int64)
+    for t in range(n_ref):
+        m = tid == t
+        pos_all[m] = np.sort(rng.integers(0, refs[t][1], int(m.sum())))
+    flag_pool = np.array([0, 16, 99, 147, 4, 256, 512, 1024, 2048, 1 | 64, 4 | 16, 256 | 16, 1024 | 99])
+    for i in range(n):
+        cg = cigs[int(rng.integers(0, len(cigs)))]
+        qlen = sum(l for l, o in cg if o in "MIS=X")
+        words = bamio.parse_cigar("".join(f"{l}{o}" for l, o in cg))
+        no_seq = rng.random() < 0.02
+        seq = "*" if no_seq else "".join(CODES[int(c)] for c in rng.integers(0, 16, qlen))
+        qual = b"" if no_seq or rng.random() < 0.3 else bytes(rng.integers(0, 42, qlen, dtype=np.uint8))
+        name = "r%d" % i + "x" * (int(rng.integers(0, 190)) if rng.random() < 0.05 else int(rng.integers(0, 20)))
+        t = int(tid[i])
+        if rng.random() < 0.01:                    # an unplaced read at the end of its target's records would break the order: keep tid, drop pos
+            flag = 4
+        else:
+            flag = int(flag_pool[int(rng.integers(0, len(flag_pool)))])
+        recs.append(bamio.BamRecord(tid=t, pos=int(pos_all[i]), flag=flag, cigar=words, seq=seq, qual=qual, name=name,
+                                    mapq=int(rng.integers(0, 61)), mtid=t if rng.random() < 0.5 else -1,
+                                    mpos=int(rng.integers(0, refs[t][1])) if rng.random() < 0.5 else -1, isize=int(rng.integers(-500, 500))))
+    level = int(rng.integers(1, 10))
+    bamio.write_bam(path, refs, recs, level=level)
+    layout = "samtools"
+    if rng.random() < 0.5:
+        block = int(rng.choice([700, 3000, 20000, 65280]))
+        bamio.repack_bam(path, path + ".packed", block, level=level)
+        os.replace(path + ".packed", path), os.replace(path + ".packed.bai", path + ".bai")
+        layout = f"packed {block}"
+    return n, layout
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    td = tempfile.mkdtemp(prefix="soak_bam_")
+    on_device = on_host = refused = 0
+    for i in range(first, first + N):
+        rng = np.random.default_rng(31_000 + i)
+        d = os.path.join(td, "w")
+        os.makedirs(d)
+        bam = os.path.join(d, "s.bam")
+        n, layout = make_bam(rng, bam)
+        soa = bamio.read_bam_records(bam)
+        W = int(rng.choice([37, 100, 1000, 20000, 65536]))
+        env = {**os.environ, "HPN_TIMING": "1", "HPN_NGPU": str(int(rng.integers(1, 4)))}
+        if rng.random() < 0.6:
+            env["HPN_BAM_CHUNK"] = str(int(rng.integers(60_000, 2_000_000)))
+            env["HPN_BAM_ROUNDS"] = str(int(rng.integers(1, 8)))
+        knobs = {k: v for k, v in env.items() if k.startswith("HPN_BAM") or k == "HPN_NGPU"}
+        what = (i, n, layout, W, knobs)
+        try:
+            bed, dep, wig, chrom = orc.bam2depth_text(soa, W, wig=True)
+            domain = True
+        except AssertionError:
+            domain = False                       # (an M block beyond the reference's key range: the tool must say so, not compute)
+        p = subprocess.run([os.path.join(BIN, "bam2depth"), "-w", str(W), "-W", "-o", "d", "s.bam"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=600)
+        if not domain:
+            assert p.returncode != 0, what
+            refused += 1
+        else:
+            assert p.returncode == 0, (what, p.stderr.decode()[-1500:])
+            for f, want in (("s.bam.1.bedGraph", bed), ("d.1.depth", dep), ("d.1.wig", wig), ("d.1.chromSize.txt", chrom)):
+                assert open(os.path.join(d, f), "rb").read() == want, (what, f, p.stderr.decode()[-1500:])
+            wwig, wchrom = orc.bam2wig_text(soa, W)
+            p2 = subprocess.run([os.path.join(BIN, "bam2wig"), "-w", str(W), "-o", "w", "s.bam"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert p2.returncode == 0, (what, p2.stderr.decode()[-1500:])
+            assert open(os.path.join(d, "w.1.wig"), "rb").read() == wwig and open(os.path.join(d, "w.1.chromSize.txt"), "rb").read() == wchrom, (what, "bam2wig")
+        if max(l // W for _, l in soa.refs) < 65536:
+            want = orc.window_report(soa, W)
+            p3 = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", str(W), "-o", "s", "s.bam"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                timeout=600)
+            assert p3.returncode == 0, (what, p3.stderr.decode()[-1500:])
+            assert open(os.path.join(d, "s.txt"), "rb").read() == want, (what, "bam_sliding_count", p3.stderr.decode()[-1500:])
+        if b"GPU ingest" in p.stderr and b"host ingest" not in p.stderr:
+            on_device += 1
+        else:
+            on_host += 1
+        shutil.rmtree(d)
+    os.rmdir(td)
+    print(json.dumps({"bam_files": N, "first": first, "ingested_on_the_device": on_device, "ingested_on_the_host": on_host, "outside_the_domain_and_refused": refused,
+                      "outputs": "bedGraph, depth, wig, chromSize (bam2depth -W), wig + chromSize (bam2wig), out.txt (bam_sliding_count): all equal to the oracle's"}))
+
+
+if __name__ == "__main__":
+    main()
