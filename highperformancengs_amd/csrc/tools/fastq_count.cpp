@@ -52,7 +52,7 @@ static void count_file(hpn_ctx *ctx, WorkerLanes &lanes, const char *infile, FIL
     rc = tally_file(ctx, infile, &acc, &too_long, lanes.for_file(infile));  // count_read's loop (:112-119), tally on the GPU(s)
     if (too_long) {
         fprintf(stderr, "%s: read longer than 511 bases (outside fastq_count's SeqLen[512])\n", infile);
-        exit(2);
+        leave(2);     // (not exit(): other workers are inside the runtime; found by scripts/soak_fastq_tools.py as a SIGSEGV of the kthread tool)
     }
     if (rc != HPN_OK) die_hpn(ctx, rc, infile);
     const CountSummary s = summarise(acc);

@@ -56,7 +56,7 @@ static void count_file(hpn_ctx *ctx, WorkerLanes &lanes, FileAcc &fa, const char
     rc = tally_file(ctx, infile, &fa.t, &too_long, lanes.for_file(infile));  // count_read's loop (:126-135), tally on the GPU(s)
     if (too_long) {
         fprintf(stderr, "%s: read longer than 511 bases (outside SeqLen[512])\n", infile);
-        exit(2);
+        leave(2);     // (not exit(): other workers are inside the runtime, whose exit handlers crash under them -- a SIGSEGV instead of code 2; scripts/soak_fastq_tools.py)
     }
     if (rc != HPN_OK) die_hpn(ctx, rc, infile);
     fa.s = summarise(fa.t);

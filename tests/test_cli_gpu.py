@@ -563,3 +563,23 @@ def test_feeders_next_to_the_device_or_not_same_bytes(manifest, tmp_path):
             d = tmp_path / f"{case}_{k}"
             d.mkdir()
             _check(manifest, case, d, env)
+
+
+@pytest.mark.parametrize("tool,threads", [("fastq_count", "1"), ("fastq_count", "4"), ("fastq_count_kthread", "4")])
+def test_a_read_of_512_bases_ends_the_tool_with_code_2_whatever_the_other_workers_do(tool, threads, tmp_path):
+    """SeqLen[512] has no slot for it (the reference writes behind the array): message, exit code 2, no report.  With other
+    workers still inside the runtime the way out must not run the runtime's exit handlers -- fastq_count_kthread -t 4 died of
+    SIGSEGV here instead (scripts/soak_fastq_tools.py, round 6)."""
+    rng = np.random.default_rng(3)
+    names = []
+    for k in range(4):
+        n = 20000
+        recs = [b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 100)), bytes(rng.integers(35, 74, 100, dtype=np.uint8)))
+                for i in range(n)]
+        if k == 2:
+            recs[n // 2] = b"@long\n" + b"A" * 600 + b"\n+\n" + b"I" * 600 + b"\n"
+        names.append("f%d.fq" % k)
+        (tmp_path / names[-1]).write_bytes(b"".join(recs))
+    p = subprocess.run([os.path.join(BIN, tool), "-t", threads, "-o", "m.tsv"] + names, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 2, (p.returncode, p.stderr.decode())
+    assert b"read longer than 511 bases" in p.stderr
