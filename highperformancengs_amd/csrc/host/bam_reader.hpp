@@ -86,6 +86,8 @@ public:
     }
     void skip(size_t n) { pos_ += n; }  // only what peek() just showed
     const char *error() const { return err_; }
+    // before open(): also verify every block's CRC-32 (a block that fails ends the stream with error() set, like a data error)
+    void check_crc(bool on) { check_crc_ = on; }
 
 private:
     enum State { kFree, kRaw, kBusy, kDone };
@@ -95,6 +97,7 @@ private:
         uint32_t isize = 0;
         bool bad = false;
     };
+    bool check_crc_ = false;
 
     // file order = slot order (round robin): the reader fills slot w_, the consumer takes slot r_
     void io_loop()
@@ -182,8 +185,24 @@ private:
                     zs.avail_in = (uInt)(s->raw.size() - 8);
                     zs.next_out = s->data.data();
                     zs.avail_out = s->isize;
-                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END) s->bad = true;
+                    // (a stream that ends short of ISIZE is a damaged block too: its last bytes would be whatever the buffer held)
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) s->bad = true;
                 }
+            }
+            if (!s->isize && s->raw.size() > 8 + 2) {   // an empty block is the two bytes 03 00; anything longer must not hide data
+                uint8_t one;
+                if (!zs_ok || inflateReset(&zs) != Z_OK) s->bad = true;
+                else {
+                    zs.next_in = s->raw.data(), zs.avail_in = (uInt)(s->raw.size() - 8), zs.next_out = &one, zs.avail_out = 1;
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 1) s->bad = true;
+                }
+            }
+            // Where the bytes are TEXT the reference reads them through gzread, which checks every member's CRC-32 and hands out
+            // nothing of a member that fails (the BAM tools' reader, samtools' bgzf.c, checks none: check_crc_ stays off there)
+            if (!s->bad && check_crc_) {
+                uint32_t want;
+                memcpy(&want, s->raw.data() + s->raw.size() - 8, 4);
+                if (crc32_fast(0, s->data.data(), s->data.size()) != want) s->bad = true;
             }
             {
                 std::lock_guard<std::mutex> lk(m_);

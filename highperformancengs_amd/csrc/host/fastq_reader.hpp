@@ -60,7 +60,7 @@ struct InStream {
     bool gz_error = false;
     // a reader noticed that the stream is not sound (CRC-32, ISIZE, a data error): what it delivered may differ from what
     // gzgets hands out, and the caller reads the input again through open_input_stream_exact
-    bool damaged() const { return gz_error || (pz && pz->damaged()) || (mz && mz->damaged()); }
+    bool damaged() const { return gz_error || (pz && pz->damaged()) || (mz && mz->damaged()) || (bz && bz->error() != nullptr); }
     int read(void *dst, unsigned n)
     {
         if (pre && pre_pos < pre->size()) {
@@ -141,6 +141,7 @@ inline InStream open_input_stream(const char *name)
         if (fd != -1 && pread(fd, h, 18, 0) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) &&
             h[12] == 'B' && h[13] == 'C' && !test_env("HPN_NO_BGZF")) {
             auto bz = std::make_shared<BgzfReader>();
+            bz->check_crc(true);   // (text: gzread's checks; InStream::damaged)
             const long share = usable_cpus() / text_workers_in_flight();
             if (bz->open(name, getenv("HPN_BGZF_THREADS") ? 0 : (int)(share < 1 ? 1 : share > 16 ? 16 : share))) {
                 close(fd);

@@ -91,6 +91,24 @@ def one_file(rng, path_stem):
     else:
         path, blob = path_stem + ".bgz.fq.gz", bgzf(rng, text)
         what.append("bgzf")
+    if c >= 0.4 and rng.random() < 0.2:          # the CONTAINER damaged: the tools must deliver what zlib's gzread delivers of it
+        b = bytearray(blob)
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            at = int(rng.integers(0, len(b) * 8))
+            b[at >> 3] ^= 1 << (at & 7)
+            what.append("a bit flipped in the container")
+        elif k == 1:
+            del b[int(rng.integers(1, len(b))):]
+            what.append("container cut short")
+        elif k == 2:
+            b += bytes(rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8))
+            what.append("bytes behind the container")
+        else:
+            at = int(rng.integers(0, len(b)))
+            b[at:at] = bytes(rng.integers(0, 256, int(rng.integers(1, 50)), dtype=np.uint8))
+            what.append("bytes inserted into the container")
+        blob = bytes(b)
     open(path, "wb").write(blob)
     return path, what
 

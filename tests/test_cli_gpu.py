@@ -583,3 +583,54 @@ def test_a_read_of_512_bases_ends_the_tool_with_code_2_whatever_the_other_worker
     p = subprocess.run([os.path.join(BIN, tool), "-t", threads, "-o", "m.tsv"] + names, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 2, (p.returncode, p.stderr.decode())
     assert b"read longer than 511 bases" in p.stderr
+
+
+@pytest.mark.parametrize("damage", ["literal", "isize"])
+def test_bgzip_fastq_with_a_block_that_fails_its_check_ends_where_gzread_ends(damage, tmp_path):
+    """A bgzip-compressed FASTQ is a gzip file to the reference: gzread checks every member's CRC-32 and ISIZE and hands out
+    nothing from the failing member on.  samtools' BGZF reader (what the BAM tools stand in for) checks no CRC, and until round 6
+    neither did the text routes built on the same decoders: a flipped bit inside a literal passed through fastq_count and
+    fastq_trim on the device and on the host alike (found by scripts/soak_fastq_tools.py)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(17)
+    n = 9000
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 100)), bytes(rng.integers(35, 74, 100, dtype=np.uint8)))
+                    for i in range(n))
+    blocks = []
+    for a in range(0, len(text), 30000):
+        piece = text[a:a + 30000]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)      # (literals only: a flipped bit changes a byte, not the length)
+        comp = co.compress(piece) + co.flush()
+        blocks.append(bytearray(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp +
+                                struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece))))
+    k = len(blocks) // 2
+    if damage == "literal":
+        for at in range(len(blocks[k]) // 2, len(blocks[k]) - 8):               # a bit that leaves the block decodable to its stated length
+            trial = bytearray(blocks[k])
+            trial[at] ^= 4
+            try:
+                if len(zlib.decompress(bytes(trial[18:-8]), -15)) == 30000:
+                    blocks[k] = trial
+                    break
+            except zlib.error:
+                continue
+        else:
+            pytest.skip("no length-preserving bit found")
+    else:
+        blocks[k][-4:] = struct.pack("<I", 29999)
+    blob = b"".join(bytes(b) for b in blocks) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    (tmp_path / "d.fq.gz").write_bytes(blob)
+    want = orc.fastq_count_report([str(tmp_path / "d.fq.gz")], names=["d.fq.gz"], header=True, length_detail=True)
+    assert int(want.split(b"\n")[1].split(b"\t")[1]) < n          # the reference stops at the member
+    for env in ({}, {"HPN_BAM_GPU": "0"}, {"HPN_NGPU": "2"}):
+        p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "d.fq.gz"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env={**os.environ, **env})
+        assert p.returncode == 0 and p.stdout == want, (env, p.stderr.decode())
+        p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-i", "d.fq.gz", "-o", "t", "-s", "0", "-e", "60"], cwd=tmp_path, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env={**os.environ, **env})
+        assert p.returncode == 0, (env, p.stderr.decode())
+        got = open(tmp_path / "t.trim.fastq", "rb").read()
+        reads = int(want.split(b"\n")[1].split(b"\t")[1])
+        assert reads - 1 <= got.count(b"\n+\n") <= reads, (env, got.count(b"\n+\n"), reads)     # (the record the failure falls into: test_trim_of_a_damaged_gzip)
+        os.unlink(tmp_path / "t.trim.fastq")
