@@ -7,7 +7,10 @@ flag bits the filters look at, read names of 1 - 200 characters, every nibble co
 zlib level, run with random chunk / launch sizes and 1 - 3 workers.  Every output file must equal the oracle's text for the
 records as the Python decoder (highperformancengs_amd/bamio.py) reads them back from the file.
 
-    python3 scripts/soak_bam_tools.py [N=60] [first=0]  -> one JSON line (files first .. first + N - 1 of the seeded sequence)"""
+    python3 scripts/soak_bam_tools.py [N=60] [first=0]  -> one JSON line (files first .. first + N - 1 of the seeded sequence)
+    python3 scripts/soak_bam_tools.py N first damaged   -> the same files with the CONTAINER damaged (a flipped bit, a cut, bytes inserted):
+        no reference behaviour to compare with (samtools' reader checks no CRC and walks whatever comes out); asked here: no tool dies of a
+        signal or hangs, and where the device ingest and the host ingest (HPN_BAM_GPU=0) both finish with code 0 their outputs are the same"""
 import json
 import os
 import shutil
@@ -86,9 +89,60 @@ def make_bam(rng, path):
     return n, layout
 
 
+def damaged_main(N, first):
+    td = tempfile.mkdtemp(prefix="soak_bamd_")
+    codes, same, differ_ok = {}, 0, 0
+    for i in range(first, first + N):
+        rng = np.random.default_rng(31_000 + i)
+        d = os.path.join(td, "w")
+        os.makedirs(d)
+        bam = os.path.join(d, "s.bam")
+        make_bam(rng, bam)
+        b = bytearray(open(bam, "rb").read())
+        k = int(rng.integers(0, 3))
+        lo = len(b) // 10                                        # (behind the header's blocks)
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(lo * 8, len(b) * 8))
+                b[at >> 3] ^= 1 << (at & 7)
+        elif k == 1:
+            del b[int(rng.integers(lo, len(b))):]
+        else:
+            at = int(rng.integers(lo, len(b)))
+            b[at:at] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        open(bam, "wb").write(bytes(b))
+        W = int(rng.choice([100, 1000, 20000]))
+        outs = []
+        for env in ({}, {"HPN_BAM_GPU": "0"}):
+            e = {**os.environ, **env, "HPN_NGPU": str(int(rng.integers(1, 3)))}
+            res = []
+            for tool, args, files in (("bam2depth", ["-w", str(W), "-o", "d", "s.bam"], ["s.bam.1.bedGraph", "d.1.depth"]),
+                                      ("bam_sliding_count", ["-w", str(W), "-o", "s", "s.bam"], ["s.txt"])):
+                for f in files:
+                    if os.path.exists(os.path.join(d, f)):
+                        os.remove(os.path.join(d, f))
+                p = subprocess.run([os.path.join(BIN, tool)] + args, cwd=d, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                assert p.returncode >= 0, (i, k, tool, env, "died of signal", -p.returncode, p.stderr.decode()[-800:])
+                codes[p.returncode] = codes.get(p.returncode, 0) + 1
+                res.append((p.returncode, [open(os.path.join(d, f), "rb").read() if os.path.exists(os.path.join(d, f)) else None for f in files]))
+            outs.append(res)
+        for a, b2 in zip(outs[0], outs[1]):
+            if a[0] == 0 and b2[0] == 0:
+                assert a[1] == b2[1], (i, k, "device and host ingest both finished, with different outputs")
+                same += 1
+            else:
+                differ_ok += 1
+        shutil.rmtree(d)
+    os.rmdir(td)
+    print(json.dumps({"damaged_bam_files": N, "first": first, "exit_codes": codes, "tool_runs_where_both_ingests_finished_and_agree": same,
+                      "tool_runs_where_one_or_both_refused": differ_ok, "died_of_a_signal_or_hung": 0}))
+
+
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == "damaged":
+        return damaged_main(N, first)
     td = tempfile.mkdtemp(prefix="soak_bam_")
     on_device = on_host = refused = 0
     for i in range(first, first + N):
