@@ -174,6 +174,19 @@ def main():
             assert open(os.path.join(d, "t.trim.fastq"), "rb").read() == wtext, (what, "fastq_trim", S, E, p.stderr.decode()[-1500:])
             assert b"Total_reads: %d\n" % nw in p.stderr, (what, p.stderr[-300:])
             runs["fastq_trim"] += 1
+        # ---- the pipes: fastq_trim from stdin to stdout, fastq_count from stdin (a sound container only: output that cannot be rewound
+        # is refused for a damaged one, tests/test_cli_gpu.py::test_trim_of_a_damaged_gzip) ----
+        if rc == 0 and not any("container" in w for w in whats[0]) and rng.random() < 0.5:
+            with open(paths[0], "rb") as fh:
+                p = subprocess.run([os.path.join(BIN, "fastq_trim"), "-s", str(S), "-e", str(E)], cwd=d, env=env, stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   timeout=600)
+            assert p.returncode == 0 and p.stdout == wtext, (what, "fastq_trim stdin -> stdout", S, E, p.returncode, p.stderr.decode()[-800:])
+            runs["fastq_trim through pipes"] = runs.get("fastq_trim through pipes", 0) + 1
+            if not long_read:
+                with open(paths[0], "rb") as fh:
+                    p = subprocess.run([os.path.join(BIN, "fastq_count"), "-H", "-L", "-"], cwd=d, env=env, stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                assert p.returncode == 0 and p.stdout == orc.fastq_count_report([paths[0]], names=["-"], header=True, length_detail=True), (what, "fastq_count -")
+                runs["fastq_count from stdin"] = runs.get("fastq_count from stdin", 0) + 1
         shutil.rmtree(d)
     os.rmdir(td)
     print(json.dumps({"rounds": N, "first": first, "tool_runs_compared": runs, "files_by_kind": kinds, "outputs": "all equal to the oracle's"}))
