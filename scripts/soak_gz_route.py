@@ -6,7 +6,7 @@ the host / the device and framing slices.  The report must be the oracle's (the 
 byte for byte, whether the route takes the file or hands it back (fixed codes and stored blocks give the search nothing
 to find: counted, not an error).
 
-    python3 scripts/soak_gz_route.py [N=200]  -> one JSON line"""
+    python3 scripts/soak_gz_route.py [N=200] [first=0]  -> one JSON line"""
 import json
 import os
 import subprocess
@@ -59,10 +59,11 @@ def gz(rng, data):
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     td = tempfile.mkdtemp(prefix="soak_gz_")
     taken = handed_back = 0
     why = {}
-    for i in range(N):
+    for i in range(first, first + N):
         rng = np.random.default_rng(7_100_000 + i)
         text = fastq(rng)
         cuts = sorted(int(x) for x in rng.integers(1, len(text), int(rng.integers(0, 4))))
@@ -92,7 +93,7 @@ def main():
             why[k] = why.get(k, 0) + 1
     os.remove(path)
     os.rmdir(td)
-    print(json.dumps({"files": N, "inflated_on_the_device": taken, "handed_back_to_the_host_readers": handed_back,
+    print(json.dumps({"files": N, "first": first, "inflated_on_the_device": taken, "handed_back_to_the_host_readers": handed_back,
                       "handed_back_because": why, "reports": "all equal to the oracle's"}))
 
 
