@@ -144,7 +144,7 @@ def main():
     if len(sys.argv) > 3 and sys.argv[3] == "damaged":
         return damaged_main(N, first)
     td = tempfile.mkdtemp(prefix="soak_bam_")
-    on_device = on_host = refused = 0
+    on_device = on_host = refused = regions = 0
     for i in range(first, first + N):
         rng = np.random.default_rng(31_000 + i)
         d = os.path.join(td, "w")
@@ -183,13 +183,25 @@ def main():
                                 timeout=600)
             assert p3.returncode == 0, (what, p3.stderr.decode()[-1500:])
             assert open(os.path.join(d, "s.txt"), "rb").read() == want, (what, "bam_sliding_count", p3.stderr.decode()[-1500:])
+        if rng.random() < 0.6:                   # -r: the records bam_fetch would hand over (index start, is_overlap), window report of those
+            t = int(rng.integers(0, len(soa.refs)))
+            name, tlen = soa.refs[t]
+            a = int(rng.integers(0, tlen))
+            b_ = int(rng.integers(a + 1, tlen + 1))
+            want = orc.window_report(orc.region_subset(soa, t, a, b_), W)
+            p4 = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", str(W), "-r", "%s:%d-%d" % (name, a + 1, b_), "-o", "reg", "s.bam"], cwd=d, env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert p4.returncode == 0, (what, "region", p4.stderr.decode()[-1500:])
+            assert p4.stdout == b"%s\t%d\t%d\n" % (name.encode(), a, b_), (what, "region stdout", p4.stdout)
+            assert open(os.path.join(d, "reg.txt"), "rb").read() == want, (what, "bam_sliding_count -r", name, a, b_, p4.stderr.decode()[-1500:])
+            regions += 1
         if b"GPU ingest" in p.stderr and b"host ingest" not in p.stderr:
             on_device += 1
         else:
             on_host += 1
         shutil.rmtree(d)
     os.rmdir(td)
-    print(json.dumps({"bam_files": N, "first": first, "ingested_on_the_device": on_device, "ingested_on_the_host": on_host, "outside_the_domain_and_refused": refused,
+    print(json.dumps({"bam_files": N, "first": first, "ingested_on_the_device": on_device, "ingested_on_the_host": on_host, "outside_the_domain_and_refused": refused, "region_runs_(-r)_equal": regions,
                       "outputs": "bedGraph, depth, wig, chromSize (bam2depth -W), wig + chromSize (bam2wig), out.txt (bam_sliding_count): all equal to the oracle's"}))
 
 
