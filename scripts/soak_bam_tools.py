@@ -144,7 +144,7 @@ def main():
     if len(sys.argv) > 3 and sys.argv[3] == "damaged":
         return damaged_main(N, first)
     td = tempfile.mkdtemp(prefix="soak_bam_")
-    on_device = on_host = refused = regions = 0
+    on_device = on_host = refused = regions = pairs = 0
     for i in range(first, first + N):
         rng = np.random.default_rng(31_000 + i)
         d = os.path.join(td, "w")
@@ -195,13 +195,30 @@ def main():
             assert p4.stdout == b"%s\t%d\t%d\n" % (name.encode(), a, b_), (what, "region stdout", p4.stdout)
             assert open(os.path.join(d, "reg.txt"), "rb").read() == want, (what, "bam_sliding_count -r", name, a, b_, p4.stderr.decode()[-1500:])
             regions += 1
+        if domain and rng.random() < 0.3:         # two inputs: bam2depth writes .1. and .2. files, bam_sliding_count reports the first input only
+            make_bam(rng, os.path.join(d, "b.bam"))
+            soa2 = bamio.read_bam_records(os.path.join(d, "b.bam"))
+            try:
+                bed2, dep2, _, _ = orc.bam2depth_text(soa2, W, wig=True)
+            except AssertionError:
+                bed2 = None
+            if bed2 is not None:
+                p5 = subprocess.run([os.path.join(BIN, "bam2depth"), "-w", str(W), "-o", "two", "s.bam", "b.bam"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                    timeout=600)
+                assert p5.returncode == 0, (what, "two inputs", p5.stderr.decode()[-1500:])
+                for f, want2 in (("s.bam.1.bedGraph", bed), ("two.1.depth", dep), ("b.bam.2.bedGraph", bed2), ("two.2.depth", dep2)):
+                    assert open(os.path.join(d, f), "rb").read() == want2, (what, "two inputs", f)
+                p6 = subprocess.run([os.path.join(BIN, "bam_sliding_count"), "-w", str(W), "-o", "two", "s.bam", "b.bam"], cwd=d, env=env, stdout=subprocess.PIPE,
+                                    stderr=subprocess.PIPE, timeout=600)
+                assert p6.returncode == 0 and open(os.path.join(d, "two.txt"), "rb").read() == orc.window_report(soa, W), (what, "sliding, two inputs")
+                pairs += 1
         if b"GPU ingest" in p.stderr and b"host ingest" not in p.stderr:
             on_device += 1
         else:
             on_host += 1
         shutil.rmtree(d)
     os.rmdir(td)
-    print(json.dumps({"bam_files": N, "first": first, "ingested_on_the_device": on_device, "ingested_on_the_host": on_host, "outside_the_domain_and_refused": refused, "region_runs_(-r)_equal": regions,
+    print(json.dumps({"bam_files": N, "first": first, "ingested_on_the_device": on_device, "ingested_on_the_host": on_host, "outside_the_domain_and_refused": refused, "region_runs_(-r)_equal": regions, "runs_on_two_inputs_equal": pairs,
                       "outputs": "bedGraph, depth, wig, chromSize (bam2depth -W), wig + chromSize (bam2wig), out.txt (bam_sliding_count): all equal to the oracle's"}))
 
 
